@@ -1,0 +1,159 @@
+"""ctypes access to the CPU checkers under oracle/ (test infrastructure only).
+
+* ``oracle/liboracle.so``  -- our scalar restatement (oracle/ssw_oracle.c)
+* ``oracle/_ref/libssw.so`` -- the reference's own ssw.c compiled by oracle/Makefile (optional)
+
+Nothing in the product package imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, 'oracle')
+
+_LUT = np.full(256, 4, dtype=np.int8)
+for _c, _v in zip('ACGTN', range(5)):
+    _LUT[ord(_c)] = _v
+    _LUT[ord(_c.lower())] = _v
+
+
+def encode(seq):
+    """A/a->0 C/c->1 G/g->2 T/t->3 everything else->4 (libs/striped_smith_waterman/ssw_wrap.py:50,243-250)."""
+    if isinstance(seq, str):
+        seq = seq.encode('latin-1')
+    return _LUT[np.frombuffer(seq, dtype=np.uint8)]
+
+
+def make_mat(match, mismatch):
+    """5x5 matrix of ssw_wrap.py:146-159 (N row/column = 0)."""
+    m = np.full((5, 5), -mismatch, dtype=np.int8)
+    np.fill_diagonal(m, match)
+    m[4, :] = 0
+    m[:, 4] = 0
+    return m.reshape(-1).copy()
+
+
+def mask_len(qlen):
+    return qlen // 2 if qlen > 30 else 15  # ssw_wrap.py:196-199
+
+
+class CloAlign(C.Structure):
+    _fields_ = [('score1', C.c_uint16), ('score2', C.c_uint16), ('ref_begin1', C.c_int32), ('ref_end1', C.c_int32),
+                ('read_begin1', C.c_int32), ('read_end1', C.c_int32), ('ref_end2', C.c_int32),
+                ('cigar', C.POINTER(C.c_uint32)), ('cigarLen', C.c_int32)]
+
+
+def ensure_built():
+    so = os.path.join(ORACLE_DIR, 'liboracle.so')
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith('.c')]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(['make', '-s', '-C', ORACLE_DIR, os.path.join(ORACLE_DIR, 'liboracle.so')])
+    return so
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(ensure_built())
+        lib.clo_ssw_align.restype = C.c_int
+        lib.clo_ssw_align.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int8, C.c_void_p, C.c_int32,
+                                      C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16, C.c_int32, C.c_int32,
+                                      C.POINTER(CloAlign)]
+        lib.clo_free_cigar.argtypes = [C.POINTER(CloAlign)]
+        lib.clo_ssw_batch.restype = C.c_int
+        lib.clo_ssw_batch.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.c_uint8, C.c_uint8, C.c_uint8, C.c_int8, C.c_void_p, C.c_void_p, C.c_int64]
+        _oracle = lib
+    return _oracle
+
+
+def cigar_to_string(cig, qb, qe, qlen):
+    """BAM-style u32 cigar -> SAM string with soft clips (ssw_wrap.py:349-379)."""
+    s = ''
+    if qb > 0:
+        s += '%dS' % qb
+    for c in cig:
+        s += '%d%s' % (int(c) >> 4, 'MIDNSHP=X'[int(c) & 0xf] if (int(c) & 0xf) < 9 else 'M')
+    if qlen - qe - 1 != 0:
+        s += '%dS' % (qlen - qe - 1)
+    return s
+
+
+def oracle_align(ref, query, match=1, mismatch=1, gap_open=1, gap_extend=1, flag=1, score_size=2, mat=None,
+                 maskl=None):
+    """Returns dict(score, score2, ref_begin, ref_end, query_begin, query_end, ref_end2, cigar(list), cigar_string)
+    or None where the reference returns NULL."""
+    r = encode(ref) if not isinstance(ref, np.ndarray) else ref
+    q = encode(query) if not isinstance(query, np.ndarray) else query
+    r = np.ascontiguousarray(r, dtype=np.int8)
+    q = np.ascontiguousarray(q, dtype=np.int8)
+    m = make_mat(match, mismatch) if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
+    n = int(round(len(m) ** 0.5))
+    res = CloAlign()
+    ml = mask_len(len(q)) if maskl is None else maskl
+    rc = oracle().clo_ssw_align(q.ctypes.data, len(q), m.ctypes.data, n, score_size, r.ctypes.data, len(r),
+                                gap_open, gap_extend, flag, 0, 0, ml, C.byref(res))
+    if rc != 0:
+        return None
+    cig = [res.cigar[i] for i in range(res.cigarLen)]
+    out = dict(score=res.score1, score2=res.score2, ref_begin=res.ref_begin1, ref_end=res.ref_end1,
+               query_begin=res.read_begin1, query_end=res.read_end1, ref_end2=res.ref_end2, cigar=cig,
+               cigar_string=cigar_to_string(cig, res.read_begin1, res.read_end1, len(q)) if cig else None)
+    oracle().clo_free_cigar(C.byref(res))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own library (optional)
+# ------------------------------------------------------------------------------------------------
+REF_SO = os.path.join(ORACLE_DIR, '_ref', 'libssw.so')
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SO)
+        lib.ssw_init.restype = C.c_void_p
+        lib.ssw_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int8]
+        lib.init_destroy.argtypes = [C.c_void_p]
+        lib.ssw_align.restype = C.POINTER(CloAlign)  # same layout as s_align (ssw.h:42-52)
+        lib.ssw_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16,
+                                  C.c_int32, C.c_int32]
+        lib.align_destroy.argtypes = [C.POINTER(CloAlign)]
+        _ref = lib
+    return _ref
+
+
+def ref_align(ref, query, match=1, mismatch=1, gap_open=1, gap_extend=1, flag=1, score_size=2, mat=None, maskl=None):
+    r = encode(ref) if not isinstance(ref, np.ndarray) else ref
+    q = encode(query) if not isinstance(query, np.ndarray) else query
+    r = np.ascontiguousarray(r, dtype=np.int8)
+    q = np.ascontiguousarray(q, dtype=np.int8)
+    m = make_mat(match, mismatch) if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
+    n = int(round(len(m) ** 0.5))
+    lib = ref_lib()
+    prof = lib.ssw_init(q.ctypes.data, len(q), m.ctypes.data, n, score_size)
+    ml = mask_len(len(q)) if maskl is None else maskl
+    p = lib.ssw_align(prof, r.ctypes.data, len(r), gap_open, gap_extend, flag, 0, 0, ml)
+    if not p:
+        lib.init_destroy(prof)
+        return None
+    res = p.contents
+    cig = [res.cigar[i] for i in range(res.cigarLen)]
+    out = dict(score=res.score1, score2=res.score2, ref_begin=res.ref_begin1, ref_end=res.ref_end1,
+               query_begin=res.read_begin1, query_end=res.read_end1, ref_end2=res.ref_end2, cigar=cig,
+               cigar_string=cigar_to_string(cig, res.read_begin1, res.read_end1, len(q)) if cig else None)
+    lib.align_destroy(p)
+    lib.init_destroy(prof)
+    return out

@@ -1,0 +1,40 @@
+"""The CPU restatement (oracle/ssw_oracle.c) against golden vectors captured from the reference's own
+libssw.so + ssw_wrap.py (tests/golden/make_golden.py).  This is what pins the oracle."""
+import pytest
+
+from oracle_lib import oracle_align
+
+KEYS = ('score', 'ref_begin', 'ref_end', 'query_begin', 'query_end', 'cigar_string')
+
+
+def _check(c):
+    got = oracle_align(c['ref'], c['query'], c['match'], c['mismatch'], c['gap_open'], c['gap_extend'])
+    assert got is not None, c['name']
+    for k in KEYS:
+        assert got[k] == c[k], (c['name'], k, got[k], c[k])
+    assert got['score2'] == c['raw_score2'], (c['name'], 'score2')
+    assert got['ref_end2'] == c['raw_ref_end2'], (c['name'], 'ref_end2')
+    assert len(got['cigar']) == c['raw_cigar_len']
+
+
+def test_oracle_matches_all_golden_vectors(golden_cases):
+    assert len(golden_cases) >= 1400
+    for c in golden_cases:
+        _check(c)
+
+
+def test_reference_test_fa_known_answers(golden_cases):
+    """tests/test.fa in the orientation of tests/test_ssw.py and of find_bsj.py:196-205."""
+    by = {c['name']: c for c in golden_cases}
+    a = by['testfa_ref_seq1_query_seq2']
+    assert (a['score'], a['ref_begin'], a['ref_end'], a['query_begin'], a['query_end']) == (349, 20, 436, 229781, 230207)
+    b = by['testfa_ref_seq2_query_seq1']
+    assert (b['score'], b['ref_begin'], b['ref_end'], b['query_begin'], b['query_end']) == (349, 229790, 230207, 20, 436)
+    assert (b['raw_score2'], b['raw_ref_end2']) == (140, 230425)
+
+
+def test_zero_score_is_degenerate_but_deterministic(golden_cases):
+    z = [c for c in golden_cases if c['name'] == 'zero_score'][0]
+    assert (z['score'], z['ref_begin'], z['ref_end'], z['query_begin'], z['query_end'], z['cigar_string']) == \
+        (0, -1, -1, 0, 0, '1M7S')
+    _check(z)

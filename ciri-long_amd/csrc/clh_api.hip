@@ -1,0 +1,436 @@
+// clh_api.hip -- host side of libclh.so: contexts, batch plans, launches, and the reference's legacy symbols.
+// Public interface and the reference lines each entry point replaces: include/ciri_long_hip.h, include/ssw_legacy.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ciri_long_hip.h"
+#include "../../include/ssw_legacy.h"
+#include "clh_device.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(CLH_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* clh_last_error(void) { return g_err.c_str(); }
+extern "C" const char* clh_version(void) { return "libclh 0.1 (gfx950)"; }
+
+extern "C" int clh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// context: device + stream + a small caching allocator (hipMalloc is milliseconds; the legacy path calls us per alignment)
+// ------------------------------------------------------------------------------------------------------------
+struct clh_ctx {
+    int device;
+    hipStream_t stream;
+    std::mutex mu;
+    std::vector<std::pair<size_t, void*>> cache;
+
+    void* alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 256;
+        std::lock_guard<std::mutex> g(mu);
+        int best = -1;
+        for (size_t i = 0; i < cache.size(); ++i)
+            if (cache[i].first >= bytes && cache[i].first <= bytes * 4 + 4096 && (best < 0 || cache[i].first < cache[best].first)) best = (int)i;
+        if (best >= 0) { void* p = cache[best].second; sizes.push_back({p, cache[best].first}); cache.erase(cache.begin() + best); return p; }
+        size_t cap = 256;
+        while (cap < bytes) cap += cap < (64u << 20) ? cap : (64u << 20);
+        void* p = nullptr;
+        if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+        sizes.push_back({p, cap});
+        return p;
+    }
+    void release(void* p)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < sizes.size(); ++i)
+            if (sizes[i].first == p) { cache.push_back({sizes[i].second, p}); sizes.erase(sizes.begin() + i); return; }
+    }
+    std::vector<std::pair<void*, size_t>> sizes;   // live allocations
+};
+
+extern "C" clh_ctx* clh_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(CLH_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e)); return nullptr; }
+    if (device < 0 || device >= n) { fail(CLH_E_ARG, "device index out of range"); return nullptr; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { fail(CLH_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); return nullptr; }
+    clh_ctx* c = new clh_ctx();
+    c->device = device;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        fail(CLH_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void clh_destroy(clh_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->cache) hipFree(kv.second);
+    for (auto& kv : c->sizes) hipFree(kv.first);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int clh_device_of(const clh_ctx* c) { return c ? c->device : -1; }
+
+// ------------------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------------------
+struct clh_plan {
+    clh_ctx* ctx = nullptr;
+    int n = 0;
+    clh_ssw_opts opts;
+    clh::SswParams params;          // device pointers filled at run time
+    bool quirk = false, do_cigar = false;
+    std::vector<clh::SswTask> tasks;    // launch order
+    struct Seg { int rv, begin, count; };
+    std::vector<Seg> segs;
+    void *d_tasks = nullptr, *d_results = nullptr, *d_colmax = nullptr, *d_cigars = nullptr, *d_cigar_len = nullptr,
+         *d_pool = nullptr, *d_pool_head = nullptr, *d_reads = nullptr, *d_refs = nullptr;
+    size_t colmax_elems = 0, cigar_elems = 0;
+    unsigned long long pool_bytes = 0;
+    hipStream_t last_stream = nullptr;
+    bool ran = false;
+};
+
+extern "C" void clh_plan_destroy(clh_plan* pl)
+{
+    if (!pl) return;
+    clh_ctx* c = pl->ctx;
+    hipSetDevice(c->device);
+    if (pl->ran) hipStreamSynchronize(pl->last_stream);
+    void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
+                    pl->d_reads, pl->d_refs};
+    for (void* b : bufs) c->release(b);
+    delete pl;
+}
+
+static int rv_class_for(int rows)
+{
+    for (int i = 0; i < clh::kNumRvClasses; ++i)
+        if (128 * clh::kRvClasses[i] >= rows) return clh::kRvClasses[i];
+    return -1;
+}
+
+extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
+                                  const int32_t* mask_len, const clh_ssw_opts* o)
+{
+    if (!ctx || n < 0 || !read_off || !ref_off || !o || !o->mat) { fail(CLH_E_ARG, "clh_ssw_plan: null argument"); return nullptr; }
+    if (o->n_mat < 1 || o->n_mat > 5) { fail(CLH_E_UNSUPPORTED, "substitution matrix edge must be 1..5"); return nullptr; }
+    if (o->gap_open < o->gap_extend) {
+        fail(CLH_E_UNSUPPORTED, "gap_open < gap_extend: the reference's 8-bit lazy-F loop is not a plain recurrence there; not implemented");
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail(CLH_E_HIP, "hipSetDevice failed"); return nullptr; }
+    clh_plan* pl = new clh_plan();
+    pl->ctx = ctx; pl->n = n; pl->opts = *o;
+    clh::SswParams& P = pl->params;
+    memset(&P, 0, sizeof(P));
+    int mn = 0, mx = -128;
+    for (int i = 0; i < o->n_mat * o->n_mat; ++i) { P.mat[i] = o->mat[i]; mn = std::min(mn, (int)o->mat[i]); mx = std::max(mx, (int)o->mat[i]); }
+    P.n = o->n_mat; P.gapO = o->gap_open; P.gapE = o->gap_extend; P.bias = -mn; P.max_match = mx; P.score_size = o->score_size;
+    P.flag = o->flag; P.filters = o->filters; P.filterd = o->filterd;
+    pl->opts.mat = nullptr;
+    pl->quirk = o->gap_open <= o->gap_extend;
+    pl->do_cigar = o->want_cigar && (o->flag & 7) != 0;
+    if (!(o->score_size == 0 || o->score_size == 1 || o->score_size == 2)) {
+        fail(CLH_E_ARG, "Please call the function ssw_init before ssw_align.");   // ssw.c:818-821
+        delete pl; return nullptr;
+    }
+
+    std::vector<int> cls(n);
+    pl->tasks.resize(n);
+    size_t colmax = 0, cig = 0;
+    unsigned long long pool = 0;
+    for (int a = 0; a < n; ++a) {
+        const int64_t L = read_off[a + 1] - read_off[a], R = ref_off[a + 1] - ref_off[a];
+        if (L < 1 || R < 0 || L > 0x7fffffff || R > 0x7fffffff) { fail(CLH_E_ARG, "empty read or negative length in batch"); delete pl; return nullptr; }
+        const int rows = (int)((L + 15) / 16) * 16;
+        const int rv = rv_class_for(rows);
+        if (rv < 0) {
+            fail(CLH_E_UNSUPPORTED, "read longer than 4096 bases: row strips are not implemented yet");
+            delete pl; return nullptr;
+        }
+        cls[a] = rv;
+        clh::SswTask& t = pl->tasks[a];
+        t.read_off = read_off[a]; t.ref_off = ref_off[a];
+        t.read_len = (int)L; t.ref_len = (int)R;
+        t.mask_len = mask_len ? mask_len[a] : (L > 30 ? (int)(L / 2) : 15);
+        t.out_index = a;
+        t.colmax_off = (int64_t)colmax;
+        if (o->want_score2) colmax += (size_t)((R + 7) & ~7ll);
+        t.cigar_off = (int32_t)cig; t.cigar_cap = 0; t.dir_off = 0;
+        if (pl->do_cigar) {
+            t.cigar_cap = (int32_t)(2 * L + 2);
+            if (cig + (size_t)t.cigar_cap > 0x7fffffffull) { fail(CLH_E_CAPACITY, "batch too large for 32-bit CIGAR offsets; split it"); delete pl; return nullptr; }
+            cig += (size_t)t.cigar_cap;
+            // traceback workspace estimate: two band doublings of a 64-wide band over the anti-diagonals of an L x L problem
+            pool += (unsigned long long)(2 * L + 64) * 130ull * 2ull;
+        }
+    }
+    pl->colmax_elems = colmax; pl->cigar_elems = cig;
+    if (pl->do_cigar) pl->pool_bytes = std::min<unsigned long long>(std::max<unsigned long long>(pool, 64ull << 20), 16ull << 30);
+
+    // launch order: by row class, heaviest alignments first inside a class
+    std::vector<int> order(n);
+    for (int a = 0; a < n; ++a) order[a] = a;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        if (cls[x] != cls[y]) return cls[x] < cls[y];
+        const int64_t wx = (int64_t)pl->tasks[x].read_len * pl->tasks[x].ref_len, wy = (int64_t)pl->tasks[y].read_len * pl->tasks[y].ref_len;
+        return wx > wy;
+    });
+    std::vector<clh::SswTask> sorted(n);
+    for (int k = 0; k < n; ++k) sorted[k] = pl->tasks[order[k]];
+    for (int k = 0; k < n;) {
+        int e = k;
+        while (e < n && cls[order[e]] == cls[order[k]]) ++e;
+        pl->segs.push_back({cls[order[k]], k, e - k});
+        k = e;
+    }
+    pl->tasks.swap(sorted);
+
+    pl->d_tasks = ctx->alloc(sizeof(clh::SswTask) * (size_t)std::max(n, 1));
+    pl->d_results = ctx->alloc(sizeof(clh::SswResult) * (size_t)std::max(n, 1));
+    pl->d_cigar_len = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
+    if (o->want_score2) pl->d_colmax = ctx->alloc(sizeof(uint16_t) * std::max<size_t>(colmax, 1));
+    if (pl->do_cigar) {
+        pl->d_cigars = ctx->alloc(sizeof(uint32_t) * std::max<size_t>(cig, 1));
+        pl->d_pool = ctx->alloc((size_t)pl->pool_bytes);
+        pl->d_pool_head = ctx->alloc(256);
+    }
+    if (!pl->d_tasks || !pl->d_results || !pl->d_cigar_len || (o->want_score2 && !pl->d_colmax) ||
+        (pl->do_cigar && (!pl->d_cigars || !pl->d_pool || !pl->d_pool_head))) {
+        fail(CLH_E_HIP, "out of device memory while building the plan");
+        clh_plan_destroy(pl); return nullptr;
+    }
+    if (n > 0 && hipMemcpy(pl->d_tasks, pl->tasks.data(), sizeof(clh::SswTask) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) {
+        fail(CLH_E_HIP, "task upload failed");
+        clh_plan_destroy(pl); return nullptr;
+    }
+    return pl;
+}
+
+extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs, void* stream_)
+{
+    if (!pl || !d_reads || !d_refs) return fail(CLH_E_ARG, "clh_ssw_run: null argument");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : pl->ctx->stream;
+    clh::SswParams P = pl->params;
+    P.reads = (const int8_t*)d_reads; P.refs = (const int8_t*)d_refs;
+    P.results = (clh::SswResult*)pl->d_results;
+    P.colmax = (uint16_t*)pl->d_colmax;
+    P.cigars = (uint32_t*)pl->d_cigars; P.cigar_len = (int32_t*)pl->d_cigar_len; P.dirs = nullptr;
+    for (const auto& s : pl->segs) {
+        P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
+        HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, st));
+    }
+    if (pl->do_cigar && pl->n > 0) {
+        HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 8, st));
+        for (const auto& s : pl->segs) {
+            P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
+            HIPCHK(clh::launch_traceback_pool(s.rv, P, s.count, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+        }
+    }
+    pl->last_stream = st;
+    pl->ran = true;
+    return 0;
+}
+
+extern "C" const void* clh_ssw_results_dev(const clh_plan* pl) { return pl ? pl->d_results : nullptr; }
+
+extern "C" int clh_ssw_fetch(clh_plan* pl, clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used)
+{
+    if (!pl || !out) return fail(CLH_E_ARG, "clh_ssw_fetch: null argument");
+    if (!pl->ran) return fail(CLH_E_ARG, "clh_ssw_fetch before clh_ssw_run");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    const int n = pl->n;
+    std::vector<clh::SswResult> res((size_t)std::max(n, 1));
+    std::vector<int32_t> clen((size_t)std::max(n, 1), 0);
+    if (n > 0) HIPCHK(hipMemcpy(res.data(), pl->d_results, sizeof(clh::SswResult) * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> cig;
+    if (pl->do_cigar && n > 0) {
+        HIPCHK(hipMemcpy(clen.data(), pl->d_cigar_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+        if (cigar_buf) {
+            cig.resize(pl->cigar_elems);
+            HIPCHK(hipMemcpy(cig.data(), pl->d_cigars, sizeof(uint32_t) * pl->cigar_elems, hipMemcpyDeviceToHost));
+        }
+    }
+    std::vector<int32_t> share_off((size_t)std::max(n, 1), 0);
+    for (const auto& t : pl->tasks) share_off[t.out_index] = t.cigar_off;
+    int64_t used = 0;
+    int rc = 0;
+    for (int a = 0; a < n; ++a) {
+        const clh::SswResult& r = res[a];
+        clh_align_t& o = out[a];
+        o.score1 = (uint16_t)r.score1; o.score2 = (uint16_t)r.score2;
+        o.ref_begin1 = r.ref_begin1; o.ref_end1 = r.ref_end1; o.read_begin1 = r.read_begin1; o.read_end1 = r.read_end1;
+        o.ref_end2 = r.ref_end2;
+        o.status = 0;
+        if (r.status & clh::CLH_STATUS_WORD) o.status |= CLH_ST_WORD;
+        if (r.status & clh::CLH_STATUS_OVERFLOW8) o.status |= CLH_ST_NULL;
+        if (r.status & clh::CLH_STATUS_TRACE_ERR) o.status |= CLH_ST_TRACE_ERR;
+        if (r.status & clh::CLH_STATUS_NO_CIGAR) o.status |= CLH_ST_NO_CIGAR;
+        if (r.status & clh::CLH_STATUS_CIGAR_TRUNC) o.status |= CLH_ST_CIGAR_TRUNC;
+        o.cigar_off = -1; o.cigar_len = 0;
+        if (!pl->do_cigar) { o.status |= CLH_ST_NO_CIGAR; continue; }
+        const int len = clen[a];
+        if (len > 0) {
+            o.cigar_len = len;
+            if (cigar_buf) {
+                if (used + len > cigar_cap) { rc = CLH_E_CAPACITY; o.cigar_len = 0; continue; }
+                memcpy(cigar_buf + used, cig.data() + share_off[a], sizeof(uint32_t) * (size_t)len);
+                o.cigar_off = (int32_t)used;
+            }
+            used += len;
+        }
+    }
+    if (cigar_used) *cigar_used = used;
+    if (rc) return fail(rc, "cigar buffer too small");
+    return 0;
+}
+
+extern "C" int clh_ssw_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, const int8_t* refs,
+                             const int64_t* ref_off, const int32_t* mask_len, const clh_ssw_opts* opts, clh_align_t* out,
+                             uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used)
+{
+    if (!ctx || !reads || !refs || !read_off || !ref_off) return fail(CLH_E_ARG, "clh_ssw_batch: null argument");
+    clh_plan* pl = clh_ssw_plan(ctx, n, read_off, ref_off, mask_len, opts);
+    if (!pl) return g_err.empty() ? CLH_E_ARG : (g_err.find("not implemented") != std::string::npos ? CLH_E_UNSUPPORTED : CLH_E_ARG);
+    int rc = 0;
+    const size_t rb = (size_t)read_off[n], fb = (size_t)ref_off[n];
+    pl->d_reads = ctx->alloc(rb + 64);
+    pl->d_refs = ctx->alloc(fb + 64);
+    if (!pl->d_reads || !pl->d_refs) { rc = fail(CLH_E_HIP, "out of device memory for the batch"); }
+    if (!rc && hipMemcpyAsync(pl->d_reads, reads, rb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D reads failed");
+    if (!rc && hipMemcpyAsync(pl->d_refs, refs, fb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D refs failed");
+    if (!rc) rc = clh_ssw_run(pl, pl->d_reads, pl->d_refs, nullptr);
+    if (!rc) rc = clh_ssw_fetch(pl, out, cigar_buf, cigar_cap, cigar_used);
+    clh_plan_destroy(pl);
+    return rc;
+}
+
+extern "C" void clh_encode_dna(const char* seq, int64_t len, int8_t* out)
+{
+    static int8_t lut[256];
+    static bool init = false;
+    if (!init) {
+        memset(lut, 4, sizeof(lut));
+        lut['A'] = lut['a'] = 0; lut['C'] = lut['c'] = 1; lut['G'] = lut['g'] = 2; lut['T'] = lut['t'] = 3; lut['N'] = lut['n'] = 4;
+        init = true;
+    }
+    for (int64_t i = 0; i < len; ++i) out[i] = lut[(unsigned char)seq[i]];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the reference's six symbols (include/ssw_legacy.h)
+// ------------------------------------------------------------------------------------------------------------
+struct _profile {
+    const int8_t* read;
+    const int8_t* mat;
+    int32_t readLen;
+    int32_t n;
+    int8_t score_size;
+};
+
+static clh_ctx* legacy_ctx()
+{
+    static std::mutex mu;
+    static clh_ctx* ctx = nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (!ctx) {
+        const char* d = getenv("CIRI_LONG_DEVICE");
+        ctx = clh_create(d ? atoi(d) : 0);
+        if (!ctx) fprintf(stderr, "libclh: no usable GPU (%s); there is no CPU fallback.\n", clh_last_error());
+    }
+    return ctx;
+}
+
+extern "C" s_profile* ssw_init(const int8_t* read, const int32_t readLen, const int8_t* mat, const int32_t n, const int8_t score_size)
+{
+    s_profile* p = (s_profile*)calloc(1, sizeof(struct _profile));
+    p->read = read; p->mat = mat; p->readLen = readLen; p->n = n; p->score_size = score_size;
+    return p;
+}
+
+extern "C" void init_destroy(s_profile* p) { free(p); }
+
+extern "C" s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, const uint8_t weight_gapO,
+                              const uint8_t weight_gapE, const uint8_t flag, const uint16_t filters, const int32_t filterd,
+                              const int32_t maskLen)
+{
+    if (maskLen < 15)
+        fprintf(stderr, "When maskLen < 15, the function ssw_align doesn't return 2nd best alignment information.\n");
+    if (!(prof->score_size == 0 || prof->score_size == 1 || prof->score_size == 2)) {
+        fprintf(stderr, "Please call the function ssw_init before ssw_align.\n");
+        return NULL;
+    }
+    clh_ctx* ctx = legacy_ctx();
+    if (!ctx) return NULL;
+    clh_ssw_opts o;
+    memset(&o, 0, sizeof(o));
+    o.mat = prof->mat; o.n_mat = prof->n; o.gap_open = weight_gapO; o.gap_extend = weight_gapE; o.flag = flag;
+    o.score_size = prof->score_size; o.filters = filters; o.filterd = filterd; o.want_score2 = 1; o.want_cigar = 1;
+    const int64_t roff[2] = {0, prof->readLen}, foff[2] = {0, refLen};
+    const int32_t ml = maskLen;
+    clh_align_t a;
+    std::vector<uint32_t> cig((size_t)2 * (size_t)std::max(prof->readLen, 1) + 8);
+    int64_t used = 0;
+    int rc = clh_ssw_batch(ctx, 1, prof->read, roff, ref, foff, &ml, &o, &a, cig.data(), (int64_t)cig.size(), &used);
+    if (rc != 0) { fprintf(stderr, "libclh: ssw_align failed: %s\n", clh_last_error()); return NULL; }
+    if (a.status & CLH_ST_NULL) {
+        fprintf(stderr, "Please set 2 to the score_size parameter of the function ssw_init, otherwise the alignment results will be incorrect.\n");
+        return NULL;
+    }
+    if (a.status & (CLH_ST_TRACE_ERR | CLH_ST_CIGAR_TRUNC)) { fprintf(stderr, "Trace back error.\n"); return NULL; }
+    s_align* r = (s_align*)calloc(1, sizeof(s_align));
+    r->score1 = a.score1; r->score2 = a.score2; r->ref_end1 = a.ref_end1; r->read_end1 = a.read_end1; r->ref_end2 = a.ref_end2;
+    r->ref_begin1 = a.ref_begin1; r->read_begin1 = a.read_begin1;
+    r->cigar = 0; r->cigarLen = 0;
+    if (a.cigar_len > 0 && a.cigar_off >= 0) {
+        r->cigar = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)a.cigar_len);
+        memcpy(r->cigar, cig.data() + a.cigar_off, sizeof(uint32_t) * (size_t)a.cigar_len);
+        r->cigarLen = a.cigar_len;
+    }
+    return r;
+}
+
+extern "C" void align_destroy(s_align* a)
+{
+    if (!a) return;
+    free(a->cigar);
+    free(a);
+}
+
+extern "C" char cigar_int_to_op(uint32_t cigar_int)
+{
+    static const char map[] = {'M', 'I', 'D', 'N', 'S', 'H', 'P', '=', 'X'};
+    const uint32_t c = cigar_int & 0xfU;
+    return c >= sizeof(map) ? 'M' : map[c];
+}
+
+extern "C" uint32_t cigar_int_to_len(uint32_t cigar_int) { return cigar_int >> 4; }

@@ -1,0 +1,54 @@
+// clh_device.h -- structures shared by the HIP kernels and the host side of libclh (internal; the public
+// C ABI is include/ciri_long_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clh {
+
+enum {
+    CLH_STATUS_WORD = 1,        // scores come from the 16-bit regime (ssw.c:806-809)
+    CLH_STATUS_OVERFLOW8 = 2,   // score_size 0 and the 8-bit pass overflowed: reference returns NULL (ssw.c:810-813)
+    CLH_STATUS_TRACE_ERR = 4,   // traceback left the band (reference: "Trace back error", ssw.c:674-682)
+    CLH_STATUS_NO_CIGAR = 8,    // CIGAR not requested / filtered by flag (ssw.c:850)
+    CLH_STATUS_CIGAR_TRUNC = 16 // CIGAR buffer share exhausted
+};
+
+// One alignment = one workgroup of one wavefront.  Offsets are into the packed batch arrays.
+struct SswTask {
+    int64_t read_off;     // into reads (int8 codes)
+    int64_t ref_off;      // into refs (int8 codes)
+    int64_t colmax_off;   // into the column-maximum workspace (u16), one slot per reference base
+    int64_t dir_off;      // into the traceback direction workspace (bytes)
+    int32_t read_len;
+    int32_t ref_len;
+    int32_t mask_len;
+    int32_t out_index;    // row of the result / cigar tables this task fills
+    int32_t cigar_off;    // first u32 of this task's share of the CIGAR buffer
+    int32_t cigar_cap;    // u32 slots in that share
+};
+
+struct SswResult {        // 32 bytes; the s_align fields of ssw.h:42-52 minus the pointer
+    int32_t score1, score2, ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, status;
+};
+
+struct SswParams {
+    const int8_t* reads;
+    const int8_t* refs;
+    const SswTask* tasks;
+    SswResult* results;
+    uint16_t* colmax;     // nullptr: skip the second-best scan (score2 = 0)
+    uint32_t* cigars;     // BAM-style u32 (len<<4|op), ssw.h:131-170
+    int32_t* cigar_len;   // per out_index
+    uint8_t* dirs;        // traceback workspace
+    int8_t mat[32];       // n*n substitution matrix (n <= 5)
+    int32_t n, gapO, gapE, bias, max_match, score_size, flag, filters, filterd;
+};
+
+extern const int kRvClasses[];
+extern const int kNumRvClasses;
+hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStream_t stream);
+hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t* pool_base, unsigned long long* pool_head,
+                                 unsigned long long pool_size, hipStream_t stream);
+
+}  // namespace clh

@@ -1,0 +1,225 @@
+// ssw_traceback.hip -- K1b: banded Smith-Waterman traceback (CIGAR), one alignment per wavefront (gfx950).
+//
+// Replaces banded_sw (reference: libs/striped_smith_waterman/ssw.c:548-735) bit for bit on every input whose
+// traceback stays inside the band (the reference reads unrelated memory otherwise).  The reference sweeps the
+// band row by row with a scalar loop; here the cells of one anti-diagonal (row + column = a) are independent,
+// so the 64 lanes take consecutive rows of the anti-diagonal and the H/E/F values of the two previous
+// anti-diagonals sit in an LDS window indexed by row modulo the window size.
+//
+// Reference behaviour that is kept on purpose (oracle/ssw_oracle.c:banded_traceback states the same rules):
+//   * out-of-band neighbours read as H = E = F = 0 through the sentinel slots of ssw.c:596;
+//   * the sentinel at `edge` overwrites the live entry of the last reference column when the band is clipped by
+//     the reference end in a row i <= band+1, so that column's upper neighbour reads as 0 there;
+//   * row 0 opens vertical gaps from -gapO / -gapE (ssw.c:607-608); E and F are not clamped, only the values
+//     that enter H are (ssw.c:618-619);
+//   * tie rules of the direction codes (ssw.c:611,616,626-627) and the band doubling loop whose running maximum
+//     is not reset (ssw.c:560,631-632).
+// One direction byte per cell: bits 0-2 = H code (1..5), bit 3 = E opened (code 3), bit 4 = F opened (code 5),
+// stored anti-diagonal-major so that a wave's stores are contiguous.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "clh_device.h"
+
+namespace clh {
+
+// DP state lives in dynamic LDS as int16 (scores <= 32767; E and F never drop below -gapO-gapE): 7 arrays of `ws`
+// rows, ws = row capacity of the launch's read-length class + 2.  While the band is narrow the arrays are a ring
+// indexed by row & (wsp-1); once the band is wider than the ring they are indexed by the row itself.
+
+struct TbPool {
+    uint8_t* base;
+    unsigned long long* head;   // bump pointer (bytes)
+    unsigned long long size;
+};
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+
+// first row of anti-diagonal a inside the band: ceil((a - w) / 2), not clamped
+__device__ __forceinline__ int ad_first_row(int a, int w) { int t = a - w; return t >= 0 ? (t + 1) >> 1 : -((-t) >> 1); }
+
+__global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp)
+{
+    extern __shared__ __attribute__((aligned(16))) short tb_lds[];
+    short* const H0 = tb_lds;                 // H[3][ws]
+    short* const E0 = tb_lds + 3 * ws;        // E[2][ws]
+    short* const F0 = tb_lds + 5 * ws;        // F[2][ws]
+    __shared__ uint8_t stage[64 * 66];
+    __shared__ int smat[32];
+    const int lane = threadIdx.x & 63;
+    if (lane < 25) smat[lane] = p.mat[lane];
+    __syncthreads();
+    const SswTask task = p.tasks[blockIdx.x];
+    SswResult res = p.results[task.out_index];
+    uint32_t* cig = p.cigars + task.cigar_off;
+    int* cig_len = p.cigar_len + task.out_index;
+
+    const bool no_cigar = (res.status & CLH_STATUS_OVERFLOW8) || (7 & p.flag) == 0 ||
+                          ((2 & p.flag) != 0 && res.score1 < p.filters) ||
+                          ((4 & p.flag) != 0 && (res.ref_end1 - res.ref_begin1 > p.filterd || res.read_end1 - res.read_begin1 > p.filterd));
+    if (no_cigar) {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_NO_CIGAR; }
+        return;
+    }
+    if (res.ref_begin1 < 0) {   // score 0: the reference's 1x1 problem never enters its traceback loop -> 1M
+        if (lane == 0) { cig[0] = (1u << 4); *cig_len = 1; }
+        return;
+    }
+    const int8_t* ref = p.refs + task.ref_off + res.ref_begin1;
+    const int8_t* read = p.reads + task.read_off + res.read_begin1;
+    const int refLen = res.ref_end1 - res.ref_begin1 + 1, readLen = res.read_end1 - res.read_begin1 + 1;
+    const int score = res.score1, gO = p.gapO, gE = p.gapE, n = p.n;
+    int w = refLen > readLen ? refLen - readLen : readLen - refLen;
+    w += 1;
+    const int nAD = readLen + refLen - 1;
+    int maxv = 0;
+    uint8_t* dir = nullptr;
+    int status = 0;
+
+    for (;;) {
+        const bool ring = w + 3 <= wsp;   // the active rows of an anti-diagonal span <= w+1 rows
+        if (!ring && readLen + 1 > ws) { status = CLH_STATUS_TRACE_ERR; break; }
+        const int imask = ring ? wsp - 1 : -1;
+        unsigned long long need = ((unsigned long long)nAD * (unsigned long long)(w + 1) + 63ull) & ~63ull;
+        unsigned long long at = 0;
+        if (lane == 0) at = atomicAdd(pool.head, need);
+        at = __shfl(at, 0);
+        if (at + need > pool.size) { status = CLH_STATUS_CIGAR_TRUNC; break; }
+        dir = pool.base + at;
+        int itmax = 0;
+        for (int a = 0; a < nAD; ++a) {
+            const int cur = a % 3, p1 = (a + 2) % 3, p2 = (a + 1) % 3, e0 = a & 1, e1 = e0 ^ 1;
+            int ilo = ad_first_row(a, w);
+            const int band_lo = ilo;
+            if (ilo < 0) ilo = 0;
+            if (ilo < a - (refLen - 1)) ilo = a - (refLen - 1);
+            int ihi = (a + w) >> 1;
+            if (ihi > readLen - 1) ihi = readLen - 1;
+            if (ihi > a) ihi = a;
+            for (int i0 = ilo; i0 <= ihi; i0 += 64) {
+                const int i = i0 + lane;
+                if (i <= ihi) {
+                    const int j = a - i;
+                    const int m = i & imask, mu = (i - 1) & imask;
+                    int hu = 0, eu = 0, hl = 0, fl = 0, hd = 0;
+                    if (i >= 1) {
+                        const bool up_in = j <= i - 1 + w;
+                        const bool clobber = (i - 1 <= w) && (refLen - 1 < i + w) && (j == refLen - 1);
+                        if (up_in && !clobber) { hu = H0[p1 * ws + mu]; eu = E0[e1 * ws + mu]; }
+                        if (j >= 1) hd = H0[p2 * ws + mu];
+                    }
+                    if (j >= 1 && j - 1 >= i - w) { hl = H0[p1 * ws + m]; fl = F0[e1 * ws + m]; }
+                    int t1 = i == 0 ? -gO : hu - gO, t2 = i == 0 ? -gE : eu - gE;
+                    const int e = t1 > t2 ? t1 : t2;
+                    const int de = t1 > t2 ? 3 : 2;
+                    t1 = hl - gO; t2 = fl - gE;
+                    const int f = t1 > t2 ? t1 : t2;
+                    const int df = t1 > t2 ? 5 : 4;
+                    const int e1v = e > 0 ? e : 0, f1v = f > 0 ? f : 0;
+                    t1 = e1v > f1v ? e1v : f1v;
+                    t2 = hd + smat[(int)ref[j] * n + (int)read[i]];
+                    const int h = t1 > t2 ? t1 : t2;
+                    const int dh = t1 <= t2 ? 1 : (e1v > f1v ? de : df);
+                    itmax = h > itmax ? h : itmax;
+                    H0[cur * ws + m] = (short)h; E0[e0 * ws + m] = (short)e; F0[e0 * ws + m] = (short)f;
+                    dir[(size_t)a * (w + 1) + (i - band_lo)] = (uint8_t)(dh | (de == 3 ? 8 : 0) | (df == 5 ? 16 : 0));
+                }
+            }
+            __syncthreads();
+        }
+        itmax = wave_max(itmax);
+        maxv = itmax > maxv ? itmax : maxv;
+        w *= 2;
+        if (!(maxv < score && w < 2 * readLen)) break;
+    }
+    if (status) {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | status; }
+        return;
+    }
+    w /= 2;
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- walk back from the bottom-right corner (ssw.c:636-696); direction bytes staged 64 anti-diagonals at a time
+    int i = readLen - 1, j = refLen - 1, state = 2, run = 0, nops = 0, fail = 0;
+    int op = 0, prev_op = 0;             // 0 M, 1 I, 2 D
+    const int stride = w + 1;
+    const int srow = stride < 66 ? stride : 0;      // staging only when an anti-diagonal fits 66 bytes
+    int staged_lo = 1 << 30, staged_hi = -1;
+    while (i > 0) {
+        const int a = i + j;
+        if (j < 0 || j > i + w || j < i - w || j >= refLen) { fail = 1; break; }
+        int code;
+        const int slot = i - ad_first_row(a, w);
+        if (srow) {
+            if (a < staged_lo || a > staged_hi) {
+                staged_hi = a; staged_lo = a - 63 > 0 ? a - 63 : 0;
+                const int nbytes = (staged_hi - staged_lo + 1) * stride;
+                __syncthreads();
+                for (int b = lane; b < nbytes; b += 64) stage[b] = dir[(size_t)staged_lo * stride + b];
+                __syncthreads();
+            }
+            code = stage[(a - staged_lo) * stride + slot];
+        } else {
+            code = dir[(size_t)a * stride + slot];
+        }
+        const int c = state == 2 ? (code & 7) : (state == 0 ? ((code & 8) ? 3 : 2) : ((code & 16) ? 5 : 4));
+        switch (c) {
+            case 1: --i; --j; state = 2; op = 0; break;
+            case 2: --i; state = 0; op = 1; break;
+            case 3: --i; state = 2; op = 1; break;
+            case 4: --j; state = 1; op = 2; break;
+            case 5: --j; state = 2; op = 2; break;
+            default: fail = 1; break;
+        }
+        if (fail) break;
+        if (op == prev_op) ++run;
+        else {
+            if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)run << 4) | (uint32_t)prev_op;
+            ++nops; prev_op = op; run = 1;
+        }
+    }
+    if (fail) {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_TRACE_ERR; }
+        return;
+    }
+    if (op == 0) {                                   // ssw.c:697-714
+        if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)(run + 1) << 4);
+        ++nops;
+    } else {
+        if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)run << 4) | (uint32_t)op;
+        ++nops;
+        if (nops < task.cigar_cap && lane == 0) cig[nops] = (1u << 4);
+        ++nops;
+    }
+    if (nops > task.cigar_cap) {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
+        return;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = lane; k < nops / 2; k += 64) {      // reverse in place, ssw.c:716-725
+        const uint32_t x = cig[k], y = cig[nops - 1 - k];
+        cig[k] = y; cig[nops - 1 - k] = x;
+    }
+    if (lane == 0) *cig_len = nops;
+}
+
+// rv = read-length class of every task in the launch (rows <= 128*rv)
+hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t* pool_base, unsigned long long* pool_head,
+                                 unsigned long long pool_size, hipStream_t stream)
+{
+    TbPool pool; pool.base = pool_base; pool.head = pool_head; pool.size = pool_size;
+    const int ws = 128 * rv + 2;
+    int wsp = 1;
+    while (wsp * 2 <= ws) wsp *= 2;
+    const size_t lds = (size_t)7 * ws * sizeof(short);
+    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(ntasks), dim3(64), lds, stream, p, pool, ws, wsp);
+    return hipGetLastError();
+}
+
+}  // namespace clh

@@ -1,0 +1,385 @@
+// ssw_wavefront.hip -- K1: Smith-Waterman scores and coordinates, one alignment per wavefront (gfx950).
+//
+// Replaces, bit for bit, sw_sse2_byte / sw_sse2_word and the forward+reverse orchestration of ssw_align
+// (reference: libs/striped_smith_waterman/ssw.c:123-345, 371-546, 779-849).  The recurrence actually
+// implemented is the row-major form proven equal to the stripe mechanics in oracle/rowmajor_spec.c, laid out
+// the way tools/wavefront_model.py describes:
+//
+//   * a 64-lane wave is 128 virtual lanes: the low and high 16-bit halves of every VGPR are two independent
+//     DP chains, so each v_pk_* instruction updates two cells;
+//   * virtual lane v owns RV consecutive rows and processes column t-v at step t (anti-diagonal wavefront);
+//     the bottom-row H, the vertical-gap carry F and the running column maximum travel to virtual lane v+1
+//     one step later: hi half <- own lo half, lo half <- previous lane's hi half (one DPP wave_shr + one
+//     v_alignbit per value);
+//   * the query profile (substitution scores of the lane's own rows against each of 6 base codes) lives in LDS
+//     as lane-private rows, read with ds_read_b128; the reference window streams through one byte load per lane
+//     per 64 steps and enters lane 0 through v_readlane;
+//   * H/E of the previous column stay in VGPRs for the whole pass: nothing per-cell ever touches HBM.
+//
+// Arithmetic is the 16-bit arithmetic of the reference's word pass (signed saturating add, unsigned saturating
+// subtract); the 8-bit pass computes the same numbers until it overflows, so it only adds the overflow test.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "clh_device.h"
+
+namespace clh {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) {   // v_pk_add_i16 clamp
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {    // v_pk_max_i16
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_subus(uint32_t a, uint32_t b) {  // v_pk_sub_u16 clamp
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
+// value of the previous lane (lane 0 receives `lane0`)
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v, uint32_t lane0) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+// hand a packed (lo,hi) value to the next virtual lane: new lo = previous lane's hi, new hi = own lo
+__device__ __forceinline__ uint32_t hand_down(uint32_t v, uint32_t lane0_lo) {
+    uint32_t x = from_prev_lane(v, lane0_lo << 16);
+    return __builtin_amdgcn_alignbit(v, x, 16);
+}
+
+static constexpr int NEG16 = -32768;
+static constexpr int CODE_NULL = 5;   // pipeline fill/drain: scores 0 against every row
+
+struct PassOut {
+    int max;        // best score (255 when the 8-bit pass overflowed)
+    int col;        // first column (processing order) that reached it, -1 if max == 0
+    int row;        // smallest row with that score in that column, clamped to readLen-1
+    int overflow;   // 8-bit pass only
+    int term_col;   // column at which the terminate score was met, -1 otherwise
+};
+
+struct PassIn {
+    const int8_t* read;   // first row's base
+    int rstep;            // +1 / -1
+    int L;                // rows of the read
+    const int8_t* ref;    // first column's base
+    int cstep;            // +1 / -1
+    int ncols;
+    int terminate;        // column maximum that ends the pass (ssw.c:296,499); > 32767 = never
+    uint16_t* colmax;     // per-column maxima in processing order, or nullptr
+};
+
+// One pass.  RV = rows per virtual lane (capacity 128*RV rows).  WORD selects the row padding (8 vs 16) and
+// QUIRK the truncated vertical gaps of the 16-bit pass when gapO <= gapE (rowmajor_spec.c).
+template <int RV, bool WORD, bool QUIRK>
+__device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, const int* __restrict__ lds_mat,
+                            int gapO, int gapE, int bias)
+{
+    constexpr int CH = (RV + 3) / 4;             // 16-byte chunks of profile per lane and base
+    constexpr int BASE_STRIDE = CH * 1024;       // bytes between two bases' profiles
+    const int lane = threadIdx.x & 63;
+    const int W = WORD ? 8 : 16;
+    const int S = (in.L + W - 1) / W;
+    const int rows = S * W;
+    const int off = 128 * RV - rows;             // leading dummy slots
+    const bool quirk = QUIRK && WORD;
+
+    // ---- query profile, lane-private rows in LDS: prof[base][chunk][lane][4] -------------------------------
+    uint32_t cut[QUIRK ? RV : 1];
+    const int Lm1 = in.L - 1;
+#pragma unroll
+    for (int k = 0; k < RV; ++k) {
+        const int rlo = lane * 2 * RV + k - off, rhi = rlo + RV;
+        // clamped, unconditional loads; dummy (row < 0) and wildcard (row >= L) rows are selected afterwards
+        const int clo = rlo < 0 ? 0 : (rlo > Lm1 ? Lm1 : rlo), chi = rhi < 0 ? 0 : (rhi > Lm1 ? Lm1 : rhi);
+        const int qlo = (int)in.read[(int64_t)clo * in.rstep] & 7, qhi = (int)in.read[(int64_t)chi * in.rstep] & 7;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int mlo = lds_mat[b * 8 + qlo], mhi = lds_mat[b * 8 + qhi];
+            const int slo = rlo < 0 ? NEG16 : (rlo > Lm1 ? 0 : mlo);
+            const int shi = rhi < 0 ? NEG16 : (rhi > Lm1 ? 0 : mhi);
+            lds_prof[((b * CH + (k >> 2)) * 64 + lane) * 4 + (k & 3)] = (uint32_t)(slo & 0xffff) | ((uint32_t)shi << 16);
+        }
+        if (QUIRK) {
+            uint32_t m = 0xffffffffu;
+            if (quirk && rlo > 0 && rlo % S == 0) m &= 0xffff0000u;
+            if (quirk && rhi > 0 && rhi % S == 0) m &= 0x0000ffffu;
+            cut[k] = m;
+        }
+    }
+
+    // ---- state ------------------------------------------------------------------------------------------
+    uint32_t Hp[RV], E[RV], SH[RV];
+#pragma unroll
+    for (int k = 0; k < RV; ++k) { Hp[k] = 0; E[k] = 0; SH[k] = 0; }
+    uint32_t outH = 0, outC = 0, outM = 0, diagIn = 0, best = 0, RB = dup16(CODE_NULL);
+    int colLo = -1, colHi = -1;
+    uint32_t flags = 0;                           // bit0 overflow, bit1 exceeded (any lane)
+    const uint32_t gO2 = dup16(gapO), gE2 = dup16(gapE);
+    const uint32_t ovf2 = dup16(254 - bias);      // cm > 254-bias  <=>  cm + bias >= 255
+    const uint32_t term2 = dup16(in.terminate > 32767 ? 32767 : in.terminate);
+    const int ncols = in.ncols;
+
+    auto load_chunk = [&](int t0) -> int {
+        int j = t0 + lane;
+        return j < ncols ? (int)in.ref[(int64_t)j * in.cstep] : CODE_NULL;
+    };
+    int chunk = load_chunk(0), nxt = load_chunk(64);
+    int term_col = -1;
+    const int nsteps = ncols > 0 ? ncols + 127 : 0;
+    const char* prof_bytes = (const char*)lds_prof;
+
+    for (int t = 0; t < nsteps; ++t) {
+        if ((t & 63) == 0 && t > 0) { chunk = nxt; nxt = load_chunk(t + 64); }
+        const int sb = __builtin_amdgcn_readlane(chunk, t & 63);
+        RB = hand_down(RB, (uint32_t)sb);
+        const uint32_t aLo = (RB & 0xffffu) * BASE_STRIDE + lane * 16;
+        const uint32_t aHi = (RB >> 16) * BASE_STRIDE + lane * 16;
+
+        const uint32_t inH = hand_down(outH, 0), inC = hand_down(outC, 0), inM = hand_down(outM, 0);
+        uint32_t F = inC, diag = diagIn, cm = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const uint4 pl = *(const uint4*)(prof_bytes + aLo + c * 1024);
+            const uint4 ph = *(const uint4*)(prof_bytes + aHi + c * 1024);
+            const uint32_t plv[4] = {pl.x, pl.y, pl.z, pl.w}, phv[4] = {ph.x, ph.y, ph.z, ph.w};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = c * 4 + kk;
+                if (k < RV) {
+                    const uint32_t s = (plv[kk] & 0xffffu) | (phv[kk] & 0xffff0000u);
+                    const uint32_t tt = pk_adds(diag, s);
+                    uint32_t h;
+                    if (QUIRK) {
+                        const uint32_t Fm = F & cut[k];
+                        h = pk_max(pk_max(tt, E[k]), Fm);
+                        diag = Hp[k];
+                        Hp[k] = pk_max(h, F);
+                        const uint32_t hg = pk_subus(h, gO2);
+                        E[k] = pk_max(pk_subus(E[k], gE2), hg);
+                        F = pk_max(pk_subus(Fm, gE2), hg);
+                    } else {
+                        h = pk_max(pk_max(tt, E[k]), F);
+                        diag = Hp[k];
+                        Hp[k] = h;
+                        const uint32_t hg = pk_subus(h, gO2);
+                        E[k] = pk_max(pk_subus(E[k], gE2), hg);
+                        F = pk_max(pk_subus(F, gE2), hg);
+                    }
+                    cm = pk_max(cm, h);
+                }
+            }
+        }
+        diagIn = inH;
+        outH = Hp[RV - 1];
+        outC = F;
+        outM = pk_max(inM, cm);
+
+        // ---- per-lane best (first column wins, strict >), snapshot of that column -------------------------
+        const int jLo = t - 2 * lane, jHi = jLo - 1;
+        const uint32_t vm = ((uint32_t)jLo < (uint32_t)ncols ? 0x0000ffffu : 0u) | ((uint32_t)jHi < (uint32_t)ncols ? 0xffff0000u : 0u);
+        const uint32_t cmv = cm & vm;
+        const uint32_t nb = pk_max(best, cmv);
+        const uint32_t ch = nb ^ best;
+        best = nb;
+        if (!WORD) flags |= (pk_subus(cmv, ovf2) != 0u) ? 1u : 0u;
+        flags |= (pk_subus(cmv, term2) != 0u) ? 2u : 0u;
+        if (__builtin_amdgcn_ballot_w64(ch != 0u)) {
+            const uint32_t m = ((ch & 0xffffu) ? 0x0000ffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
+            colLo = (ch & 0xffffu) ? jLo : colLo;
+            colHi = (ch >> 16) ? jHi : colHi;
+#pragma unroll
+            for (int k = 0; k < RV; ++k) SH[k] = (Hp[k] & m) | (SH[k] & ~m);
+        }
+        if (!WORD) {
+            if (__builtin_amdgcn_ballot_w64((flags & 1u) != 0u)) {
+                PassOut o; o.max = 255; o.col = -1; o.row = 0; o.overflow = 1; o.term_col = -1;
+                return o;
+            }
+        }
+        // ---- the last virtual lane has the finished column maximum of column t-127 -------------------------
+        const int jl = t - 127;
+        if (jl >= 0) {
+            const int cmLast = (int)((uint32_t)__builtin_amdgcn_readlane((int)outM, 63) >> 16);
+            if (in.colmax && lane == 63) in.colmax[jl] = (uint16_t)cmLast;
+            if (cmLast == in.terminate) { term_col = jl; break; }
+        }
+    }
+
+    // ---- wave reduction: (score desc, column asc, virtual lane asc) ------------------------------------------
+    const int exceeded = __builtin_amdgcn_ballot_w64((flags & 2u) != 0u) != 0;
+    PassOut o;
+    o.overflow = 0;
+    o.term_col = term_col;
+    if (term_col >= 0 && exceeded) {   // caller re-runs on columns [0, term_col] without early stop
+        o.max = -1; o.col = -1; o.row = 0;
+        return o;
+    }
+    int bLo = (int)(best & 0xffffu), bHi = (int)(best >> 16);
+    int val = bLo, col = colLo, vl = 2 * lane;
+    if (bHi > bLo || (bHi == bLo && bHi > 0 && colHi < colLo)) { val = bHi; col = colHi; vl = 2 * lane + 1; }
+    if (val == 0) col = 0x7fffffff;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v2 = __shfl_xor(val, d), c2 = __shfl_xor(col, d), l2 = __shfl_xor(vl, d);
+        const bool take = v2 > val || (v2 == val && (c2 < col || (c2 == col && l2 < vl)));
+        val = take ? v2 : val; col = take ? c2 : col; vl = take ? l2 : vl;
+    }
+    o.max = val;
+    if (val == 0) { o.col = -1; o.row = 0; return o; }
+    o.col = col;
+    // the winning virtual lane finds the first of its rows holding the score in the snapshot column
+    int kfound = RV - 1;
+    const int half = vl & 1;
+#pragma unroll
+    for (int k = RV - 1; k >= 0; --k) {
+        const int hv = half ? (int)(SH[k] >> 16) : (int)(SH[k] & 0xffffu);
+        kfound = (hv == val) ? k : kfound;
+    }
+    const int owner = vl >> 1;
+    const int krow = __builtin_amdgcn_readlane(kfound, owner);   // owner is wave-uniform
+    int row = vl * RV + krow - off;
+    o.row = row < in.L - 1 ? row : in.L - 1;
+    return o;
+}
+
+// masked second-best column maximum, ssw.c:325-340 (8 bit) / 528-541 (16 bit); wave-parallel
+__device__ void second_best(const uint16_t* colmax, int refLen, int end_ref, int maskLen, int word, int& score2, int& ref_end2)
+{
+    const int lane = threadIdx.x & 63;
+    int e1 = end_ref - maskLen; if (e1 < 0) e1 = 0;
+    int e2 = end_ref + maskLen; if (e2 > refLen) e2 = refLen;
+    e2 += word ? 0 : 1;
+    int bv = 0, bp = 0x7fffffff;
+    for (int i = lane; i < refLen; i += 64) {
+        if (i < e1 || i >= e2) {
+            const int v = colmax[i];
+            if (v > bv) { bv = v; bp = i; }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v2 = __shfl_xor(bv, d), p2 = __shfl_xor(bp, d);
+        const bool take = v2 > bv || (v2 == bv && p2 < bp);
+        bv = take ? v2 : bv; bp = take ? p2 : bp;
+    }
+    score2 = bv;
+    ref_end2 = bv > 0 ? bp : 0;
+}
+
+template <int RV, bool QUIRK>
+__global__ void __launch_bounds__(64) ssw_align_kernel(const SswParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* lds_prof = lds;
+    int* lds_mat = (int*)(lds + 6 * ((RV + 3) / 4) * 256);
+    const int lane = threadIdx.x & 63;
+    if (lane < 48) {   // 6 base codes x 8 query codes; anything outside the n x n matrix scores 0
+        const int b = lane >> 3, q = lane & 7;
+        lds_mat[lane] = (b < p.n && q < p.n) ? (int)p.mat[b * p.n + q] : 0;
+    }
+    __syncthreads();
+
+    const SswTask task = p.tasks[blockIdx.x];
+    const int8_t* read = p.reads + task.read_off;
+    const int8_t* ref = p.refs + task.ref_off;
+    const int L = task.read_len, refLen = task.ref_len;
+    uint16_t* colmax = p.colmax ? p.colmax + task.colmax_off : nullptr;
+    const int bias = p.bias, gO = p.gapO, gE = p.gapE;
+    SswResult res;
+    res.score1 = 0; res.score2 = 0; res.ref_begin1 = -1; res.ref_end1 = -1; res.read_begin1 = -1; res.read_end1 = 0;
+    res.ref_end2 = 0; res.status = 0;
+
+    // ---- forward: which regime?  (ssw.c:804-822; tools/wavefront_model.py:wf_align) ---------------------------
+    int regime = -1;
+    PassOut fw;
+    bool byte_overflowed = false;
+    int job_word = (p.score_size == 1 || (p.score_size == 2 && p.max_match * L + bias >= 255)) ? 1 : 0;
+    PassIn in;
+    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = 1; in.ncols = refLen; in.terminate = 1 << 30;
+    in.colmax = colmax;
+    while (regime < 0) {
+        if (job_word) {
+            PassOut r = run_pass<RV, true, QUIRK>(in, lds_prof, lds_mat, gO, gE, 0);
+            if (p.score_size == 1 || byte_overflowed || r.max + bias >= 255) { fw = r; regime = 1; }
+            else job_word = 0;
+        } else {
+            PassOut r = run_pass<RV, false, false>(in, lds_prof, lds_mat, gO, gE, bias);
+            if (!r.overflow) { fw = r; regime = 0; }
+            else if (p.score_size == 0) { res.status = CLH_STATUS_OVERFLOW8; if (lane == 0) p.results[task.out_index] = res; return; }
+            else { byte_overflowed = true; job_word = 1; }
+        }
+    }
+    res.status = regime ? CLH_STATUS_WORD : 0;
+    res.score1 = fw.max;
+    if (fw.max == 0) { res.ref_end1 = regime ? 0 : -1; res.read_end1 = 0; }
+    else { res.ref_end1 = fw.col; res.read_end1 = fw.row; }
+    if (task.mask_len >= 15 && colmax) second_best(colmax, refLen, res.ref_end1, task.mask_len, regime, res.score2, res.ref_end2);
+    else { res.score2 = 0; res.ref_end2 = task.mask_len >= 15 ? 0 : -1; }
+
+    // ---- reverse: begin coordinates (ssw.c:834-849) ---------------------------------------------------------
+    const bool want_begin = !(p.flag == 0 || (p.flag == 2 && res.score1 < p.filters));
+    if (want_begin) {
+        PassIn rv;
+        rv.L = res.read_end1 + 1; rv.read = read + res.read_end1; rv.rstep = -1;
+        rv.ncols = res.ref_end1 + 1; rv.ref = ref + res.ref_end1; rv.cstep = -1;
+        rv.terminate = res.score1; rv.colmax = nullptr;
+        PassOut r;
+        for (;;) {
+            if (regime) r = run_pass<RV, true, QUIRK>(rv, lds_prof, lds_mat, gO, gE, 0);
+            else r = run_pass<RV, false, false>(rv, lds_prof, lds_mat, gO, gE, bias);
+            if (r.max >= 0) break;
+            rv.ncols = r.term_col + 1; rv.terminate = 1 << 30;     // see PassOut: rare re-run
+        }
+        if (r.max == 0) { res.ref_begin1 = regime ? 0 : -1; res.read_begin1 = res.read_end1; }
+        else { res.ref_begin1 = res.ref_end1 - r.col; res.read_begin1 = res.read_end1 - r.row; }
+    }
+    if (lane == 0) p.results[task.out_index] = res;
+}
+
+}  // namespace clh
+
+// -------------------------------------------------------------------------------------------------------------
+// launcher (host)
+// -------------------------------------------------------------------------------------------------------------
+namespace clh {
+
+template <int RV, bool QUIRK>
+static hipError_t launch_one(const SswParams& p, int ntasks, hipStream_t stream)
+{
+    const size_t lds_bytes = (size_t)6 * ((RV + 3) / 4) * 1024 + 64 * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ssw_align_kernel<RV, QUIRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ssw_align_kernel<RV, QUIRK>), dim3(ntasks), dim3(64), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+template <bool QUIRK>
+static hipError_t launch_rv(int rv, const SswParams& p, int ntasks, hipStream_t stream)
+{
+    switch (rv) {
+#define CLH_CASE(R) case R: return launch_one<R, QUIRK>(p, ntasks, stream);
+#ifdef CLH_PROBE_BUILD
+        CLH_CASE(8)
+#else
+        CLH_CASE(1) CLH_CASE(2) CLH_CASE(3) CLH_CASE(4) CLH_CASE(5) CLH_CASE(6) CLH_CASE(7) CLH_CASE(8)
+        CLH_CASE(10) CLH_CASE(12) CLH_CASE(16) CLH_CASE(20) CLH_CASE(24) CLH_CASE(32)
+#endif
+#undef CLH_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+const int kRvClasses[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32};
+const int kNumRvClasses = sizeof(kRvClasses) / sizeof(kRvClasses[0]);
+
+hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStream_t stream)
+{
+    return quirk ? launch_rv<true>(rv, p, ntasks, stream) : launch_rv<false>(rv, p, ntasks, stream);
+}
+
+}  // namespace clh

@@ -1,0 +1,224 @@
+"""ctypes binding of libclh.so's batched C ABI (include/ciri_long_hip.h).
+
+The shared object is built in-tree by csrc/Makefile (``python -c 'import __graft_entry__ as g; g.build()'``) and must
+sit next to this file, as the reference's libssw.so sits next to its wrapper (ssw_wrap.py:17).  Nothing here falls
+back to the CPU: a missing library or GPU raises ``HipUnavailable``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'libclh.so')
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class ClhError(RuntimeError):
+    pass
+
+
+class AlignRow(C.Structure):
+    _fields_ = [('score1', C.c_uint16), ('score2', C.c_uint16), ('ref_begin1', C.c_int32), ('ref_end1', C.c_int32),
+                ('read_begin1', C.c_int32), ('read_end1', C.c_int32), ('ref_end2', C.c_int32),
+                ('cigar_off', C.c_int32), ('cigar_len', C.c_int32), ('status', C.c_int32)]
+
+
+ALIGN_DTYPE = np.dtype([('score1', '<u2'), ('score2', '<u2'), ('ref_begin1', '<i4'), ('ref_end1', '<i4'),
+                        ('read_begin1', '<i4'), ('read_end1', '<i4'), ('ref_end2', '<i4'), ('cigar_off', '<i4'),
+                        ('cigar_len', '<i4'), ('status', '<i4')])
+assert ALIGN_DTYPE.itemsize == C.sizeof(AlignRow)
+
+ST_WORD, ST_NULL, ST_TRACE_ERR, ST_NO_CIGAR, ST_CIGAR_TRUNC = 1, 2, 4, 8, 16
+
+
+class SswOpts(C.Structure):
+    _fields_ = [('mat', C.c_void_p), ('n_mat', C.c_int32), ('gap_open', C.c_uint8), ('gap_extend', C.c_uint8),
+                ('flag', C.c_uint8), ('score_size', C.c_int8), ('filters', C.c_uint16), ('filterd', C.c_int32),
+                ('want_score2', C.c_int32), ('want_cigar', C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libclh.so (once).  Raises HipUnavailable if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise HipUnavailable('%s not found: build it with `make -C %s/csrc` (needs hipcc); there is no CPU fallback'
+                                 % (SO_PATH, _HERE))
+        L = C.CDLL(SO_PATH)
+        L.clh_last_error.restype = C.c_char_p
+        L.clh_version.restype = C.c_char_p
+        L.clh_create.restype = C.c_void_p
+        L.clh_create.argtypes = [C.c_int]
+        L.clh_destroy.argtypes = [C.c_void_p]
+        L.clh_ssw_plan.restype = C.c_void_p
+        L.clh_ssw_plan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SswOpts)]
+        L.clh_plan_destroy.argtypes = [C.c_void_p]
+        L.clh_ssw_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_ssw_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.clh_ssw_results_dev.restype = C.c_void_p
+        L.clh_ssw_results_dev.argtypes = [C.c_void_p]
+        L.clh_ssw_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(SswOpts), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.clh_encode_dna.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().clh_last_error().decode()
+
+
+_LUT = np.full(256, 4, dtype=np.int8)
+for _c, _v in zip('ACGTN', range(5)):
+    _LUT[ord(_c)] = _v
+    _LUT[ord(_c.lower())] = _v
+
+
+def encode(seq):
+    """ASCII -> int8 codes, the mapping of ssw_wrap.py:50,243-250 (vectorised; the reference loops per base)."""
+    if isinstance(seq, str):
+        seq = seq.encode('latin-1')
+    return _LUT[np.frombuffer(seq, dtype=np.uint8)]
+
+
+def score_matrix(match, mismatch):
+    """ssw_wrap.py:146-159: match on the diagonal, -mismatch elsewhere, 0 for N."""
+    m = np.full((5, 5), -int(mismatch), dtype=np.int8)
+    np.fill_diagonal(m, int(match))
+    m[4, :] = 0
+    m[:, 4] = 0
+    return np.ascontiguousarray(m.reshape(-1))
+
+
+def pack(seqs):
+    """list of int8 arrays / str -> (packed int8 array, int64 offsets[n+1])"""
+    arrs = [encode(s) if isinstance(s, (str, bytes)) else np.asarray(s, dtype=np.int8) for s in seqs]
+    off = np.zeros(len(arrs) + 1, dtype=np.int64)
+    if arrs:
+        np.cumsum([len(a) for a in arrs], out=off[1:])
+    data = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.int8)
+    return np.ascontiguousarray(data, dtype=np.int8), off
+
+
+class Context(object):
+    """One per (process, GPU)."""
+
+    def __init__(self, device=0):
+        L = lib()
+        self._h = L.clh_create(int(device))
+        if not self._h:
+            raise HipUnavailable('clh_create(%d) failed: %s (there is no CPU fallback)' % (device, last_error()))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib().clh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _opts(self, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, filters=0, filterd=0):
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        o = SswOpts()
+        o.mat = mat.ctypes.data
+        o.n_mat = int(round(len(mat) ** 0.5))
+        o.gap_open, o.gap_extend, o.flag, o.score_size = int(gap_open), int(gap_extend), int(flag), int(score_size)
+        o.filters, o.filterd, o.want_score2, o.want_cigar = int(filters), int(filterd), int(want_score2), int(want_cigar)
+        return o, mat
+
+    def ssw_batch(self, reads, read_off, refs, ref_off, mat, gap_open, gap_extend, flag=1, score_size=2,
+                  want_score2=True, want_cigar=True, mask_len=None):
+        """Host arrays in, (rows: structured array, cigars: uint32 array) out."""
+        L = lib()
+        reads = np.ascontiguousarray(reads, dtype=np.int8)
+        refs = np.ascontiguousarray(refs, dtype=np.int8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
+        n = len(read_off) - 1
+        o, _keep = self._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar)
+        out = np.zeros(n, dtype=ALIGN_DTYPE)
+        cap = int(2 * (read_off[-1] if n else 0) + 2 * n + 8) if want_cigar else 1
+        cig = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        ml = None
+        if mask_len is not None:
+            ml = np.ascontiguousarray(mask_len, dtype=np.int32)
+        rc = L.clh_ssw_batch(self._h, n, reads.ctypes.data, read_off.ctypes.data, refs.ctypes.data, ref_off.ctypes.data,
+                             ml.ctypes.data if ml is not None else None, C.byref(o), out.ctypes.data,
+                             cig.ctypes.data if want_cigar else None, cap, C.byref(used))
+        if rc != 0:
+            raise ClhError('clh_ssw_batch failed (%d): %s' % (rc, last_error()))
+        return out, cig[:used.value]
+
+    def plan(self, read_off, ref_off, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,
+             want_cigar=True, mask_len=None):
+        return Plan(self, read_off, ref_off, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, mask_len)
+
+
+class Plan(object):
+    """A batch shape resident on the GPU: run() it on device pointers any number of times."""
+
+    def __init__(self, ctx, read_off, ref_off, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, mask_len):
+        L = lib()
+        self.ctx = ctx
+        self.read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        self.ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
+        self.n = len(self.read_off) - 1
+        self.want_cigar = bool(want_cigar)
+        o, self._mat = ctx._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar)
+        ml = np.ascontiguousarray(mask_len, dtype=np.int32) if mask_len is not None else None
+        self._h = L.clh_ssw_plan(ctx._h, self.n, self.read_off.ctypes.data, self.ref_off.ctypes.data,
+                                 ml.ctypes.data if ml is not None else None, C.byref(o))
+        if not self._h:
+            raise ClhError('clh_ssw_plan failed: %s' % last_error())
+
+    def run(self, d_reads_ptr, d_refs_ptr, stream=0):
+        rc = lib().clh_ssw_run(self._h, C.c_void_p(d_reads_ptr), C.c_void_p(d_refs_ptr), C.c_void_p(stream))
+        if rc != 0:
+            raise ClhError('clh_ssw_run failed (%d): %s' % (rc, last_error()))
+
+    def fetch(self):
+        out = np.zeros(self.n, dtype=ALIGN_DTYPE)
+        cap = int(2 * (self.read_off[-1] if self.n else 0) + 2 * self.n + 8) if self.want_cigar else 1
+        cig = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        rc = lib().clh_ssw_fetch(self._h, out.ctypes.data, cig.ctypes.data if self.want_cigar else None, cap, C.byref(used))
+        if rc != 0:
+            raise ClhError('clh_ssw_fetch failed (%d): %s' % (rc, last_error()))
+        return out, cig[:used.value]
+
+    def results_dev_ptr(self):
+        return lib().clh_ssw_results_dev(self._h)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib().clh_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    if device is None:
+        device = int(os.environ.get('CIRI_LONG_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,107 @@
+/*
+ * ciri_long_hip.h -- C ABI of libclh.so, the MI355X (gfx950) implementation of CIRI-long's per-read hot path.
+ *
+ * Plain C: pointers and sizes only.  Two groups of entry points:
+ *
+ *  (1) The six symbols of the reference's libssw.so, with identical signatures, struct layout, ownership and error
+ *      conventions, so that the reference's ctypes wrapper (libs/striped_smith_waterman/ssw_wrap.py:54-72,278-288)
+ *      can load this library in place of libssw.so.  Declared in ssw_legacy.h.
+ *
+ *  (2) Batched entry points (this file).  The reference makes one FFI round trip per alignment
+ *      (ssw_wrap.py:187-209 <- CIRI_long/find_bsj.py:203-216, CIRI_long/collapse.py:157-173,251-265); a GPU wants
+ *      thousands of alignments per launch.  A batch is a pair of packed int8 code arrays (A=0 C=1 G=2 T=3 N=4, the
+ *      encoding of ssw_wrap.py:50,243-250) plus offset tables; alignment a is reads[read_off[a]..read_off[a+1]) against
+ *      refs[ref_off[a]..ref_off[a+1]).  Results are what n sequential ssw_init+ssw_align calls would return.
+ *
+ * All functions return 0 on success and a negative CLH_E_* code on failure; clh_last_error() gives the text.
+ * There is no CPU fallback: without a usable HIP device every compute entry point fails.
+ */
+#ifndef CIRI_LONG_HIP_H
+#define CIRI_LONG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLH_E_HIP        (-1)   /* HIP runtime error (no device, launch failure, out of memory) */
+#define CLH_E_ARG        (-2)   /* invalid argument */
+#define CLH_E_UNSUPPORTED (-3)  /* valid for the reference but not implemented here (see text) */
+#define CLH_E_CAPACITY   (-4)   /* caller's output buffer too small */
+
+/* status bits of clh_align_t.status */
+#define CLH_ST_WORD        1    /* 16-bit regime (ssw.c:806-809) */
+#define CLH_ST_NULL        2    /* the reference would have returned NULL (ssw.c:810-813: score_size 0 overflow) */
+#define CLH_ST_TRACE_ERR   4    /* the reference's "Trace back error" (ssw.c:674-682) */
+#define CLH_ST_NO_CIGAR    8    /* CIGAR not produced because of flag/filters (ssw.c:834,850) */
+#define CLH_ST_CIGAR_TRUNC 16   /* internal CIGAR/traceback workspace exhausted (retry with a smaller batch) */
+
+/* One result row: the fields of s_align (ssw.h:42-52) with the cigar pointer replaced by a slice of the
+ * caller's cigar buffer. */
+typedef struct {
+    uint16_t score1;
+    uint16_t score2;
+    int32_t ref_begin1;
+    int32_t ref_end1;
+    int32_t read_begin1;
+    int32_t read_end1;
+    int32_t ref_end2;
+    int32_t cigar_off;    /* first u32 of this alignment's CIGAR in cigar_buf, -1 if none */
+    int32_t cigar_len;
+    int32_t status;
+} clh_align_t;
+
+typedef struct clh_ctx clh_ctx;     /* one per (process, GPU) */
+typedef struct clh_plan clh_plan;   /* a batch shape: offsets, scoring, bucketing, device workspaces */
+
+int clh_device_count(void);
+const char* clh_last_error(void);
+const char* clh_version(void);
+
+clh_ctx* clh_create(int device);    /* NULL on failure */
+void clh_destroy(clh_ctx* ctx);
+int clh_device_of(const clh_ctx* ctx);
+
+/* Scoring and reporting options; meaning and defaults follow ssw_init/ssw_align (ssw.h:54-120). */
+typedef struct {
+    const int8_t* mat;     /* n_mat x n_mat substitution matrix, row = reference code (ssw.c:621) */
+    int32_t n_mat;         /* <= 5 */
+    uint8_t gap_open;      /* absolute values, gap_open >= gap_extend required */
+    uint8_t gap_extend;
+    uint8_t flag;          /* ssw_align flag; ssw_wrap.py always passes 1 */
+    int8_t score_size;     /* ssw_init score_size; ssw_wrap.py always passes 2 */
+    uint16_t filters;
+    int32_t filterd;
+    int32_t want_score2;   /* 0: skip the second-best scan (score2 = 0, ref_end2 = 0); CIRI-long never reads it */
+    int32_t want_cigar;    /* 0: skip the traceback even if flag asks for it (find_bsj.py:204,214 never reads it) */
+} clh_ssw_opts;
+
+/* mask_len may be NULL: ssw_wrap.py:196-199 rule (len/2 if len > 30 else 15). */
+clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
+                       const int32_t* mask_len, const clh_ssw_opts* opts);
+void clh_plan_destroy(clh_plan* plan);
+
+/* Launch the batch on packed code arrays that already live in HBM (device pointers).  Asynchronous on `stream`
+ * (a hipStream_t, NULL = the context's own stream).  Results stay in HBM until clh_ssw_fetch. */
+int clh_ssw_run(clh_plan* plan, const void* d_reads, const void* d_refs, void* stream);
+
+/* Wait for the last run and copy results out.  cigar_buf may be NULL.  *cigar_used receives the u32 count. */
+int clh_ssw_fetch(clh_plan* plan, clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used);
+
+/* Device pointer of the raw result table of the last run (8 x int32 per alignment: score1 score2 ref_begin1 ref_end1
+ * read_begin1 read_end1 ref_end2 status), for callers that keep post-processing on the GPU. */
+const void* clh_ssw_results_dev(const clh_plan* plan);
+
+/* Host-buffer convenience: plan + upload + run + fetch. */
+int clh_ssw_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, const int8_t* refs,
+                  const int64_t* ref_off, const int32_t* mask_len, const clh_ssw_opts* opts,
+                  clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used);
+
+/* ASCII -> codes exactly as ssw_wrap.py:234-252 (A/a C/c G/g T/t N/n, anything else 4), on the host. */
+void clh_encode_dna(const char* seq, int64_t len, int8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -533,3 +533,17 @@ int clo_ssw_batch(int32_t nAln, const int8_t *reads, const int64_t *read_off, co
     }
     return used <= cigar_cap || !cigar_buf ? 0 : 1;
 }
+
+/* One striped pass on its own (debug/verification entry: lets tests compare the row-major spec of
+ * rowmajor_spec.c and the GPU passes with the literal stripe emulation pass by pass).
+ * out: [0] score [1] end_ref [2] end_read [3] score2 [4] ref_end2 */
+void clo_striped_pass(const int8_t *ref, int ref_dir, int refLen, const int8_t *read, int readLen, const int8_t *mat, int n,
+                      int gapO, int gapE, int word, int bias, int terminate, int maskLen, int32_t *out)
+{
+    pass_end b[2];
+    profile_t P = make_profile(read, readLen, mat, n, word ? 8 : 16, word ? 0 : bias);
+    if (word) pass_word(ref, ref_dir, refLen, readLen, gapO, gapE, &P, terminate, maskLen, b);
+    else pass_byte(ref, ref_dir, refLen, readLen, gapO, gapE, &P, terminate, bias, maskLen, b);
+    free(P.prof);
+    out[0] = b[0].score; out[1] = b[0].ref; out[2] = b[0].read; out[3] = b[1].score; out[4] = b[1].ref;
+}

@@ -1,0 +1,134 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of libclh.so) against the golden vectors captured from the
+reference and against the CPU oracle on seeded random batches.  Bit-exact: scores, coordinates, second-best, CIGARs."""
+import numpy as np
+import pytest
+
+from oracle_lib import cigar_to_string, oracle_align
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from ciri_long_amd import hip
+    return hip.Context(0)
+
+
+def _run(ctx, refs, queries, scheme, **kw):
+    from ciri_long_amd import hip
+    m, x, o, e = scheme
+    rd, ro = hip.pack(queries)
+    fd, fo = hip.pack(refs)
+    rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(m, x), o, e, **kw)
+    return rows, cig
+
+
+def _row_tuple(r):
+    return (int(r['score1']), int(r['score2']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']),
+            int(r['read_end1']), int(r['ref_end2']))
+
+
+def test_golden_vectors_bit_exact(ctx, golden_cases):
+    cases = [c for c in golden_cases if len(c['query']) <= 4096]
+    by_scheme = {}
+    for c in cases:
+        by_scheme.setdefault((c['match'], c['mismatch'], c['gap_open'], c['gap_extend']), []).append(c)
+    checked = 0
+    for scheme, cs in by_scheme.items():
+        rows, cig = _run(ctx, [c['ref'] for c in cs], [c['query'] for c in cs], scheme)
+        for c, r in zip(cs, rows):
+            got = _row_tuple(r)
+            want = (c['score'], c['raw_score2'], c['ref_begin'], c['ref_end'], c['query_begin'], c['query_end'], c['raw_ref_end2'])
+            assert got == want, (c['name'], got, want)
+            assert r['status'] & ~1 == 0, (c['name'], r['status'])
+            cg = cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]
+            assert len(cg) == c['raw_cigar_len'], c['name']
+            assert cigar_to_string(cg, c['query_begin'], c['query_end'], len(c['query'])) == c['cigar_string'], c['name']
+            checked += 1
+    assert checked >= 1400
+
+
+def _rnd(rng, n):
+    return ''.join('ACGT'[i] for i in rng.integers(0, 4, n))
+
+
+def _mut(s, rng, p):
+    out = []
+    for c in s:
+        u = rng.random()
+        if u < p / 3:
+            continue
+        if u < 2 * p / 3:
+            out.append('ACGT'[rng.integers(4)]); continue
+        out.append(c)
+        if u < p:
+            out.append(_rnd(rng, int(rng.integers(1, 6))))
+    return ''.join(out)
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (10, 4, 8, 2), (2, 2, 3, 1), (3, 5, 7, 7)])
+def test_random_batch_vs_oracle(ctx, scheme):
+    rng = np.random.default_rng(sum(scheme) * 13 + 1)
+    refs, qs = [], []
+    for _ in range(300):
+        L = int(rng.choice([1, 16, 17, 40, 127, 129, 255, 256, 400, 513, 700, 1030, 1500]))
+        R = int(rng.choice([1, 50, 400, 1000, 2000]))
+        ref = _rnd(rng, R)
+        st = int(rng.integers(0, max(1, R - L)))
+        q = _mut(ref[st:st + L], rng, float(rng.choice([0.03, 0.13, 0.3])))
+        if rng.random() < 0.2:
+            q = q + q[:len(q) // 2]
+        if rng.random() < 0.1:
+            q = _rnd(rng, L)
+        if rng.random() < 0.15:
+            ref = ref[:R // 2] + 'N' * int(rng.integers(1, 12)) + ref[R // 2:]
+        if rng.random() < 0.05:
+            q = q[:len(q) // 2] + 'N' + q[len(q) // 2:]
+        if not q:
+            q = 'A'
+        refs.append(ref); qs.append(q[:4096])
+    rows, cig = _run(ctx, refs, qs, scheme)
+    for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
+        want = oracle_align(ref, q, *scheme)
+        got = _row_tuple(r)
+        assert got == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
+                       want['query_end'], want['ref_end2']), (k, len(q), len(ref), got, want)
+        cg = [int(x) for x in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]]
+        assert cg == want['cigar'], (k, len(q), len(ref))
+
+
+def test_production_shape_testfa(ctx, testfa):
+    """tests/test.fa in the orientation of find_bsj.py:196-205: 437-nt clip against a 430 kb window."""
+    seq1, seq2 = testfa
+    rows, cig = _run(ctx, [seq2], [seq1], (1, 1, 1, 1))
+    r = rows[0]
+    assert _row_tuple(r) == (349, 140, 229790, 230207, 20, 436, 230425)
+    cg = cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]
+    assert cigar_to_string(cg, 20, 436, len(seq1)).startswith('20S6M1D2M2I2M1I1M1I5M3I7M2I3M1D5M3D96M1D2M2D8M1D5M1D1M1D58M1I118M2D38M2I48M')
+
+
+def test_options_score_size_flag_and_skips(ctx):
+    rng = np.random.default_rng(99)
+    refs = [_rnd(rng, 500) for _ in range(40)]
+    qs = [_mut(r[100:100 + int(rng.choice([40, 300]))], rng, 0.1) for r in refs]
+    for score_size in (0, 1, 2):
+        rows, _ = _run(ctx, refs, qs, (1, 1, 1, 1), score_size=score_size)
+        for ref, q, r in zip(refs, qs, rows):
+            want = oracle_align(ref, q, 1, 1, 1, 1, score_size=score_size)
+            if want is None:
+                assert r['status'] & 2
+            else:
+                assert _row_tuple(r) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'],
+                                         want['query_begin'], want['query_end'], want['ref_end2'])
+    rows, cig = _run(ctx, refs, qs, (1, 1, 1, 1), flag=0)
+    for ref, q, r in zip(refs, qs, rows):
+        want = oracle_align(ref, q, 1, 1, 1, 1, flag=0)
+        assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])) == \
+            (want['score'], -1, want['ref_end'], -1, want['query_end'])
+        assert r['cigar_len'] == 0
+    # what CIRI-long's call path needs (find_bsj.py:204-224): no second best, no cigar
+    rows, cig = _run(ctx, refs, qs, (1, 1, 1, 1), want_score2=False, want_cigar=False)
+    for ref, q, r in zip(refs, qs, rows):
+        want = oracle_align(ref, q, 1, 1, 1, 1)
+        assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])) == \
+            (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end'])

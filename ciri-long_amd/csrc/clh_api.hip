@@ -115,6 +115,8 @@ struct clh_plan {
     unsigned long long pool_bytes = 0;
     hipStream_t last_stream = nullptr;
     bool ran = false;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;     // per segment: K1 start, K1 stop, K1b start, K1b stop
 };
 
 extern "C" void clh_plan_destroy(clh_plan* pl)
@@ -126,6 +128,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
                     pl->d_reads, pl->d_refs};
     for (void* b : bufs) c->release(b);
+    for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
     delete pl;
 }
 
@@ -244,20 +247,65 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     P.results = (clh::SswResult*)pl->d_results;
     P.colmax = (uint16_t*)pl->d_colmax;
     P.cigars = (uint32_t*)pl->d_cigars; P.cigar_len = (int32_t*)pl->d_cigar_len; P.dirs = nullptr;
-    for (const auto& s : pl->segs) {
+    if (pl->profiling && pl->ev.empty()) {
+        pl->ev.resize(pl->segs.size() * 4);
+        for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
+    }
+    for (size_t k = 0; k < pl->segs.size(); ++k) {
+        const auto& s = pl->segs[k];
         P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
+        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[4 * k + 0], st));
         HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, st));
+        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[4 * k + 1], st));
     }
     if (pl->do_cigar && pl->n > 0) {
         HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 8, st));
-        for (const auto& s : pl->segs) {
+        for (size_t k = 0; k < pl->segs.size(); ++k) {
+            const auto& s = pl->segs[k];
             P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
+            if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[4 * k + 2], st));
             HIPCHK(clh::launch_traceback_pool(s.rv, P, s.count, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+            if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[4 * k + 3], st));
         }
     }
     pl->last_stream = st;
     pl->ran = true;
     return 0;
+}
+
+extern "C" int clh_plan_set_profiling(clh_plan* pl, int on)
+{
+    if (!pl) return fail(CLH_E_ARG, "null plan");
+    pl->profiling = on != 0;
+    return 0;
+}
+
+extern "C" int clh_plan_segments(const clh_plan* pl, int32_t cap, int32_t* rv, int32_t* count, int64_t* read_bases, int64_t* ref_bases)
+{
+    if (!pl) return fail(CLH_E_ARG, "null plan");
+    const int ns = (int)pl->segs.size();
+    for (int k = 0; k < ns && k < cap; ++k) {
+        rv[k] = pl->segs[k].rv; count[k] = pl->segs[k].count;
+        int64_t a = 0, b = 0;
+        for (int t = pl->segs[k].begin; t < pl->segs[k].begin + pl->segs[k].count; ++t) { a += pl->tasks[t].read_len; b += pl->tasks[t].ref_len; }
+        read_bases[k] = a; ref_bases[k] = b;
+    }
+    return ns;
+}
+
+// durations of the last run's launches, in ms (HIP events on the run's stream); waits for the run
+extern "C" int clh_plan_timing(clh_plan* pl, int32_t cap, float* k1_ms, float* k1b_ms)
+{
+    if (!pl || !pl->ran || !pl->profiling || pl->ev.empty()) return fail(CLH_E_ARG, "profiling was not enabled for the last run");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    const int ns = (int)pl->segs.size();
+    for (int k = 0; k < ns && k < cap; ++k) {
+        HIPCHK(hipEventElapsedTime(&k1_ms[k], pl->ev[4 * k + 0], pl->ev[4 * k + 1]));
+        k1b_ms[k] = 0.f;
+        if (pl->do_cigar) HIPCHK(hipEventElapsedTime(&k1b_ms[k], pl->ev[4 * k + 2], pl->ev[4 * k + 3]));
+    }
+    return ns;
 }
 
 extern "C" const void* clh_ssw_results_dev(const clh_plan* pl) { return pl ? pl->d_results : nullptr; }

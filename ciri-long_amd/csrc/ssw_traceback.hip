@@ -50,6 +50,8 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     short* const F0 = tb_lds + 5 * ws;        // F[2][ws]
     __shared__ uint8_t stage[64 * 66];
     __shared__ int smat[32];
+    __shared__ unsigned long long hist_at[24];   // every band iteration keeps its direction bytes (see hist_lookup)
+    __shared__ int hist_w[24];
     const int lane = threadIdx.x & 63;
     if (lane < 25) smat[lane] = p.mat[lane];
     __syncthreads();
@@ -78,7 +80,7 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     const int nAD = readLen + refLen - 1;
     int maxv = 0;
     uint8_t* dir = nullptr;
-    int status = 0;
+    int status = 0, niter = 0;
 
     for (;;) {
         const bool ring = w + 3 <= wsp;   // the active rows of an anti-diagonal span <= w+1 rows
@@ -90,6 +92,8 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
         at = __shfl(at, 0);
         if (at + need > pool.size) { status = CLH_STATUS_CIGAR_TRUNC; break; }
         dir = pool.base + at;
+        if (lane == 0 && niter < 24) { hist_at[niter] = at; hist_w[niter] = w; }
+        ++niter;
         int itmax = 0;
         for (int a = 0; a < nAD; ++a) {
             const int cur = a % 3, p1 = (a + 2) % 3, p2 = (a + 1) % 3, e0 = a & 1, e1 = e0 ^ 1;
@@ -144,28 +148,53 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     __threadfence_block();
     __syncthreads();
 
-    // ---- walk back from the bottom-right corner (ssw.c:636-696); direction bytes staged 64 anti-diagonals at a time
+    // ---- walk back from the bottom-right corner (ssw.c:636-696); direction bytes staged 64 anti-diagonals at a time.
+    // The reference indexes a flat byte array (3 bytes per cell, 2w+1 cells per row) without bounds checks and
+    // re-uses it across band doublings, so a step that leaves the band reads whatever an earlier, narrower
+    // iteration left at that byte.  hist_lookup reproduces that: every iteration's direction bytes are still in the
+    // pool, and the byte -> (iteration, cell) mapping is pure index arithmetic.  Bytes no iteration wrote are
+    // uninitialised memory in the reference; those end in CLH_STATUS_TRACE_ERR here.
     int i = readLen - 1, j = refLen - 1, state = 2, run = 0, nops = 0, fail = 0;
     int op = 0, prev_op = 0;             // 0 M, 1 I, 2 D
     const int stride = w + 1;
     const int srow = stride < 66 ? stride : 0;      // staging only when an anti-diagonal fits 66 bytes
     int staged_lo = 1 << 30, staged_hi = -1;
+    const long long wd_final = 2ll * w + 1;
     while (i > 0) {
-        const int a = i + j;
-        if (j < 0 || j > i + w || j < i - w || j >= refLen) { fail = 1; break; }
-        int code;
-        const int slot = i - ad_first_row(a, w);
-        if (srow) {
-            if (a < staged_lo || a > staged_hi) {
-                staged_hi = a; staged_lo = a - 63 > 0 ? a - 63 : 0;
-                const int nbytes = (staged_hi - staged_lo + 1) * stride;
-                __syncthreads();
-                for (int b = lane; b < nbytes; b += 64) stage[b] = dir[(size_t)staged_lo * stride + b];
-                __syncthreads();
+        int code = 0;
+        if (j >= 0 && j <= i + w && j >= i - w && j < refLen) {
+            const int a = i + j;
+            const int slot = i - ad_first_row(a, w);
+            if (srow) {
+                if (a < staged_lo || a > staged_hi) {
+                    staged_hi = a; staged_lo = a - 63 > 0 ? a - 63 : 0;
+                    const int nbytes = (staged_hi - staged_lo + 1) * stride;
+                    __syncthreads();
+                    for (int b = lane; b < nbytes; b += 64) stage[b] = dir[(size_t)staged_lo * stride + b];
+                    __syncthreads();
+                }
+                code = stage[(a - staged_lo) * stride + slot];
+            } else {
+                code = dir[(size_t)a * stride + slot];
             }
-            code = stage[(a - staged_lo) * stride + slot];
         } else {
-            code = dir[(size_t)a * stride + slot];
+            const long long xi = i - w > 0 ? i - w : 0;
+            const long long C = (long long)i * wd_final + ((long long)j - xi);   // cell index in the final layout
+            code = -1;
+            if (C >= 0 && niter <= 24) {
+                for (int k = niter - 1; k >= 0; --k) {
+                    const long long wk = hist_w[k], wd = 2 * wk + 1;
+                    const long long ii = C / wd, pos = C % wd;
+                    if (ii >= readLen) continue;
+                    const long long xk = ii - wk > 0 ? ii - wk : 0, jj = xk + pos;
+                    const long long endk = ii + wk < refLen - 1 ? ii + wk : refLen - 1;
+                    if (jj > endk) continue;
+                    const int a = (int)(ii + jj);
+                    code = pool.base[hist_at[k] + (size_t)a * (size_t)(wk + 1) + (size_t)(ii - ad_first_row(a, (int)wk))];
+                    break;
+                }
+            }
+            if (code < 0) { fail = 1; break; }
         }
         const int c = state == 2 ? (code & 7) : (state == 0 ? ((code & 8) ? 3 : 2) : ((code & 16) ? 5 : 4));
         switch (c) {

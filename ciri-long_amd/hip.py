@@ -67,6 +67,9 @@ def lib():
         L.clh_ssw_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.POINTER(SswOpts), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.clh_encode_dna.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
+        L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -197,6 +200,24 @@ class Plan(object):
         if rc != 0:
             raise ClhError('clh_ssw_fetch failed (%d): %s' % (rc, last_error()))
         return out, cig[:used.value]
+
+    def set_profiling(self, on=True):
+        lib().clh_plan_set_profiling(self._h, 1 if on else 0)
+
+    def segments(self):
+        """[(rows-per-lane class, alignments, read bases, ref bases)] in launch order"""
+        rv = np.zeros(32, dtype=np.int32); cnt = np.zeros(32, dtype=np.int32)
+        rb = np.zeros(32, dtype=np.int64); fb = np.zeros(32, dtype=np.int64)
+        ns = lib().clh_plan_segments(self._h, 32, rv.ctypes.data, cnt.ctypes.data, rb.ctypes.data, fb.ctypes.data)
+        return [(int(rv[k]), int(cnt[k]), int(rb[k]), int(fb[k])) for k in range(ns)]
+
+    def timing(self):
+        """[(K1 ms, K1b ms)] per segment for the last run (needs set_profiling before run)"""
+        a = np.zeros(32, dtype=np.float32); b = np.zeros(32, dtype=np.float32)
+        ns = lib().clh_plan_timing(self._h, 32, a.ctypes.data, b.ctypes.data)
+        if ns < 0:
+            raise ClhError('clh_plan_timing: %s' % last_error())
+        return [(float(a[k]), float(b[k])) for k in range(ns)]
 
     def results_dev_ptr(self):
         return lib().clh_ssw_results_dev(self._h)

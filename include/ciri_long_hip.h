@@ -93,6 +93,12 @@ int clh_ssw_fetch(clh_plan* plan, clh_align_t* out, uint32_t* cigar_buf, int64_t
  * read_begin1 read_end1 ref_end2 status), for callers that keep post-processing on the GPU. */
 const void* clh_ssw_results_dev(const clh_plan* plan);
 
+/* Measurement hooks (bench.py): per launch-segment (one read-length class each) HIP-event durations of the score
+ * kernel (K1) and the traceback kernel (K1b) of the last run.  Both return the number of segments. */
+int clh_plan_set_profiling(clh_plan* plan, int on);
+int clh_plan_segments(const clh_plan* plan, int32_t cap, int32_t* rv, int32_t* count, int64_t* read_bases, int64_t* ref_bases);
+int clh_plan_timing(clh_plan* plan, int32_t cap, float* k1_ms, float* k1b_ms);
+
 /* Host-buffer convenience: plan + upload + run + fetch. */
 int clh_ssw_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, const int8_t* refs,
                   const int64_t* ref_off, const int32_t* mask_len, const clh_ssw_opts* opts,

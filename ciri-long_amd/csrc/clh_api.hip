@@ -39,6 +39,8 @@ extern "C" int clh_device_count(void)
 struct clh_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the read-length classes of a batch are launched on 4 streams so their tails overlap
+    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     std::mutex mu;
     std::vector<std::pair<size_t, void*>> cache;
 
@@ -81,17 +83,24 @@ extern "C" clh_ctx* clh_create(int device)
         delete c;
         return nullptr;
     }
+    bool ok = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 3 && ok; ++i)
+        ok = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { fail(CLH_E_HIP, "could not create side streams"); delete c; return nullptr; }
     return c;
 }
 
 extern "C" void clh_destroy(clh_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    for (auto& kv : c->cache) hipFree(kv.second);
-    for (auto& kv : c->sizes) hipFree(kv.first);
-    hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->cache) (void)hipFree(kv.second);
+    for (auto& kv : c->sizes) (void)hipFree(kv.first);
+    for (int i = 0; i < 3; ++i) { if (c->side[i]) (void)hipStreamDestroy(c->side[i]); if (c->join_ev[i]) (void)hipEventDestroy(c->join_ev[i]); }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -116,15 +125,15 @@ struct clh_plan {
     hipStream_t last_stream = nullptr;
     bool ran = false;
     bool profiling = false;
-    std::vector<hipEvent_t> ev;     // per segment: K1 start, K1 stop, K1b start, K1b stop
+    std::vector<hipEvent_t> ev;     // per segment: K1 start, K1 stop; then K1b small-window start/stop, large-window start/stop
 };
 
 extern "C" void clh_plan_destroy(clh_plan* pl)
 {
     if (!pl) return;
     clh_ctx* c = pl->ctx;
-    hipSetDevice(c->device);
-    if (pl->ran) hipStreamSynchronize(pl->last_stream);
+    (void)hipSetDevice(c->device);
+    if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
                     pl->d_reads, pl->d_refs};
     for (void* b : bufs) c->release(b);
@@ -157,6 +166,12 @@ extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_o
     for (int i = 0; i < o->n_mat * o->n_mat; ++i) { P.mat[i] = o->mat[i]; mn = std::min(mn, (int)o->mat[i]); mx = std::max(mx, (int)o->mat[i]); }
     P.n = o->n_mat; P.gapO = o->gap_open; P.gapE = o->gap_extend; P.bias = -mn; P.max_match = mx; P.score_size = o->score_size;
     P.flag = o->flag; P.filters = o->filters; P.filterd = o->filterd;
+    P.null_code = 5;
+    if (o->n_mat == 5) {
+        bool z = true;
+        for (int i = 0; i < 5; ++i) z = z && o->mat[4 * 5 + i] == 0 && o->mat[i * 5 + 4] == 0;
+        if (z) P.null_code = 4;
+    }
     pl->opts.mat = nullptr;
     pl->quirk = o->gap_open <= o->gap_extend;
     pl->do_cigar = o->want_cigar && (o->flag & 7) != 0;
@@ -248,25 +263,50 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     P.colmax = (uint16_t*)pl->d_colmax;
     P.cigars = (uint32_t*)pl->d_cigars; P.cigar_len = (int32_t*)pl->d_cigar_len; P.dirs = nullptr;
     if (pl->profiling && pl->ev.empty()) {
-        pl->ev.resize(pl->segs.size() * 4);
+        pl->ev.resize(pl->segs.size() * 2 + 4);
         for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
     }
-    for (size_t k = 0; k < pl->segs.size(); ++k) {
-        const auto& s = pl->segs[k];
-        P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
-        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[4 * k + 0], st));
-        HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, st));
-        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[4 * k + 1], st));
+    // K1: one launch per read-length class.  Classes are independent, so outside profiling runs they go round-robin to
+    // the caller's stream and three side streams (fork/join with events) and the tail of one class overlaps the next.
+    clh_ctx* c = pl->ctx;
+    const bool fan = !pl->profiling && pl->segs.size() > 1;
+    if (fan) {
+        HIPCHK(hipEventRecord(c->fork_ev, st));
+        for (int i = 0; i < 3; ++i) HIPCHK(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
     }
+    // heaviest class first
+    std::vector<size_t> ord(pl->segs.size());
+    for (size_t k = 0; k < ord.size(); ++k) ord[k] = k;
+    std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return pl->segs[x].count > pl->segs[y].count; });
+    for (size_t q = 0; q < ord.size(); ++q) {
+        const size_t k = ord[q];
+        const auto& s = pl->segs[k];
+        hipStream_t ls = (fan && (q & 3)) ? c->side[(q & 3) - 1] : st;
+        P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
+        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], ls));
+        HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
+        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], ls));
+    }
+    if (fan)
+        for (int i = 0; i < 3; ++i) {
+            HIPCHK(hipEventRecord(c->join_ev[i], c->side[i]));
+            HIPCHK(hipStreamWaitEvent(st, c->join_ev[i], 0));
+        }
     if (pl->do_cigar && pl->n > 0) {
         HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 8, st));
-        for (size_t k = 0; k < pl->segs.size(); ++k) {
-            const auto& s = pl->segs[k];
-            P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
-            if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[4 * k + 2], st));
-            HIPCHK(clh::launch_traceback_pool(s.rv, P, s.count, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
-            if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[4 * k + 3], st));
+        // first attempt: every alignment, small LDS window; then per read-length class the few that outgrew it
+        P.tasks = (const clh::SswTask*)pl->d_tasks;
+        const size_t eb = pl->segs.size() * 2;
+        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[eb + 0], st));
+        HIPCHK(clh::launch_traceback_pool(0, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+        if (pl->profiling) { HIPCHK(hipEventRecord(pl->ev[eb + 1], st)); HIPCHK(hipEventRecord(pl->ev[eb + 2], st)); }
+        {   // one launch sized for the longest read class; workgroups of unmarked alignments return at once
+            int rvmax = 1;
+            for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv);
+            if (rvmax > 4)   // below that the small window (514 rows) already covers every read
+                HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
         }
+        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[eb + 3], st));
     }
     pl->last_stream = st;
     pl->ran = true;
@@ -293,17 +333,19 @@ extern "C" int clh_plan_segments(const clh_plan* pl, int32_t cap, int32_t* rv, i
     return ns;
 }
 
-// durations of the last run's launches, in ms (HIP events on the run's stream); waits for the run
+// durations of the last run's launches, in ms (HIP events on the run's stream); waits for the run.
+// k1_ms[segment]; k1b_ms[0] = small-window traceback launch (all alignments), k1b_ms[1] = large-window launches.
 extern "C" int clh_plan_timing(clh_plan* pl, int32_t cap, float* k1_ms, float* k1b_ms)
 {
     if (!pl || !pl->ran || !pl->profiling || pl->ev.empty()) return fail(CLH_E_ARG, "profiling was not enabled for the last run");
     HIPCHK(hipSetDevice(pl->ctx->device));
     HIPCHK(hipStreamSynchronize(pl->last_stream));
     const int ns = (int)pl->segs.size();
-    for (int k = 0; k < ns && k < cap; ++k) {
-        HIPCHK(hipEventElapsedTime(&k1_ms[k], pl->ev[4 * k + 0], pl->ev[4 * k + 1]));
-        k1b_ms[k] = 0.f;
-        if (pl->do_cigar) HIPCHK(hipEventElapsedTime(&k1b_ms[k], pl->ev[4 * k + 2], pl->ev[4 * k + 3]));
+    for (int k = 0; k < ns && k < cap; ++k) HIPCHK(hipEventElapsedTime(&k1_ms[k], pl->ev[2 * k + 0], pl->ev[2 * k + 1]));
+    k1b_ms[0] = k1b_ms[1] = 0.f;
+    if (pl->do_cigar && pl->n > 0) {
+        HIPCHK(hipEventElapsedTime(&k1b_ms[0], pl->ev[2 * ns + 0], pl->ev[2 * ns + 1]));   // small-window launch, all alignments
+        HIPCHK(hipEventElapsedTime(&k1b_ms[1], pl->ev[2 * ns + 2], pl->ev[2 * ns + 3]));   // large-window launches, outliers only
     }
     return ns;
 }

@@ -11,7 +11,8 @@ enum {
     CLH_STATUS_OVERFLOW8 = 2,   // score_size 0 and the 8-bit pass overflowed: reference returns NULL (ssw.c:810-813)
     CLH_STATUS_TRACE_ERR = 4,   // traceback left the band (reference: "Trace back error", ssw.c:674-682)
     CLH_STATUS_NO_CIGAR = 8,    // CIGAR not requested / filtered by flag (ssw.c:850)
-    CLH_STATUS_CIGAR_TRUNC = 16 // CIGAR buffer share exhausted
+    CLH_STATUS_CIGAR_TRUNC = 16, // CIGAR buffer share / traceback pool exhausted
+    CLH_STATUS_NEED_BIG = 32     // internal: traceback must be redone with the large LDS window
 };
 
 // One alignment = one workgroup of one wavefront.  Offsets are into the packed batch arrays.
@@ -43,6 +44,7 @@ struct SswParams {
     uint8_t* dirs;        // traceback workspace
     int8_t mat[32];       // n*n substitution matrix (n <= 5)
     int32_t n, gapO, gapE, bias, max_match, score_size, flag, filters, filterd;
+    int32_t null_code;    // 4 if mat scores code 4 as 0 against everything (then fill/drain columns reuse it), else 5
 };
 
 extern const int kRvClasses[];

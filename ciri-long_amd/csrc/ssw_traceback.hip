@@ -42,7 +42,9 @@ __device__ __forceinline__ int wave_max(int v)
 // first row of anti-diagonal a inside the band: ceil((a - w) / 2), not clamped
 __device__ __forceinline__ int ad_first_row(int a, int w) { int t = a - w; return t >= 0 ? (t + 1) >> 1 : -((-t) >> 1); }
 
-__global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp)
+// big = 0: first attempt with a small LDS window (high occupancy); alignments whose band outgrows it are marked
+// CLH_STATUS_NEED_BIG.  big = 1: only the marked ones, with a window sized for the launch's read-length class.
+__global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp, int big)
 {
     extern __shared__ __attribute__((aligned(16))) short tb_lds[];
     short* const H0 = tb_lds;                 // H[3][ws]
@@ -59,6 +61,11 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     SswResult res = p.results[task.out_index];
     uint32_t* cig = p.cigars + task.cigar_off;
     int* cig_len = p.cigar_len + task.out_index;
+    if (big) {
+        if (!(res.status & CLH_STATUS_NEED_BIG)) return;
+        res.status &= ~CLH_STATUS_NEED_BIG;
+        if (lane == 0) p.results[task.out_index].status = res.status;
+    }
 
     const bool no_cigar = (res.status & CLH_STATUS_OVERFLOW8) || (7 & p.flag) == 0 ||
                           ((2 & p.flag) != 0 && res.score1 < p.filters) ||
@@ -84,7 +91,7 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
 
     for (;;) {
         const bool ring = w + 3 <= wsp;   // the active rows of an anti-diagonal span <= w+1 rows
-        if (!ring && readLen + 1 > ws) { status = CLH_STATUS_TRACE_ERR; break; }
+        if (!ring && readLen + 1 > ws) { status = big ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG; break; }
         const int imask = ring ? wsp - 1 : -1;
         unsigned long long need = ((unsigned long long)nAD * (unsigned long long)(w + 1) + 63ull) & ~63ull;
         unsigned long long at = 0;
@@ -133,7 +140,9 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
                     dir[(size_t)a * (w + 1) + (i - band_lo)] = (uint8_t)(dh | (de == 3 ? 8 : 0) | (df == 5 ? 16 : 0));
                 }
             }
-            __syncthreads();
+            // one wave per workgroup: LDS operations of a wave execute in order, so the next anti-diagonal's reads see
+            // these writes; only the compiler has to be told not to move them.
+            asm volatile("" ::: "memory");
         }
         itmax = wave_max(itmax);
         maxv = itmax > maxv ? itmax : maxv;
@@ -243,11 +252,12 @@ hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t
                                  unsigned long long pool_size, hipStream_t stream)
 {
     TbPool pool; pool.base = pool_base; pool.head = pool_head; pool.size = pool_size;
-    const int ws = 128 * rv + 2;
+    // rv == 0: the small-window first attempt (any read length)
+    const int ws = rv > 0 ? 128 * rv + 2 : 514;
     int wsp = 1;
     while (wsp * 2 <= ws) wsp *= 2;
     const size_t lds = (size_t)7 * ws * sizeof(short);
-    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(ntasks), dim3(64), lds, stream, p, pool, ws, wsp);
+    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(ntasks), dim3(64), lds, stream, p, pool, ws, wsp, rv > 0 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -48,7 +48,6 @@ __device__ __forceinline__ uint32_t hand_down(uint32_t v, uint32_t lane0_lo) {
 }
 
 static constexpr int NEG16 = -32768;
-static constexpr int CODE_NULL = 5;   // pipeline fill/drain: scores 0 against every row
 
 struct PassOut {
     int max;        // best score (255 when the 8-bit pass overflowed)
@@ -71,10 +70,14 @@ struct PassIn {
 
 // One pass.  RV = rows per virtual lane (capacity 128*RV rows).  WORD selects the row padding (8 vs 16) and
 // QUIRK the truncated vertical gaps of the 16-bit pass when gapO <= gapE (rowmajor_spec.c).
+// null_code: base code used for pipeline fill/drain columns; it must score 0 against every row.  5 (an extra
+// profile row) in general, 4 when the matrix already scores code 4 ("N") as 0 everywhere, as CIRI-long's do
+// (ssw_wrap.py:154-159) -- that saves one sixth of the LDS footprint.
 template <int RV, bool WORD, bool QUIRK>
 __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, const int* __restrict__ lds_mat,
-                            int gapO, int gapE, int bias)
+                            int gapO, int gapE, int bias, const int null_code)
 {
+    const int CODE_NULL = null_code;
     constexpr int CH = (RV + 3) / 4;             // 16-byte chunks of profile per lane and base
     constexpr int BASE_STRIDE = CH * 1024;       // bytes between two bases' profiles
     const int lane = threadIdx.x & 63;
@@ -93,8 +96,7 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
         // clamped, unconditional loads; dummy (row < 0) and wildcard (row >= L) rows are selected afterwards
         const int clo = rlo < 0 ? 0 : (rlo > Lm1 ? Lm1 : rlo), chi = rhi < 0 ? 0 : (rhi > Lm1 ? Lm1 : rhi);
         const int qlo = (int)in.read[(int64_t)clo * in.rstep] & 7, qhi = (int)in.read[(int64_t)chi * in.rstep] & 7;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
+        for (int b = 0; b <= null_code; ++b) {
             const int mlo = lds_mat[b * 8 + qlo], mhi = lds_mat[b * 8 + qhi];
             const int slo = rlo < 0 ? NEG16 : (rlo > Lm1 ? 0 : mlo);
             const int shi = rhi < 0 ? NEG16 : (rhi > Lm1 ? 0 : mhi);
@@ -109,9 +111,11 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
     }
 
     // ---- state ------------------------------------------------------------------------------------------
-    uint32_t Hp[RV], E[RV], SH[RV];
+    // H of the previous column is kept twice (HA/HB) and the step body is instantiated for both roles, so that the
+    // "previous column" registers never have to be rotated at the loop back-edge.
+    uint32_t HA[RV], HB[RV], E[RV], SH[RV];
 #pragma unroll
-    for (int k = 0; k < RV; ++k) { Hp[k] = 0; E[k] = 0; SH[k] = 0; }
+    for (int k = 0; k < RV; ++k) { HA[k] = 0; HB[k] = 0; E[k] = 0; SH[k] = 0; }
     uint32_t outH = 0, outC = 0, outM = 0, diagIn = 0, best = 0, RB = dup16(CODE_NULL);
     int colLo = -1, colHi = -1;
     uint32_t flags = 0;                           // bit0 overflow, bit1 exceeded (any lane)
@@ -119,23 +123,21 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
     const uint32_t ovf2 = dup16(254 - bias);      // cm > 254-bias  <=>  cm + bias >= 255
     const uint32_t term2 = dup16(in.terminate > 32767 ? 32767 : in.terminate);
     const int ncols = in.ncols;
+    const char* prof_bytes = (const char*)lds_prof;
 
     auto load_chunk = [&](int t0) -> int {
         int j = t0 + lane;
         return j < ncols ? (int)in.ref[(int64_t)j * in.cstep] : CODE_NULL;
     };
-    int chunk = load_chunk(0), nxt = load_chunk(64);
-    int term_col = -1;
+    int term_col = -1, stop = 0;
     const int nsteps = ncols > 0 ? ncols + 127 : 0;
-    const char* prof_bytes = (const char*)lds_prof;
 
-    for (int t = 0; t < nsteps; ++t) {
-        if ((t & 63) == 0 && t > 0) { chunk = nxt; nxt = load_chunk(t + 64); }
-        const int sb = __builtin_amdgcn_readlane(chunk, t & 63);
+    // one step of the wavefront: reads the previous column from HR, writes the current one to HW.
+    // Returns 1 when the pass must end (8-bit overflow or terminate score met).
+    auto step = [&](const int t, const int sb, uint32_t (&HR)[RV], uint32_t (&HW)[RV], int& ring) -> int {
         RB = hand_down(RB, (uint32_t)sb);
         const uint32_t aLo = (RB & 0xffffu) * BASE_STRIDE + lane * 16;
         const uint32_t aHi = (RB >> 16) * BASE_STRIDE + lane * 16;
-
         const uint32_t inH = hand_down(outH, 0), inC = hand_down(outC, 0), inM = hand_down(outM, 0);
         uint32_t F = inC, diag = diagIn, cm = 0;
 #pragma unroll
@@ -149,19 +151,18 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
                 if (k < RV) {
                     const uint32_t s = (plv[kk] & 0xffffu) | (phv[kk] & 0xffff0000u);
                     const uint32_t tt = pk_adds(diag, s);
+                    diag = HR[k];
                     uint32_t h;
                     if (QUIRK) {
                         const uint32_t Fm = F & cut[k];
                         h = pk_max(pk_max(tt, E[k]), Fm);
-                        diag = Hp[k];
-                        Hp[k] = pk_max(h, F);
+                        HW[k] = pk_max(h, F);
                         const uint32_t hg = pk_subus(h, gO2);
                         E[k] = pk_max(pk_subus(E[k], gE2), hg);
                         F = pk_max(pk_subus(Fm, gE2), hg);
                     } else {
                         h = pk_max(pk_max(tt, E[k]), F);
-                        diag = Hp[k];
-                        Hp[k] = h;
+                        HW[k] = h;
                         const uint32_t hg = pk_subus(h, gO2);
                         E[k] = pk_max(pk_subus(E[k], gE2), hg);
                         F = pk_max(pk_subus(F, gE2), hg);
@@ -171,11 +172,11 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
             }
         }
         diagIn = inH;
-        outH = Hp[RV - 1];
+        outH = HW[RV - 1];
         outC = F;
         outM = pk_max(inM, cm);
 
-        // ---- per-lane best (first column wins, strict >), snapshot of that column -------------------------
+        // per-lane best (first column wins, strict >) and a snapshot of that column
         const int jLo = t - 2 * lane, jHi = jLo - 1;
         const uint32_t vm = ((uint32_t)jLo < (uint32_t)ncols ? 0x0000ffffu : 0u) | ((uint32_t)jHi < (uint32_t)ncols ? 0xffff0000u : 0u);
         const uint32_t cmv = cm & vm;
@@ -189,22 +190,42 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
             colLo = (ch & 0xffffu) ? jLo : colLo;
             colHi = (ch >> 16) ? jHi : colHi;
 #pragma unroll
-            for (int k = 0; k < RV; ++k) SH[k] = (Hp[k] & m) | (SH[k] & ~m);
+            for (int k = 0; k < RV; ++k) SH[k] = (HW[k] & m) | (SH[k] & ~m);
         }
         if (!WORD) {
-            if (__builtin_amdgcn_ballot_w64((flags & 1u) != 0u)) {
-                PassOut o; o.max = 255; o.col = -1; o.row = 0; o.overflow = 1; o.term_col = -1;
-                return o;
-            }
+            if (__builtin_amdgcn_ballot_w64((flags & 1u) != 0u)) return 2;
         }
-        // ---- the last virtual lane has the finished column maximum of column t-127 -------------------------
+        // the last virtual lane has the finished column maximum of column t-127
         const int jl = t - 127;
-        if (jl >= 0) {
+        if (jl >= 0 && jl < ncols) {
             const int cmLast = (int)((uint32_t)__builtin_amdgcn_readlane((int)outM, 63) >> 16);
-            if (in.colmax && lane == 63) in.colmax[jl] = (uint16_t)cmLast;
-            if (cmLast == in.terminate) { term_col = jl; break; }
+            ring = lane == (t & 63) ? cmLast : ring;
+            if (cmLast == in.terminate) { term_col = jl; return 1; }
+        }
+        return 0;
+    };
+
+    // 64 steps per block: the block's reference bases were loaded one block earlier (lane i <-> step t0+i) and
+    // its finished column maxima leave through one coalesced store per block; no vector-memory op inside.
+    int nxt = load_chunk(0);
+    for (int t0 = 0; t0 < nsteps && !stop; t0 += 64) {
+        int chunk = nxt;
+        asm volatile("" : "+v"(chunk));      // the wait for last block's prefetch lands here, not inside the step loop
+        nxt = load_chunk(t0 + 64);
+        int ring = 0;
+        int done = 64;
+        for (int u = 0; u < 64; u += 2) {
+            int r = step(t0 + u, __builtin_amdgcn_readlane(chunk, u), HA, HB, ring);
+            if (r) { stop = r; done = u + 1; break; }
+            r = step(t0 + u + 1, __builtin_amdgcn_readlane(chunk, u + 1), HB, HA, ring);
+            if (r) { stop = r; done = u + 2; break; }
+        }
+        if (in.colmax) {
+            const int col = t0 - 127 + lane;
+            if (lane < done && col >= 0 && col < ncols) in.colmax[col] = (uint16_t)ring;
         }
     }
+    if (stop == 2) { PassOut o; o.max = 255; o.col = -1; o.row = 0; o.overflow = 1; o.term_col = -1; return o; }
 
     // ---- wave reduction: (score desc, column asc, virtual lane asc) ------------------------------------------
     const int exceeded = __builtin_amdgcn_ballot_w64((flags & 2u) != 0u) != 0;
@@ -267,12 +288,15 @@ __device__ void second_best(const uint16_t* colmax, int refLen, int end_ref, int
     ref_end2 = bv > 0 ? bp : 0;
 }
 
+// registers: ask for 4 waves/SIMD (<=128 VGPRs) while the per-lane state is small, fewer for the long-read classes
+constexpr int waves_per_simd(int rv) { return rv <= 8 ? 4 : (rv <= 12 ? 3 : (rv <= 16 ? 2 : 1)); }
+
 template <int RV, bool QUIRK>
-__global__ void __launch_bounds__(64) ssw_align_kernel(const SswParams p)
+__global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const SswParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* lds_prof = lds;
-    int* lds_mat = (int*)(lds + 6 * ((RV + 3) / 4) * 256);
+    int* lds_mat = (int*)(lds + (p.null_code + 1) * ((RV + 3) / 4) * 256);
     const int lane = threadIdx.x & 63;
     if (lane < 48) {   // 6 base codes x 8 query codes; anything outside the n x n matrix scores 0
         const int b = lane >> 3, q = lane & 7;
@@ -300,11 +324,11 @@ __global__ void __launch_bounds__(64) ssw_align_kernel(const SswParams p)
     in.colmax = colmax;
     while (regime < 0) {
         if (job_word) {
-            PassOut r = run_pass<RV, true, QUIRK>(in, lds_prof, lds_mat, gO, gE, 0);
+            PassOut r = run_pass<RV, true, QUIRK>(in, lds_prof, lds_mat, gO, gE, 0, p.null_code);
             if (p.score_size == 1 || byte_overflowed || r.max + bias >= 255) { fw = r; regime = 1; }
             else job_word = 0;
         } else {
-            PassOut r = run_pass<RV, false, false>(in, lds_prof, lds_mat, gO, gE, bias);
+            PassOut r = run_pass<RV, false, false>(in, lds_prof, lds_mat, gO, gE, bias, p.null_code);
             if (!r.overflow) { fw = r; regime = 0; }
             else if (p.score_size == 0) { res.status = CLH_STATUS_OVERFLOW8; if (lane == 0) p.results[task.out_index] = res; return; }
             else { byte_overflowed = true; job_word = 1; }
@@ -326,8 +350,8 @@ __global__ void __launch_bounds__(64) ssw_align_kernel(const SswParams p)
         rv.terminate = res.score1; rv.colmax = nullptr;
         PassOut r;
         for (;;) {
-            if (regime) r = run_pass<RV, true, QUIRK>(rv, lds_prof, lds_mat, gO, gE, 0);
-            else r = run_pass<RV, false, false>(rv, lds_prof, lds_mat, gO, gE, bias);
+            if (regime) r = run_pass<RV, true, QUIRK>(rv, lds_prof, lds_mat, gO, gE, 0, p.null_code);
+            else r = run_pass<RV, false, false>(rv, lds_prof, lds_mat, gO, gE, bias, p.null_code);
             if (r.max >= 0) break;
             rv.ncols = r.term_col + 1; rv.terminate = 1 << 30;     // see PassOut: rare re-run
         }
@@ -347,10 +371,11 @@ namespace clh {
 template <int RV, bool QUIRK>
 static hipError_t launch_one(const SswParams& p, int ntasks, hipStream_t stream)
 {
-    const size_t lds_bytes = (size_t)6 * ((RV + 3) / 4) * 1024 + 64 * sizeof(int);
+    const size_t lds_bytes = (size_t)(p.null_code + 1) * ((RV + 3) / 4) * 1024 + 64 * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ssw_align_kernel<RV, QUIRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)ssw_align_kernel<RV, QUIRK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           6 * ((RV + 3) / 4) * 1024 + 256);
         if (e != hipSuccess) return e;
         attr_set = true;
     }

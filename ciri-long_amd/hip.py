@@ -212,12 +212,12 @@ class Plan(object):
         return [(int(rv[k]), int(cnt[k]), int(rb[k]), int(fb[k])) for k in range(ns)]
 
     def timing(self):
-        """[(K1 ms, K1b ms)] per segment for the last run (needs set_profiling before run)"""
-        a = np.zeros(32, dtype=np.float32); b = np.zeros(32, dtype=np.float32)
+        """([K1 ms per segment], (K1b small-window ms, K1b large-window ms)) for the last run"""
+        a = np.zeros(32, dtype=np.float32); b = np.zeros(2, dtype=np.float32)
         ns = lib().clh_plan_timing(self._h, 32, a.ctypes.data, b.ctypes.data)
         if ns < 0:
             raise ClhError('clh_plan_timing: %s' % last_error())
-        return [(float(a[k]), float(b[k])) for k in range(ns)]
+        return [float(a[k]) for k in range(ns)], (float(b[0]), float(b[1]))
 
     def results_dev_ptr(self):
         return lib().clh_ssw_results_dev(self._h)

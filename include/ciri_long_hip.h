@@ -94,7 +94,8 @@ int clh_ssw_fetch(clh_plan* plan, clh_align_t* out, uint32_t* cigar_buf, int64_t
 const void* clh_ssw_results_dev(const clh_plan* plan);
 
 /* Measurement hooks (bench.py): per launch-segment (one read-length class each) HIP-event durations of the score
- * kernel (K1) and the traceback kernel (K1b) of the last run.  Both return the number of segments. */
+ * kernel (K1), and of the traceback kernel (K1b): k1b_ms[0] = the small-window launch over all alignments,
+ * k1b_ms[1] = the large-window launches that redo the outliers.  Both return the number of segments. */
 int clh_plan_set_profiling(clh_plan* plan, int on);
 int clh_plan_segments(const clh_plan* plan, int32_t cap, int32_t* rv, int32_t* count, int64_t* read_bases, int64_t* ref_bases);
 int clh_plan_timing(clh_plan* plan, int32_t cap, float* k1_ms, float* k1b_ms);

@@ -266,18 +266,22 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         pl->ev.resize(pl->segs.size() * 2 + 4);
         for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
     }
-    // K1: one launch per read-length class.  Classes are independent, so outside profiling runs they go round-robin to
-    // the caller's stream and three side streams (fork/join with events) and the tail of one class overlaps the next.
+    // One launch per read-length class for K1, followed on the same stream by that class's small-window traceback.
+    // Classes are independent, so outside profiling runs they go round-robin to the caller's stream and three side
+    // streams (fork/join with events): the tail of one class overlaps the next, and the latency-bound traceback of
+    // one class overlaps the VALU-bound score kernel of another.
     clh_ctx* c = pl->ctx;
+    const bool tb = pl->do_cigar && pl->n > 0;
     const bool fan = !pl->profiling && pl->segs.size() > 1;
+    const size_t eb = pl->segs.size() * 2;
+    if (tb) HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 8, st));
     if (fan) {
         HIPCHK(hipEventRecord(c->fork_ev, st));
         for (int i = 0; i < 3; ++i) HIPCHK(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
     }
-    // heaviest class first
     std::vector<size_t> ord(pl->segs.size());
     for (size_t k = 0; k < ord.size(); ++k) ord[k] = k;
-    std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return pl->segs[x].count > pl->segs[y].count; });
+    std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return pl->segs[x].count > pl->segs[y].count; });   // heaviest first
     for (size_t q = 0; q < ord.size(); ++q) {
         const size_t k = ord[q];
         const auto& s = pl->segs[k];
@@ -286,26 +290,28 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], ls));
         HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], ls));
+        if (tb && !pl->profiling)
+            HIPCHK(clh::launch_traceback_pool(0, P, s.count, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, ls));
     }
     if (fan)
         for (int i = 0; i < 3; ++i) {
             HIPCHK(hipEventRecord(c->join_ev[i], c->side[i]));
             HIPCHK(hipStreamWaitEvent(st, c->join_ev[i], 0));
         }
-    if (pl->do_cigar && pl->n > 0) {
-        HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 8, st));
-        // first attempt: every alignment, small LDS window; then per read-length class the few that outgrew it
+    if (tb) {
         P.tasks = (const clh::SswTask*)pl->d_tasks;
-        const size_t eb = pl->segs.size() * 2;
-        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[eb + 0], st));
-        HIPCHK(clh::launch_traceback_pool(0, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
-        if (pl->profiling) { HIPCHK(hipEventRecord(pl->ev[eb + 1], st)); HIPCHK(hipEventRecord(pl->ev[eb + 2], st)); }
-        {   // one launch sized for the longest read class; workgroups of unmarked alignments return at once
-            int rvmax = 1;
-            for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv);
-            if (rvmax > 4)   // below that the small window (514 rows) already covers every read
-                HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+        if (pl->profiling) {   // profiling runs keep the two traceback phases as separate, serial launches
+            HIPCHK(hipEventRecord(pl->ev[eb + 0], st));
+            HIPCHK(clh::launch_traceback_pool(0, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+            HIPCHK(hipEventRecord(pl->ev[eb + 1], st));
+            HIPCHK(hipEventRecord(pl->ev[eb + 2], st));
         }
+        // alignments whose band outgrew the small window: one launch sized for the longest read class; workgroups of
+        // unmarked alignments return at once
+        int rvmax = 1;
+        for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv);
+        if (rvmax > 4)   // below that the small window (514 rows) already covers every read
+            HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[eb + 3], st));
     }
     pl->last_stream = st;

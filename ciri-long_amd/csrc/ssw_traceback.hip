@@ -41,15 +41,31 @@ __device__ __forceinline__ int wave_max(int v)
 
 // first row of anti-diagonal a inside the band: ceil((a - w) / 2), not clamped
 __device__ __forceinline__ int ad_first_row(int a, int w) { int t = a - w; return t >= 0 ? (t + 1) >> 1 : -((-t) >> 1); }
+// storage of one band iteration: anti-diagonal a holds its active rows [ad_lo, ...] in ad_stride consecutive bytes.
+// Both are independent of w once the band covers the whole matrix, so such iterations share one copy.
+__device__ __forceinline__ int ad_lo(int a, int w, int refLen)
+{
+    int lo = ad_first_row(a, w);
+    if (lo < 0) lo = 0;
+    const int t = a - (refLen - 1);
+    return lo < t ? t : lo;
+}
+__device__ __forceinline__ int ad_stride(int w, int readLen, int refLen)
+{
+    int s = w + 1;
+    if (s > readLen) s = readLen;
+    return s > refLen ? refLen : s;
+}
 
 // big = 0: first attempt with a small LDS window (high occupancy); alignments whose band outgrows it are marked
 // CLH_STATUS_NEED_BIG.  big = 1: only the marked ones, with a window sized for the launch's read-length class.
-__global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp, int big)
+__global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp, int big, int seq_cap)
 {
     extern __shared__ __attribute__((aligned(16))) short tb_lds[];
     short* const H0 = tb_lds;                 // H[3][ws]
     short* const E0 = tb_lds + 3 * ws;        // E[2][ws]
     short* const F0 = tb_lds + 5 * ws;        // F[2][ws]
+    int8_t* const sseq = (int8_t*)(tb_lds + 7 * ws);   // read then reference codes of the aligned region, if they fit
     __shared__ uint8_t stage[64 * 66];
     __shared__ int smat[32];
     __shared__ unsigned long long hist_at[24];   // every band iteration keeps its direction bytes (see hist_lookup)
@@ -82,32 +98,55 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     const int8_t* read = p.reads + task.read_off + res.read_begin1;
     const int refLen = res.ref_end1 - res.ref_begin1 + 1, readLen = res.read_end1 - res.read_begin1 + 1;
     const int score = res.score1, gO = p.gapO, gE = p.gapE, n = p.n;
+    // the DP touches read[i] and ref[j] once per cell: both are staged in LDS.  A vector-memory LOAD inside the loop
+    // would force s_waitcnt vmcnt(0), which also waits for the previous step's direction store (an HBM round trip per
+    // anti-diagonal); with LDS-only reads the stores are fire-and-forget.
+    if (readLen + refLen > seq_cap) {   // does not fit this launch's LDS: retry in the large configuration, or give up
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | (big ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG); }
+        return;
+    }
+    for (int k = lane; k < readLen; k += 64) sseq[k] = read[k];
+    for (int k = lane; k < refLen; k += 64) sseq[readLen + k] = ref[k];
+    __syncthreads();
+    const int8_t* const sread = sseq;
+    const int8_t* const sref = sseq + readLen;
     int w = refLen > readLen ? refLen - readLen : readLen - refLen;
     w += 1;
     const int nAD = readLen + refLen - 1;
     int maxv = 0;
     uint8_t* dir = nullptr;
     int status = 0, niter = 0;
+    bool covered = false;
+    unsigned long long last_at = 0;
 
     for (;;) {
+        const int stride_w = ad_stride(w, readLen, refLen);
+        if (covered) {
+            // the previous iteration's band already held every cell: this one would recompute identical values into an
+            // identical layout (the reference does recompute; only its flat indexing, i.e. w, differs)
+            if (lane == 0 && niter < 24) { hist_at[niter] = last_at; hist_w[niter] = w; }
+            ++niter;
+            w *= 2;
+            if (!(maxv < score && w < 2 * readLen)) break;
+            continue;
+        }
         const bool ring = w + 3 <= wsp;   // the active rows of an anti-diagonal span <= w+1 rows
         if (!ring && readLen + 1 > ws) { status = big ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG; break; }
         const int imask = ring ? wsp - 1 : -1;
-        unsigned long long need = ((unsigned long long)nAD * (unsigned long long)(w + 1) + 63ull) & ~63ull;
+        unsigned long long need = ((unsigned long long)nAD * (unsigned long long)stride_w + 63ull) & ~63ull;
         unsigned long long at = 0;
         if (lane == 0) at = atomicAdd(pool.head, need);
         at = __shfl(at, 0);
         if (at + need > pool.size) { status = CLH_STATUS_CIGAR_TRUNC; break; }
         dir = pool.base + at;
+        last_at = at;
         if (lane == 0 && niter < 24) { hist_at[niter] = at; hist_w[niter] = w; }
         ++niter;
+        covered = w >= readLen && w >= refLen;
         int itmax = 0;
         for (int a = 0; a < nAD; ++a) {
             const int cur = a % 3, p1 = (a + 2) % 3, p2 = (a + 1) % 3, e0 = a & 1, e1 = e0 ^ 1;
-            int ilo = ad_first_row(a, w);
-            const int band_lo = ilo;
-            if (ilo < 0) ilo = 0;
-            if (ilo < a - (refLen - 1)) ilo = a - (refLen - 1);
+            const int ilo = ad_lo(a, w, refLen);
             int ihi = (a + w) >> 1;
             if (ihi > readLen - 1) ihi = readLen - 1;
             if (ihi > a) ihi = a;
@@ -132,12 +171,12 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
                     const int df = t1 > t2 ? 5 : 4;
                     const int e1v = e > 0 ? e : 0, f1v = f > 0 ? f : 0;
                     t1 = e1v > f1v ? e1v : f1v;
-                    t2 = hd + smat[(int)ref[j] * n + (int)read[i]];
+                    t2 = hd + smat[(int)sref[j] * n + (int)sread[i]];
                     const int h = t1 > t2 ? t1 : t2;
                     const int dh = t1 <= t2 ? 1 : (e1v > f1v ? de : df);
                     itmax = h > itmax ? h : itmax;
                     H0[cur * ws + m] = (short)h; E0[e0 * ws + m] = (short)e; F0[e0 * ws + m] = (short)f;
-                    dir[(size_t)a * (w + 1) + (i - band_lo)] = (uint8_t)(dh | (de == 3 ? 8 : 0) | (df == 5 ? 16 : 0));
+                    dir[(size_t)a * stride_w + (i - ilo)] = (uint8_t)(dh | (de == 3 ? 8 : 0) | (df == 5 ? 16 : 0));
                 }
             }
             // one wave per workgroup: LDS operations of a wave execute in order, so the next anti-diagonal's reads see
@@ -165,7 +204,7 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     // uninitialised memory in the reference; those end in CLH_STATUS_TRACE_ERR here.
     int i = readLen - 1, j = refLen - 1, state = 2, run = 0, nops = 0, fail = 0;
     int op = 0, prev_op = 0;             // 0 M, 1 I, 2 D
-    const int stride = w + 1;
+    const int stride = ad_stride(w, readLen, refLen);
     const int srow = stride < 66 ? stride : 0;      // staging only when an anti-diagonal fits 66 bytes
     int staged_lo = 1 << 30, staged_hi = -1;
     const long long wd_final = 2ll * w + 1;
@@ -173,7 +212,7 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
         int code = 0;
         if (j >= 0 && j <= i + w && j >= i - w && j < refLen) {
             const int a = i + j;
-            const int slot = i - ad_first_row(a, w);
+            const int slot = i - ad_lo(a, w, refLen);
             if (srow) {
                 if (a < staged_lo || a > staged_hi) {
                     staged_hi = a; staged_lo = a - 63 > 0 ? a - 63 : 0;
@@ -199,7 +238,7 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
                     const long long endk = ii + wk < refLen - 1 ? ii + wk : refLen - 1;
                     if (jj > endk) continue;
                     const int a = (int)(ii + jj);
-                    code = pool.base[hist_at[k] + (size_t)a * (size_t)(wk + 1) + (size_t)(ii - ad_first_row(a, (int)wk))];
+                    code = pool.base[hist_at[k] + (size_t)a * (size_t)ad_stride((int)wk, readLen, refLen) + (size_t)(ii - ad_lo(a, (int)wk, refLen))];
                     break;
                 }
             }
@@ -256,8 +295,9 @@ hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t
     const int ws = rv > 0 ? 128 * rv + 2 : 514;
     int wsp = 1;
     while (wsp * 2 <= ws) wsp *= 2;
-    const size_t lds = (size_t)7 * ws * sizeof(short);
-    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(ntasks), dim3(64), lds, stream, p, pool, ws, wsp, rv > 0 ? 1 : 0);
+    const int seq_cap = rv > 0 ? 128 * rv * 3 + 64 : 6144;
+    const size_t lds = (size_t)7 * ws * sizeof(short) + (size_t)seq_cap;
+    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(ntasks), dim3(64), lds, stream, p, pool, ws, wsp, rv > 0 ? 1 : 0, seq_cap);
     return hipGetLastError();
 }
 

@@ -68,16 +68,20 @@ struct PassIn {
     uint16_t* colmax;     // per-column maxima in processing order, or nullptr
 };
 
-// One pass.  RV = rows per virtual lane (capacity 128*RV rows).  WORD selects the row padding (8 vs 16) and
-// QUIRK the truncated vertical gaps of the 16-bit pass when gapO <= gapE (rowmajor_spec.c).
+// One pass.  RV = rows per virtual lane (capacity 128*RV rows).  WORD selects the row padding (8 vs 16).
+// GEQ = (gapO == gapE) (gapO < gapE is rejected by the host).  Two consequences of GEQ:
+//   * the 16-bit pass truncates vertical gaps at stripe starts (QUIRK, rowmajor_spec.c);
+//   * H >= E and H >= F always, so E' = max(E-g, H-g) = H-g = F': both gap states collapse into one saturating
+//     subtract per cell pair, 4 packed ops fewer (CIRI-long's call path scores 1/1/1/1, find_bsj.py:204).
 // null_code: base code used for pipeline fill/drain columns; it must score 0 against every row.  5 (an extra
 // profile row) in general, 4 when the matrix already scores code 4 ("N") as 0 everywhere, as CIRI-long's do
 // (ssw_wrap.py:154-159) -- that saves one sixth of the LDS footprint.
-template <int RV, bool WORD, bool QUIRK>
+template <int RV, bool WORD, bool GEQ>
 __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, const int* __restrict__ lds_mat,
                             int gapO, int gapE, int bias, const int null_code)
 {
     const int CODE_NULL = null_code;
+    constexpr bool QUIRK = WORD && GEQ;
     constexpr int CH = (RV + 3) / 4;             // 16-byte chunks of profile per lane and base
     constexpr int BASE_STRIDE = CH * 1024;       // bytes between two bases' profiles
     const int lane = threadIdx.x & 63;
@@ -85,7 +89,6 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
     const int S = (in.L + W - 1) / W;
     const int rows = S * W;
     const int off = 128 * RV - rows;             // leading dummy slots
-    const bool quirk = QUIRK && WORD;
 
     // ---- query profile, lane-private rows in LDS: prof[base][chunk][lane][4] -------------------------------
     uint32_t cut[QUIRK ? RV : 1];
@@ -104,8 +107,8 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
         }
         if (QUIRK) {
             uint32_t m = 0xffffffffu;
-            if (quirk && rlo > 0 && rlo % S == 0) m &= 0xffff0000u;
-            if (quirk && rhi > 0 && rhi % S == 0) m &= 0x0000ffffu;
+            if (rlo > 0 && rlo % S == 0) m &= 0xffff0000u;
+            if (rhi > 0 && rhi % S == 0) m &= 0x0000ffffu;
             cut[k] = m;
         }
     }
@@ -157,9 +160,13 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
                         const uint32_t Fm = F & cut[k];
                         h = pk_max(pk_max(tt, E[k]), Fm);
                         HW[k] = pk_max(h, F);
-                        const uint32_t hg = pk_subus(h, gO2);
-                        E[k] = pk_max(pk_subus(E[k], gE2), hg);
-                        F = pk_max(pk_subus(Fm, gE2), hg);
+                        F = pk_subus(h, gO2);
+                        E[k] = F;
+                    } else if (GEQ) {
+                        h = pk_max(pk_max(tt, E[k]), F);
+                        HW[k] = h;
+                        F = pk_subus(h, gO2);
+                        E[k] = F;
                     } else {
                         h = pk_max(pk_max(tt, E[k]), F);
                         HW[k] = h;
@@ -288,10 +295,10 @@ __device__ void second_best(const uint16_t* colmax, int refLen, int end_ref, int
     ref_end2 = bv > 0 ? bp : 0;
 }
 
-// registers: ask for 4 waves/SIMD (<=128 VGPRs) while the per-lane state is small, fewer for the long-read classes
-constexpr int waves_per_simd(int rv) { return rv <= 8 ? 4 : (rv <= 12 ? 3 : (rv <= 16 ? 2 : 1)); }
+// half-rate packed ops keep a SIMD busy with two waves; asking for more only causes spills
+constexpr int waves_per_simd(int rv) { return rv <= 12 ? 3 : (rv <= 16 ? 2 : 1); }
 
-template <int RV, bool QUIRK>
+template <int RV, bool GEQ>
 __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const SswParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -324,11 +331,11 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
     in.colmax = colmax;
     while (regime < 0) {
         if (job_word) {
-            PassOut r = run_pass<RV, true, QUIRK>(in, lds_prof, lds_mat, gO, gE, 0, p.null_code);
+            PassOut r = run_pass<RV, true, GEQ>(in, lds_prof, lds_mat, gO, gE, 0, p.null_code);
             if (p.score_size == 1 || byte_overflowed || r.max + bias >= 255) { fw = r; regime = 1; }
             else job_word = 0;
         } else {
-            PassOut r = run_pass<RV, false, false>(in, lds_prof, lds_mat, gO, gE, bias, p.null_code);
+            PassOut r = run_pass<RV, false, GEQ>(in, lds_prof, lds_mat, gO, gE, bias, p.null_code);
             if (!r.overflow) { fw = r; regime = 0; }
             else if (p.score_size == 0) { res.status = CLH_STATUS_OVERFLOW8; if (lane == 0) p.results[task.out_index] = res; return; }
             else { byte_overflowed = true; job_word = 1; }
@@ -350,8 +357,8 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
         rv.terminate = res.score1; rv.colmax = nullptr;
         PassOut r;
         for (;;) {
-            if (regime) r = run_pass<RV, true, QUIRK>(rv, lds_prof, lds_mat, gO, gE, 0, p.null_code);
-            else r = run_pass<RV, false, false>(rv, lds_prof, lds_mat, gO, gE, bias, p.null_code);
+            if (regime) r = run_pass<RV, true, GEQ>(rv, lds_prof, lds_mat, gO, gE, 0, p.null_code);
+            else r = run_pass<RV, false, GEQ>(rv, lds_prof, lds_mat, gO, gE, bias, p.null_code);
             if (r.max >= 0) break;
             rv.ncols = r.term_col + 1; rv.terminate = 1 << 30;     // see PassOut: rare re-run
         }
@@ -368,26 +375,26 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
 // -------------------------------------------------------------------------------------------------------------
 namespace clh {
 
-template <int RV, bool QUIRK>
+template <int RV, bool GEQ>
 static hipError_t launch_one(const SswParams& p, int ntasks, hipStream_t stream)
 {
     const size_t lds_bytes = (size_t)(p.null_code + 1) * ((RV + 3) / 4) * 1024 + 64 * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ssw_align_kernel<RV, QUIRK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)ssw_align_kernel<RV, GEQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            6 * ((RV + 3) / 4) * 1024 + 256);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((ssw_align_kernel<RV, QUIRK>), dim3(ntasks), dim3(64), lds_bytes, stream, p);
+    hipLaunchKernelGGL((ssw_align_kernel<RV, GEQ>), dim3(ntasks), dim3(64), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
-template <bool QUIRK>
+template <bool GEQ>
 static hipError_t launch_rv(int rv, const SswParams& p, int ntasks, hipStream_t stream)
 {
     switch (rv) {
-#define CLH_CASE(R) case R: return launch_one<R, QUIRK>(p, ntasks, stream);
+#define CLH_CASE(R) case R: return launch_one<R, GEQ>(p, ntasks, stream);
 #ifdef CLH_PROBE_BUILD
         CLH_CASE(8)
 #else
@@ -402,9 +409,9 @@ static hipError_t launch_rv(int rv, const SswParams& p, int ntasks, hipStream_t 
 const int kRvClasses[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32};
 const int kNumRvClasses = sizeof(kRvClasses) / sizeof(kRvClasses[0]);
 
-hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStream_t stream)
+hipError_t launch_ssw(int rv, bool geq, const SswParams& p, int ntasks, hipStream_t stream)
 {
-    return quirk ? launch_rv<true>(rv, p, ntasks, stream) : launch_rv<false>(rv, p, ntasks, stream);
+    return geq ? launch_rv<true>(rv, p, ntasks, stream) : launch_rv<false>(rv, p, ntasks, stream);
 }
 
 }  // namespace clh

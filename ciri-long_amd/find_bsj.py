@@ -1,0 +1,277 @@
+"""Back-splice-junction calling for cyclic consensus reads (counterpart of CIRI_long/find_bsj.py:139-490).
+
+Same functions and signatures as the reference (``find_bsj``, ``align_clip_segments``, ``scan_ccs_chunk``,
+``scan_ccs_reads``, ``recover_ccs_chunk``, ``recover_ccs_reads``).  What changes is the shape of the work: the reference
+aligns clipped bases read by read inside the chunk loop (one ctypes round trip each, find_bsj.py:203-216); here a chunk is
+processed in three phases -- (1) mapper-dependent filtering per read, which also collects the clip-vs-window pairs that
+need Smith-Waterman, (2) ONE batched call into the HIP kernels for the whole chunk, (3) coordinate arithmetic, splice
+signal search and record assembly per read -- with identical outputs in identical order.
+
+The mapper stays external and pluggable: ``env.ALIGNER.map(seq)`` (mappy, bwapy adaptor, or a test double).
+"""
+from collections import defaultdict
+
+from . import env
+from .align import (find_annotated_signal, find_denovo_signal, find_host_gene, get_blocks, get_primary_alignment,
+                    merge_clip_exon)
+from .utils import grouper, revcomp
+
+CLIP_MIN = 20            # find_bsj.py:191
+CLIP_MAX_FRACTION = 0.6  # find_bsj.py:193
+WINDOW_FLANK = 200000    # find_bsj.py:196-197
+WINDOW_MAX_N = 0.3       # find_bsj.py:200
+
+
+def find_bsj(ccs):
+    """Rotate the consensus until the mapper's primary hit stops improving (find_bsj.py:139-179).
+    Returns (rotated sequence, junction offset on ccs) or (None, None)."""
+    n = len(ccs)
+    first = get_primary_alignment(env.ALIGNER.map(ccs * 2))
+    if first is None:
+        return None, None
+
+    junc = first.q_st % n
+    best_junc, best_mlen = 0, 0
+    visited = set()
+    while True:
+        circ = ccs[junc:] + ccs[:junc]
+        hit = get_primary_alignment(env.ALIGNER.map(circ))
+        if hit is None or hit.mlen <= best_mlen:
+            junc = best_junc
+            break
+        best_mlen, best_junc = hit.mlen, junc
+        head_clip, tail_clip = hit.q_st, n - hit.q_en
+        if head_clip == 0 and tail_clip == 0:
+            break
+        # move the junction past the larger clip
+        junc = (junc + (head_clip if head_clip >= tail_clip else hit.q_en)) % n
+        if junc in visited:
+            junc = best_junc
+            break
+        visited.add(junc)
+    return ccs[junc:] + ccs[:junc], junc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# clipped bases: decide, batch, finish
+# ---------------------------------------------------------------------------------------------------------------
+class _ClipJob(object):
+    """One pending Smith-Waterman of clipped bases against the genomic window around the hit."""
+    __slots__ = ('circ', 'hit', 'clip_seq', 'window', 'win_start', 'win_end')
+
+    def __init__(self, circ, hit, clip_seq, window, win_start, win_end):
+        self.circ, self.hit, self.clip_seq = circ, hit, clip_seq
+        self.window, self.win_start, self.win_end = window, win_start, win_end
+
+
+_REJECT = (None, None, None, None)
+
+
+def _clip_prepare(circ, hit):
+    """Everything of align_clip_segments that precedes the alignment (find_bsj.py:189-201, 227-231).
+    Returns a finished 4-tuple, or a _ClipJob when Smith-Waterman is needed."""
+    head_clip, tail_clip = hit.q_st, len(circ) - hit.q_en
+    if head_clip + tail_clip < CLIP_MIN:
+        return (circ[hit.q_st:] + circ[:hit.q_st], hit.r_st - 1, hit.r_en, (None, None, head_clip + tail_clip))
+    clip_seq = circ[hit.q_en:] + circ[:hit.q_st]
+    if len(clip_seq) > CLIP_MAX_FRACTION * len(circ):
+        return _REJECT
+    win_start = max(hit.r_st - WINDOW_FLANK, 0)
+    win_end = min(hit.r_en + WINDOW_FLANK, env.CONTIG_LEN[hit.ctg])
+    window = env.GENOME.seq(hit.ctg, win_start, win_end)
+    if window.count('N') >= WINDOW_MAX_N * (win_end - win_start):
+        return _REJECT
+    # minus-strand hits are aligned against the reverse-complemented window (find_bsj.py:213-216)
+    return _ClipJob(circ, hit, clip_seq, window if hit.strand > 0 else revcomp(window), win_start, win_end)
+
+
+def _clip_finish(job, res):
+    """Coordinates and rotation from the alignment result (find_bsj.py:205-226)."""
+    circ, hit, clip_seq = job.circ, job.hit, job.clip_seq
+    if hit.strand > 0:
+        clip_r_st, clip_r_en = job.win_start + res.ref_begin, job.win_start + res.ref_end
+        rotate = clip_r_st < hit.r_st
+    else:
+        clip_r_st, clip_r_en = job.win_end - res.ref_end, job.win_end - res.ref_begin
+        rotate = clip_r_en > hit.r_en
+    if rotate:
+        clipped = clip_seq[res.query_begin:] + circ[hit.q_st:hit.q_en] + clip_seq[:res.query_begin]
+    else:
+        clipped = circ[hit.q_st:] + circ[:hit.q_st]
+    clip_base = hit.q_st + len(circ) - hit.q_en - (res.query_end - res.query_begin) + 1
+    return clipped, min(hit.r_st, clip_r_st) - 1, max(hit.r_en, clip_r_en), (clip_r_st, clip_r_en, clip_base)
+
+
+def _run_clip_jobs(jobs):
+    """Phase 2: all pending clip alignments of a chunk in ONE GPU call (scoring 1/1/1/1, find_bsj.py:204,214)."""
+    if not jobs:
+        return []
+    from .ssw_wrap import align_pairs
+    res = align_pairs([j.window for j in jobs], [j.clip_seq for j in jobs], match=1, mismatch=1, gap_open=1, gap_extend=1)
+    for r in res:
+        if r is None:   # the reference dereferences None here (find_bsj.py:206); make the failure explicit
+            raise RuntimeError('Smith-Waterman of clipped bases returned no result')
+    return res
+
+
+def align_clip_segments(circ, hit):
+    """(clipped_circ, circ_start, circ_end, (clip_r_st, clip_r_en, clip_base)) or four Nones (find_bsj.py:182-233)."""
+    job = _clip_prepare(circ, hit)
+    if not isinstance(job, _ClipJob):
+        return job
+    return _clip_finish(job, _run_clip_jobs([job])[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# chunk workers
+# ---------------------------------------------------------------------------------------------------------------
+def _segment_span(segments):
+    parts = segments.split(';')
+    return int(parts[0].split('-')[0]), int(parts[-1].split('-')[1])
+
+
+def _assemble(read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_start, circ_end, clip_info, reads_cnt):
+    """Phase 3 for one read: splice signal, coordinates, exon tags, sequence rotation (find_bsj.py:279-323)."""
+    clip_base = clip_info[2]
+    if clip_base > 0.15 * len(ccs) or clip_base > 20:
+        return None
+    reads_cnt['bsj'] += 1
+
+    host_strand = find_host_gene(circ_hit.ctg, circ_start, circ_end)
+    ss_site, us_free, ds_free, tmp_signal = find_annotated_signal(circ_hit.ctg, circ_start, circ_end, clip_base, clip_base + 10)
+    if ss_site is None:
+        ss_site = find_denovo_signal(circ_hit.ctg, circ_start, circ_end, host_strand, tmp_signal, us_free, ds_free,
+                                     clip_base, clip_base + 10, 3, True)
+    if ss_site is None:
+        ss_id, strand, shift = 'NA', 'NA', 0
+    else:
+        reads_cnt['signal'] += 1
+        ss_id, strand, us_shift, ds_shift = ss_site
+        circ_start += us_shift
+        circ_end += ds_shift
+        shift = min(max(us_shift, us_free), ds_free)
+
+    exons = merge_clip_exon(get_blocks(circ_hit), clip_info)
+    exons[0][0] = circ_start
+    exons[-1][1] = circ_end
+    exon_tag = ','.join('{}-{}|{}'.format(st + 1, en, length) for st, en, length in exons)
+
+    seq = clipped_circ if circ_hit.strand > 0 else revcomp(clipped_circ)
+    seq = seq[shift:] + seq[:shift]           # BSJ correction for the 5' region
+    return (read_id, '{}:{}-{}'.format(circ_hit.ctg, circ_start + 1, circ_end), strand, exon_tag, ss_id,
+            '{}|{}-{}'.format(junc, clip_base, len(circ)), segments, seq)
+
+
+def _scan_chunk(chunk, raw_filters, min_circ_fraction):
+    reads_cnt = defaultdict(int)
+    short_reads = []
+    pending = []          # (read fields..., prepared clip result or job) in input order
+    jobs = []
+    for read_id, segments, ccs, raw in chunk:
+        seg_st, seg_en = _segment_span(segments)
+        if raw_filters:
+            # filter 1: reads that map linearly over (almost) their whole length are not circular (find_bsj.py:243-247)
+            raw_hit = get_primary_alignment(env.ALIGNER.map(raw))
+            if raw_hit and raw_hit.mlen > max(len(raw) * 0.8, len(raw) - 200):
+                continue
+            if raw_hit and raw_hit.mlen > 1.5 * len(ccs):
+                continue
+            reads_cnt['raw_unmapped'] += 1
+            # filter 2: the raw hit must touch the repeat region (find_bsj.py:254-257)
+            if raw_hit and (raw_hit.q_en < seg_st or raw_hit.q_st > seg_en):
+                continue
+        ccs_hit = get_primary_alignment(env.ALIGNER.map(ccs * 2))
+        if raw_filters and ccs_hit is None and len(ccs) < 150:
+            short_reads.append((read_id, segments, ccs, raw))
+        if ccs_hit is None or seg_en - seg_st < ccs_hit.q_en - ccs_hit.q_st:
+            continue
+        reads_cnt['ccs_mapped'] += 1
+
+        circ, junc = find_bsj(ccs)
+        circ_hit = get_primary_alignment(env.ALIGNER.map(circ))
+        if circ_hit is None or (min_circ_fraction and circ_hit.mlen < min_circ_fraction * len(circ)):
+            continue
+        prep = _clip_prepare(circ, circ_hit)
+        if isinstance(prep, _ClipJob):
+            jobs.append(prep)
+        pending.append((read_id, segments, ccs, circ, junc, circ_hit, prep))
+
+    results = iter(_run_clip_jobs(jobs))
+    ret = []
+    for read_id, segments, ccs, circ, junc, circ_hit, prep in pending:
+        if isinstance(prep, _ClipJob):
+            prep = _clip_finish(prep, next(results))
+        clipped_circ, circ_start, circ_end, clip_info = prep
+        if circ_start is None or circ_end is None:
+            continue
+        rec = _assemble(read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_start, circ_end, clip_info, reads_cnt)
+        if rec is not None:
+            ret.append(rec)
+    return reads_cnt, short_reads, ret
+
+
+def scan_ccs_chunk(chunk, is_canonical):
+    """One chunk of (read_id, segments, ccs, raw) -> (counters, short reads for the bwa pass, records)
+    (find_bsj.py:236-325)."""
+    return _scan_chunk(chunk, raw_filters=True, min_circ_fraction=0.75)
+
+
+def recover_ccs_chunk(chunk, is_canonical):
+    """Second pass over short consensus reads: no raw-read filters, no 0.75 coverage test (find_bsj.py:375-448)."""
+    reads_cnt, _short, ret = _scan_chunk(chunk, raw_filters=False, min_circ_fraction=0)
+    return reads_cnt, ret
+
+
+def _write_records(out, records):
+    for rec in records:
+        out.write('>{}\t{}\t{}\t{}\t{}\t{}\t{}\n{}\n'.format(*rec))
+
+
+def scan_ccs_reads(ccs_seq, ref_fasta, ss_index, gtf_index, intron_index, is_canonical, out_dir, prefix, threads,
+                   aligner=None, genome=None, contig_len=None):
+    """Stage driver (find_bsj.py:328-372).  The reference forks a process pool per stage; here the calling process
+    (one per GPU) walks the chunks itself.  ``aligner``/``genome``/``contig_len`` may be injected (tests, or an already
+    built index); by default a mappy splice-preset aligner is built from ``ref_fasta`` exactly as the reference does."""
+    if aligner is None:
+        import mappy as mp
+        aligner = mp.Aligner(ref_fasta, n_threads=threads, preset='splice')
+    if genome is None:
+        genome = aligner
+    if contig_len is None:
+        from .align import Fasta
+        contig_len = Fasta(ref_fasta).contig_len
+    env.initializer(aligner, contig_len, genome, gtf_index, intron_index, ss_index)
+
+    reads_count = defaultdict(int)
+    short_reads = []
+    with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'w') as out:
+        for reads in grouper(list(ccs_seq), 250):
+            chunk = [[i, ] + ccs_seq[i] for i in reads if i is not None]
+            cnt, short, ret = scan_ccs_chunk(chunk, is_canonical)
+            for key, value in cnt.items():
+                reads_count[key] += value
+            short_reads += short
+            _write_records(out, ret)
+    return reads_count, short_reads
+
+
+def recover_ccs_reads(short_reads, ref_fasta, ss_index, gtf_index, intron_index, is_canonical, out_dir, prefix, threads,
+                      aligner=None, genome=None):
+    """bwa pass over the short consensus reads, appended to the same output (find_bsj.py:451-490)."""
+    from .align import Aligner, Fasta
+    if genome is None:
+        genome = Fasta(ref_fasta)
+    if aligner is None:
+        from bwapy import BwaAligner
+        aligner = Aligner(BwaAligner(ref_fasta, options='-x ont2d -T 19'))
+    env.initializer(aligner, genome.contig_len, genome, gtf_index, intron_index, ss_index)
+
+    reads_count = defaultdict(int)
+    with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'a') as out:
+        for reads in grouper(short_reads, 250):
+            chunk = [i for i in reads if i is not None]
+            cnt, ret = recover_ccs_chunk(chunk, is_canonical)
+            for key, value in cnt.items():
+                reads_count[key] += value
+            _write_records(out, ret)
+    return reads_count

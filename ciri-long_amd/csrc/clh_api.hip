@@ -530,3 +530,170 @@ extern "C" char cigar_int_to_op(uint32_t cigar_int)
 }
 
 extern "C" uint32_t cigar_int_to_len(uint32_t cigar_int) { return cigar_int >> 4; }
+
+// ------------------------------------------------------------------------------------------------------------
+// cyclic consensus: find_consensus for a batch of reads (K2 + K3)
+// ------------------------------------------------------------------------------------------------------------
+struct clh_ccs_plan;
+static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off, int mcap_hint);
+extern "C" clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off) { return ccs_plan_create(ctx, n, read_off, 0); }
+
+struct clh_ccs_plan {
+    clh_ctx* ctx = nullptr;
+    int n = 0, lcap = 0, nslots = 0;
+    int64_t total = 0;
+    size_t slot_bytes = 0;
+    void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr,
+         *d_counter = nullptr, *d_order = nullptr, *d_reads = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool ran = false;
+};
+
+extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
+{
+    if (!pl) return;
+    (void)hipSetDevice(pl->ctx->device);
+    if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
+    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_counter, pl->d_order, pl->d_reads};
+    for (void* b : bufs) pl->ctx->release(b);
+    delete pl;
+}
+
+static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off, int mcap_hint)
+{
+    if (!ctx || n < 0 || !read_off) { fail(CLH_E_ARG, "clh_ccs_plan_create: null argument"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail(CLH_E_HIP, "hipSetDevice failed"); return nullptr; }
+    clh_ccs_plan* pl = new clh_ccs_plan();
+    pl->ctx = ctx; pl->n = n; pl->total = read_off[n];
+    int lmax = 1;
+    std::vector<int32_t> order(n);
+    for (int i = 0; i < n; ++i) {
+        const int64_t L = read_off[i + 1] - read_off[i];
+        if (L < 0 || L > 30000) { fail(CLH_E_UNSUPPORTED, "read longer than 30000 bases (LDS capacity of the repeat scan)"); delete pl; return nullptr; }
+        lmax = std::max(lmax, (int)L);
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return read_off[x + 1] - read_off[x] > read_off[y + 1] - read_off[y]; });
+    pl->lcap = (lmax + 63) & ~63;
+    // workspace slot: graph of at most L+8 nodes, copies of at most L/2 + L/16 + 1 bases (period <= L/2, tolerance period/8)
+    pl->slot_bytes = clh::poa_slot_bytes_host(lmax + 8, mcap_hint > 0 ? mcap_hint + 1 : lmax / 2 + lmax / 16 + 8);
+    const unsigned long long budget = 24ull << 30;
+    long long slots = (long long)(budget / pl->slot_bytes);
+    pl->nslots = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(slots, 4096), std::max(n, 1)));
+    pl->d_off = ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));
+    pl->d_scan = ctx->alloc(sizeof(clh::CcsScan) * (size_t)std::max(n, 1));
+    pl->d_res = ctx->alloc(sizeof(clh::CcsResult) * (size_t)std::max(n, 1));
+    pl->d_segs = ctx->alloc(sizeof(int32_t) * 2 * clh::CCS_SEG_CAP * (size_t)std::max(n, 1));
+    pl->d_ccs = ctx->alloc((size_t)std::max<int64_t>(pl->total, 1) + 64);
+    pl->d_ws = ctx->alloc(pl->slot_bytes * (size_t)pl->nslots);
+    pl->d_counter = ctx->alloc(256);
+    pl->d_order = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
+    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || !pl->d_counter || !pl->d_order) {
+        fail(CLH_E_HIP, "out of device memory while building the consensus plan");
+        clh_ccs_plan_destroy(pl); return nullptr;
+    }
+    if (hipMemcpy(pl->d_off, read_off, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice) != hipSuccess ||
+        (n > 0 && hipMemcpy(pl->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)) {
+        fail(CLH_E_HIP, "plan upload failed");
+        clh_ccs_plan_destroy(pl); return nullptr;
+    }
+    return pl;
+}
+
+extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
+{
+    if (!pl || !d_reads) return fail(CLH_E_ARG, "clh_ccs_run: null argument");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : pl->ctx->stream;
+    if (pl->n == 0) { pl->ran = true; pl->last_stream = st; return 0; }
+    clh::CcsParams P;
+    memset(&P, 0, sizeof(P));
+    P.reads = (const int8_t*)d_reads; P.read_off = (const int64_t*)pl->d_off; P.scan = (clh::CcsScan*)pl->d_scan;
+    P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
+    P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
+    P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
+    HIPCHK(hipMemsetAsync(pl->d_counter, 0, 4, st));
+    HIPCHK(clh::launch_ccs_scan(P, st));
+    HIPCHK(clh::launch_poa(P, pl->nslots, st));
+    pl->last_stream = st; pl->ran = true;
+    return 0;
+}
+
+extern "C" int clh_ccs_fetch(clh_ccs_plan* pl, clh_ccs_t* out, int32_t* segs, int8_t* ccs)
+{
+    if (!pl || !out) return fail(CLH_E_ARG, "clh_ccs_fetch: null argument");
+    if (!pl->ran) return fail(CLH_E_ARG, "clh_ccs_fetch before clh_ccs_run");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    if (pl->n == 0) return 0;
+    static_assert(sizeof(clh_ccs_t) == sizeof(clh::CcsResult), "result layout");
+    HIPCHK(hipMemcpy(out, pl->d_res, sizeof(clh::CcsResult) * (size_t)pl->n, hipMemcpyDeviceToHost));
+    if (segs) HIPCHK(hipMemcpy(segs, pl->d_segs, sizeof(int32_t) * 2 * clh::CCS_SEG_CAP * (size_t)pl->n, hipMemcpyDeviceToHost));
+    if (ccs && pl->total > 0) HIPCHK(hipMemcpy(ccs, pl->d_ccs, (size_t)pl->total, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, clh_ccs_t* out, int32_t* segs, int8_t* ccs)
+{
+    if (!ctx || !reads || !read_off || !out) return fail(CLH_E_ARG, "clh_ccs_batch: null argument");
+    clh_ccs_plan* pl = clh_ccs_plan_create(ctx, n, read_off);
+    if (!pl) return CLH_E_ARG;
+    int rc = 0;
+    pl->d_reads = ctx->alloc((size_t)read_off[n] + 64);
+    if (!pl->d_reads) rc = fail(CLH_E_HIP, "out of device memory for the batch");
+    if (!rc && read_off[n] > 0 && hipMemcpyAsync(pl->d_reads, reads, (size_t)read_off[n], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = fail(CLH_E_HIP, "H2D reads failed");
+    if (!rc) rc = clh_ccs_run(pl, pl->d_reads, nullptr);
+    if (!rc) rc = clh_ccs_fetch(pl, out, segs, ccs);
+    clh_ccs_plan_destroy(pl);
+    return rc;
+}
+
+// consensus of explicit groups of sequences (the spoa.poa call shape): group k = sequences [group_off[k], group_off[k+1])
+extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64_t* seq_off, const int64_t* group_off,
+                             int32_t* out_len, int8_t* out_ccs)
+{
+    if (!ctx || ngroups < 0 || !seqs || !seq_off || !group_off || !out_len || !out_ccs) return fail(CLH_E_ARG, "clh_poa_batch: null argument");
+    std::vector<int64_t> roff((size_t)ngroups + 1);
+    std::vector<clh::CcsScan> scan((size_t)std::max(ngroups, 1));
+    for (int k = 0; k < ngroups; ++k) {
+        const int64_t s0 = group_off[k], s1 = group_off[k + 1];
+        if (s1 - s0 < 1 || s1 - s0 > 65) return fail(CLH_E_UNSUPPORTED, "a consensus group must hold 1..65 sequences");
+        roff[k] = seq_off[s0];
+        clh::CcsScan& sc = scan[k];
+        memset(&sc, 0, sizeof(sc));
+        sc.period = -1; sc.ncuts = (int32_t)(s1 - s0 - 1);
+        for (int64_t i = s0 + 1; i < s1; ++i) sc.cuts[i - s0 - 1] = (int32_t)(seq_off[i] - seq_off[s0]);
+    }
+    roff[ngroups] = ngroups ? seq_off[group_off[ngroups]] : 0;
+    // groups must tile the packed array contiguously
+    for (int k = 0; k + 1 < ngroups; ++k) if (seq_off[group_off[k + 1]] != roff[k + 1]) return fail(CLH_E_ARG, "groups must be contiguous");
+    int mcap = 1;
+    for (int64_t i = 0; i < group_off[ngroups]; ++i) mcap = std::max<int>(mcap, (int)(seq_off[i + 1] - seq_off[i]));
+    clh_ccs_plan* pl = ccs_plan_create(ctx, ngroups, roff.data(), mcap);
+    if (!pl) return CLH_E_ARG;
+    int rc = 0;
+    const size_t total = (size_t)(roff[ngroups] - roff[0]);
+    pl->d_reads = ctx->alloc(total + (size_t)roff[0] + 64);
+    if (!pl->d_reads) rc = fail(CLH_E_HIP, "out of device memory");
+    if (!rc && hipMemcpyAsync(pl->d_reads, seqs, (size_t)roff[ngroups], hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D failed");
+    if (!rc && ngroups && hipMemcpyAsync(pl->d_scan, scan.data(), sizeof(clh::CcsScan) * (size_t)ngroups, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D failed");
+    if (!rc && ngroups) {
+        clh::CcsParams P;
+        memset(&P, 0, sizeof(P));
+        P.reads = (const int8_t*)pl->d_reads; P.read_off = (const int64_t*)pl->d_off; P.scan = (clh::CcsScan*)pl->d_scan;
+        P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
+        P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
+        P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
+        if (hipMemsetAsync(pl->d_counter, 0, 4, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
+        if (!rc && clh::launch_poa(P, pl->nslots, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "launch failed");
+        pl->ran = true; pl->last_stream = ctx->stream;
+    }
+    if (!rc && ngroups) {
+        std::vector<clh_ccs_t> res((size_t)ngroups);
+        rc = clh_ccs_fetch(pl, res.data(), nullptr, out_ccs);
+        for (int k = 0; k < ngroups && !rc; ++k) out_len[k] = res[k].nseg > 0 && res[k].status == 0 ? res[k].ccs_len : -1;
+    }
+    clh_ccs_plan_destroy(pl);
+    return rc;
+}

@@ -47,6 +47,42 @@ struct SswParams {
     int32_t null_code;    // 4 if mat scores code 4 as 0 against everything (then fill/drain columns reuse it), else 5
 };
 
+// ---- cyclic consensus (K2/K3, csrc/ccs_poa.hip) ----------------------------------------------------------------
+static constexpr int CCS_SEG_CAP = 65;          // 64 cuts + a partial tail
+
+struct CcsScan {          // K2 output per read
+    int32_t period;       // 0 = no tandem repeat
+    int32_t ncuts;
+    int32_t support;
+    int32_t cuts[64];     // copy boundaries after 0
+};
+
+struct CcsResult {        // K3 output per read
+    int32_t nseg;         // 0 = no consensus
+    int32_t ccs_len;
+    int32_t period;
+    int32_t status;       // 0 ok, 1 workspace slot too small, 2 graph overflow, 3 consensus overflow
+};
+
+struct CcsParams {
+    const int8_t* reads;
+    const int64_t* read_off;   // device copy, n+1 entries
+    CcsScan* scan;
+    CcsResult* results;
+    int32_t* segs;             // [n][2*CCS_SEG_CAP]
+    int8_t* ccs;               // packed like reads (a consensus is never longer than its read)
+    uint8_t* poa_ws;           // nslots * slot_bytes
+    int* work_counter;
+    const int32_t* work_order; // reads, longest first (or nullptr)
+    unsigned long long slot_bytes;
+    int32_t n;
+    int32_t lcap;              // >= longest read of the batch
+};
+
+hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream);
+hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream);
+size_t poa_slot_bytes_host(int ncap, int mcap);
+
 extern const int kRvClasses[];
 extern const int kNumRvClasses;
 hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStream_t stream);

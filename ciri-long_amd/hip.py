@@ -34,6 +34,9 @@ assert ALIGN_DTYPE.itemsize == C.sizeof(AlignRow)
 
 ST_WORD, ST_NULL, ST_TRACE_ERR, ST_NO_CIGAR, ST_CIGAR_TRUNC = 1, 2, 4, 8, 16
 
+CCS_SEG_CAP = 65
+CCS_DTYPE = np.dtype([('nseg', '<i4'), ('ccs_len', '<i4'), ('period', '<i4'), ('status', '<i4')])
+
 
 class SswOpts(C.Structure):
     _fields_ = [('mat', C.c_void_p), ('n_mat', C.c_int32), ('gap_open', C.c_uint8), ('gap_extend', C.c_uint8),
@@ -67,6 +70,13 @@ def lib():
         L.clh_ssw_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.POINTER(SswOpts), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.clh_encode_dna.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
+        L.clh_ccs_plan_create.restype = C.c_void_p
+        L.clh_ccs_plan_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.clh_ccs_plan_destroy.argtypes = [C.c_void_p]
+        L.clh_ccs_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_ccs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_ccs_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_poa_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -164,6 +174,43 @@ class Context(object):
             raise ClhError('clh_ssw_batch failed (%d): %s' % (rc, last_error()))
         return out, cig[:used.value]
 
+    def ccs_batch(self, reads, read_off):
+        """find_consensus for a batch: -> (rows CCS_DTYPE[n], segs int32[n, 65, 2], ccs int8 packed like reads)"""
+        reads = np.ascontiguousarray(reads, dtype=np.int8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        n = len(read_off) - 1
+        out = np.zeros(n, dtype=CCS_DTYPE)
+        segs = np.zeros((n, CCS_SEG_CAP, 2), dtype=np.int32)
+        ccs = np.zeros(max(1, len(reads)), dtype=np.int8)
+        rc = lib().clh_ccs_batch(self._h, n, reads.ctypes.data, read_off.ctypes.data, out.ctypes.data, segs.ctypes.data, ccs.ctypes.data)
+        if rc != 0:
+            raise ClhError('clh_ccs_batch failed (%d): %s' % (rc, last_error()))
+        return out, segs, ccs
+
+    def poa_batch(self, seqs, seq_off, group_off):
+        """Consensus per group of sequences -> list of str (None where no consensus)."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.int8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        group_off = np.ascontiguousarray(group_off, dtype=np.int64)
+        ng = len(group_off) - 1
+        lens = np.zeros(ng, dtype=np.int32)
+        out = np.zeros(max(1, len(seqs)), dtype=np.int8)
+        rc = lib().clh_poa_batch(self._h, ng, seqs.ctypes.data, seq_off.ctypes.data, group_off.ctypes.data, lens.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise ClhError('clh_poa_batch failed (%d): %s' % (rc, last_error()))
+        bases = np.frombuffer(b'ACGTN', dtype=np.uint8)
+        res = []
+        for k in range(ng):
+            if lens[k] < 0:
+                res.append(None)
+            else:
+                o = int(seq_off[group_off[k]])
+                res.append(bases[np.minimum(out[o:o + lens[k]], 4)].tobytes().decode())
+        return res
+
+    def ccs_plan(self, read_off):
+        return CcsPlan(self, read_off)
+
     def plan(self, read_off, ref_off, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,
              want_cigar=True, mask_len=None):
         return Plan(self, read_off, ref_off, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, mask_len)
@@ -225,6 +272,43 @@ class Plan(object):
     def close(self):
         if getattr(self, '_h', None):
             lib().clh_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CcsPlan(object):
+    """Consensus step for a batch shape resident on the GPU (K2 + K3)."""
+
+    def __init__(self, ctx, read_off):
+        self.ctx = ctx
+        self.read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        self.n = len(self.read_off) - 1
+        self._h = lib().clh_ccs_plan_create(ctx._h, self.n, self.read_off.ctypes.data)
+        if not self._h:
+            raise ClhError('clh_ccs_plan_create failed: %s' % last_error())
+
+    def run(self, d_reads_ptr, stream=0):
+        rc = lib().clh_ccs_run(self._h, C.c_void_p(d_reads_ptr), C.c_void_p(stream))
+        if rc != 0:
+            raise ClhError('clh_ccs_run failed (%d): %s' % (rc, last_error()))
+
+    def fetch(self):
+        out = np.zeros(self.n, dtype=CCS_DTYPE)
+        segs = np.zeros((self.n, CCS_SEG_CAP, 2), dtype=np.int32)
+        ccs = np.zeros(max(1, int(self.read_off[-1])), dtype=np.int8)
+        rc = lib().clh_ccs_fetch(self._h, out.ctypes.data, segs.ctypes.data, ccs.ctypes.data)
+        if rc != 0:
+            raise ClhError('clh_ccs_fetch failed (%d): %s' % (rc, last_error()))
+        return out, segs, ccs
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib().clh_ccs_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):

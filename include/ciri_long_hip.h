@@ -105,6 +105,29 @@ int clh_ssw_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* r
                   const int64_t* ref_off, const int32_t* mask_len, const clh_ssw_opts* opts,
                   clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used);
 
+/* ---- cyclic consensus: the batch form of pyccs.find_consensus (CIRI_long/find_ccs.py:14) -----------------------
+ * pyccs/spoa are external and absent from the reference tree: this implements the specification stated in
+ * oracle/ccs_oracle.c (PARITY UNPINNED).  Per read: tandem-repeat period by 8-mer self-matches, copy boundaries,
+ * partial-order consensus of the copies.  segs holds [start,end) pairs, 65 per read; ccs is packed like reads. */
+#define CLH_CCS_SEG_CAP 65
+typedef struct {
+    int32_t nseg;      /* 0: no tandem repeat / no consensus (find_consensus would return (None, None)) */
+    int32_t ccs_len;
+    int32_t period;
+    int32_t status;    /* 0 ok; >0 internal capacity problem, treated as no consensus */
+} clh_ccs_t;
+typedef struct clh_ccs_plan clh_ccs_plan;
+clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off);
+void clh_ccs_plan_destroy(clh_ccs_plan* plan);
+int clh_ccs_run(clh_ccs_plan* plan, const void* d_reads, void* stream);
+int clh_ccs_fetch(clh_ccs_plan* plan, clh_ccs_t* out, int32_t* segs, int8_t* ccs);
+int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, clh_ccs_t* out, int32_t* segs, int8_t* ccs);
+/* The spoa.poa call shape (collapse.py:267,504; tests/test_poa.py:30): consensus of explicit groups of sequences.
+ * Group k = sequences [group_off[k], group_off[k+1]) of the packed array (1..65 per group, groups contiguous).
+ * out_ccs is packed by the offset of each group's first sequence; out_len[k] = -1 when no consensus could be built. */
+int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64_t* seq_off, const int64_t* group_off,
+                  int32_t* out_len, int8_t* out_ccs);
+
 /* ASCII -> codes exactly as ssw_wrap.py:234-252 (A/a C/c G/g T/t N/n, anything else 4), on the host. */
 void clh_encode_dna(const char* seq, int64_t len, int8_t* out);
 

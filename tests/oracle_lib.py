@@ -157,3 +157,46 @@ def ref_align(ref, query, match=1, mismatch=1, gap_open=1, gap_extend=1, flag=1,
     lib.align_destroy(p)
     lib.init_destroy(prof)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# cyclic consensus (oracle/ccs_oracle.c) -- specification of THIS repository, parity unpinned
+# ------------------------------------------------------------------------------------------------
+def _ccs_lib():
+    lib = oracle()
+    if not getattr(lib, '_ccs_ready', False):
+        lib.clo_find_consensus.restype = C.c_int
+        lib.clo_find_consensus.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        lib.clo_poa_consensus.restype = C.c_int
+        lib.clo_poa_consensus.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.clo_ccs_segments.restype = C.c_int
+        lib.clo_ccs_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib._ccs_ready = True
+    return lib
+
+
+def decode(codes):
+    return ''.join('ACGTN'[int(c)] if 0 <= int(c) <= 4 else 'N' for c in codes)
+
+
+def oracle_find_consensus(seq):
+    """-> (segments 'a-b;c-d;...', ccs str, period) or (None, None, 0)"""
+    s = np.ascontiguousarray(encode(seq) if not isinstance(seq, np.ndarray) else seq, dtype=np.int8)
+    segs = np.zeros(2 * 70, dtype=np.int32)
+    nseg = C.c_int32(0); period = C.c_int32(0)
+    out = np.zeros(len(s) + 8, dtype=np.int8)
+    n = _ccs_lib().clo_find_consensus(s.ctypes.data, len(s), segs.ctypes.data, C.byref(nseg), out.ctypes.data, len(out), C.byref(period))
+    if n <= 0:
+        return None, None, 0
+    seg = ';'.join('%d-%d' % (segs[2 * i], segs[2 * i + 1]) for i in range(nseg.value))
+    return seg, decode(out[:n]), period.value
+
+
+def oracle_poa(seqs):
+    arrs = [np.ascontiguousarray(encode(s) if not isinstance(s, np.ndarray) else s, dtype=np.int8) for s in seqs]
+    off = np.zeros(len(arrs) + 1, dtype=np.int32)
+    np.cumsum([len(a) for a in arrs], out=off[1:])
+    data = np.concatenate(arrs)
+    out = np.zeros(int(off[-1]) + 8, dtype=np.int8)
+    n = _ccs_lib().clo_poa_consensus(len(arrs), data.ctypes.data, off.ctypes.data, out.ctypes.data, len(out))
+    return None if n < 0 else decode(out[:n])

@@ -1,0 +1,97 @@
+"""K2/K3 (repeat scan + partial-order consensus) through the C ABI against the CPU statement of the same specification
+(oracle/ccs_oracle.c).  PARITY UNPINNED with respect to pyccs/spoa (absent); bit-exact with respect to the oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+SEGMENTS = [   # the 6 copies of the reference's tests/test_poa.py:8-15
+    'TCCCGGTCATCATAACCCCGATCGTACCCTCTGTCATAATAGTCTCGGCGGCGAGAACTGCCACTGTAAATCTGATCCCTGTCTTGAGCTGCTCTCCATCCACCTCCCTCCACCACCTCCTCCTCTGTATGATCTGCTGTAATAG',
+    'TCCCGGTCATCATAACCCCGATCATTGCCACCTGTCATAGTCTCGGCGGCGAGAACTGCCACTGTAAATCCCCTGATCCCTGTCTTGAGCTGCTCTCCATCCCCTCCTCCACCACCTCCTCCTCTGTATGATCTGCTGTAATAG',
+    'TCCCGGTCATCATAACCCCGATCGTACCCTCTGTCATAATGGTCTCGGCGGCGAGAACTGCCACTGTAAATCTGATCCCTGTCTTGAGCTGCTCTCCATCCACCTCCTCCACCACCTCCTCCTCTGTATGATCTGCTGTAATAG',
+    'TCCCGGTCATCATAACCCCGATCGTACTCTGTCATAATAGTCTCGGCGGCGAGAGGCGCCACTGTAAATCTGATCCCTGTCTTGAGCTGCTCTCCATCCACCTCCTCCACCACCTCCTCCCCTCTGTATGATCTGCTGTAATAG',
+    'TCCCGGTCATCATAACCCCGATCGTACCCATAATAGTCTCGGCGAGAACTGCCACTGTAAATCCTGATCCCTGTCTTGAGCTGCTCTCCATCCACCTCCTCCACCACCTCCTCCTCTGTATGATCTGCTGTAATAG',
+    'TCCGGTCATCATAACCCCGATCCATAATAGTCTCGGCG',
+]
+
+
+def test_reference_test_poa_input():
+    """Structural expectations of SURVEY.md section 8c for the only input the reference tests hold."""
+    from ciri_long_amd import pyccs
+    raw = ''.join(SEGMENTS)
+    seg, ccs = pyccs.find_consensus(raw)
+    want = oracle_lib.oracle_find_consensus(raw)
+    assert (seg, ccs) == want[:2]
+    parts = seg.split(';')
+    assert len(parts) >= 5
+    assert 140 <= len(ccs) <= 160
+    assert set(ccs) <= set('ACGT')
+
+
+def test_batch_equals_oracle_on_synthetic_reads():
+    from ciri_long_amd import pyccs, synth
+    rng = np.random.Generator(np.random.PCG64(77))
+    reads = []
+    for it in range(300):
+        tm = synth.template(rng)
+        L = int(rng.choice([400, 700, 1000, 1300, 2000]))
+        kind = it % 4
+        if kind == 3:
+            reads.append(synth.mutate(rng.integers(0, 4, L, dtype=np.int8), rng))
+        else:
+            r = synth.rolling_circle_read(rng, tm, L)
+            if kind == 2 and len(r) > 50:
+                r = r.copy(); r[rng.integers(0, len(r), 3)] = 4       # a few N
+            reads.append(r)
+    reads.append(np.zeros(40, dtype=np.int8))                     # shorter than two minimal periods
+    reads.append(np.tile(np.array([0, 1, 2, 3], dtype=np.int8), 200))   # microsatellite: period below the minimum offset
+    got = pyccs.find_consensus_batch(reads)
+    n_found = 0
+    for k, r in enumerate(reads):
+        want = oracle_lib.oracle_find_consensus(r)
+        assert got[k] == want[:2], (k, len(r), got[k][0], want[0])
+        n_found += got[k][0] is not None
+    assert n_found >= 120
+
+
+def test_spoa_call_shape():
+    from ciri_long_amd import spoa
+    cons, msa = spoa.poa(SEGMENTS, 0, True, 10, -4, -8, -2, -24, -1)     # tests/test_poa.py:30
+    assert cons == oracle_lib.oracle_poa(SEGMENTS) and msa == []
+    cons2, _ = spoa.poa(SEGMENTS, 2, False, 10, -4, -8, -2, -24, -1)     # collapse.py:267,504
+    assert cons2 == cons
+    assert spoa.poa(['ACGTACGTAA'], 0, True, 10, -4, -8, -2, -24, -1)[0] == 'ACGTACGTAA'
+    with pytest.raises(NotImplementedError):
+        spoa.poa(SEGMENTS, 1, True, -1, -1, -1, -1, -1)                   # find_bsj.py:496 (dead code in the reference)
+
+
+def test_find_ccs_reads_files_and_resume(tmp_path):
+    """Stage driver: FASTA/FASTQ(.gz) in, tmp/{prefix}.ccs.fa + .raw.fa out in the reference's format, resume reads them."""
+    import gzip
+    from ciri_long_amd import find_ccs, synth
+    rng = np.random.Generator(np.random.PCG64(3))
+    reads = []
+    for k in range(30):
+        tm = synth.template(rng)
+        r = synth.rolling_circle_read(rng, tm, 900) if k % 3 else synth.mutate(rng.integers(0, 4, 900, dtype=np.int8), rng)
+        reads.append(('read%02d extra words' % k, oracle_lib.decode(r)))
+    (tmp_path / 'tmp').mkdir()
+    fq = tmp_path / 'in.fq.gz'
+    with gzip.open(fq, 'wt') as f:
+        for h, s in reads:
+            f.write('@%s\n%s\n+\n%s\n' % (h, s, 'I' * len(s)))
+    total, ro, ccs_seq = find_ccs.find_ccs_reads(str(fq), str(tmp_path), 'p', 4, False)
+    assert total == 30
+    want = {h.split(' ')[0]: oracle_lib.oracle_find_consensus(s) for h, s in reads}
+    keep = [h for h in want if want[h][0] is not None]
+    assert ro == len(keep) and list(ccs_seq) == keep                      # input order
+    for h in keep:
+        assert ccs_seq[h][:2] == [want[h][0], want[h][1]]
+    lines = (tmp_path / 'tmp' / 'p.ccs.fa').read_text().split('\n')
+    assert lines[0] == '>%s\t%s\t%d' % (keep[0], want[keep[0]][0], len(want[keep[0]][1])) and lines[1] == want[keep[0]][1]
+    assert find_ccs.load_ccs_reads(str(tmp_path), 'p') == ccs_seq
+    fa = tmp_path / 'in.fa'
+    fa.write_text(''.join('>%s\n%s\n' % hs for hs in reads))
+    assert find_ccs.find_ccs_reads(str(fa), str(tmp_path), 'q', 1, False)[2] == ccs_seq

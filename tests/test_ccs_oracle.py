@@ -56,6 +56,6 @@ def test_recovers_templates_and_rejects_linear_reads():
 def test_degenerate_inputs():
     assert oracle_lib.oracle_find_consensus('ACGT' * 5)[0] is None              # shorter than two minimal periods
     seg, ccs, period = oracle_lib.oracle_find_consensus('ACGT' * 200)          # microsatellite: reported at a multiple >= 30
-    assert seg is not None and period % 4 == 0 and period >= 30
+    assert seg is not None and period >= 30 and all(int(x.split('-')[1]) % 4 == 0 for x in seg.split(';'))
     assert oracle_lib.oracle_find_consensus('N' * 500)[0] is None
     assert oracle_lib.oracle_poa(['ACGTACGT']) == 'ACGTACGT'

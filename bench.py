@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the Smith-Waterman step of CIRI-long's hot path on MI355X.
+"""bench.py -- throughput of the GPU part of CIRI-long's per-read hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): 10 000 synthetic NanoSim-shaped reads of ~1 kb per GPU, each aligned
-against its own 2 kb reference window with CIRI-long's call-path scoring (1/1/1/1, find_bsj.py:204), producing the
-complete s_align of the reference (score, second best, begin/end coordinates, CIGAR).  A step = one pass of the
-batch, inputs (packed int8 codes) already resident in HBM.  One process per GPU; reads shard across ranks with no
-data-path collective (weak scaling: 10 000 reads per GPU).
+Workloads (BASELINE.json `configs`):
+  c3 (default)  "100k NanoSim reads ~1 kb, full CCS+POA+SSW+BSJ pipeline, 1 MI355X": per GPU 100 000 synthetic
+                NanoSim-shaped reads (half rolling-circle, half linear negatives).  A step = cyclic consensus of every read
+                (K2 repeat scan + K3 partial-order consensus) followed by the Smith-Waterman re-alignment of the clipped
+                part of every consensus against the read's 2 kb window (K1, call-path options: no second best, no CIGAR,
+                find_bsj.py:204-224).  The mapper between the two stages (minimap2/bwa) is external CPU code and is not
+                part of the step; the clip batch is built once from a warm-up run and is resident in HBM like the reads.
+  c2            "10k reads ~1 kb, SSW-only kernel vs 2 kb window": the complete s_align of the reference (second best,
+                begin/end, CIGAR) for 10 000 read-vs-window pairs per GPU.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel vs the HBM roofline, as the task
-contract asks, plus the integer-VALU view that actually bounds a DP kernel) and `cpu_baseline` (the reference's own
-libssw.so -- or our scalar port if that build is absent -- timed on this box's host cores on a bounded sample).
+One process per GPU, reads sharded by rank, no data-path collective (weak scaling).  Inputs are packed int8 codes in
+HBM before the timed region.  Prints ONE JSON line on rank 0 with `roofline` (dominant launch vs the HBM roofline, plus
+the integer-VALU view that actually bounds these DP kernels) and `cpu_baseline` (host cores of this box).
 """
 import argparse
 import json
@@ -23,71 +27,83 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz (packed 16-bit ops do 2 cells each)
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+PK_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0       # SIMDs x Hz / 4 cycles: packed-16 ops are half rate (tools/ubench/valu_rate.hip)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (spawned processes; never fork a process that has initialised HIP)
+# ------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(arg):
-    """One host process of the CPU baseline: the reference's libssw.so (or the scalar port) on its share of a sample."""
-    tid, nproc, seconds, nsample = arg
-    import ctypes as C
+    tid, nproc, seconds, nsample, workload = arg
     import oracle_lib
     from ciri_long_amd import synth
-    reads, wins = synth.c2_batch(nsample, seed=synth.SEEDS['C2'], rank=0)
-    kind = 'reference' if oracle_lib.have_ref() else 'port'
+    seed = synth.SEEDS['C3'] if workload == 'c3' else synth.SEEDS['C2']
+    reads, wins = synth.c2_batch(nsample, seed=seed, rank=0)
+    have_ref = oracle_lib.have_ref()
     mat = oracle_lib.make_mat(1, 1)
+    ref = oracle_lib.ref_lib() if have_ref else None
     done, k = 0, tid
     t0 = time.time()
     deadline = t0 + seconds
-    if kind == 'reference':
-        lib = oracle_lib.ref_lib()
-        while time.time() < deadline:
-            q = reads[k % nsample]; r = wins[k % nsample]
-            prof = lib.ssw_init(q.ctypes.data, len(q), mat.ctypes.data, 5, 2)
-            p = lib.ssw_align(prof, r.ctypes.data, len(r), 1, 1, 1, 0, 0, oracle_lib.mask_len(len(q)))
-            lib.align_destroy(p)
-            lib.init_destroy(prof)
-            done += 1
-            k += nproc
-    else:
-        lib = oracle_lib.oracle()
-        res = oracle_lib.CloAlign()
-        while time.time() < deadline:
-            q = reads[k % nsample]; r = wins[k % nsample]
-            lib.clo_ssw_align(q.ctypes.data, len(q), mat.ctypes.data, 5, 2, r.ctypes.data, len(r), 1, 1, 1, 0, 0,
-                              oracle_lib.mask_len(len(q)), C.byref(res))
-            lib.clo_free_cigar(C.byref(res))
-            done += 1
-            k += nproc
-    return done, time.time() - t0, kind
+
+    def ssw(q, r):
+        if have_ref:
+            prof = ref.ssw_init(q.ctypes.data, len(q), mat.ctypes.data, 5, 2)
+            p = ref.ssw_align(prof, r.ctypes.data, len(r), 1, 1, 1, 0, 0, oracle_lib.mask_len(len(q)))
+            ref.align_destroy(p)
+            ref.init_destroy(prof)
+        else:
+            oracle_lib.oracle_align(r, q, 1, 1, 1, 1)
+
+    while time.time() < deadline:
+        q, r = reads[k % nsample], wins[k % nsample]
+        if workload == 'c3':
+            seg, ccs, _ = oracle_lib.oracle_find_consensus(q)
+            if seg is not None:
+                c = oracle_lib.encode(ccs)
+                ssw(np.ascontiguousarray(c[-max(20, int(0.3 * len(c))):]), r)
+        else:
+            ssw(q, r)
+        done += 1
+        k += nproc
+    return done, time.time() - t0, ('reference' if have_ref else 'port')
 
 
-def cpu_baseline(seconds, nsample=2048):
-    """CIRI-long's own parallelism is a process pool (find_bsj.py:340-345); so is this: one spawned process per host
-    core, each aligning its share of the first `nsample` alignments of the C2 batch over and over for `seconds`."""
+def cpu_baseline(seconds, workload, nsample=2048):
+    """One spawned process per host core (CIRI-long's own parallelism is a process pool, find_bsj.py:340-345), each
+    working through its share of the first `nsample` reads of the batch over and over for `seconds`."""
     import multiprocessing as mp
-    ncores = os.cpu_count() or 1
-    ctx = mp.get_context('spawn')       # never fork a process that has initialised HIP
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    ctx = mp.get_context('spawn')
     with ctx.Pool(ncores) as pool:
-        res = pool.map(_cpu_worker, [(i, ncores, seconds, nsample) for i in range(ncores)])
+        res = pool.map(_cpu_worker, [(i, ncores, seconds, nsample, workload) for i in range(ncores)])
     total = sum(r[0] for r in res)
     el = max(r[1] for r in res)
-    kind = res[0][2]
+    if workload == 'c3':
+        kind = 'port'
+        what = ('consensus by the CPU statement of this project\'s own specification (oracle/ccs_oracle.c; pyccs/spoa are '
+                'not available) + clip re-alignment by ' + ('the reference\'s libssw.so' if res[0][2] == 'reference' else 'the scalar port'))
+    else:
+        kind = res[0][2]
+        what = 'ssw_init+ssw_align flag=1 per alignment, inputs pre-encoded'
     return {'value': total / el, 'unit': 'reads/s', 'cores': ncores, 'kind': kind,
-            'sample': '%d alignments (first %d of the C2 batch, repeated; ssw_init+ssw_align flag=1 per alignment, inputs '
-                      'pre-encoded) in %.1f s on %d processes' % (total, nsample, el, ncores)}
+            'sample': '%d reads (first %d of the batch, repeated; %s) in %.1f s on %d processes' % (total, nsample, what, el, ncores)}
 
 
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--reads', type=int, default=10000, help='reads per GPU')
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', choices=('c3', 'c2'), default='c3')
+    ap.add_argument('--reads', type=int, default=0, help='reads per GPU (default: 100000 for c3, 10000 for c2)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--no-cigar', action='store_true', help='call-path variant: skip second best and traceback')
     args = ap.parse_args()
+    wl = args.workload
+    nreads = args.reads or (100000 if wl == 'c3' else 10000)
 
     import torch
     import torch.distributed as dist
@@ -102,37 +118,70 @@ def main():
         dist.init_process_group('nccl')   # RCCL
 
     from ciri_long_amd import hip, synth
-    reads, wins = synth.c2_batch(args.reads, seed=synth.SEEDS['C2'], rank=rank)
+    from oracle_lib import oracle_align, oracle_find_consensus
+    reads, wins = synth.c2_batch(nreads, seed=synth.SEEDS['C3' if wl == 'c3' else 'C2'], rank=rank)
     rd, ro = hip.pack(reads)
-    fd, fo = hip.pack(wins)
     d_reads = torch.from_numpy(rd.view(np.uint8)).cuda()
-    d_refs = torch.from_numpy(fd.view(np.uint8)).cuda()
     ctx = hip.Context(local_rank)
-    full = not args.no_cigar
-    plan = ctx.plan(ro, fo, hip.score_matrix(1, 1), 1, 1, flag=1, score_size=2, want_score2=full, want_cigar=full)
     stream = torch.cuda.current_stream().cuda_stream
+    mat = hip.score_matrix(1, 1)
+    launches = []
 
-    def step():
-        plan.run(d_reads.data_ptr(), d_refs.data_ptr(), stream)
+    if wl == 'c3':
+        ccs_plan = ctx.ccs_plan(ro)
+        ccs_plan.run(d_reads.data_ptr(), stream)
+        crow, csegs, ccs = ccs_plan.fetch()
+        assert int((crow['status'] != 0).sum()) == 0, 'consensus kernel reported capacity errors'
+        has = np.nonzero(crow['nseg'] > 0)[0]
+        # the clipped part the BSJ step would re-align: here the last 30 % (>= 20 bases) of each consensus
+        clips, cwins = [], []
+        for k in has:
+            c = ccs[ro[k]:ro[k] + int(crow['ccs_len'][k])]
+            clips.append(np.ascontiguousarray(c[-max(20, int(0.3 * len(c))):]))
+            cwins.append(wins[k])
+        cd, co = hip.pack(clips)
+        fd, fo = hip.pack(cwins)
+        d_clips = torch.from_numpy(cd.view(np.uint8)).cuda()
+        d_wins = torch.from_numpy(fd.view(np.uint8)).cuda()
+        ssw_plan = ctx.plan(co, fo, mat, 1, 1, flag=1, score_size=2, want_score2=False, want_cigar=False)
+        if rank == 0:   # parity spot check outside the timed region
+            ssw_plan.run(d_clips.data_ptr(), d_wins.data_ptr(), stream)
+            srow, _ = ssw_plan.fetch()
+            for k in range(min(24, nreads)):
+                want = oracle_find_consensus(reads[k])
+                n = int(crow['nseg'][k])
+                got_seg = ';'.join('%d-%d' % (csegs[k, i, 0], csegs[k, i, 1]) for i in range(n)) if n > 0 else None
+                assert got_seg == want[0], (k, got_seg, want[0])
+            for j in range(min(24, len(clips))):
+                w = oracle_align(cwins[j], clips[j], 1, 1, 1, 1)
+                r = srow[j]
+                assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])) == \
+                    (w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']), j
+
+        def step():
+            ccs_plan.run(d_reads.data_ptr(), stream)
+            ssw_plan.run(d_clips.data_ptr(), d_wins.data_ptr(), stream)
+    else:
+        fd, fo = hip.pack(wins)
+        d_wins = torch.from_numpy(fd.view(np.uint8)).cuda()
+        ssw_plan = ctx.plan(ro, fo, mat, 1, 1, flag=1, score_size=2, want_score2=True, want_cigar=True)
+        ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
+        srow, scig = ssw_plan.fetch()
+        assert int((srow['status'] & ~9).sum()) == 0, 'alignments with error status'
+        if rank == 0:
+            for k in range(min(48, nreads)):
+                w = oracle_align(wins[k], reads[k], 1, 1, 1, 1)
+                r = srow[k]
+                assert (int(r['score1']), int(r['score2']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']),
+                        int(r['read_end1']), int(r['ref_end2'])) == (w['score'], w['score2'], w['ref_begin'], w['ref_end'],
+                                                                     w['query_begin'], w['query_end'], w['ref_end2']), k
+                assert [int(x) for x in scig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == w['cigar'], k
+
+        def step():
+            ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-
-    # parity spot check outside the timed region (rank 0): first 48 alignments vs the oracle
-    rows, cig = plan.fetch()
-    if rank == 0:
-        from oracle_lib import oracle_align
-        for k in range(min(48, len(reads))):
-            w = oracle_align(wins[k], reads[k], 1, 1, 1, 1)
-            r = rows[k]
-            got = (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1']))
-            assert got == (w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']), (k, got, w)
-            if full:
-                assert (int(r['score2']), int(r['ref_end2'])) == (w['score2'], w['ref_end2']), k
-                assert [int(x) for x in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == w['cigar'], k
-    assert int((rows['status'] & ~9).sum()) == 0, 'alignments with error status'
-
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -148,40 +197,47 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    # per-launch durations (HIP events on the stream the kernels are launched on), outside the timed region
-    plan.set_profiling(True)
+    # ---- per-launch durations (HIP events on the stream the kernels run on), outside the timed region ----
+    PROF = 3
+    if wl == 'c3':
+        k2 = k3 = 0.0
+        for _ in range(PROF):
+            ccs_plan.run(d_reads.data_ptr(), stream)
+            a, b = ccs_plan.timing()
+            k2 += a / PROF; k3 += b / PROF
+        L = np.diff(ro)
+        b_k3 = int(L[has].sum() + crow['ccs_len'][has].sum() + 16 * crow['nseg'][has].sum() + 16 * nreads)
+        launches.append({'kernel': 'ccs_scan_kernel', 'reads': nreads, 'ms': k2, 'alg_bytes': int(L.sum() + 272 * nreads)})
+        launches.append({'kernel': 'poa_consensus_kernel', 'reads': int(len(has)), 'ms': k3, 'alg_bytes': b_k3})
+    ssw_plan.set_profiling(True)
     acc, accb = None, [0.0, 0.0]
-    PROF_STEPS = 5
-    for _ in range(PROF_STEPS):
-        step()
-        tm, tb = plan.timing()
-        acc = tm if acc is None else [a + b for a, b in zip(acc, tm)]
+    for _ in range(PROF):
+        if wl == 'c3':
+            ssw_plan.run(d_clips.data_ptr(), d_wins.data_ptr(), stream)
+        else:
+            ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
+        tm, tb = ssw_plan.timing()
+        acc = tm if acc is None else [x + y for x, y in zip(acc, tm)]
         accb = [accb[0] + tb[0], accb[1] + tb[1]]
-    segs = plan.segments()
-    # algorithmic bytes: qlen + reflen + 40 (s_align) + 4*cigarLen per alignment
-    lens = np.diff(ro)
-    rlen = np.diff(fo)
-    clen = rows['cigar_len'].astype(np.int64)
-    b_alg = lens + rlen + 40 + 4 * clen
-    # map alignments to segments through their row class
+    srow, _c = ssw_plan.fetch()
+    qoff, woff = (co, fo) if wl == 'c3' else (ro, fo)
+    qlen, wlen = np.diff(qoff), np.diff(woff)
+    b_alg = qlen + wlen + 40 + 4 * srow['cigar_len'].astype(np.int64)
     classes = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32]
-    rows16 = ((lens + 15) // 16) * 16
-    cls = np.array([next(c for c in classes if 128 * c >= r) for r in rows16])
-    launches = []
-    for (rv, cnt, rb, fb), k1 in zip(segs, acc):
+    rows16 = ((qlen + 15) // 16) * 16
+    cls = np.array([next(c for c in classes if 128 * c >= r) for r in rows16]) if len(qlen) else np.zeros(0, dtype=int)
+    cells_total, k1ms = 0, 0.0
+    for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
         sel = cls == rv
-        cells_fw = int((lens[sel] * rlen[sel]).sum())
-        span_r = (rows['ref_end1'][sel].astype(np.int64) - rows['ref_begin1'][sel] + 1)
-        cells_rv = int(((rows['read_end1'][sel].astype(np.int64) + 1) * span_r).sum())
-        launches.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv, 'alignments': cnt, 'ms': k1 / PROF_STEPS,
-                         'alg_bytes': int(b_alg[sel].sum()), 'cells': cells_fw + cells_rv})
-    if full:
-        launches.append({'kernel': 'ssw_traceback_kernel[small window]', 'alignments': int(len(lens)), 'ms': accb[0] / PROF_STEPS,
-                         'alg_bytes': int(b_alg.sum()), 'cells': 0})
-        launches.append({'kernel': 'ssw_traceback_kernel[large window, outliers]', 'alignments': None, 'ms': accb[1] / PROF_STEPS,
-                         'alg_bytes': 0, 'cells': 0})
+        span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
+        cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
+        cells_total += cells; k1ms += k1 / PROF
+        launches.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv, 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+    if wl == 'c2':
+        launches.append({'kernel': 'ssw_traceback_kernel[small window]', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
+        launches.append({'kernel': 'ssw_traceback_kernel[large window, outliers]', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0})
     dom = max(launches, key=lambda x: x['ms'])
-    ach = dom['alg_bytes'] / (dom['ms'] * 1e-3) / 1e9
+    ach = dom['alg_bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     if os.path.exists(tf):
@@ -189,42 +245,38 @@ def main():
             traffic = json.load(open(tf)).get(dom['kernel'])
         except Exception:
             traffic = None
-    roofline = {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'launch_ms': dom['ms'],
-                'alg_bytes_per_launch': dom['alg_bytes'],
-                'note': 'integer DP: ~650 cell updates per compulsory byte, so the VALU bound below is the binding one'}
-    k1s = [l for l in launches if l['kernel'].startswith('ssw_align')]
-    cells = sum(l['cells'] for l in k1s)
-    k1ms = sum(l['ms'] for l in k1s)
-    valu = {'bound': 'valu', 'unit': 'GCUPS', 'achieved': cells / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
-            'peak': VALU_PEAK_LANEOPS * 2 / 10 / 1e9, 'peak_note': 'lane-ops/s x 2 cells per packed op / 10 ops per cell pair',
-            'k1_ms_per_step': k1ms, 'k1b_ms_per_step': sum(l['ms'] for l in launches if 'traceback' in l['kernel'])}
+    roofline = {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                'traffic': traffic, 'launch_ms': dom['ms'], 'alg_bytes_per_launch': dom['alg_bytes'],
+                'note': 'integer DP kernels: hundreds of cell updates per compulsory byte; the VALU issue rate binds, not HBM (DESIGN.md section 3)'}
+    valu = {'bound': 'valu', 'kernel': 'ssw_align_kernel (all classes)', 'unit': 'GCUPS',
+            'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
+            'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,
+            'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / 6 packed ops per cell pair (gapO == gapE path)'}
     valu['frac'] = valu['achieved'] / valu['peak'] if valu['achieved'] else None
 
     out = {
         'metric': 'reads/s through CCS+SSW+BSJ (1/2/4/8 MI355X); % HBM roofline',
-        'value': world * args.reads * args.steps / el,
-        'unit': 'reads/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': el / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'int16', 'data': 'synthetic',
-        'config': {'workload': 'C2: %d NanoSim-shaped ~1 kb reads per GPU, SSW step only (score+second best+begin/end+CIGAR'
-                               if full else 'C2: %d NanoSim-shaped ~1 kb reads per GPU, SSW step only (score+begin/end, call-path variant',
-                   'window': 2000, 'scoring': '1/1/1/1', 'reads_per_gpu': args.reads, 'parallelism': 'reads sharded x%d' % world,
-                   'stage': 'SSW-only (CCS/POA/BSJ stages not in this number)'},
-        'roofline': roofline,
-        'valu_roofline': valu,
-        'launches': launches,
+        'value': world * nreads * args.steps / el, 'unit': 'reads/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic',
+        'config': {
+            'workload': ('C3: %d NanoSim-shaped ~1 kb reads per GPU through the GPU stages of the call path: cyclic consensus '
+                         '(K2+K3) of every read, then Smith-Waterman re-alignment (K1) of each consensus\' clipped part against '
+                         'its 2 kb window; the external mapper between them is not part of the step' % nreads) if wl == 'c3' else
+                        ('C2: %d NanoSim-shaped ~1 kb reads per GPU, SSW step only, complete s_align (second best, begin/end, '
+                         'CIGAR) vs own 2 kb window' % nreads),
+            'reads_per_gpu': nreads, 'window': 2000, 'scoring': '1/1/1/1', 'parallelism': 'reads sharded x%d, no data-path collective' % world,
+            'consensus_parity': 'unpinned (pyccs/spoa absent; own specification, oracle/ccs_oracle.c)' if wl == 'c3' else None},
+        'roofline': roofline, 'valu_roofline': valu, 'launches': launches,
     }
-    out['config']['workload'] = out['config']['workload'] % args.reads + ') vs own 2 kb window'
+    if wl == 'c3':
+        out['config']['reads_with_consensus'] = int(len(has))
     if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
-    elif rank == 0:
+        out['cpu_baseline'] = cpu_baseline(args.cpu_seconds, wl)
+    else:
         out['cpu_baseline'] = None
     if rank == 0:
         print(json.dumps(out))
-    plan.close()
     if world > 1:
         dist.destroy_process_group()
 

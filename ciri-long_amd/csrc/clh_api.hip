@@ -547,6 +547,7 @@ struct clh_ccs_plan {
          *d_counter = nullptr, *d_order = nullptr, *d_reads = nullptr;
     hipStream_t last_stream = nullptr;
     bool ran = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // K2 start, K2 stop = K3 start, K3 stop
 };
 
 extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
@@ -556,6 +557,7 @@ extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
     void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_counter, pl->d_order, pl->d_reads};
     for (void* b : bufs) pl->ctx->release(b);
+    for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
     delete pl;
 }
 
@@ -612,10 +614,25 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
     P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
     P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
+    if (!pl->ev[0]) for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMemsetAsync(pl->d_counter, 0, 4, st));
+    HIPCHK(hipEventRecord(pl->ev[0], st));
     HIPCHK(clh::launch_ccs_scan(P, st));
+    HIPCHK(hipEventRecord(pl->ev[1], st));
     HIPCHK(clh::launch_poa(P, pl->nslots, st));
+    HIPCHK(hipEventRecord(pl->ev[2], st));
     pl->last_stream = st; pl->ran = true;
+    return 0;
+}
+
+// durations of the last run's two launches in ms: ms[0] = K2 ccs_scan_kernel, ms[1] = K3 poa_consensus_kernel
+extern "C" int clh_ccs_plan_timing(clh_ccs_plan* pl, float* ms)
+{
+    if (!pl || !pl->ran || !pl->ev[0] || !ms) return fail(CLH_E_ARG, "no timed run");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    HIPCHK(hipEventElapsedTime(&ms[0], pl->ev[0], pl->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms[1], pl->ev[1], pl->ev[2]));
     return 0;
 }
 

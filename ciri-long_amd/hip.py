@@ -76,6 +76,7 @@ def lib():
         L.clh_ccs_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_ccs_plan_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_poa_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -296,6 +297,13 @@ class CcsPlan(object):
         rc = lib().clh_ccs_run(self._h, C.c_void_p(d_reads_ptr), C.c_void_p(stream))
         if rc != 0:
             raise ClhError('clh_ccs_run failed (%d): %s' % (rc, last_error()))
+
+    def timing(self):
+        """(K2 ms, K3 ms) of the last run"""
+        ms = np.zeros(2, dtype=np.float32)
+        if lib().clh_ccs_plan_timing(self._h, ms.ctypes.data) != 0:
+            raise ClhError('clh_ccs_plan_timing: %s' % last_error())
+        return float(ms[0]), float(ms[1])
 
     def fetch(self):
         out = np.zeros(self.n, dtype=CCS_DTYPE)

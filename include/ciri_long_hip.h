@@ -121,6 +121,8 @@ clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_o
 void clh_ccs_plan_destroy(clh_ccs_plan* plan);
 int clh_ccs_run(clh_ccs_plan* plan, const void* d_reads, void* stream);
 int clh_ccs_fetch(clh_ccs_plan* plan, clh_ccs_t* out, int32_t* segs, int8_t* ccs);
+/* HIP-event durations (ms) of the last run: ms[0] = repeat scan (K2), ms[1] = partial-order consensus (K3). */
+int clh_ccs_plan_timing(clh_ccs_plan* plan, float* ms);
 int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, clh_ccs_t* out, int32_t* segs, int8_t* ccs);
 /* The spoa.poa call shape (collapse.py:267,504; tests/test_poa.py:30): consensus of explicit groups of sequences.
  * Group k = sequences [group_off[k], group_off[k+1]) of the packed array (1..65 per group, groups contiguous).

@@ -40,6 +40,17 @@ __device__ __forceinline__ void phase_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// inclusive prefix maximum over the 64 lanes with DPP (row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 and
+// 31 to carry the row totals): 12 VALU instructions instead of 6 dependent ds_bpermute round trips through the LDS
+__device__ __forceinline__ int wave_prefix_max(int v) {
+    constexpr int NEG = -(1 << 28);
+#define CLH_DPP_MAX(ctrl, rowmask) { const int o = __builtin_amdgcn_update_dpp(NEG, v, ctrl, rowmask, 0xf, false); v = o > v ? o : v; }
+    CLH_DPP_MAX(0x111, 0xf) CLH_DPP_MAX(0x112, 0xf) CLH_DPP_MAX(0x114, 0xf) CLH_DPP_MAX(0x118, 0xf)
+    CLH_DPP_MAX(0x142, 0xa) CLH_DPP_MAX(0x143, 0xc)
+#undef CLH_DPP_MAX
+    return v;
+}
+
 __device__ __forceinline__ int wmax_i(int v) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
@@ -244,9 +255,28 @@ __device__ void poa_rerank(const PoaWs& w, int n_old, int n_new, int lane)
     phase_sync();
 }
 
+#ifdef CLH_DEBUG_POA
+__device__ unsigned long long g_t[8];
+#define TSTAMP(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define TSTAMP(k) do {} while (0)
+#endif
+static constexpr int POA_LDS_ROWS = 1023;          // rows whose graph info fits the LDS table
+static constexpr int POA_LDS_SEQ = 2304;           // longest copy staged in LDS
+static constexpr int POA_LDS_RING_BYTES = 6144;    // ring of recent H rows
+extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];
+#define lds_rinfo (poa_lds)
+#define lds_ring ((short*)(poa_lds + 2 * (POA_LDS_ROWS + 1)))
+#define lds_seq ((int8_t*)(poa_lds + 2 * (POA_LDS_ROWS + 1)) + POA_LDS_RING_BYTES)
+static constexpr size_t POA_LDS_BYTES = 8 * (POA_LDS_ROWS + 1) + POA_LDS_RING_BYTES + POA_LDS_SEQ;
+
 // returns the new node count, or -1 on overflow
-__device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* seq, int m, int lane)
+__device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* seq, int m, int lane, unsigned long long* tacc)
 {
+    unsigned long long tlast = 0;
+#ifdef CLH_DEBUG_POA
+    tlast = __builtin_amdgcn_s_memtime();
+#endif
     if (N == 0) {
         if (m > ncap) return -1;
         for (int j = lane; j < m; j += 64) {
@@ -259,61 +289,129 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
         return m;
     }
     const int Wd = m + 1;
-    // row 0
+    int bs = -(1 << 28), br = 0x7fffffff;          // end cell: largest H[r][m], lowest rank on ties
+    // ---- DP rows --------------------------------------------------------------------------------------------
+    // Fast path: per-row graph info (base, in-degree, ranks of up to 4 sources), the sequence, and a ring of the last
+    // RING rows of H live in LDS, so a row whose sources are recent (the rule: a chain) touches HBM only to store its
+    // H row (needed by a far source, rarely) and its direction bytes.  Row 0 is arithmetic (j*gap).
+    const int mpad = (m + 1 + 63) & ~63;
+    int RING = 16;                                   // power of two, so slot = rank & (RING-1)
+    while (RING * mpad > POA_LDS_RING_BYTES / 2) RING >>= 1;
+    const int rmask = RING - 1;
+    const bool fast = N <= POA_LDS_ROWS && m <= POA_LDS_SEQ && RING >= 2;
     for (int j = lane; j <= m; j += 64) { w.H[j] = (short)(j * POA_GAP); w.dir[j] = 3; }
-    phase_sync();
-    for (int r = 1; r <= N; ++r) {
-        const int v = w.order[r - 1];
-        const int np = w.np[v];
-        const int vb = w.base[v];
-        short* Hr = w.H + (size_t)r * Wd;
-        uint8_t* dr = w.dir + (size_t)r * Wd;
-        int pr[POA_MAXP];
-#pragma unroll
-        for (int e = 0; e < POA_MAXP; ++e) pr[e] = e < np ? w.rank[w.pred[v * POA_MAXP + e]] : 0;
-        int carry = 0;                 // H[v][j0-1] of the previous chunk; H[v][0] = 0
-        for (int j0 = 1; j0 <= m; j0 += 64) {
-            const int j = j0 + lane;
-            int best = -(1 << 28), bd = 0;
-            if (j <= m) {
-                const int sb = seq[j - 1];
-                const int s = (vb == sb && sb < 4) ? POA_MATCH : POA_MISMATCH;
-#pragma unroll
-                for (int e = 0; e < POA_MAXP; ++e)
-                    if (e < np) { const int c = (int)w.H[(size_t)pr[e] * Wd + j - 1] + s; if (c > best) { best = c; bd = 1 | (e << 4); } }
-                { const int c = (int)w.H[j - 1] + s; if (c > best) { best = c; bd = 1 | (15 << 4); } }
-#pragma unroll
-                for (int e = 0; e < POA_MAXP; ++e)
-                    if (e < np) { const int c = (int)w.H[(size_t)pr[e] * Wd + j] + POA_GAP; if (c > best) { best = c; bd = 2 | (e << 4); } }
-            }
-            // horizontal chain: H[j] = max(A[j], H[j-1]+g)  ==  max over k<=j of A[k] + (j-k) g, with A[j0-1] := carry
-            // scan on X[k] = A[k] - k*g (g < 0): prefix max, then add j*g
-            int x = j <= m ? best - j * POA_GAP : -(1 << 28);
-            const int xc = carry - (j0 - 1) * POA_GAP;
-            if (lane == 0 && xc > x) { /* handled below through pm */ }
-            int pm = x;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(pm, d); if (lane >= d && o > pm) pm = o; }
-            if (xc > pm) pm = xc;
-            const int hval = pm + j * POA_GAP;
-            if (j <= m) {
-                if (hval > best) { bd = 3; }
-                Hr[j] = (short)hval; dr[j] = (uint8_t)bd;
-            }
-            const int last = j0 + 63 <= m ? 63 : m - j0;
-            carry = __shfl(hval, last);
+    if (fast) {
+        uint32_t* rinfo = lds_rinfo;
+        for (int r = 1 + lane; r <= N; r += 64) {
+            const int v = w.order[r - 1];
+            const int np = w.np[v];
+            uint32_t pr[3] = {0, 0, 0};
+            for (int e = 0; e < 3; ++e) if (e < np) pr[e] = (uint32_t)w.rank[w.pred[v * POA_MAXP + e]];
+            rinfo[r * 2 + 0] = (uint32_t)(w.base[v] & 0xff) | ((uint32_t)np << 8) | (pr[0] << 16);
+            rinfo[r * 2 + 1] = pr[1] | (pr[2] << 16);
         }
-        if (lane == 0) { Hr[0] = 0; dr[0] = 0; }
-        __syncthreads();
+        for (int j = lane; j < m; j += 64) lds_seq[j] = seq[j];
+        phase_sync();
+        for (int r = 1; r <= N; ++r) {
+            const uint32_t d0 = rinfo[r * 2], d1 = rinfo[r * 2 + 1];
+            const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0xff);
+            int pr[POA_MAXP];
+            pr[0] = d0 >> 16; pr[1] = d1 & 0xffff; pr[2] = d1 >> 16;
+            if (np > 3) {
+                const int v = w.order[r - 1];
+                for (int e = 3; e < np; ++e) pr[e] = w.rank[w.pred[v * POA_MAXP + e]];
+            }
+            short* cur = lds_ring + (r & rmask) * mpad;
+            short* Hr = w.H + (size_t)r * Wd;
+            uint8_t* dr = w.dir + (size_t)r * Wd;
+            int carry = 0;
+            for (int j0 = 1; j0 <= m; j0 += 64) {
+                const int j = j0 + lane;
+                int best = -(1 << 28), bd = 0;
+                if (j <= m) {
+                    const int sb = lds_seq[j - 1];
+                    const int s = (vb == sb && sb < 4) ? POA_MATCH : POA_MISMATCH;
+                    for (int e = 0; e < np; ++e) {
+                        const int q = pr[e];
+                        const int hv = (r - q < RING) ? (int)lds_ring[(q & rmask) * mpad + j - 1] : (int)w.H[(size_t)q * Wd + j - 1];
+                        const int c = hv + s;
+                        if (c > best) { best = c; bd = 1 | (e << 4); }
+                    }
+                    { const int c = (j - 1) * POA_GAP + s; if (c > best) { best = c; bd = 1 | (15 << 4); } }
+                    for (int e = 0; e < np; ++e) {
+                        const int q = pr[e];
+                        const int hv = (r - q < RING) ? (int)lds_ring[(q & rmask) * mpad + j] : (int)w.H[(size_t)q * Wd + j];
+                        const int c = hv + POA_GAP;
+                        if (c > best) { best = c; bd = 2 | (e << 4); }
+                    }
+                }
+                const int x = j <= m ? best - j * POA_GAP : -(1 << 28);
+                const int xc = carry - (j0 - 1) * POA_GAP;
+                int pm = wave_prefix_max(x);
+                if (xc > pm) pm = xc;
+                const int hval = pm + j * POA_GAP;
+                if (j <= m) {
+                    if (hval > best) bd = 3;
+                    cur[j] = (short)hval; Hr[j] = (short)hval; dr[j] = (uint8_t)bd;
+                    if (j == m && hval > bs) { bs = hval; br = r; }
+                }
+                const int last = j0 + 63 <= m ? 63 : m - j0;
+                carry = __builtin_amdgcn_readlane(hval, last);
+            }
+            if (lane == 0) { cur[0] = 0; Hr[0] = 0; dr[0] = 0; }
+            asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
+        }
+    } else {
+        phase_sync();
+        for (int r = 1; r <= N; ++r) {
+            const int v = w.order[r - 1];
+            const int np = w.np[v];
+            const int vb = w.base[v];
+            short* Hr = w.H + (size_t)r * Wd;
+            uint8_t* dr = w.dir + (size_t)r * Wd;
+            int pr[POA_MAXP];
+#pragma unroll
+            for (int e = 0; e < POA_MAXP; ++e) pr[e] = e < np ? w.rank[w.pred[v * POA_MAXP + e]] : 0;
+            int carry = 0;                 // H[v][j0-1] of the previous chunk; H[v][0] = 0
+            for (int j0 = 1; j0 <= m; j0 += 64) {
+                const int j = j0 + lane;
+                int best = -(1 << 28), bd = 0;
+                if (j <= m) {
+                    const int sb = seq[j - 1];
+                    const int s = (vb == sb && sb < 4) ? POA_MATCH : POA_MISMATCH;
+#pragma unroll
+                    for (int e = 0; e < POA_MAXP; ++e)
+                        if (e < np) { const int c = (int)w.H[(size_t)pr[e] * Wd + j - 1] + s; if (c > best) { best = c; bd = 1 | (e << 4); } }
+                    { const int c = (int)w.H[j - 1] + s; if (c > best) { best = c; bd = 1 | (15 << 4); } }
+#pragma unroll
+                    for (int e = 0; e < POA_MAXP; ++e)
+                        if (e < np) { const int c = (int)w.H[(size_t)pr[e] * Wd + j] + POA_GAP; if (c > best) { best = c; bd = 2 | (e << 4); } }
+                }
+                // horizontal chain: H[j] = max(A[j], H[j-1]+g)  ==  max over k<=j of A[k] + (j-k) g, with A[j0-1] := carry
+                // scan on X[k] = A[k] - k*g (g < 0): prefix max, then add j*g
+                const int x = j <= m ? best - j * POA_GAP : -(1 << 28);
+                const int xc = carry - (j0 - 1) * POA_GAP;
+                int pm = wave_prefix_max(x);
+                if (xc > pm) pm = xc;
+                const int hval = pm + j * POA_GAP;
+                if (j <= m) {
+                    if (hval > best) { bd = 3; }
+                    Hr[j] = (short)hval; dr[j] = (uint8_t)bd;
+                    if (j == m && hval > bs) { bs = hval; br = r; }
+                }
+                const int last = j0 + 63 <= m ? 63 : m - j0;
+                carry = __builtin_amdgcn_readlane(hval, last);
+            }
+            if (lane == 0) { Hr[0] = 0; dr[0] = 0; }
+            __syncthreads();
+        }
     }
     phase_sync();
-    // end cell: largest H[r][m], lowest rank on ties
-    int bs = -(1 << 28), br = 0x7fffffff;
-    for (int r = 1 + lane; r <= N; r += 64) { const int hv = w.H[(size_t)r * Wd + m]; if (hv > bs) { bs = hv; br = r; } }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int s2 = __shfl_xor(bs, d), r2 = __shfl_xor(br, d);
-        if (s2 > bs || (s2 == bs && r2 < br)) { bs = s2; br = r2; }
+    TSTAMP(0);
+    // the lane that owns column m saw every H[r][m] in rank order (strict > kept the lowest rank)
+    {
+        const int owner = (m - 1) & 63;
+        bs = __shfl(bs, owner); br = __shfl(br, owner);
     }
     // walk back (wave-uniform)
     int npair = 0, r = br, j = m;
@@ -322,12 +420,19 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
         const int d = w.dir[(size_t)r * Wd + j];
         const int v = w.order[r - 1];
         const int kind = d & 3, e = d >> 4;
-        if (kind == 1) { --j; w.pn[npair] = v; w.pj[npair] = j; ++npair; r = e == 15 ? 0 : w.rank[w.pred[v * POA_MAXP + e]]; }
-        else if (kind == 2) { r = w.rank[w.pred[v * POA_MAXP + e]]; }
+        // rank of the e-th source: from the LDS row table when this copy used it, else two dependent HBM loads
+        int pre = 0;
+        if (kind != 3 && e != 15) {
+            if (fast && e < 3) { const uint32_t q0 = lds_rinfo[r * 2], q1 = lds_rinfo[r * 2 + 1]; pre = e == 0 ? (int)(q0 >> 16) : (e == 1 ? (int)(q1 & 0xffff) : (int)(q1 >> 16)); }
+            else pre = w.rank[w.pred[v * POA_MAXP + e]];
+        }
+        if (kind == 1) { --j; w.pn[npair] = v; w.pj[npair] = j; ++npair; r = pre; }
+        else if (kind == 2) { r = pre; }
         else if (kind == 3) { --j; w.pn[npair] = -1; w.pj[npair] = j; ++npair; }
         else break;
     }
     phase_sync();
+    TSTAMP(1);
     int lead = 0, first_anchor = -1;
     for (int t = npair - 1; t >= 0; --t) { const int q = w.pn[t]; if (q >= 0) { first_anchor = q; break; } ++lead; }
     long long anchor_key = first_anchor >= 0 ? w.key[first_anchor] - (lead + 1) : (long long)N << 20;   // max key == N<<20 after a re-rank
@@ -380,7 +485,9 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
     }
     if (rc != 0) return -1;
     phase_sync();
+    TSTAMP(2);
     poa_rerank(w, N, n, lane);
+    TSTAMP(3);
     return n;
 }
 
@@ -444,11 +551,12 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const CcsParams p)
         if (poa_slot_bytes(ncap, mcap) > p.slot_bytes) { res.status = 1; if (lane == 0) p.results[rd] = res; continue; }
         const PoaWs w = carve(slot, ncap, mcap);
         phase_sync();
+        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int N = 0;
         b = 0;
         for (int s = 0; s < nseg && N >= 0; ++s) {
             const int e = s < sc.ncuts ? sc.cuts[s] : L;
-            N = poa_add(w, N, ncap, mcap, seq + b, e - b, lane);
+            N = poa_add(w, N, ncap, mcap, seq + b, e - b, lane, tacc);
 #ifdef CLH_DEBUG_POA
             if (lane == 0 && 40 + s < CCS_SEG_CAP) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (40 + s)] = N;
 #endif
@@ -462,7 +570,14 @@ __global__ void __launch_bounds__(64) poa_consensus_kernel(const CcsParams p)
             p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * 50] = (int)snp; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * 51] = (int)spw; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * 52] = (int)(hsh & 0x7fffffff);
         }
 #endif
+#ifdef CLH_DEBUG_POA
+        unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
         const int len = poa_consensus(w, N, p.ccs + off, L, lane);
+#ifdef CLH_DEBUG_POA
+        tacc[4] += __builtin_amdgcn_s_memtime() - tc0;
+        if (lane == 0) for (int k = 0; k < 5; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
+#endif
         if (len < 0) { res.status = 3; if (lane == 0) p.results[rd] = res; continue; }
         res.nseg = nseg; res.ccs_len = len;
         if (lane == 0) p.results[rd] = res;
@@ -485,7 +600,7 @@ hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream)
 
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream)
 {
-    hipLaunchKernelGGL(poa_consensus_kernel, dim3(nslots), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(poa_consensus_kernel, dim3(nslots), dim3(64), POA_LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 

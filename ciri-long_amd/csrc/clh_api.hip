@@ -581,7 +581,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->slot_bytes = clh::poa_slot_bytes_host(lmax + 8, mcap_hint > 0 ? mcap_hint + 1 : lmax / 2 + lmax / 16 + 8);
     const unsigned long long budget = 24ull << 30;
     long long slots = (long long)(budget / pl->slot_bytes);
-    pl->nslots = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(slots, 4096), std::max(n, 1)));
+    pl->nslots = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(slots, 2304), std::max(n, 1))   /* ~17 KiB of LDS per wave: 9 waves per CU x 256 CUs */);
     pl->d_off = ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));
     pl->d_scan = ctx->alloc(sizeof(clh::CcsScan) * (size_t)std::max(n, 1));
     pl->d_res = ctx->alloc(sizeof(clh::CcsResult) * (size_t)std::max(n, 1));

@@ -312,9 +312,21 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
         }
         for (int j = lane; j < m; j += 64) lds_seq[j] = seq[j];
         phase_sync();
+        // a row's H values go to HBM only if some later row reads them from there, i.e. it is a source of a row at
+        // least RING ranks further on (bit 15 of the in-degree byte field is free: in-degree <= 12)
+        for (int r = 1 + lane; r <= N; r += 64) {
+            const uint32_t d0 = rinfo[r * 2], d1 = rinfo[r * 2 + 1];
+            const int np = (int)((d0 >> 8) & 0x7f);
+            int pr[POA_MAXP];
+            pr[0] = d0 >> 16; pr[1] = d1 & 0xffff; pr[2] = d1 >> 16;
+            if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) pr[e] = w.rank[w.pred[v * POA_MAXP + e]]; }
+            for (int e = 0; e < np; ++e) if (r - pr[e] >= RING) atomicOr(&rinfo[pr[e] * 2], 0x8000u);
+        }
+        phase_sync();
         for (int r = 1; r <= N; ++r) {
             const uint32_t d0 = rinfo[r * 2], d1 = rinfo[r * 2 + 1];
-            const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0xff);
+            const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0x7f);
+            const bool keep = (d0 & 0x8000u) != 0;    // read later from HBM by a far successor
             int pr[POA_MAXP];
             pr[0] = d0 >> 16; pr[1] = d1 & 0xffff; pr[2] = d1 >> 16;
             if (np > 3) {
@@ -352,13 +364,14 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
                 const int hval = pm + j * POA_GAP;
                 if (j <= m) {
                     if (hval > best) bd = 3;
-                    cur[j] = (short)hval; Hr[j] = (short)hval; dr[j] = (uint8_t)bd;
+                    cur[j] = (short)hval; dr[j] = (uint8_t)bd;
+                    if (keep) Hr[j] = (short)hval;
                     if (j == m && hval > bs) { bs = hval; br = r; }
                 }
                 const int last = j0 + 63 <= m ? 63 : m - j0;
                 carry = __builtin_amdgcn_readlane(hval, last);
             }
-            if (lane == 0) { cur[0] = 0; Hr[0] = 0; dr[0] = 0; }
+            if (lane == 0) { cur[0] = 0; dr[0] = 0; if (keep) Hr[0] = 0; }
             asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
         }
     } else {

@@ -120,8 +120,9 @@ struct clh_plan {
     std::vector<Seg> segs;
     void *d_tasks = nullptr, *d_results = nullptr, *d_colmax = nullptr, *d_cigars = nullptr, *d_cigar_len = nullptr,
          *d_pool = nullptr, *d_pool_head = nullptr, *d_reads = nullptr, *d_refs = nullptr;
-    size_t colmax_elems = 0, cigar_elems = 0;
+    size_t colmax_elems = 0, cigar_elems = 0, strip_bytes = 0;
     unsigned long long pool_bytes = 0;
+    void* d_strips = nullptr;
     hipStream_t last_stream = nullptr;
     bool ran = false;
     bool profiling = false;
@@ -135,7 +136,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     (void)hipSetDevice(c->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
-                    pl->d_reads, pl->d_refs};
+                    pl->d_reads, pl->d_refs, pl->d_strips};
     for (void* b : bufs) c->release(b);
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
     delete pl;
@@ -145,7 +146,7 @@ static int rv_class_for(int rows)
 {
     for (int i = 0; i < clh::kNumRvClasses; ++i)
         if (128 * clh::kRvClasses[i] >= rows) return clh::kRvClasses[i];
-    return -1;
+    return clh::kRvStrips;      // longer than 4096 rows: RV = 32 kernel with row strips
 }
 
 extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
@@ -189,10 +190,6 @@ extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_o
         if (L < 1 || R < 0 || L > 0x7fffffff || R > 0x7fffffff) { fail(CLH_E_ARG, "empty read or negative length in batch"); delete pl; return nullptr; }
         const int rows = (int)((L + 15) / 16) * 16;
         const int rv = rv_class_for(rows);
-        if (rv < 0) {
-            fail(CLH_E_UNSUPPORTED, "read longer than 4096 bases: row strips are not implemented yet");
-            delete pl; return nullptr;
-        }
         cls[a] = rv;
         clh::SswTask& t = pl->tasks[a];
         t.read_off = read_off[a]; t.ref_off = ref_off[a];
@@ -202,6 +199,10 @@ extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_o
         t.colmax_off = (int64_t)colmax;
         if (o->want_score2) colmax += (size_t)((R + 7) & ~7ll);
         t.cigar_off = (int32_t)cig; t.cigar_cap = 0; t.dir_off = 0;
+        if (rv == clh::kRvStrips) {     // two boundary buffers of (reference length rounded up to 64) x 8 bytes
+            t.dir_off = (int64_t)pl->strip_bytes;
+            pl->strip_bytes += 2 * (size_t)((R + 63) & ~63ll) * 8 + 256;
+        }
         if (pl->do_cigar) {
             t.cigar_cap = (int32_t)(2 * L + 2);
             if (cig + (size_t)t.cigar_cap > 0x7fffffffull) { fail(CLH_E_CAPACITY, "batch too large for 32-bit CIGAR offsets; split it"); delete pl; return nullptr; }
@@ -240,7 +241,8 @@ extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_o
         pl->d_pool = ctx->alloc((size_t)pl->pool_bytes);
         pl->d_pool_head = ctx->alloc(256);
     }
-    if (!pl->d_tasks || !pl->d_results || !pl->d_cigar_len || (o->want_score2 && !pl->d_colmax) ||
+    if (pl->strip_bytes) pl->d_strips = ctx->alloc(pl->strip_bytes);
+    if (!pl->d_tasks || !pl->d_results || !pl->d_cigar_len || (pl->strip_bytes && !pl->d_strips) || (o->want_score2 && !pl->d_colmax) ||
         (pl->do_cigar && (!pl->d_cigars || !pl->d_pool || !pl->d_pool_head))) {
         fail(CLH_E_HIP, "out of device memory while building the plan");
         clh_plan_destroy(pl); return nullptr;
@@ -261,7 +263,7 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     P.reads = (const int8_t*)d_reads; P.refs = (const int8_t*)d_refs;
     P.results = (clh::SswResult*)pl->d_results;
     P.colmax = (uint16_t*)pl->d_colmax;
-    P.cigars = (uint32_t*)pl->d_cigars; P.cigar_len = (int32_t*)pl->d_cigar_len; P.dirs = nullptr;
+    P.cigars = (uint32_t*)pl->d_cigars; P.cigar_len = (int32_t*)pl->d_cigar_len; P.dirs = (uint8_t*)pl->d_strips;
     if (pl->profiling && pl->ev.empty()) {
         pl->ev.resize(pl->segs.size() * 2 + 4);
         for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
@@ -309,7 +311,7 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         // alignments whose band outgrew the small window: one launch sized for the longest read class; workgroups of
         // unmarked alignments return at once
         int rvmax = 1;
-        for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv);
+        for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv == clh::kRvStrips ? 32 : s.rv);
         if (rvmax > 4)   // below that the small window (514 rows) already covers every read
             HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[eb + 3], st));

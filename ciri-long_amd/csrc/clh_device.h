@@ -20,7 +20,7 @@ struct SswTask {
     int64_t read_off;     // into reads (int8 codes)
     int64_t ref_off;      // into refs (int8 codes)
     int64_t colmax_off;   // into the column-maximum workspace (u16), one slot per reference base
-    int64_t dir_off;      // into the traceback direction workspace (bytes)
+    int64_t dir_off;      // strip-boundary workspace of this task inside `dirs` (bytes; reads longer than 4096 bases only)
     int32_t read_len;
     int32_t ref_len;
     int32_t mask_len;
@@ -41,7 +41,7 @@ struct SswParams {
     uint16_t* colmax;     // nullptr: skip the second-best scan (score2 = 0)
     uint32_t* cigars;     // BAM-style u32 (len<<4|op), ssw.h:131-170
     int32_t* cigar_len;   // per out_index
-    uint8_t* dirs;        // traceback workspace
+    uint8_t* dirs;        // strip-boundary workspace (row strips of long reads)
     int8_t mat[32];       // n*n substitution matrix (n <= 5)
     int32_t n, gapO, gapE, bias, max_match, score_size, flag, filters, filterd;
     int32_t null_code;    // 4 if mat scores code 4 as 0 against everything (then fill/drain columns reuse it), else 5
@@ -83,6 +83,7 @@ hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream);
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream);
 size_t poa_slot_bytes_host(int ncap, int mcap);
 
+static constexpr int kRvStrips = 1000;   // pseudo class: RV = 32 with row strips (reads longer than 4096 bases)
 extern const int kRvClasses[];
 extern const int kNumRvClasses;
 hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStream_t stream);

@@ -76,9 +76,21 @@ struct PassIn {
 // null_code: base code used for pipeline fill/drain columns; it must score 0 against every row.  5 (an extra
 // profile row) in general, 4 when the matrix already scores code 4 ("N") as 0 everywhere, as CIRI-long's do
 // (ssw_wrap.py:154-159) -- that saves one sixth of the LDS footprint.
-template <int RV, bool WORD, bool GEQ>
-__device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, const int* __restrict__ lds_mat,
-                            int gapO, int gapE, int bias, const int null_code)
+//
+// Reads longer than the 128*RV rows of a launch class are cut into row strips (STRIPS): every strip is a full pass
+// over all columns; the bottom row of strip s (its H, its vertical-gap carry and the running column maximum, per
+// column) goes through HBM to virtual lane 0 of strip s+1.  row_base = read row held by slot 0 (negative: leading
+// dummy slots, the single-strip layout).
+struct StripIo {
+    int row_base;          // read row of slot 0
+    const uint2* bnd_in;   // per column {H | carry << 16, colmax} of the strip above, or nullptr
+    uint2* bnd_out;        // same, produced for the strip below, or nullptr
+    int last;              // last strip: owns the finished column maxima (terminate test, colmax output)
+};
+
+template <int RV, bool WORD, bool GEQ, bool STRIPS>
+__device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __restrict__ lds_prof, const int* __restrict__ lds_mat,
+                             int gapO, int gapE, int bias, const int null_code, int& exceeded_out)
 {
     const int CODE_NULL = null_code;
     constexpr bool QUIRK = WORD && GEQ;
@@ -88,7 +100,7 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
     const int W = WORD ? 8 : 16;
     const int S = (in.L + W - 1) / W;
     const int rows = S * W;
-    const int off = 128 * RV - rows;             // leading dummy slots
+    const int off = -io.row_base;                // slot -> read row: row = slot - off
 
     // ---- query profile, lane-private rows in LDS: prof[base][chunk][lane][4] -------------------------------
     uint32_t cut[QUIRK ? RV : 1];
@@ -101,14 +113,15 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
         const int qlo = (int)in.read[(int64_t)clo * in.rstep] & 7, qhi = (int)in.read[(int64_t)chi * in.rstep] & 7;
         for (int b = 0; b <= null_code; ++b) {
             const int mlo = lds_mat[b * 8 + qlo], mhi = lds_mat[b * 8 + qhi];
-            const int slo = rlo < 0 ? NEG16 : (rlo > Lm1 ? 0 : mlo);
-            const int shi = rhi < 0 ? NEG16 : (rhi > Lm1 ? 0 : mhi);
+            // before the read or past its padded length: dummy row (pins H/E/F at 0); past the read: wildcard row
+            const int slo = (rlo < 0 || rlo >= rows) ? NEG16 : (rlo > Lm1 ? 0 : mlo);
+            const int shi = (rhi < 0 || rhi >= rows) ? NEG16 : (rhi > Lm1 ? 0 : mhi);
             lds_prof[((b * CH + (k >> 2)) * 64 + lane) * 4 + (k & 3)] = (uint32_t)(slo & 0xffff) | ((uint32_t)shi << 16);
         }
         if (QUIRK) {
             uint32_t m = 0xffffffffu;
-            if (rlo > 0 && rlo % S == 0) m &= 0xffff0000u;
-            if (rhi > 0 && rhi % S == 0) m &= 0x0000ffffu;
+            if (rlo > 0 && rlo < rows && rlo % S == 0) m &= 0xffff0000u;
+            if (rhi > 0 && rhi < rows && rhi % S == 0) m &= 0x0000ffffu;
             cut[k] = m;
         }
     }
@@ -137,11 +150,13 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
 
     // one step of the wavefront: reads the previous column from HR, writes the current one to HW.
     // Returns 1 when the pass must end (8-bit overflow or terminate score met).
-    auto step = [&](const int t, const int sb, uint32_t (&HR)[RV], uint32_t (&HW)[RV], int& ring) -> int {
+    auto step = [&](const int t, const int sb, const uint32_t bHC, const uint32_t bM, uint32_t (&HR)[RV], uint32_t (&HW)[RV],
+                    int& ring, int& ringHC) -> int {
         RB = hand_down(RB, (uint32_t)sb);
         const uint32_t aLo = (RB & 0xffffu) * BASE_STRIDE + lane * 16;
         const uint32_t aHi = (RB >> 16) * BASE_STRIDE + lane * 16;
-        const uint32_t inH = hand_down(outH, 0), inC = hand_down(outC, 0), inM = hand_down(outM, 0);
+        const uint32_t inH = hand_down(outH, STRIPS ? (bHC & 0xffffu) : 0u), inC = hand_down(outC, STRIPS ? (bHC >> 16) : 0u),
+                       inM = hand_down(outM, STRIPS ? bM : 0u);
         uint32_t F = inC, diag = diagIn, cm = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -207,39 +222,57 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
         if (jl >= 0 && jl < ncols) {
             const int cmLast = (int)((uint32_t)__builtin_amdgcn_readlane((int)outM, 63) >> 16);
             ring = lane == (t & 63) ? cmLast : ring;
-            if (cmLast == in.terminate) { term_col = jl; return 1; }
+            if (STRIPS) {
+                const uint32_t hL = (uint32_t)__builtin_amdgcn_readlane((int)outH, 63) >> 16, cL = (uint32_t)__builtin_amdgcn_readlane((int)outC, 63) >> 16;
+                ringHC = lane == (t & 63) ? (int)(hL | (cL << 16)) : ringHC;
+            }
+            if (io.last && cmLast == in.terminate) { term_col = jl; return 1; }
         }
         return 0;
     };
 
     // 64 steps per block: the block's reference bases were loaded one block earlier (lane i <-> step t0+i) and
     // its finished column maxima leave through one coalesced store per block; no vector-memory op inside.
+    auto load_bnd = [&](int t0) -> uint2 {
+        const int j = t0 + lane;
+        return (STRIPS && io.bnd_in && j < ncols) ? io.bnd_in[j] : make_uint2(0u, 0u);
+    };
     int nxt = load_chunk(0);
+    uint2 nxtb = load_bnd(0);
     for (int t0 = 0; t0 < nsteps && !stop; t0 += 64) {
         int chunk = nxt;
+        uint2 cb = nxtb;
         asm volatile("" : "+v"(chunk));      // the wait for last block's prefetch lands here, not inside the step loop
+        if (STRIPS) asm volatile("" : "+v"(cb.x), "+v"(cb.y));
         nxt = load_chunk(t0 + 64);
-        int ring = 0;
+        nxtb = load_bnd(t0 + 64);
+        int ring = 0, ringHC = 0;
         int done = 64;
         for (int u = 0; u < 64; u += 2) {
-            int r = step(t0 + u, __builtin_amdgcn_readlane(chunk, u), HA, HB, ring);
+            int r = step(t0 + u, __builtin_amdgcn_readlane(chunk, u), STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.x, u) : 0u,
+                         STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u) : 0u, HA, HB, ring, ringHC);
             if (r) { stop = r; done = u + 1; break; }
-            r = step(t0 + u + 1, __builtin_amdgcn_readlane(chunk, u + 1), HB, HA, ring);
+            r = step(t0 + u + 1, __builtin_amdgcn_readlane(chunk, u + 1), STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.x, u + 1) : 0u,
+                     STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u + 1) : 0u, HB, HA, ring, ringHC);
             if (r) { stop = r; done = u + 2; break; }
         }
-        if (in.colmax) {
-            const int col = t0 - 127 + lane;
+        const int col = t0 - 127 + lane;
+        if (in.colmax && io.last) {
             if (lane < done && col >= 0 && col < ncols) in.colmax[col] = (uint16_t)ring;
+        }
+        if (STRIPS && io.bnd_out) {
+            if (lane < done && col >= 0 && col < ncols) io.bnd_out[col] = make_uint2((uint32_t)ringHC, (uint32_t)ring);
         }
     }
     if (stop == 2) { PassOut o; o.max = 255; o.col = -1; o.row = 0; o.overflow = 1; o.term_col = -1; return o; }
 
     // ---- wave reduction: (score desc, column asc, virtual lane asc) ------------------------------------------
     const int exceeded = __builtin_amdgcn_ballot_w64((flags & 2u) != 0u) != 0;
+    exceeded_out |= exceeded;
     PassOut o;
     o.overflow = 0;
     o.term_col = term_col;
-    if (term_col >= 0 && exceeded) {   // caller re-runs on columns [0, term_col] without early stop
+    if (!STRIPS && term_col >= 0 && exceeded) {   // caller re-runs on columns [0, term_col] without early stop
         o.max = -1; o.col = -1; o.row = 0;
         return o;
     }
@@ -271,6 +304,37 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
     return o;
 }
 
+template <int RV, bool WORD, bool GEQ, bool STRIPS>
+__device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, const int* __restrict__ lds_mat,
+                            int gapO, int gapE, int bias, const int null_code, uint2* bnd)
+{
+    const int W = WORD ? 8 : 16;
+    const int rows = ((in.L + W - 1) / W) * W;
+    constexpr int CAP = 128 * RV;
+    int exceeded = 0;
+    if (!STRIPS || rows <= CAP) {
+        StripIo io; io.row_base = rows - CAP; io.bnd_in = nullptr; io.bnd_out = nullptr; io.last = 1;
+        PassOut o = run_strip<RV, WORD, GEQ, false>(in, io, lds_prof, lds_mat, gapO, gapE, bias, null_code, exceeded);
+        return o;
+    }
+    const int ns = (rows + CAP - 1) / CAP;
+    uint2* buf[2] = {bnd, bnd + ((in.ncols + 63) & ~63)};
+    PassOut best; best.max = 0; best.col = -1; best.row = 0; best.overflow = 0; best.term_col = -1;
+    for (int s = 0; s < ns; ++s) {
+        StripIo io;
+        io.row_base = s * CAP; io.bnd_in = s > 0 ? buf[(s - 1) & 1] : nullptr; io.bnd_out = s < ns - 1 ? buf[s & 1] : nullptr; io.last = s == ns - 1;
+        const PassOut o = run_strip<RV, WORD, GEQ, true>(in, io, lds_prof, lds_mat, gapO, gapE, bias, null_code, exceeded);
+        if (o.overflow) return o;
+        if (io.last) best.term_col = o.term_col;
+        // strips are in row order: on a full tie the earlier strip (smaller rows) stays
+        if (o.max > best.max || (o.max == best.max && o.max > 0 && o.col < best.col)) { best.max = o.max; best.col = o.col; best.row = o.row; }
+        __syncthreads();     // the boundary rows written by this strip are read by the next one (same wave, through HBM)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (best.term_col >= 0 && exceeded) { best.max = -1; best.col = -1; best.row = 0; }
+    return best;
+}
+
 // masked second-best column maximum, ssw.c:325-340 (8 bit) / 528-541 (16 bit); wave-parallel
 __device__ void second_best(const uint16_t* colmax, int refLen, int end_ref, int maskLen, int word, int& score2, int& ref_end2)
 {
@@ -298,7 +362,7 @@ __device__ void second_best(const uint16_t* colmax, int refLen, int end_ref, int
 // half-rate packed ops keep a SIMD busy with two waves; asking for more only causes spills
 constexpr int waves_per_simd(int rv) { return rv <= 12 ? 3 : (rv <= 16 ? 2 : 1); }
 
-template <int RV, bool GEQ>
+template <int RV, bool GEQ, bool STRIPS>
 __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const SswParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -316,6 +380,7 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
     const int8_t* ref = p.refs + task.ref_off;
     const int L = task.read_len, refLen = task.ref_len;
     uint16_t* colmax = p.colmax ? p.colmax + task.colmax_off : nullptr;
+    uint2* bnd = STRIPS ? (uint2*)(p.dirs + task.dir_off) : nullptr;     // strip boundary rows (2 x ncols x 8 bytes)
     const int bias = p.bias, gO = p.gapO, gE = p.gapE;
     SswResult res;
     res.score1 = 0; res.score2 = 0; res.ref_begin1 = -1; res.ref_end1 = -1; res.read_begin1 = -1; res.read_end1 = 0;
@@ -331,11 +396,11 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
     in.colmax = colmax;
     while (regime < 0) {
         if (job_word) {
-            PassOut r = run_pass<RV, true, GEQ>(in, lds_prof, lds_mat, gO, gE, 0, p.null_code);
+            PassOut r = run_pass<RV, true, GEQ, STRIPS>(in, lds_prof, lds_mat, gO, gE, 0, p.null_code, bnd);
             if (p.score_size == 1 || byte_overflowed || r.max + bias >= 255) { fw = r; regime = 1; }
             else job_word = 0;
         } else {
-            PassOut r = run_pass<RV, false, GEQ>(in, lds_prof, lds_mat, gO, gE, bias, p.null_code);
+            PassOut r = run_pass<RV, false, GEQ, STRIPS>(in, lds_prof, lds_mat, gO, gE, bias, p.null_code, bnd);
             if (!r.overflow) { fw = r; regime = 0; }
             else if (p.score_size == 0) { res.status = CLH_STATUS_OVERFLOW8; if (lane == 0) p.results[task.out_index] = res; return; }
             else { byte_overflowed = true; job_word = 1; }
@@ -357,8 +422,8 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
         rv.terminate = res.score1; rv.colmax = nullptr;
         PassOut r;
         for (;;) {
-            if (regime) r = run_pass<RV, true, GEQ>(rv, lds_prof, lds_mat, gO, gE, 0, p.null_code);
-            else r = run_pass<RV, false, GEQ>(rv, lds_prof, lds_mat, gO, gE, bias, p.null_code);
+            if (regime) r = run_pass<RV, true, GEQ, STRIPS>(rv, lds_prof, lds_mat, gO, gE, 0, p.null_code, bnd);
+            else r = run_pass<RV, false, GEQ, STRIPS>(rv, lds_prof, lds_mat, gO, gE, bias, p.null_code, bnd);
             if (r.max >= 0) break;
             rv.ncols = r.term_col + 1; rv.terminate = 1 << 30;     // see PassOut: rare re-run
         }
@@ -375,24 +440,25 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
 // -------------------------------------------------------------------------------------------------------------
 namespace clh {
 
-template <int RV, bool GEQ>
+template <int RV, bool GEQ, bool STRIPS = false>
 static hipError_t launch_one(const SswParams& p, int ntasks, hipStream_t stream)
 {
     const size_t lds_bytes = (size_t)(p.null_code + 1) * ((RV + 3) / 4) * 1024 + 64 * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ssw_align_kernel<RV, GEQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)ssw_align_kernel<RV, GEQ, STRIPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            6 * ((RV + 3) / 4) * 1024 + 256);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((ssw_align_kernel<RV, GEQ>), dim3(ntasks), dim3(64), lds_bytes, stream, p);
+    hipLaunchKernelGGL((ssw_align_kernel<RV, GEQ, STRIPS>), dim3(ntasks), dim3(64), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
 template <bool GEQ>
 static hipError_t launch_rv(int rv, const SswParams& p, int ntasks, hipStream_t stream)
 {
+    if (rv == kRvStrips) return launch_one<32, GEQ, true>(p, ntasks, stream);   // reads longer than 4096 bases: row strips
     switch (rv) {
 #define CLH_CASE(R) case R: return launch_one<R, GEQ>(p, ntasks, stream);
 #ifdef CLH_PROBE_BUILD

@@ -29,7 +29,7 @@ def _row_tuple(r):
 
 
 def test_golden_vectors_bit_exact(ctx, golden_cases):
-    cases = [c for c in golden_cases if len(c['query']) <= 4096]
+    cases = [c for c in golden_cases if len(c['query']) <= 4096]        # the 430 kb query has its own test below
     by_scheme = {}
     for c in cases:
         by_scheme.setdefault((c['match'], c['mismatch'], c['gap_open'], c['gap_extend']), []).append(c)
@@ -132,3 +132,38 @@ def test_options_score_size_flag_and_skips(ctx):
         want = oracle_align(ref, q, 1, 1, 1, 1)
         assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])) == \
             (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end'])
+
+
+def test_reference_test_ssw_orientation_430kb_query(ctx, testfa):
+    """tests/test_ssw.py:5-15 of the reference: Aligner(seq1 (437 nt)) . align(seq2 (430 314 nt)) -- the QUERY is the long
+    sequence, so its rows do not fit one launch class and run as 106 row strips of 4096."""
+    seq1, seq2 = testfa
+    rows, cig = _run(ctx, [seq1], [seq2], (1, 1, 1, 1))
+    r = rows[0]
+    assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])) == \
+        (349, 20, 436, 229781, 230207)
+    want = oracle_align(seq1, seq2, 1, 1, 1, 1)
+    assert _row_tuple(r) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
+                             want['query_end'], want['ref_end2'])
+    assert [int(x) for x in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar']
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (10, 4, 8, 2)])
+def test_long_reads_row_strips_vs_oracle(ctx, scheme):
+    """Reads of 4 097 ... 13 000 bases (2-4 row strips), mutated copies and unrelated pairs, both regimes."""
+    rng = np.random.default_rng(sum(scheme) + 5)
+    refs, qs = [], []
+    for L in (4097, 4200, 5000, 8192, 8193, 9000, 13000):
+        R = int(rng.choice([600, 3000, 9000]))
+        ref = _rnd(rng, R)
+        if rng.random() < 0.7:
+            core = (ref * (L // R + 2))[:L]
+            q = _mut(core, rng, 0.08)
+        else:
+            q = _rnd(rng, L)
+        refs.append(ref); qs.append(q)
+    rows, cig = _run(ctx, refs, qs, scheme, want_cigar=False)
+    for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
+        want = oracle_align(ref, q, *scheme)
+        assert _row_tuple(r) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
+                                 want['query_end'], want['ref_end2']), (k, len(q), len(ref))

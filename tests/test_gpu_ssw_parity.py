@@ -167,3 +167,69 @@ def test_long_reads_row_strips_vs_oracle(ctx, scheme):
         want = oracle_align(ref, q, *scheme)
         assert _row_tuple(r) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
                                  want['query_end'], want['ref_end2']), (k, len(q), len(ref))
+
+
+def test_legacy_six_symbols_as_the_reference_wrapper_binds_them(golden_cases):
+    """The zero-change route of INTEGRATION.md: the ctypes stub of ssw_wrap.py:54-72,278-288 against libclh.so."""
+    import ctypes as C
+    import os
+    from ciri_long_amd import hip
+
+    class CAlignRes(C.Structure):          # ssw_wrap.py:29-37
+        _fields_ = [('score', C.c_uint16), ('score2', C.c_uint16), ('ref_begin', C.c_int32), ('ref_end', C.c_int32),
+                    ('query_begin', C.c_int32), ('query_end', C.c_int32), ('ref_end2', C.c_int32),
+                    ('cigar', C.POINTER(C.c_uint32)), ('cigarLen', C.c_int32)]
+    lib = C.CDLL(hip.SO_PATH)
+    lib.ssw_init.restype = C.c_void_p
+    lib.ssw_init.argtypes = [C.POINTER(C.c_int8), C.c_int32, C.POINTER(C.c_int8), C.c_int32, C.c_int8]
+    lib.init_destroy.restype = None
+    lib.init_destroy.argtypes = [C.c_void_p]
+    lib.ssw_align.restype = C.POINTER(CAlignRes)
+    lib.ssw_align.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.c_int32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16, C.c_int32, C.c_int32]
+    lib.align_destroy.restype = None
+    lib.align_destroy.argtypes = [C.POINTER(CAlignRes)]
+    lib.cigar_int_to_len.restype = C.c_int32
+    lib.cigar_int_to_len.argtypes = [C.c_int32]
+    lib.cigar_int_to_op.restype = C.c_char
+    lib.cigar_int_to_op.argtypes = [C.c_int32]
+    picked = [c for c in golden_cases if c['name'] in ('tiny_gap', 'zero_score', 'n_in_ref', 'periodic_word')] + golden_cases[40:70]
+    for c in picked:
+        q = hip.encode(c['query']); r = hip.encode(c['ref'])
+        mat = hip.score_matrix(c['match'], c['mismatch'])
+        qa = (C.c_int8 * len(q))(*q.tolist()); ra = (C.c_int8 * len(r))(*r.tolist()); ma = (C.c_int8 * 25)(*mat.tolist())
+        prof = lib.ssw_init(qa, len(q), ma, 5, 2)
+        mask = len(q) // 2 if len(q) > 30 else 15
+        res = lib.ssw_align(prof, ra, len(r), c['gap_open'], c['gap_extend'], 1, 0, 0, mask)
+        assert res, c['name']
+        x = res.contents
+        assert (x.score, x.score2, x.ref_begin, x.ref_end, x.query_begin, x.query_end, x.ref_end2, x.cigarLen) == \
+            (c['score'], c['raw_score2'], c['ref_begin'], c['ref_end'], c['query_begin'], c['query_end'], c['raw_ref_end2'], c['raw_cigar_len']), c['name']
+        s = ''.join('%d%s' % (lib.cigar_int_to_len(x.cigar[i]), lib.cigar_int_to_op(x.cigar[i]).decode()) for i in range(x.cigarLen))
+        clip_l = '%dS' % x.query_begin if x.query_begin > 0 else ''
+        clip_r = '%dS' % (len(q) - x.query_end - 1) if len(q) - x.query_end - 1 else ''
+        assert clip_l + s + clip_r == c['cigar_string'], c['name']
+        lib.align_destroy(res)
+        lib.init_destroy(prof)
+
+
+def test_ssw_wrap_mirror_behaves_like_the_reference_wrapper(golden_cases):
+    from ciri_long_amd import ssw_wrap
+    by = {c['name']: c for c in golden_cases}
+    c = by['tiny_gap']
+    al = ssw_wrap.Aligner(c['ref'], match=c['match'], mismatch=c['mismatch'], gap_open=c['gap_open'], gap_extend=c['gap_extend'],
+                          report_secondary=True, report_cigar=True)
+    res = al.align(c['query'])
+    assert (res.score, res.ref_begin, res.ref_end, res.query_begin, res.query_end, res.cigar_string, res.score2, res.ref_end2) == \
+        (c['score'], c['ref_begin'], c['ref_end'], c['query_begin'], c['query_end'], c['cigar_string'], c['score2'], c['ref_end2'])
+    assert al.align(c['query'], min_score=10 ** 6) is None and al.align(c['query'], 0, 10 ** 6) is None     # ssw_wrap.py:219-222
+    plain = ssw_wrap.Aligner(c['ref'], 1, 1, 1, 1).align(c['query'])
+    assert plain.cigar_string is None and plain.score2 is None                                              # defaults report nothing extra
+    some = golden_cases[100:130]
+    got = ssw_wrap.align_pairs([x['ref'] for x in some], [x['query'] for x in some], some[0]['match'], some[0]['mismatch'],
+                               some[0]['gap_open'], some[0]['gap_extend'], report_cigar=True)
+    for x, g in zip(some, got):
+        if (x['match'], x['mismatch'], x['gap_open'], x['gap_extend']) == (some[0]['match'], some[0]['mismatch'], some[0]['gap_open'], some[0]['gap_extend']):
+            assert (g.score, g.ref_begin, g.ref_end, g.query_begin, g.query_end, g.cigar_string) == \
+                (x['score'], x['ref_begin'], x['ref_end'], x['query_begin'], x['query_end'], x['cigar_string'])
+    batch = al.align_batch([c['query'], c['query'][2:], 'ACGT'])
+    assert batch[0].score == c['score'] and len(batch) == 3

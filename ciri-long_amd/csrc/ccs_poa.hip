@@ -51,6 +51,13 @@ __device__ __forceinline__ int wave_prefix_max(int v) {
     return v;
 }
 
+// H value of a far source row, read from HBM without letting the compiler merge it with an LDS read (see poa_add)
+__device__ __forceinline__ int far_h(const short* ptr) {
+    int x;
+    asm volatile("global_load_sshort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(ptr) : "memory");
+    return x;
+}
+
 __device__ __forceinline__ int wmax_i(int v) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
@@ -158,6 +165,10 @@ struct PoaWs {            // views into one wave's workspace slot
     int32_t* pn; int32_t* pj; int32_t* score; int32_t* bp; short* H; uint8_t* dir;
 };
 
+// row pitch (elements) of the DP matrix and of the direction bytes for a copy of m bases: column j sits at element j+7,
+// so the 2/4/8 columns a lane owns start at an aligned element, and the pitch is a multiple of 16
+__host__ __device__ inline int poa_pitch(int m) { return (m + 8 + 15) & ~15; }
+
 __device__ PoaWs carve(uint8_t* slot, int ncap, int mcap)
 {
     PoaWs w;
@@ -175,8 +186,8 @@ __device__ PoaWs carve(uint8_t* slot, int ncap, int mcap)
     w.bp = (int32_t*)take(sizeof(int32_t) * ncap);
     w.base = (int8_t*)take(ncap);
     w.np = (int8_t*)take(ncap);
-    w.H = (short*)take(sizeof(short) * (size_t)(ncap + 1) * mcap);
-    w.dir = (uint8_t*)take((size_t)(ncap + 1) * mcap);
+    w.H = (short*)take(sizeof(short) * (size_t)(ncap + 1) * poa_pitch(mcap - 1));
+    w.dir = (uint8_t*)take((size_t)(ncap + 1) * poa_pitch(mcap - 1));
     return w;
 }
 
@@ -188,7 +199,7 @@ __host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)
     add(sizeof(int32_t) * (size_t)ncap * 3); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap);
     add(sizeof(int32_t) * (size_t)(ncap + mcap + 2)); add(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
     add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap); add(ncap); add(ncap);
-    add(sizeof(short) * (size_t)(ncap + 1) * mcap); add((size_t)(ncap + 1) * mcap);
+    add(sizeof(short) * (size_t)(ncap + 1) * poa_pitch(mcap - 1)); add((size_t)(ncap + 1) * poa_pitch(mcap - 1));
     return o + 64;
 }
 
@@ -270,6 +281,157 @@ extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];
 #define lds_seq ((int8_t*)(poa_lds + 2 * (POA_LDS_ROWS + 1)) + POA_LDS_RING_BYTES)
 static constexpr size_t POA_LDS_BYTES = 8 * (POA_LDS_ROWS + 1) + POA_LDS_RING_BYTES + POA_LDS_SEQ;
 
+// direction byte of the fast path = 255 - ordinal of the winning candidate in the specification's evaluation order:
+// diagonal from in-edge e (ordinal e), diagonal from row 0 (12), vertical from in-edge e (13+e), horizontal (25).
+// A candidate is carried as (value << 8) | (255 - ordinal), so one signed max per candidate both takes the larger
+// value and, between equal values, keeps the earlier candidate -- the strict '>' chain of the specification.
+static constexpr int POA_ORD_ROW0 = 12, POA_ORD_VERT = 13, POA_ORD_HORIZ = 25;
+
+// C+1 H values (columns first-1 .. first+C-1) of a far source row from HBM; assembly for the reason given at far_h
+template <int C>
+__device__ __forceinline__ void far_row(const short* ptr, int (&h)[C], int& hprev) {
+    asm volatile("global_load_sshort %0, %1, off" : "=v"(hprev) : "v"(ptr) : "memory");
+#pragma unroll
+    for (int k = 0; k < C; ++k) asm volatile("global_load_sshort %0, %1, off" : "=v"(h[k]) : "v"(ptr + 1 + k) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < C; ++k) asm volatile("" : "+v"(h[k]));
+    asm volatile("" : "+v"(hprev));
+}
+
+// DP rows of one copy against the graph, fast path: lane l owns C adjacent columns (C = 2, 4, 8 by copy length), so a
+// row of up to 64*C columns is one pass: one wide LDS read per source row, the candidates of the C cells in registers,
+// an in-lane max-plus scan, ONE cross-lane DPP scan per row, one wide LDS write, one wide direction-byte store.
+template <int C>
+__device__ void dp_rows_fast(const PoaWs& w, int N, int m, int lane, int RING, int pitch, int& bs_out, int& br_out)
+{
+    constexpr int NEG = -(1 << 28);
+    const int rmask = RING - 1;
+    const int npass = (m + 64 * C - 1) / (64 * C);
+    const uint32_t* rinfo = lds_rinfo;
+    if (lane < RING) lds_ring[lane * pitch + 7] = 0;             // column 0 of every ring slot: H[r][0] = 0, never rewritten
+    const int lm = ((m - 1) % (64 * C)) / C, km = (m - 1) % C, pm = (m - 1) / (64 * C);   // where column m lives
+    int bs = NEG, br = 0x7fffffff;
+    auto base_masks = [&](int pass) {                            // bit 8*b+k: cell k of this lane holds base b
+        uint32_t sbm = 0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int j = pass * 64 * C + C * lane + k + 1;
+            const int sb = j <= m ? (int)lds_seq[j - 1] : 4;
+            if (sb < 4) sbm |= 1u << (8 * sb + k);
+        }
+        return sbm;
+    };
+    uint32_t sbm = base_masks(0);
+    uint32_t n0 = rinfo[2], n1 = rinfo[3];
+    for (int r = 1; r <= N; ++r) {
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0), d1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
+        if (r < N) { n0 = rinfo[(r + 1) * 2]; n1 = rinfo[(r + 1) * 2 + 1]; }      // next row's graph info, off the critical path
+        const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0x7f);
+        const bool keep = (d0 & 0x8000u) != 0;                   // read later from HBM by a far successor
+        const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
+        const int vnode = np > 3 ? __builtin_amdgcn_readfirstlane(w.order[r - 1]) : 0;
+        short* cur = lds_ring + (r & rmask) * pitch;
+        int carry = 0;                                           // H[r][last column of the previous pass]; H[r][0] = 0
+        for (int pass = 0; pass < npass; ++pass) {
+            if (npass > 1) sbm = base_masks(pass);
+            const uint32_t mk = vb >= 0 && vb < 4 ? (sbm >> (8 * vb)) & 0xffu : 0u;
+            const int col0 = pass * 64 * C + C * lane;           // cell k is column col0+k+1, element col0+k+8 of a row
+            int best[C];
+            int ss[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                ss[k] = ((mk >> k) & 1u) ? (POA_MATCH << 8) : (POA_MISMATCH * 256);
+                best[k] = (col0 + k) * (POA_GAP * 256) + ss[k] + (255 - POA_ORD_ROW0);
+            }
+            auto source = [&](int e, int q) {
+                int h[C], hprev;
+                if (r - q < RING) {
+                    const short* src = lds_ring + (q & rmask) * pitch + col0 + 8;
+                    hprev = src[-1];
+                    if constexpr (C == 8) { const uint4 t = *(const uint4*)src; const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) h[k] = (k & 1) ? (int)u[k >> 1] >> 16 : (int)(short)(u[k >> 1] & 0xffff); }
+                    else if constexpr (C == 4) { const uint2 t = *(const uint2*)src; const uint32_t u[2] = {t.x, t.y};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) h[k] = (k & 1) ? (int)u[k >> 1] >> 16 : (int)(short)(u[k >> 1] & 0xffff); }
+                    else { const uint32_t t = *(const uint32_t*)src; h[0] = (int)(short)(t & 0xffff); h[1] = (int)t >> 16; }
+                } else {
+                    far_row<C>(w.H + (size_t)q * pitch + col0 + 7, h, hprev);
+                }
+                const int cd = 255 - e, cv = POA_GAP * 256 + 255 - POA_ORD_VERT - e;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int up = k == 0 ? hprev : h[k - 1];
+                    const int c1 = (up << 8) + ss[k] + cd;
+                    const int c2 = (h[k] << 8) + cv;
+                    best[k] = c1 > best[k] ? c1 : best[k];
+                    best[k] = c2 > best[k] ? c2 : best[k];
+                }
+            };
+            if (np > 0) source(0, p0);
+            if (np > 1) source(1, p1);
+            if (np > 2) source(2, p2);
+            for (int e = 3; e < np; ++e) source(e, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + e]]));
+            // horizontal chain H[j] = max(A[j], H[j-1]+g) == max over k<=j of A[k] + (j-k) g: prefix max of
+            // X[k] = A[k] - k g (g < 0), in the packed domain (the low byte rides along and never matters)
+            int x[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                x[k] = best[k] + (col0 + k + 1) * (-POA_GAP * 256);
+                if (k) x[k] = x[k - 1] > x[k] ? x[k - 1] : x[k];
+            }
+            const int incl = wave_prefix_max(x[C - 1]);
+            int excl = __builtin_amdgcn_update_dpp(NEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1
+            const int xc = (carry + (pass * 64 * C) * (-POA_GAP)) * 256;
+            excl = xc > excl ? xc : excl;
+            int hv[C];
+            uint32_t db[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const int pk = excl > x[k] ? excl : x[k];
+                hv[k] = (pk >> 8) + (col0 + k + 1) * POA_GAP;
+                db[k] = hv[k] > (best[k] >> 8) ? (uint32_t)(255 - POA_ORD_HORIZ) : ((uint32_t)best[k] & 0xffu);
+            }
+            if (col0 + 1 <= m) {
+                short* dst = cur + col0 + 8;
+                uint8_t* dd = w.dir + (size_t)r * pitch + col0 + 8;
+                if constexpr (C == 8) {
+                    uint4 t;
+                    t.x = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16); t.y = ((uint32_t)hv[2] & 0xffffu) | ((uint32_t)hv[3] << 16);
+                    t.z = ((uint32_t)hv[4] & 0xffffu) | ((uint32_t)hv[5] << 16); t.w = ((uint32_t)hv[6] & 0xffffu) | ((uint32_t)hv[7] << 16);
+                    *(uint4*)dst = t;
+                    uint2 b;
+                    b.x = db[0] | (db[1] << 8) | (db[2] << 16) | (db[3] << 24); b.y = db[4] | (db[5] << 8) | (db[6] << 16) | (db[7] << 24);
+                    *(uint2*)dd = b;
+                    if (keep) *(uint4*)(w.H + (size_t)r * pitch + col0 + 8) = t;
+                } else if constexpr (C == 4) {
+                    uint2 t;
+                    t.x = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16); t.y = ((uint32_t)hv[2] & 0xffffu) | ((uint32_t)hv[3] << 16);
+                    *(uint2*)dst = t;
+                    *(uint32_t*)dd = db[0] | (db[1] << 8) | (db[2] << 16) | (db[3] << 24);
+                    if (keep) *(uint2*)(w.H + (size_t)r * pitch + col0 + 8) = t;
+                } else {
+                    const uint32_t t = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16);
+                    *(uint32_t*)dst = t;
+                    *(uint16_t*)dd = (uint16_t)(db[0] | (db[1] << 8));
+                    if (keep) *(uint32_t*)(w.H + (size_t)r * pitch + col0 + 8) = t;
+                }
+            }
+            if (pass == pm) {
+                int hm = hv[0];
+#pragma unroll
+                for (int k = 1; k < C; ++k) hm = km == k ? hv[k] : hm;
+                if (lane == lm && hm > bs) { bs = hm; br = r; }      // strict >: lowest rank on ties
+            }
+            if (pass + 1 < npass) carry = __builtin_amdgcn_readlane(hv[C - 1], 63);
+        }
+        if (keep && lane == 0) w.H[(size_t)r * pitch + 7] = 0;
+        asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
+    }
+    bs_out = __shfl(bs, lm); br_out = __shfl(br, lm);
+}
+
 // returns the new node count, or -1 on overflow
 __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* seq, int m, int lane, unsigned long long* tacc)
 {
@@ -294,14 +456,13 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
     // Fast path: per-row graph info (base, in-degree, ranks of up to 4 sources), the sequence, and a ring of the last
     // RING rows of H live in LDS, so a row whose sources are recent (the rule: a chain) touches HBM only to store its
     // H row (needed by a far source, rarely) and its direction bytes.  Row 0 is arithmetic (j*gap).
-    const int mpad = (m + 1 + 63) & ~63;
+    const int pitch = poa_pitch(m);
     int RING = 16;                                   // power of two, so slot = rank & (RING-1)
-    while (RING * mpad > POA_LDS_RING_BYTES / 2) RING >>= 1;
-    const int rmask = RING - 1;
+    while (RING * pitch > POA_LDS_RING_BYTES / 2) RING >>= 1;
     const bool fast = N <= POA_LDS_ROWS && m <= POA_LDS_SEQ && RING >= 2;
-    for (int j = lane; j <= m; j += 64) { w.H[j] = (short)(j * POA_GAP); w.dir[j] = 3; }
     if (fast) {
         uint32_t* rinfo = lds_rinfo;
+#pragma unroll 4
         for (int r = 1 + lane; r <= N; r += 64) {
             const int v = w.order[r - 1];
             const int np = w.np[v];
@@ -317,64 +478,18 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
         for (int r = 1 + lane; r <= N; r += 64) {
             const uint32_t d0 = rinfo[r * 2], d1 = rinfo[r * 2 + 1];
             const int np = (int)((d0 >> 8) & 0x7f);
-            int pr[POA_MAXP];
-            pr[0] = d0 >> 16; pr[1] = d1 & 0xffff; pr[2] = d1 >> 16;
-            if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) pr[e] = w.rank[w.pred[v * POA_MAXP + e]]; }
-            for (int e = 0; e < np; ++e) if (r - pr[e] >= RING) atomicOr(&rinfo[pr[e] * 2], 0x8000u);
+            const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
+            if (np > 0 && r - p0 >= RING) atomicOr(&rinfo[p0 * 2], 0x8000u);
+            if (np > 1 && r - p1 >= RING) atomicOr(&rinfo[p1 * 2], 0x8000u);
+            if (np > 2 && r - p2 >= RING) atomicOr(&rinfo[p2 * 2], 0x8000u);
+            if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) { const int q = w.rank[w.pred[v * POA_MAXP + e]]; if (r - q >= RING) atomicOr(&rinfo[q * 2], 0x8000u); } }
         }
         phase_sync();
-        for (int r = 1; r <= N; ++r) {
-            const uint32_t d0 = rinfo[r * 2], d1 = rinfo[r * 2 + 1];
-            const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0x7f);
-            const bool keep = (d0 & 0x8000u) != 0;    // read later from HBM by a far successor
-            int pr[POA_MAXP];
-            pr[0] = d0 >> 16; pr[1] = d1 & 0xffff; pr[2] = d1 >> 16;
-            if (np > 3) {
-                const int v = w.order[r - 1];
-                for (int e = 3; e < np; ++e) pr[e] = w.rank[w.pred[v * POA_MAXP + e]];
-            }
-            short* cur = lds_ring + (r & rmask) * mpad;
-            short* Hr = w.H + (size_t)r * Wd;
-            uint8_t* dr = w.dir + (size_t)r * Wd;
-            int carry = 0;
-            for (int j0 = 1; j0 <= m; j0 += 64) {
-                const int j = j0 + lane;
-                int best = -(1 << 28), bd = 0;
-                if (j <= m) {
-                    const int sb = lds_seq[j - 1];
-                    const int s = (vb == sb && sb < 4) ? POA_MATCH : POA_MISMATCH;
-                    for (int e = 0; e < np; ++e) {
-                        const int q = pr[e];
-                        const int hv = (r - q < RING) ? (int)lds_ring[(q & rmask) * mpad + j - 1] : (int)w.H[(size_t)q * Wd + j - 1];
-                        const int c = hv + s;
-                        if (c > best) { best = c; bd = 1 | (e << 4); }
-                    }
-                    { const int c = (j - 1) * POA_GAP + s; if (c > best) { best = c; bd = 1 | (15 << 4); } }
-                    for (int e = 0; e < np; ++e) {
-                        const int q = pr[e];
-                        const int hv = (r - q < RING) ? (int)lds_ring[(q & rmask) * mpad + j] : (int)w.H[(size_t)q * Wd + j];
-                        const int c = hv + POA_GAP;
-                        if (c > best) { best = c; bd = 2 | (e << 4); }
-                    }
-                }
-                const int x = j <= m ? best - j * POA_GAP : -(1 << 28);
-                const int xc = carry - (j0 - 1) * POA_GAP;
-                int pm = wave_prefix_max(x);
-                if (xc > pm) pm = xc;
-                const int hval = pm + j * POA_GAP;
-                if (j <= m) {
-                    if (hval > best) bd = 3;
-                    cur[j] = (short)hval; dr[j] = (uint8_t)bd;
-                    if (keep) Hr[j] = (short)hval;
-                    if (j == m && hval > bs) { bs = hval; br = r; }
-                }
-                const int last = j0 + 63 <= m ? 63 : m - j0;
-                carry = __builtin_amdgcn_readlane(hval, last);
-            }
-            if (lane == 0) { cur[0] = 0; dr[0] = 0; if (keep) Hr[0] = 0; }
-            asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
-        }
+        if (m <= 128) dp_rows_fast<2>(w, N, m, lane, RING, pitch, bs, br);
+        else if (m <= 256) dp_rows_fast<4>(w, N, m, lane, RING, pitch, bs, br);
+        else dp_rows_fast<8>(w, N, m, lane, RING, pitch, bs, br);
     } else {
+        for (int j = lane; j <= m; j += 64) { w.H[j] = (short)(j * POA_GAP); w.dir[j] = 3; }
         phase_sync();
         for (int r = 1; r <= N; ++r) {
             const int v = w.order[r - 1];
@@ -422,81 +537,158 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
     phase_sync();
     TSTAMP(0);
     // the lane that owns column m saw every H[r][m] in rank order (strict > kept the lowest rank)
-    {
+    if (!fast) {
         const int owner = (m - 1) & 63;
         bs = __shfl(bs, owner); br = __shfl(br, owner);
     }
-    // walk back (wave-uniform)
-    int npair = 0, r = br, j = m;
-    while (j > 0) {
-        if (r == 0) { --j; w.pn[npair] = -1; w.pj[npair] = j; ++npair; continue; }
-        const int d = w.dir[(size_t)r * Wd + j];
-        const int v = w.order[r - 1];
-        const int kind = d & 3, e = d >> 4;
-        // rank of the e-th source: from the LDS row table when this copy used it, else two dependent HBM loads
-        int pre = 0;
-        if (kind != 3 && e != 15) {
-            if (fast && e < 3) { const uint32_t q0 = lds_rinfo[r * 2], q1 = lds_rinfo[r * 2 + 1]; pre = e == 0 ? (int)(q0 >> 16) : (e == 1 ? (int)(q1 & 0xffff) : (int)(q1 >> 16)); }
-            else pre = w.rank[w.pred[v * POA_MAXP + e]];
+    const int dpitch = fast ? pitch : Wd, dcol = fast ? 7 : 0;     // direction bytes: row pitch, element of column 0
+    // ---- walk back (sequential by nature, wave-uniform) -------------------------------------------------------
+    // One dependent HBM load per step would cost ~1 us each; instead the lanes hold a 32x32 patch of direction bytes
+    // (ranks r0..r0-31, columns j0..j0-31; 16 bytes per lane) and, on the fast path, the LDS graph rows of those ranks,
+    // so the chain runs on v_readlane until it leaves the patch (~28 steps).  pn[j] = rank matched to sequence position j (0: inserted base), staged in
+    // one register per lane and stored 64 positions at a time; ranks become node ids in parallel afterwards.
+    {
+        int r = __builtin_amdgcn_readfirstlane(br), j = m;
+        int r0 = -64, j0 = -64;
+        uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0, ri = 0;     // lane l: row r0-(l>>1), columns j0-16*(l&1)-15 .. j0-16*(l&1)
+        int buf = 0;
+        while (j > 0 && r > 0) {
+            int a = r0 - r, b = j0 - j;
+            if ((unsigned)a >= 32u || (unsigned)b >= 32u) {
+                r0 = r; j0 = j;
+                const int rr = r - (lane >> 1), jlo = j - 16 * (lane & 1) - 15;       // lowest column of this lane's 16
+                pw0 = pw1 = pw2 = pw3 = 0;
+                if (rr >= 1 && jlo + 15 >= 1) {
+                    // bytes at columns jlo..jlo+15 (row-internal; columns below 0 belong to the previous row or, for
+                    // row 1, to row 0 -- in bounds, never looked at)
+                    const uint8_t* src = w.dir + (size_t)rr * dpitch + dcol + jlo;
+                    uint32_t t[4];
+                    __builtin_memcpy(t, src, 16);
+                    pw0 = t[0]; pw1 = t[1]; pw2 = t[2]; pw3 = t[3];
+                }
+                if (fast) ri = rr >= 1 ? lds_rinfo[rr * 2 + (lane & 1)] : 0u;
+                a = 0; b = 0;
+            }
+            // column j0-b sits in lane 2a+(b>>4) at byte 15-(b&15)
+            const int byte = 15 - (b & 15), src_lane = a * 2 + (b >> 4);
+            const uint32_t sel = (byte >> 2) == 0 ? pw0 : ((byte >> 2) == 1 ? pw1 : ((byte >> 2) == 2 ? pw2 : pw3));
+            const int d = (__builtin_amdgcn_readlane((int)sel, src_lane) >> ((byte & 3) * 8)) & 0xff;
+            int kind = d & 3, e = d >> 4;
+            if (fast) {                                   // fast-path bytes are 255 - ordinal (see dp_rows_fast)
+                const int ord = 255 - d;
+                kind = ord <= POA_ORD_ROW0 ? 1 : (ord < POA_ORD_HORIZ ? 2 : 3);
+                e = ord < POA_ORD_ROW0 ? ord : (ord == POA_ORD_ROW0 ? 15 : ord - POA_ORD_VERT);
+            }
+            int pre = 0;
+            if (kind != 3 && e != 15) {
+                if (fast && e < 3) {
+                    const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2), q1 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2 + 1);
+                    pre = e == 0 ? (int)(q0 >> 16) : (e == 1 ? (int)(q1 & 0xffff) : (int)(q1 >> 16));
+                } else {
+                    const int v = w.order[r - 1];
+                    pre = __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + e]]);
+                }
+            }
+            if (kind == 2) { r = pre; continue; }
+            if (kind == 0) break;
+            --j;
+            buf = lane == (j & 63) ? (kind == 1 ? r : 0) : buf;
+            if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
+            if (kind == 1) r = pre;
         }
-        if (kind == 1) { --j; w.pn[npair] = v; w.pj[npair] = j; ++npair; r = pre; }
-        else if (kind == 2) { r = pre; }
-        else if (kind == 3) { --j; w.pn[npair] = -1; w.pj[npair] = j; ++npair; }
-        else break;
+        int fill_to = j;
+        if (j & 63) { fill_to = j & ~63; const int q = fill_to + lane; if (q < m) w.pn[q] = buf; }
+        for (int q = lane; q < fill_to; q += 64) w.pn[q] = 0;
     }
     phase_sync();
     TSTAMP(1);
-    int lead = 0, first_anchor = -1;
-    for (int t = npair - 1; t >= 0; --t) { const int q = w.pn[t]; if (q >= 0) { first_anchor = q; break; } ++lead; }
-    long long anchor_key = first_anchor >= 0 ? w.key[first_anchor] - (lead + 1) : (long long)N << 20;   // max key == N<<20 after a re-rank
-    int n = N, prev_used = -1, since = 0, rc = 0;
-    for (int t = npair - 1; t >= 0 && rc == 0; --t) {
-        const int b = seq[w.pj[t]];
-        const int pnode = w.pn[t];
-        int use = -1;
-        if (pnode < 0) {
-            ++since;
-            if (n < ncap) {
-                use = n++;
-                w.base[use] = (int8_t)b; w.np[use] = 0; w.key[use] = anchor_key + since;
-                w.aligned[use * 3] = w.aligned[use * 3 + 1] = w.aligned[use * 3 + 2] = -1;
+    // ---- graph update, data-parallel over the sequence positions ---------------------------------------------------
+    // Position i touches only its own matched node's aligned set and the in-edge list of the node it ends up using, and
+    // the nodes of one path are distinct, so the sequential rule of the specification (oracle poa_add) is evaluated
+    // per lane; node ids of new nodes are a prefix count in position order, keys come from the last matched position.
+    int n = N, fail = 0;
+    {
+        // first matched position (keys of leading insertions count back from it)
+        int lead = m;
+        long long key_fa = 0;
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            const int rk = i < m ? w.pn[i] : 0;
+            const unsigned long long mb = __builtin_amdgcn_ballot_w64(rk > 0);
+            if (mb) {
+                const int t = __builtin_ctzll(mb);
+                lead = i0 + t;
+                const int rk0 = __builtin_amdgcn_readlane(rk, t);
+                key_fa = w.key[w.order[rk0 - 1]];
+                break;
             }
-        } else {
-            const int v = pnode;
-            anchor_key = w.key[v]; since = 0;
-            if (w.base[v] == b) use = v;
-            else for (int a = 0; a < 3; ++a) { const int x = w.aligned[v * 3 + a]; if (x >= 0 && w.base[x] == b) { use = x; break; } }
-            if (use < 0 && n < ncap) {
-                use = n++;
-                {
-                    w.base[use] = (int8_t)b; w.np[use] = 0; w.key[use] = w.key[v];
-                    w.aligned[use * 3] = w.aligned[use * 3 + 1] = w.aligned[use * 3 + 2] = -1;
+        }
+        int lmi = -1;                       // last matched position so far, and its node's key
+        long long lmk = 0;
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < m;
+            const int rk = act ? w.pn[i] : 0;
+            const int v = rk > 0 ? w.order[rk - 1] : -1;
+            const int b = act ? (int)seq[i] : 0;
+            long long kv = 0;
+            int use = -1;
+            if (v >= 0) {
+                kv = w.key[v];
+                if (w.base[v] == b) use = v;
+                else for (int q = 0; q < 3; ++q) { const int x = w.aligned[v * 3 + q]; if (x >= 0 && w.base[x] == b) { use = x; break; } }
+            }
+            const bool isnew = act && use < 0;
+            const unsigned long long nb = __builtin_amdgcn_ballot_w64(isnew);
+            const unsigned long long mb = __builtin_amdgcn_ballot_w64(v >= 0);
+            const unsigned long long below = ((unsigned long long)1 << lane) - 1;
+            if (isnew) use = n + __builtin_popcountll(nb & below);
+            n += __builtin_popcountll(nb);
+            // anchor of an inserted base: the last matched position before it
+            const unsigned long long mlow = mb & below;
+            const int src = mlow ? 63 - __builtin_clzll(mlow) : 0;
+            const int klo = __shfl((int)(kv & 0xffffffff), src), khi = __shfl((int)(kv >> 32), src);
+            if (isnew && use < ncap) {
+                long long key;
+                if (v >= 0) key = kv;
+                else if (mlow) key = (((long long)khi << 32) | (uint32_t)klo) + (i - (i0 + src));
+                else if (lmi >= 0) key = lmk + (i - lmi);
+                else if (lead < m) key = key_fa - lead + i;
+                else key = ((long long)N << 20) + i + 1;       // max key == N<<20 after a re-rank
+                w.base[use] = (int8_t)b; w.np[use] = 0; w.key[use] = key;
+                int al0 = -1, al1 = -1, al2 = -1;
+                if (v >= 0) {                                  // join the aligned set of v
                     int members[4], nm = 0;
                     members[nm++] = v;
-                    for (int a = 0; a < 3; ++a) if (w.aligned[v * 3 + a] >= 0) members[nm++] = w.aligned[v * 3 + a];
-                    int slot = 0;
+                    for (int q = 0; q < 3; ++q) if (w.aligned[v * 3 + q] >= 0) members[nm++] = w.aligned[v * 3 + q];
                     for (int q = 0; q < nm; ++q) {
                         const int x = members[q];
-                        for (int a = 0; a < 3; ++a) if (w.aligned[x * 3 + a] < 0) { w.aligned[x * 3 + a] = use; break; }
-                        if (slot < 3) w.aligned[use * 3 + slot++] = x;
+                        for (int t = 0; t < 3; ++t) if (w.aligned[x * 3 + t] < 0) { w.aligned[x * 3 + t] = use; break; }
+                        if (q == 0) al0 = x; else if (q == 1) al1 = x; else if (q == 2) al2 = x;
                     }
                 }
+                w.aligned[use * 3] = al0; w.aligned[use * 3 + 1] = al1; w.aligned[use * 3 + 2] = al2;
+            }
+            if (act) w.pj[i] = use;
+            if (mb) {
+                const int t = 63 - __builtin_clzll(mb);
+                lmi = i0 + t;
+                lmk = ((long long)__shfl((int)(kv >> 32), t) << 32) | (uint32_t)__shfl((int)(kv & 0xffffffff), t);
             }
         }
-        __syncthreads();
-        if (use < 0) { rc = -1; break; }
-        if (prev_used >= 0) {
-            const int cnt = w.np[use];
+        if (n > ncap) return -1;
+        phase_sync();
+        for (int i = 1 + lane; i < m; i += 64) {
+            const int u = w.pj[i - 1], x = w.pj[i];
+            const int cnt = w.np[x];
             int found = -1;
-            for (int e = 0; e < cnt; ++e) if (w.pred[use * POA_MAXP + e] == prev_used) { found = e; break; }
-            if (found >= 0) { const int nw = w.pw[use * POA_MAXP + found] + 1; w.pw[use * POA_MAXP + found] = nw; }
-            else if (cnt >= POA_MAXP) rc = -1;
-            else { w.pred[use * POA_MAXP + cnt] = prev_used; w.pw[use * POA_MAXP + cnt] = 1; w.np[use] = (int8_t)(cnt + 1); }
-            __syncthreads();
+            for (int e = 0; e < cnt; ++e) if (w.pred[x * POA_MAXP + e] == u) { found = e; break; }
+            if (found >= 0) w.pw[x * POA_MAXP + found] += 1;
+            else if (cnt >= POA_MAXP) fail = 1;
+            else { w.pred[x * POA_MAXP + cnt] = u; w.pw[x * POA_MAXP + cnt] = 1; w.np[x] = (int8_t)(cnt + 1); }
         }
-        prev_used = use;
+        if (__builtin_amdgcn_ballot_w64(fail != 0)) return -1;
     }
-    if (rc != 0) return -1;
     phase_sync();
     TSTAMP(2);
     poa_rerank(w, N, n, lane);
@@ -504,8 +696,67 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
     return n;
 }
 
+// heaviest path.  The pass over the rows in rank order is a dependent chain (score of a source decides ties between
+// equally heavy in-edges), so it runs wave-uniformly -- but on an LDS image of the graph in rank space (3 words per row:
+// in-degree, base, up to 3 source ranks and their weights; a score word per row), with the previous row's score
+// forwarded in a register, so the chain never waits for HBM.  Rows with more than 3 in-edges or a weight above 255
+// fetch their lists from HBM (rare).
 __device__ int poa_consensus(const PoaWs& w, int N, int8_t* out, int cap, int lane)
 {
+    if (N <= POA_LDS_ROWS) {
+        uint32_t* tab = poa_lds;                          // [N+1][3]
+        int* score = (int*)(poa_lds + 3 * (POA_LDS_ROWS + 1));
+        static_assert(16 * (POA_LDS_ROWS + 1) <= POA_LDS_BYTES, "consensus tables must fit the K3 LDS block");
+#pragma unroll 4
+        for (int r = 1 + lane; r <= N; r += 64) {
+            const int v = w.order[r - 1];
+            int np = w.np[v];
+            uint32_t pr[3] = {0, 0, 0}, wt[3] = {0, 0, 0};
+            bool wide = np > 3;
+            for (int e = 0; e < 3; ++e) if (e < np) { pr[e] = (uint32_t)w.rank[w.pred[v * POA_MAXP + e]]; wt[e] = (uint32_t)w.pw[v * POA_MAXP + e]; wide |= wt[e] > 255u; }
+            tab[r * 3 + 0] = (uint32_t)(wide ? 0x7f : np) | ((uint32_t)(w.base[v] & 0xff) << 8) | (pr[0] << 16);
+            tab[r * 3 + 1] = pr[1] | (pr[2] << 16);
+            tab[r * 3 + 2] = (wt[0] & 0xff) | ((wt[1] & 0xff) << 8) | ((wt[2] & 0xff) << 16);
+        }
+        if (lane == 0) score[0] = 0;
+        __syncthreads();
+        int top = 0, tops = -1, prev = 0;                 // prev = score of rank r-1
+        for (int r = 1; r <= N; ++r) {
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[r * 3]);
+            const uint32_t t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[r * 3 + 1]);
+            const uint32_t t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[r * 3 + 2]);
+            const int np = (int)(t0 & 0x7f);
+            int bw = -1, bsrc = 0, bscore = 0;
+            if (np == 0x7f) {
+                const int v = w.order[r - 1];
+                const int cnt = w.np[v];
+                for (int e = 0; e < cnt; ++e) {
+                    const int u = __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + e]]);
+                    const int wt = __builtin_amdgcn_readfirstlane(w.pw[v * POA_MAXP + e]);
+                    const int su = u == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[u]);
+                    if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = u; bscore = su; }
+                }
+            } else {
+                const int p0 = (int)(t0 >> 16), p1 = (int)(t1 & 0xffff), p2 = (int)(t1 >> 16);
+                if (np > 0) { const int su = p0 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p0]); bw = (int)(t2 & 0xff); bsrc = p0; bscore = su; }
+                if (np > 1) { const int su = p1 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p1]); const int wt = (int)((t2 >> 8) & 0xff); if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = p1; bscore = su; } }
+                if (np > 2) { const int su = p2 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p2]); const int wt = (int)((t2 >> 16) & 0xff); if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = p2; bscore = su; } }
+            }
+            const int sc = bsrc > 0 ? bw + bscore : 0;
+            score[r] = sc; tab[r * 3 + 1] = (uint32_t)bsrc;          // word 1 becomes the back pointer (rank, 0 = none)
+            prev = sc;
+            if (sc >= tops) { tops = sc; top = r; }
+            asm volatile("" ::: "memory");
+        }
+        __syncthreads();
+        int len = 0;
+        for (int r = top; r > 0; r = __builtin_amdgcn_readfirstlane((int)tab[r * 3 + 1])) { score[len] = r; ++len; }   // scores are dead: path ranks
+        if (len > cap) return -1;
+        __syncthreads();
+        for (int k = lane; k < len; k += 64) out[len - 1 - k] = (int8_t)((tab[score[k] * 3] >> 8) & 0xff);
+        __syncthreads();
+        return len;
+    }
     int top = -1, tops = -1;
     for (int r = 1; r <= N; ++r) {       // wave-uniform sequential pass
         const int v = w.order[r - 1];

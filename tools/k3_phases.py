@@ -1,0 +1,26 @@
+"""Per-phase clock breakdown of K3 (needs a library built with -DCLH_DEBUG_POA: tools/k3_phases.sh builds it)."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ciri_long_amd import hip, synth
+
+hip.SO_PATH = os.path.join(os.path.dirname(hip.SO_PATH), 'libclh_dbg.so')
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+reads, _ = synth.c2_batch(n, seed=synth.SEEDS['C3'])
+rd, ro = hip.pack(reads)
+d_r = torch.from_numpy(rd.view(np.uint8)).cuda()
+ctx = hip.Context(0)
+plan = ctx.ccs_plan(ro)
+st = torch.cuda.current_stream().cuda_stream
+plan.run(d_r.data_ptr(), st)
+torch.cuda.synchronize()
+rows, segs, ccs = plan.fetch()
+segs = np.asarray(segs).reshape(n, -1, 2)
+t = segs[:, 55:60, 0].astype(np.float64) * 16        # s_memtime ticks (100 MHz)
+ok = rows['nseg'] > 0
+names = ['dp rows', 'walk back', 'graph update', 'rerank', 'consensus']
+tot = t[ok].sum()
+for k, nm in enumerate(names):
+    print('%-13s %6.1f %%   mean %8.1f us per read' % (nm, 100 * t[ok, k].sum() / tot, t[ok, k].mean() / 100.0))
+print('reads with consensus %d, mean total %.1f us' % (ok.sum(), t[ok].sum(1).mean() / 100.0))

@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
 struct PoaWs {            // views into one wave's workspace slot
     int8_t* base; int8_t* np; int32_t* pred; int32_t* pw; int32_t* aligned; long long* key; int32_t* order; int32_t* rank;
     int32_t* pn; int32_t* pj; int32_t* score; int32_t* bp; short* H; uint8_t* dir;
+    uint2* ri; uint32_t* tab; short* carry; int cpitch;
 };
 
 // row pitch (elements) of the DP matrix and of the direction bytes for a copy of m bases: column j sits at element j+7,
@@ -183,7 +184,11 @@ __device__ PoaWs carve(uint8_t* slot, int ncap, int mcap)
     w.pn = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
     w.pj = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
     w.score = (int32_t*)take(sizeof(int32_t) * ncap);
-    w.bp = (int32_t*)take(sizeof(int32_t) * ncap);
+    w.bp = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + 2));
+    w.ri = (uint2*)take(sizeof(uint2) * (size_t)(ncap + 2));
+    w.tab = (uint32_t*)take(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));
+    w.cpitch = (ncap + 2 + 7) & ~7;
+    w.carry = (short*)take(sizeof(short) * 2 * (size_t)w.cpitch);
     w.base = (int8_t*)take(ncap);
     w.np = (int8_t*)take(ncap);
     w.H = (short*)take(sizeof(short) * (size_t)(ncap + 1) * poa_pitch(mcap - 1));
@@ -198,7 +203,8 @@ __host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)
     add(sizeof(long long) * ncap); add(sizeof(int32_t) * (size_t)ncap * POA_MAXP); add(sizeof(int32_t) * (size_t)ncap * POA_MAXP);
     add(sizeof(int32_t) * (size_t)ncap * 3); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap);
     add(sizeof(int32_t) * (size_t)(ncap + mcap + 2)); add(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
-    add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap); add(ncap); add(ncap);
+    add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * (size_t)(ncap + 2)); add(sizeof(uint2) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));
+    add(sizeof(short) * 2 * (size_t)((ncap + 2 + 7) & ~7)); add(ncap); add(ncap);
     add(sizeof(short) * (size_t)(ncap + 1) * poa_pitch(mcap - 1)); add((size_t)(ncap + 1) * poa_pitch(mcap - 1));
     return o + 64;
 }
@@ -272,14 +278,21 @@ __device__ unsigned long long g_t[8];
 #else
 #define TSTAMP(k) do {} while (0)
 #endif
-static constexpr int POA_LDS_ROWS = 1023;          // rows whose graph info fits the LDS table
-static constexpr int POA_LDS_SEQ = 2304;           // longest copy staged in LDS
-static constexpr int POA_LDS_RING_BYTES = 6144;    // ring of recent H rows
+static constexpr int POA_LDS_BYTES = 8192;           // ring of recent H rows (DP) / score per rank (heaviest path)
+static constexpr int POA_RING_SHORTS = POA_LDS_BYTES / 2;
+static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whose scores fit the LDS block
 extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];
-#define lds_rinfo (poa_lds)
-#define lds_ring ((short*)(poa_lds + 2 * (POA_LDS_ROWS + 1)))
-#define lds_seq ((int8_t*)(poa_lds + 2 * (POA_LDS_ROWS + 1)) + POA_LDS_RING_BYTES)
-static constexpr size_t POA_LDS_BYTES = 8 * (POA_LDS_ROWS + 1) + POA_LDS_RING_BYTES + POA_LDS_SEQ;
+#define lds_ring ((short*)poa_lds)
+
+// columns per lane, LDS row pitch and ring depth for a copy of m bases
+__device__ __forceinline__ int poa_cols(int m) { return m <= 128 ? 2 : (m <= 256 ? 4 : 8); }
+__device__ __forceinline__ int poa_ring(int m) {
+    const int W = 64 * poa_cols(m);
+    const int lp = poa_pitch(m < W ? m : W);
+    int ring = 16;                                   // power of two, so slot = rank & (ring-1); lp <= 528, so ring >= 4
+    while (ring * lp > POA_RING_SHORTS) ring >>= 1;
+    return ring;
+}
 
 // direction byte of the fast path = 255 - ordinal of the winning candidate in the specification's evaluation order:
 // diagonal from in-edge e (ordinal e), diagonal from row 0 (12), vertical from in-edge e (13+e), horizontal (25).
@@ -299,135 +312,153 @@ __device__ __forceinline__ void far_row(const short* ptr, int (&h)[C], int& hpre
     asm volatile("" : "+v"(hprev));
 }
 
-// DP rows of one copy against the graph, fast path: lane l owns C adjacent columns (C = 2, 4, 8 by copy length), so a
-// row of up to 64*C columns is one pass: one wide LDS read per source row, the candidates of the C cells in registers,
-// an in-lane max-plus scan, ONE cross-lane DPP scan per row, one wide LDS write, one wide direction-byte store.
+// DP rows of one copy against the graph.  Lane l owns C adjacent columns (C = 2, 4, 8 by copy length), so a row of up to
+// W = 64*C columns is ONE step: one wide LDS read per source row, the candidates of the C cells in registers, an in-lane
+// max-plus scan, one cross-lane DPP scan, one wide LDS write, one wide direction-byte store.  Copies longer than W are
+// swept in passes of W columns (passes outer, rows inner); the value that leaves a row on the right is handed to the next
+// pass through a per-row carry array in HBM.  The graph rows (w.ri) and the carries are streamed 64 rows at a time into
+// one register per lane and read with v_readlane, so LDS holds nothing but the ring of the last RING rows of H.
 template <int C>
-__device__ void dp_rows_fast(const PoaWs& w, int N, int m, int lane, int RING, int pitch, int& bs_out, int& br_out)
+__device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out)
 {
     constexpr int NEG = -(1 << 28);
-    const int rmask = RING - 1;
-    const int npass = (m + 64 * C - 1) / (64 * C);
-    const uint32_t* rinfo = lds_rinfo;
-    if (lane < RING) lds_ring[lane * pitch + 7] = 0;             // column 0 of every ring slot: H[r][0] = 0, never rewritten
-    const int lm = ((m - 1) % (64 * C)) / C, km = (m - 1) % C, pm = (m - 1) / (64 * C);   // where column m lives
+    constexpr int W = 64 * C;
+    const int npass = (m + W - 1) / W;
+    const int gp = poa_pitch(m);                                 // row pitch of H and dir in HBM
+    const int lp = poa_pitch(m < W ? m : W);                     // row pitch of the LDS ring (one pass wide)
+    const int RING = poa_ring(m), rmask = RING - 1;
+    const int lm = ((m - 1) % W) / C, km = (m - 1) % C;          // where column m lives in the last pass
     int bs = NEG, br = 0x7fffffff;
-    auto base_masks = [&](int pass) {                            // bit 8*b+k: cell k of this lane holds base b
-        uint32_t sbm = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int col0 = pass * W + C * lane;                    // cell k is column col0+k+1, element col0+k+8 of an HBM row
+        const bool more = pass + 1 < npass, last = !more;
+        uint32_t sbm = 0;                                        // bit 8*b+k: cell k of this lane holds base b
 #pragma unroll
         for (int k = 0; k < C; ++k) {
-            const int j = pass * 64 * C + C * lane + k + 1;
-            const int sb = j <= m ? (int)lds_seq[j - 1] : 4;
-            if (sb < 4) sbm |= 1u << (8 * sb + k);
+            const int j = col0 + k + 1;
+            const int sb = j <= m ? (int)seq[j - 1] : 4;
+            if (sb >= 0 && sb < 4) sbm |= 1u << (8 * sb + k);
         }
-        return sbm;
-    };
-    uint32_t sbm = base_masks(0);
-    uint32_t n0 = rinfo[2], n1 = rinfo[3];
-    for (int r = 1; r <= N; ++r) {
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0), d1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
-        if (r < N) { n0 = rinfo[(r + 1) * 2]; n1 = rinfo[(r + 1) * 2 + 1]; }      // next row's graph info, off the critical path
-        const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0x7f);
-        const bool keep = (d0 & 0x8000u) != 0;                   // read later from HBM by a far successor
-        const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
-        const int vnode = np > 3 ? __builtin_amdgcn_readfirstlane(w.order[r - 1]) : 0;
-        short* cur = lds_ring + (r & rmask) * pitch;
-        int carry = 0;                                           // H[r][last column of the previous pass]; H[r][0] = 0
-        for (int pass = 0; pass < npass; ++pass) {
-            if (npass > 1) sbm = base_masks(pass);
-            const uint32_t mk = vb >= 0 && vb < 4 ? (sbm >> (8 * vb)) & 0xffu : 0u;
-            const int col0 = pass * 64 * C + C * lane;           // cell k is column col0+k+1, element col0+k+8 of a row
-            int best[C];
-            int ss[C];
-#pragma unroll
-            for (int k = 0; k < C; ++k) {
-                ss[k] = ((mk >> k) & 1u) ? (POA_MATCH << 8) : (POA_MISMATCH * 256);
-                best[k] = (col0 + k) * (POA_GAP * 256) + ss[k] + (255 - POA_ORD_ROW0);
-            }
-            auto source = [&](int e, int q) {
-                int h[C], hprev;
-                if (r - q < RING) {
-                    const short* src = lds_ring + (q & rmask) * pitch + col0 + 8;
-                    hprev = src[-1];
-                    if constexpr (C == 8) { const uint4 t = *(const uint4*)src; const uint32_t u[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) h[k] = (k & 1) ? (int)u[k >> 1] >> 16 : (int)(short)(u[k >> 1] & 0xffff); }
-                    else if constexpr (C == 4) { const uint2 t = *(const uint2*)src; const uint32_t u[2] = {t.x, t.y};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) h[k] = (k & 1) ? (int)u[k >> 1] >> 16 : (int)(short)(u[k >> 1] & 0xffff); }
-                    else { const uint32_t t = *(const uint32_t*)src; h[0] = (int)(short)(t & 0xffff); h[1] = (int)t >> 16; }
-                } else {
-                    far_row<C>(w.H + (size_t)q * pitch + col0 + 7, h, hprev);
-                }
-                const int cd = 255 - e, cv = POA_GAP * 256 + 255 - POA_ORD_VERT - e;
+        const short* cprev = w.carry + (size_t)(pass & 1) * w.cpitch;
+        short* cnext = w.carry + (size_t)((pass + 1) & 1) * w.cpitch;
+        uint2 blk = 1 + lane <= N ? w.ri[1 + lane] : make_uint2(0, 0);
+        int cblk = pass > 0 && 1 + lane <= N ? (int)cprev[1 + lane] : 0;
+        for (int rb = 1; rb <= N; rb += 64) {
+            const int nr = rb + 64 + lane;
+            const uint2 nxt = nr <= N ? w.ri[nr] : make_uint2(0, 0);           // next 64 graph rows, consumed after this block
+            const int cnx = pass > 0 && nr <= N ? (int)cprev[nr] : 0;
+            const int cnt = N - rb + 1 < 64 ? N - rb + 1 : 64;
+            int cob = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const int r = rb + i;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
+                const int cin = __builtin_amdgcn_readlane(cblk, i);             // H[r][pass*W]; 0 in the first pass
+                const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0x7f);
+                const bool keep = (d0 & 0x8000u) != 0;           // read later from HBM by a far successor
+                const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
+                const uint32_t mk = vb >= 0 && vb < 4 ? (sbm >> (8 * vb)) & 0xffu : 0u;
+                short* cur = lds_ring + (r & rmask) * lp;
+                int best[C], ss[C];
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
-                    const int up = k == 0 ? hprev : h[k - 1];
-                    const int c1 = (up << 8) + ss[k] + cd;
-                    const int c2 = (h[k] << 8) + cv;
-                    best[k] = c1 > best[k] ? c1 : best[k];
-                    best[k] = c2 > best[k] ? c2 : best[k];
+                    ss[k] = ((mk >> k) & 1u) ? (POA_MATCH * 256) : (POA_MISMATCH * 256);
+                    best[k] = (col0 + k) * (POA_GAP * 256) + ss[k] + (255 - POA_ORD_ROW0);
                 }
-            };
-            if (np > 0) source(0, p0);
-            if (np > 1) source(1, p1);
-            if (np > 2) source(2, p2);
-            for (int e = 3; e < np; ++e) source(e, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + e]]));
-            // horizontal chain H[j] = max(A[j], H[j-1]+g) == max over k<=j of A[k] + (j-k) g: prefix max of
-            // X[k] = A[k] - k g (g < 0), in the packed domain (the low byte rides along and never matters)
-            int x[C];
+                auto source = [&](int e, int q) {
+                    int h[C], hprev;
+                    if (r - q < RING) {
+                        const short* src = lds_ring + (q & rmask) * lp + C * lane + 8;
+                        hprev = src[-1];
+                        if constexpr (C == 8) { const uint4 t = *(const uint4*)src; const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int k = 0; k < C; ++k) {
-                x[k] = best[k] + (col0 + k + 1) * (-POA_GAP * 256);
-                if (k) x[k] = x[k - 1] > x[k] ? x[k - 1] : x[k];
-            }
-            const int incl = wave_prefix_max(x[C - 1]);
-            int excl = __builtin_amdgcn_update_dpp(NEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1
-            const int xc = (carry + (pass * 64 * C) * (-POA_GAP)) * 256;
-            excl = xc > excl ? xc : excl;
-            int hv[C];
-            uint32_t db[C];
+                            for (int k = 0; k < 8; ++k) h[k] = (k & 1) ? (int)u[k >> 1] >> 16 : (int)(short)(u[k >> 1] & 0xffff); }
+                        else if constexpr (C == 4) { const uint2 t = *(const uint2*)src; const uint32_t u[2] = {t.x, t.y};
 #pragma unroll
-            for (int k = 0; k < C; ++k) {
-                const int pk = excl > x[k] ? excl : x[k];
-                hv[k] = (pk >> 8) + (col0 + k + 1) * POA_GAP;
-                db[k] = hv[k] > (best[k] >> 8) ? (uint32_t)(255 - POA_ORD_HORIZ) : ((uint32_t)best[k] & 0xffu);
-            }
-            if (col0 + 1 <= m) {
-                short* dst = cur + col0 + 8;
-                uint8_t* dd = w.dir + (size_t)r * pitch + col0 + 8;
-                if constexpr (C == 8) {
-                    uint4 t;
-                    t.x = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16); t.y = ((uint32_t)hv[2] & 0xffffu) | ((uint32_t)hv[3] << 16);
-                    t.z = ((uint32_t)hv[4] & 0xffffu) | ((uint32_t)hv[5] << 16); t.w = ((uint32_t)hv[6] & 0xffffu) | ((uint32_t)hv[7] << 16);
-                    *(uint4*)dst = t;
-                    uint2 b;
-                    b.x = db[0] | (db[1] << 8) | (db[2] << 16) | (db[3] << 24); b.y = db[4] | (db[5] << 8) | (db[6] << 16) | (db[7] << 24);
-                    *(uint2*)dd = b;
-                    if (keep) *(uint4*)(w.H + (size_t)r * pitch + col0 + 8) = t;
-                } else if constexpr (C == 4) {
-                    uint2 t;
-                    t.x = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16); t.y = ((uint32_t)hv[2] & 0xffffu) | ((uint32_t)hv[3] << 16);
-                    *(uint2*)dst = t;
-                    *(uint32_t*)dd = db[0] | (db[1] << 8) | (db[2] << 16) | (db[3] << 24);
-                    if (keep) *(uint2*)(w.H + (size_t)r * pitch + col0 + 8) = t;
+                            for (int k = 0; k < 4; ++k) h[k] = (k & 1) ? (int)u[k >> 1] >> 16 : (int)(short)(u[k >> 1] & 0xffff); }
+                        else { const uint32_t t = *(const uint32_t*)src; h[0] = (int)(short)(t & 0xffff); h[1] = (int)t >> 16; }
+                    } else {
+                        far_row<C>(w.H + (size_t)q * gp + col0 + 7, h, hprev);
+                    }
+                    const int cd = 255 - e, cv = POA_GAP * 256 + 255 - POA_ORD_VERT - e;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const int up = k == 0 ? hprev : h[k - 1];
+                        const int c1 = (up << 8) + ss[k] + cd;
+                        const int c2 = (h[k] << 8) + cv;
+                        best[k] = c1 > best[k] ? c1 : best[k];
+                        best[k] = c2 > best[k] ? c2 : best[k];
+                    }
+                };
+                if (np > 0) source(0, p0);
+                if (np > 1) source(1, p1);
+                if (np > 2) source(2, p2);
+                if (np > 3) {                                    // rare: in-edges beyond the third come from HBM
+                    const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
+                    for (int e = 3; e < np; ++e) source(e, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + e]]));
+                }
+                // horizontal chain H[j] = max(A[j], H[j-1]+g) == max over k<=j of A[k] + (j-k) g: prefix max of
+                // X[k] = A[k] - k g (g < 0), in the packed domain (the low byte rides along and never matters)
+                int x[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    x[k] = best[k] + (col0 + k + 1) * (-POA_GAP * 256);
+                    if (k) x[k] = x[k - 1] > x[k] ? x[k - 1] : x[k];
+                }
+                const int incl = wave_prefix_max(x[C - 1]);
+                int excl = __builtin_amdgcn_update_dpp(NEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1
+                const int xc = (cin + (pass * W) * (-POA_GAP)) * 256;
+                excl = xc > excl ? xc : excl;
+                int hv[C];
+                uint32_t db[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int pk = excl > x[k] ? excl : x[k];
+                    hv[k] = (pk >> 8) + (col0 + k + 1) * POA_GAP;
+                    db[k] = hv[k] > (best[k] >> 8) ? (uint32_t)(255 - POA_ORD_HORIZ) : ((uint32_t)best[k] & 0xffu);
+                }
+                if (lane == 0) cur[7] = (short)cin;              // element of column pass*W: the left neighbour of cell 0
+                if (col0 + 1 <= m) {
+                    short* dst = cur + C * lane + 8;
+                    uint8_t* dd = w.dir + (size_t)r * gp + col0 + 8;
+                    short* hd = w.H + (size_t)r * gp + col0 + 8;
+                    if constexpr (C == 8) {
+                        uint4 t;
+                        t.x = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16); t.y = ((uint32_t)hv[2] & 0xffffu) | ((uint32_t)hv[3] << 16);
+                        t.z = ((uint32_t)hv[4] & 0xffffu) | ((uint32_t)hv[5] << 16); t.w = ((uint32_t)hv[6] & 0xffffu) | ((uint32_t)hv[7] << 16);
+                        *(uint4*)dst = t;
+                        uint2 bb;
+                        bb.x = db[0] | (db[1] << 8) | (db[2] << 16) | (db[3] << 24); bb.y = db[4] | (db[5] << 8) | (db[6] << 16) | (db[7] << 24);
+                        *(uint2*)dd = bb;
+                        if (keep) *(uint4*)hd = t;
+                    } else if constexpr (C == 4) {
+                        uint2 t;
+                        t.x = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16); t.y = ((uint32_t)hv[2] & 0xffffu) | ((uint32_t)hv[3] << 16);
+                        *(uint2*)dst = t;
+                        *(uint32_t*)dd = db[0] | (db[1] << 8) | (db[2] << 16) | (db[3] << 24);
+                        if (keep) *(uint2*)hd = t;
+                    } else {
+                        const uint32_t t = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16);
+                        *(uint32_t*)dst = t;
+                        *(uint16_t*)dd = (uint16_t)(db[0] | (db[1] << 8));
+                        if (keep) *(uint32_t*)hd = t;
+                    }
+                }
+                if (keep && pass == 0 && lane == 0) w.H[(size_t)r * gp + 7] = 0;
+                if (last) {
+                    int hm = hv[0];
+#pragma unroll
+                    for (int k = 1; k < C; ++k) hm = km == k ? hv[k] : hm;
+                    if (lane == lm && hm > bs) { bs = hm; br = r; }          // strict >: lowest rank on ties
                 } else {
-                    const uint32_t t = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16);
-                    *(uint32_t*)dst = t;
-                    *(uint16_t*)dd = (uint16_t)(db[0] | (db[1] << 8));
-                    if (keep) *(uint32_t*)(w.H + (size_t)r * pitch + col0 + 8) = t;
+                    const int right = __builtin_amdgcn_readlane(hv[C - 1], 63);
+                    cob = lane == i ? right : cob;
                 }
+                asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
             }
-            if (pass == pm) {
-                int hm = hv[0];
-#pragma unroll
-                for (int k = 1; k < C; ++k) hm = km == k ? hv[k] : hm;
-                if (lane == lm && hm > bs) { bs = hm; br = r; }      // strict >: lowest rank on ties
-            }
-            if (pass + 1 < npass) carry = __builtin_amdgcn_readlane(hv[C - 1], 63);
+            if (more && lane < cnt) cnext[rb + lane] = (short)cob;
+            blk = nxt; cblk = cnx;
         }
-        if (keep && lane == 0) w.H[(size_t)r * pitch + 7] = 0;
-        asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
+        if (more) phase_sync();
     }
     bs_out = __shfl(bs, lm); br_out = __shfl(br, lm);
 }
@@ -450,98 +481,42 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
         phase_sync();
         return m;
     }
-    const int Wd = m + 1;
     int bs = -(1 << 28), br = 0x7fffffff;          // end cell: largest H[r][m], lowest rank on ties
     // ---- DP rows --------------------------------------------------------------------------------------------
-    // Fast path: per-row graph info (base, in-degree, ranks of up to 4 sources), the sequence, and a ring of the last
-    // RING rows of H live in LDS, so a row whose sources are recent (the rule: a chain) touches HBM only to store its
-    // H row (needed by a far source, rarely) and its direction bytes.  Row 0 is arithmetic (j*gap).
+    // Graph rows in rank space, built in parallel: base, in-degree, ranks of the first three sources (w.ri, 8 bytes a
+    // row; further in-edges are rare and fetched where needed).  Row 0 of the matrix is arithmetic (j*gap).
     const int pitch = poa_pitch(m);
-    int RING = 16;                                   // power of two, so slot = rank & (RING-1)
-    while (RING * pitch > POA_LDS_RING_BYTES / 2) RING >>= 1;
-    const bool fast = N <= POA_LDS_ROWS && m <= POA_LDS_SEQ && RING >= 2;
-    if (fast) {
-        uint32_t* rinfo = lds_rinfo;
+    const int RING = poa_ring(m);
+    {
+        uint32_t* ri32 = (uint32_t*)w.ri;
 #pragma unroll 4
         for (int r = 1 + lane; r <= N; r += 64) {
             const int v = w.order[r - 1];
             const int np = w.np[v];
             uint32_t pr[3] = {0, 0, 0};
             for (int e = 0; e < 3; ++e) if (e < np) pr[e] = (uint32_t)w.rank[w.pred[v * POA_MAXP + e]];
-            rinfo[r * 2 + 0] = (uint32_t)(w.base[v] & 0xff) | ((uint32_t)np << 8) | (pr[0] << 16);
-            rinfo[r * 2 + 1] = pr[1] | (pr[2] << 16);
+            w.ri[r] = make_uint2((uint32_t)(w.base[v] & 0xff) | ((uint32_t)np << 8) | (pr[0] << 16), pr[1] | (pr[2] << 16));
         }
-        for (int j = lane; j < m; j += 64) lds_seq[j] = seq[j];
         phase_sync();
         // a row's H values go to HBM only if some later row reads them from there, i.e. it is a source of a row at
         // least RING ranks further on (bit 15 of the in-degree byte field is free: in-degree <= 12)
         for (int r = 1 + lane; r <= N; r += 64) {
-            const uint32_t d0 = rinfo[r * 2], d1 = rinfo[r * 2 + 1];
-            const int np = (int)((d0 >> 8) & 0x7f);
-            const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
-            if (np > 0 && r - p0 >= RING) atomicOr(&rinfo[p0 * 2], 0x8000u);
-            if (np > 1 && r - p1 >= RING) atomicOr(&rinfo[p1 * 2], 0x8000u);
-            if (np > 2 && r - p2 >= RING) atomicOr(&rinfo[p2 * 2], 0x8000u);
-            if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) { const int q = w.rank[w.pred[v * POA_MAXP + e]]; if (r - q >= RING) atomicOr(&rinfo[q * 2], 0x8000u); } }
+            const uint2 d = w.ri[r];
+            const int np = (int)((d.x >> 8) & 0x7f);
+            const int p0 = (int)(d.x >> 16), p1 = (int)(d.y & 0xffff), p2 = (int)(d.y >> 16);
+            if (np > 0 && r - p0 >= RING) atomicOr(&ri32[p0 * 2], 0x8000u);
+            if (np > 1 && r - p1 >= RING) atomicOr(&ri32[p1 * 2], 0x8000u);
+            if (np > 2 && r - p2 >= RING) atomicOr(&ri32[p2 * 2], 0x8000u);
+            if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) { const int q = w.rank[w.pred[v * POA_MAXP + e]]; if (r - q >= RING) atomicOr(&ri32[q * 2], 0x8000u); } }
         }
         phase_sync();
-        if (m <= 128) dp_rows_fast<2>(w, N, m, lane, RING, pitch, bs, br);
-        else if (m <= 256) dp_rows_fast<4>(w, N, m, lane, RING, pitch, bs, br);
-        else dp_rows_fast<8>(w, N, m, lane, RING, pitch, bs, br);
-    } else {
-        for (int j = lane; j <= m; j += 64) { w.H[j] = (short)(j * POA_GAP); w.dir[j] = 3; }
-        phase_sync();
-        for (int r = 1; r <= N; ++r) {
-            const int v = w.order[r - 1];
-            const int np = w.np[v];
-            const int vb = w.base[v];
-            short* Hr = w.H + (size_t)r * Wd;
-            uint8_t* dr = w.dir + (size_t)r * Wd;
-            int pr[POA_MAXP];
-#pragma unroll
-            for (int e = 0; e < POA_MAXP; ++e) pr[e] = e < np ? w.rank[w.pred[v * POA_MAXP + e]] : 0;
-            int carry = 0;                 // H[v][j0-1] of the previous chunk; H[v][0] = 0
-            for (int j0 = 1; j0 <= m; j0 += 64) {
-                const int j = j0 + lane;
-                int best = -(1 << 28), bd = 0;
-                if (j <= m) {
-                    const int sb = seq[j - 1];
-                    const int s = (vb == sb && sb < 4) ? POA_MATCH : POA_MISMATCH;
-#pragma unroll
-                    for (int e = 0; e < POA_MAXP; ++e)
-                        if (e < np) { const int c = (int)w.H[(size_t)pr[e] * Wd + j - 1] + s; if (c > best) { best = c; bd = 1 | (e << 4); } }
-                    { const int c = (int)w.H[j - 1] + s; if (c > best) { best = c; bd = 1 | (15 << 4); } }
-#pragma unroll
-                    for (int e = 0; e < POA_MAXP; ++e)
-                        if (e < np) { const int c = (int)w.H[(size_t)pr[e] * Wd + j] + POA_GAP; if (c > best) { best = c; bd = 2 | (e << 4); } }
-                }
-                // horizontal chain: H[j] = max(A[j], H[j-1]+g)  ==  max over k<=j of A[k] + (j-k) g, with A[j0-1] := carry
-                // scan on X[k] = A[k] - k*g (g < 0): prefix max, then add j*g
-                const int x = j <= m ? best - j * POA_GAP : -(1 << 28);
-                const int xc = carry - (j0 - 1) * POA_GAP;
-                int pm = wave_prefix_max(x);
-                if (xc > pm) pm = xc;
-                const int hval = pm + j * POA_GAP;
-                if (j <= m) {
-                    if (hval > best) { bd = 3; }
-                    Hr[j] = (short)hval; dr[j] = (uint8_t)bd;
-                    if (j == m && hval > bs) { bs = hval; br = r; }
-                }
-                const int last = j0 + 63 <= m ? 63 : m - j0;
-                carry = __builtin_amdgcn_readlane(hval, last);
-            }
-            if (lane == 0) { Hr[0] = 0; dr[0] = 0; }
-            __syncthreads();
-        }
+        if (m <= 128) dp_rows<2>(w, N, m, seq, lane, bs, br);
+        else if (m <= 256) dp_rows<4>(w, N, m, seq, lane, bs, br);
+        else dp_rows<8>(w, N, m, seq, lane, bs, br);
     }
     phase_sync();
     TSTAMP(0);
-    // the lane that owns column m saw every H[r][m] in rank order (strict > kept the lowest rank)
-    if (!fast) {
-        const int owner = (m - 1) & 63;
-        bs = __shfl(bs, owner); br = __shfl(br, owner);
-    }
-    const int dpitch = fast ? pitch : Wd, dcol = fast ? 7 : 0;     // direction bytes: row pitch, element of column 0
+    const int dpitch = pitch, dcol = 7;                // direction bytes: row pitch, element of column 0
     // ---- walk back (sequential by nature, wave-uniform) -------------------------------------------------------
     // One dependent HBM load per step would cost ~1 us each; instead the lanes hold a 32x32 patch of direction bytes
     // (ranks r0..r0-31, columns j0..j0-31; 16 bytes per lane) and, on the fast path, the LDS graph rows of those ranks,
@@ -566,7 +541,7 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
                     __builtin_memcpy(t, src, 16);
                     pw0 = t[0]; pw1 = t[1]; pw2 = t[2]; pw3 = t[3];
                 }
-                if (fast) ri = rr >= 1 ? lds_rinfo[rr * 2 + (lane & 1)] : 0u;
+                ri = rr >= 1 ? ((const uint32_t*)w.ri)[rr * 2 + (lane & 1)] : 0u;
                 a = 0; b = 0;
             }
             // column j0-b sits in lane 2a+(b>>4) at byte 15-(b&15)
@@ -574,14 +549,14 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
             const uint32_t sel = (byte >> 2) == 0 ? pw0 : ((byte >> 2) == 1 ? pw1 : ((byte >> 2) == 2 ? pw2 : pw3));
             const int d = (__builtin_amdgcn_readlane((int)sel, src_lane) >> ((byte & 3) * 8)) & 0xff;
             int kind = d & 3, e = d >> 4;
-            if (fast) {                                   // fast-path bytes are 255 - ordinal (see dp_rows_fast)
+            {                                             // bytes are 255 - ordinal (see dp_rows)
                 const int ord = 255 - d;
                 kind = ord <= POA_ORD_ROW0 ? 1 : (ord < POA_ORD_HORIZ ? 2 : 3);
                 e = ord < POA_ORD_ROW0 ? ord : (ord == POA_ORD_ROW0 ? 15 : ord - POA_ORD_VERT);
             }
             int pre = 0;
             if (kind != 3 && e != 15) {
-                if (fast && e < 3) {
+                if (e < 3) {
                     const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2), q1 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2 + 1);
                     pre = e == 0 ? (int)(q0 >> 16) : (e == 1 ? (int)(q1 & 0xffff) : (int)(q1 >> 16));
                 } else {
@@ -696,17 +671,16 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
     return n;
 }
 
-// heaviest path.  The pass over the rows in rank order is a dependent chain (score of a source decides ties between
-// equally heavy in-edges), so it runs wave-uniformly -- but on an LDS image of the graph in rank space (3 words per row:
-// in-degree, base, up to 3 source ranks and their weights; a score word per row), with the previous row's score
-// forwarded in a register, so the chain never waits for HBM.  Rows with more than 3 in-edges or a weight above 255
-// fetch their lists from HBM (rare).
+// heaviest path.  The pass over the rows in rank order is a dependent chain (the score of a source decides ties between
+// equally heavy in-edges), so it runs wave-uniformly -- but on a rank-space image of the graph built in parallel (w.tab,
+// 3 words a row: in-degree, up to 3 source ranks and their weights) and streamed 64 rows at a time into registers, with
+// the scores in LDS and the previous row's score forwarded in a register, so the chain never waits for HBM.  Rows with
+// more than 3 in-edges or a weight above 255 fetch their lists from HBM (rare).  Back pointers leave through a lane
+// buffer; the final chase reads them back 64 ranks at a time.
 __device__ int poa_consensus(const PoaWs& w, int N, int8_t* out, int cap, int lane)
 {
-    if (N <= POA_LDS_ROWS) {
-        uint32_t* tab = poa_lds;                          // [N+1][3]
-        int* score = (int*)(poa_lds + 3 * (POA_LDS_ROWS + 1));
-        static_assert(16 * (POA_LDS_ROWS + 1) <= POA_LDS_BYTES, "consensus tables must fit the K3 LDS block");
+    if (N <= POA_LDS_SCORES) {
+        int* score = (int*)poa_lds;
 #pragma unroll 4
         for (int r = 1 + lane; r <= N; r += 64) {
             const int v = w.order[r - 1];
@@ -714,47 +688,66 @@ __device__ int poa_consensus(const PoaWs& w, int N, int8_t* out, int cap, int la
             uint32_t pr[3] = {0, 0, 0}, wt[3] = {0, 0, 0};
             bool wide = np > 3;
             for (int e = 0; e < 3; ++e) if (e < np) { pr[e] = (uint32_t)w.rank[w.pred[v * POA_MAXP + e]]; wt[e] = (uint32_t)w.pw[v * POA_MAXP + e]; wide |= wt[e] > 255u; }
-            tab[r * 3 + 0] = (uint32_t)(wide ? 0x7f : np) | ((uint32_t)(w.base[v] & 0xff) << 8) | (pr[0] << 16);
-            tab[r * 3 + 1] = pr[1] | (pr[2] << 16);
-            tab[r * 3 + 2] = (wt[0] & 0xff) | ((wt[1] & 0xff) << 8) | ((wt[2] & 0xff) << 16);
+            w.tab[r * 3 + 0] = (uint32_t)(wide ? 0x7f : np) | (pr[0] << 16);
+            w.tab[r * 3 + 1] = pr[1] | (pr[2] << 16);
+            w.tab[r * 3 + 2] = (wt[0] & 0xff) | ((wt[1] & 0xff) << 8) | ((wt[2] & 0xff) << 16);
         }
         if (lane == 0) score[0] = 0;
-        __syncthreads();
+        phase_sync();
         int top = 0, tops = -1, prev = 0;                 // prev = score of rank r-1
-        for (int r = 1; r <= N; ++r) {
-            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[r * 3]);
-            const uint32_t t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[r * 3 + 1]);
-            const uint32_t t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[r * 3 + 2]);
-            const int np = (int)(t0 & 0x7f);
-            int bw = -1, bsrc = 0, bscore = 0;
-            if (np == 0x7f) {
-                const int v = w.order[r - 1];
-                const int cnt = w.np[v];
-                for (int e = 0; e < cnt; ++e) {
-                    const int u = __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + e]]);
-                    const int wt = __builtin_amdgcn_readfirstlane(w.pw[v * POA_MAXP + e]);
-                    const int su = u == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[u]);
-                    if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = u; bscore = su; }
+        uint32_t b0 = 0, b1 = 0, b2 = 0;
+        if (1 + lane <= N) { b0 = w.tab[(1 + lane) * 3]; b1 = w.tab[(1 + lane) * 3 + 1]; b2 = w.tab[(1 + lane) * 3 + 2]; }
+        for (int rb = 1; rb <= N; rb += 64) {
+            const int nr = rb + 64 + lane;
+            uint32_t n0 = 0, n1 = 0, n2 = 0;
+            if (nr <= N) { n0 = w.tab[nr * 3]; n1 = w.tab[nr * 3 + 1]; n2 = w.tab[nr * 3 + 2]; }
+            const int cnt = N - rb + 1 < 64 ? N - rb + 1 : 64;
+            int bpb = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const int r = rb + i;
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, i), t1 = (uint32_t)__builtin_amdgcn_readlane((int)b1, i), t2 = (uint32_t)__builtin_amdgcn_readlane((int)b2, i);
+                const int np = (int)(t0 & 0x7f);
+                int bw = -1, bsrc = 0, bscore = 0;
+                if (np == 0x7f) {
+                    const int v = w.order[r - 1];
+                    const int cn = w.np[v];
+                    for (int e = 0; e < cn; ++e) {
+                        const int u = __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + e]]);
+                        const int wt = __builtin_amdgcn_readfirstlane(w.pw[v * POA_MAXP + e]);
+                        const int su = u == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[u]);
+                        if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = u; bscore = su; }
+                    }
+                } else {
+                    const int p0 = (int)(t0 >> 16), p1 = (int)(t1 & 0xffff), p2 = (int)(t1 >> 16);
+                    if (np > 0) { const int su = p0 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p0]); bw = (int)(t2 & 0xff); bsrc = p0; bscore = su; }
+                    if (np > 1) { const int su = p1 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p1]); const int wt = (int)((t2 >> 8) & 0xff); if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = p1; bscore = su; } }
+                    if (np > 2) { const int su = p2 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p2]); const int wt = (int)((t2 >> 16) & 0xff); if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = p2; bscore = su; } }
                 }
-            } else {
-                const int p0 = (int)(t0 >> 16), p1 = (int)(t1 & 0xffff), p2 = (int)(t1 >> 16);
-                if (np > 0) { const int su = p0 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p0]); bw = (int)(t2 & 0xff); bsrc = p0; bscore = su; }
-                if (np > 1) { const int su = p1 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p1]); const int wt = (int)((t2 >> 8) & 0xff); if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = p1; bscore = su; } }
-                if (np > 2) { const int su = p2 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p2]); const int wt = (int)((t2 >> 16) & 0xff); if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = p2; bscore = su; } }
+                const int sc = bsrc > 0 ? bw + bscore : 0;
+                score[r] = sc;
+                bpb = lane == i ? bsrc : bpb;                 // back pointer (rank, 0 = none)
+                prev = sc;
+                if (sc >= tops) { tops = sc; top = r; }       // ties: larger rank
+                asm volatile("" ::: "memory");
             }
-            const int sc = bsrc > 0 ? bw + bscore : 0;
-            score[r] = sc; tab[r * 3 + 1] = (uint32_t)bsrc;          // word 1 becomes the back pointer (rank, 0 = none)
-            prev = sc;
-            if (sc >= tops) { tops = sc; top = r; }
-            asm volatile("" ::: "memory");
+            if (lane < cnt) w.bp[rb + lane] = bpb;
+            b0 = n0; b1 = n1; b2 = n2;
         }
-        __syncthreads();
-        int len = 0;
-        for (int r = top; r > 0; r = __builtin_amdgcn_readfirstlane((int)tab[r * 3 + 1])) { score[len] = r; ++len; }   // scores are dead: path ranks
+        phase_sync();
+        // chase the back pointers: lane l holds bp[c0 - l]; the path descends a few ranks per step
+        int len = 0, r = top, c0 = -1000, pb = 0, blk = 0;
+        while (r > 0) {
+            int off = c0 - r;
+            if ((unsigned)off >= 64u) { c0 = r; blk = r - lane >= 1 ? w.bp[r - lane] : 0; off = 0; }
+            pb = lane == (len & 63) ? r : pb;
+            ++len;
+            if ((len & 63) == 0) w.pn[len - 64 + lane] = pb;
+            r = __builtin_amdgcn_readlane(blk, off);
+        }
+        if (len & 63) { const int q = (len & ~63) + lane; if (q < len) w.pn[q] = pb; }
         if (len > cap) return -1;
-        __syncthreads();
-        for (int k = lane; k < len; k += 64) out[len - 1 - k] = (int8_t)((tab[score[k] * 3] >> 8) & 0xff);
-        __syncthreads();
+        phase_sync();
+        for (int k = lane; k < len; k += 64) out[len - 1 - k] = w.base[w.order[w.pn[k] - 1]];
         return len;
     }
     int top = -1, tops = -1;
@@ -780,14 +773,14 @@ __device__ int poa_consensus(const PoaWs& w, int N, int8_t* out, int cap, int la
     return len;
 }
 
-__global__ void __launch_bounds__(64) poa_consensus_kernel(const CcsParams p)
+__global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
 {
     const int lane = threadIdx.x & 63;
     uint8_t* slot = p.poa_ws + (size_t)blockIdx.x * p.slot_bytes;
     for (;;) {
         int idx = 0;
         if (lane == 0) idx = atomicAdd(p.work_counter, 1);
-        idx = __shfl(idx, 0);
+        idx = __builtin_amdgcn_readfirstlane(idx);    // wave-uniform in the compiler's eyes too: scalar loads, scalar branches, SGPR pointers below
         if (idx >= p.n) break;
         const int rd = p.work_order ? p.work_order[idx] : idx;
         const int64_t off = p.read_off[rd];
@@ -864,7 +857,7 @@ hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream)
 
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream)
 {
-    hipLaunchKernelGGL(poa_consensus_kernel, dim3(nslots), dim3(64), POA_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(poa_consensus_kernel, dim3(nslots), dim3(64), (size_t)POA_LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 

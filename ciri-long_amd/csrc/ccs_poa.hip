@@ -6,9 +6,10 @@
 // implement, bit for bit, the specification written for this project in oracle/ccs_oracle.c ("clh-ccs v1" / "clh-poa v1");
 // read that header for every rule and tie-break.  One read per wavefront, one wavefront per workgroup.
 //
-// K2: 8-mer codes of the read sit in LDS; lane l owns offsets d = d0+l and walks i sequentially, so h[i] is an LDS
-//     broadcast and h[i+d] a conflict-free stride-1 read, and no cross-lane reduction is needed for the histogram.  The
-//     smoothed maximum, the harmonic test and the per-copy boundary search are wave reductions (shuffles).
+// K2: 8-mer codes of the read sit in LDS.  Matches per offset are counted per PAIR of equal 8-mers (positions chained per
+//     hash bucket with LDS atomics, each pair visited once: O(L * copies) instead of O(L^2/4) comparisons); the smoothed
+//     maximum, the harmonic test and the per-copy boundary search (same chains, a histogram over the candidate offsets)
+//     are lane-parallel with shuffle reductions.
 // K3: persistent waves pull reads from an atomic counter; each owns a workspace slot in HBM (graph arrays, int16 DP
 //     matrix, direction bytes).  A DP row (one graph node) is computed by the 64 lanes over the sequence positions: the
 //     diagonal/vertical maxima over the node's in-edges are independent per position, the horizontal gap chain
@@ -67,6 +68,11 @@ __device__ __forceinline__ int wmax_i(int v) {
 // ------------------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------------------
+// LDS layout for a batch whose longest read has lcap bases (lcap a multiple of 64):
+//   head[K2_BUCKETS] int32 | cnt[lcap/2+2] int32 | sm[lcap/2+2] int32 | code[lcap] uint16 | next[lcap] int16
+static constexpr int K2_BUCKETS = 2048;
+__host__ __device__ inline size_t k2_lds_bytes(int lcap) { return 4 * (size_t)K2_BUCKETS + 8 * ((size_t)lcap / 2 + 2) + 4 * (size_t)lcap; }
+
 __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t k2_lds[];
@@ -77,11 +83,20 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
     const int8_t* seq = p.reads + off;
     CcsScan out;
     out.period = 0; out.ncuts = 0; out.support = 0;
-    int32_t* h = k2_lds;                 // [Lcap]
-    int32_t* sm = k2_lds + p.lcap;       // smoothed counts, [Lcap/2 + 2]
-    int32_t* cnt = sm + p.lcap / 2 + 2;  // [Lcap/2 + 2]
+    int32_t* head = k2_lds;                         // bucket -> last inserted position, -1 = empty
+    int32_t* cnt = head + K2_BUCKETS;               // matches per offset, [lcap/2 + 2]
+    int32_t* sm = cnt + p.lcap / 2 + 2;             // smoothed counts; later the per-cut histogram of offsets
+    uint16_t* code = (uint16_t*)(sm + p.lcap / 2 + 2);
+    int16_t* next = (int16_t*)(code + p.lcap);      // chain of the positions of a bucket; -1 = end (invalid k-mers are in no chain)
     if (L < 2 * CCS_DMIN) { if (lane == 0) p.scan[rd] = out; return; }
 
+    // The specification counts, per offset d, the positions i with equal valid k-mers at i and i+d: that is one count per
+    // PAIR of equal k-mers.  A read of L bases has O(L * copies) such pairs, not O(L^2/4): the positions are chained per
+    // hash bucket and every pair is visited once, instead of comparing all (i, d).
+    const int dmax = L / 2;
+    for (int i = lane; i < K2_BUCKETS; i += 64) head[i] = -1;
+    for (int d = lane; d <= dmax + 1; d += 64) cnt[d] = 0;
+    __syncthreads();
     for (int i = lane; i < L; i += 64) {
         int32_t c = 0, ok = i + CCS_K <= L;
         if (ok)
@@ -90,18 +105,20 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
                 if (b < 0 || b > 3) ok = 0;
                 c = (c << 2) | (b & 3);
             }
-        h[i] = ok ? c : -1;
+        code[i] = (uint16_t)c;
+        next[i] = ok ? (int16_t)atomicExch(&head[(c ^ (c >> 5)) & (K2_BUCKETS - 1)], i) : (int16_t)-2;
     }
     __syncthreads();
-
-    const int dmax = L / 2;
-    for (int d0 = CCS_DMIN; d0 <= dmax; d0 += 64) {
-        const int d = d0 + lane;
-        int c = 0;
-        if (d <= dmax) {
-            const int n = L - d;
-            for (int i = 0; i < n; ++i) { const int32_t a = h[i]; c += (a >= 0 && a == h[i + d]); }
-            cnt[d] = c;
+    for (int i = lane; i < L; i += 64) {
+        int j = next[i];
+        if (j == -2) continue;
+        const int ci = code[i];
+        while (j >= 0) {                            // positions of this bucket inserted before i: each pair once
+            if (code[j] == ci) {
+                const int d = i > j ? i - j : j - i;
+                if (d >= CCS_DMIN && d <= dmax) atomicAdd(&cnt[d], 1);
+            }
+            j = next[j];
         }
     }
     __syncthreads();
@@ -129,15 +146,34 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
         for (int e = lo; e <= hi; ++e) if (sm[e] > es) { es = sm[e]; eb = e; }
         if (eb >= 0 && 2 * es >= best) p0 = eb;
     }
+    // copy boundaries: per cut, the offsets delta in [p0-tol, p0+tol] are scored by the matches (i, i+delta) with i in
+    // the window [b, b+W).  Same pairs again: the window's positions walk their bucket chains (from the head: partners on
+    // both sides are in it) into a histogram over delta (sm is free by now), the lanes then pick by the specification's
+    // order -- most matches, then closest to the previous step, then smallest delta.
     const int tol = p0 / 8 > 4 ? p0 / 8 : 4, W = p0 < 96 ? p0 : 96;
+    const int dlo = p0 - tol, nd = 2 * tol + 1;
+    int32_t* dh = sm;
+    __syncthreads();
     int b = 0, prev = p0, n = 0;
     while (n < CCS_MAX_CUTS) {
+        for (int t = lane; t < nd; t += 64) dh[t] = 0;
+        __syncthreads();
+        for (int i = b + lane; i < b + W && i < L; i += 64) {
+            if (next[i] == -2) continue;
+            const int ci = code[i];
+            int j = head[(ci ^ (ci >> 5)) & (K2_BUCKETS - 1)];
+            while (j >= 0) {
+                const int delta = j - i;
+                if (delta >= dlo && delta < dlo + nd && code[j] == ci) atomicAdd(&dh[delta - dlo], 1);
+                j = next[j];
+            }
+        }
+        __syncthreads();
         int bs = -1, bdel = 0, bdist = 0x7fffffff;
-        for (int c0 = p0 - tol; c0 <= p0 + tol; c0 += 64) {
-            const int delta = c0 + lane;
-            if (delta <= p0 + tol && delta >= 1 && b + delta <= L) {
-                int sc = 0;
-                for (int i = b; i < b + W && i + delta < L; ++i) { const int32_t a = h[i]; sc += (a >= 0 && a == h[i + delta]); }
+        for (int t = lane; t < nd; t += 64) {
+            const int delta = dlo + t;
+            if (delta >= 1 && b + delta <= L) {
+                const int sc = dh[t];
                 const int dist = delta > prev ? delta - prev : prev - delta;
                 if (sc > bs || (sc == bs && dist < bdist)) { bs = sc; bdel = delta; bdist = dist; }   // ascending delta within the lane
             }
@@ -147,6 +183,7 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
             const int s2 = __shfl_xor(bs, d), e2 = __shfl_xor(bdel, d), t2 = __shfl_xor(bdist, d);
             if (s2 > bs || (s2 == bs && (t2 < bdist || (t2 == bdist && e2 < bdel)))) { bs = s2; bdel = e2; bdist = t2; }
         }
+        __syncthreads();
         if (bs < 0) break;
         b += bdel;
         prev = bdel;
@@ -844,7 +881,7 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
 
 hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream)
 {
-    const size_t lds = sizeof(int32_t) * ((size_t)p.lcap + 2 * ((size_t)p.lcap / 2 + 2));
+    const size_t lds = k2_lds_bytes(p.lcap);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)ccs_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -573,7 +573,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     std::vector<int32_t> order(n);
     for (int i = 0; i < n; ++i) {
         const int64_t L = read_off[i + 1] - read_off[i];
-        if (L < 0 || L > 30000) { fail(CLH_E_UNSUPPORTED, "read longer than 30000 bases (LDS capacity of the repeat scan)"); delete pl; return nullptr; }
+        if (L < 0 || L > 18000) { fail(CLH_E_UNSUPPORTED, "read longer than 18000 bases (LDS capacity of the repeat scan: 8 bytes per base + 8 KiB)"); delete pl; return nullptr; }
         lmax = std::max(lmax, (int)L);
         order[i] = i;
     }
@@ -583,7 +583,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->slot_bytes = clh::poa_slot_bytes_host(lmax + 8, mcap_hint > 0 ? mcap_hint + 1 : lmax / 2 + lmax / 16 + 8);
     const unsigned long long budget = 24ull << 30;
     long long slots = (long long)(budget / pl->slot_bytes);
-    pl->nslots = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(slots, 2304), std::max(n, 1))   /* ~17 KiB of LDS per wave: 9 waves per CU x 256 CUs */);
+    pl->nslots = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(slots, 4096), std::max(n, 1))   /* K3 runs 16 waves per CU (8 KiB of LDS, <=128 VGPRs) x 256 CUs */);
     pl->d_off = ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));
     pl->d_scan = ctx->alloc(sizeof(clh::CcsScan) * (size_t)std::max(n, 1));
     pl->d_res = ctx->alloc(sizeof(clh::CcsResult) * (size_t)std::max(n, 1));

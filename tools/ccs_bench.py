@@ -22,4 +22,6 @@ for _ in range(K):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / K * 1e3
 rows, segs, ccs = plan.fetch()
+k2, k3 = plan.timing()
+print('K2 %.2f ms  K3 %.2f ms' % (k2, k3))
 print('reads %d  %.2f ms/step  %.0f reads/s  with consensus %d  status!=0 %d' % (n, ms, n / ms * 1e3, int((rows['nseg'] > 0).sum()), int((rows['status'] != 0).sum())))

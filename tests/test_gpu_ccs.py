@@ -56,6 +56,35 @@ def test_batch_equals_oracle_on_synthetic_reads():
     assert n_found >= 120
 
 
+def test_shapes_that_exercise_every_kernel_path_vs_oracle():
+    """Copies of 90..1600 bases (2, 4 and 8 columns per lane; several column passes; far source rows), up to ~60 copies
+    (in-edge weights), graphs above the LDS score capacity, low-complexity repeats (long hash chains, high in-degree),
+    N-rich reads."""
+    from ciri_long_amd import pyccs, synth
+    rng = np.random.Generator(np.random.PCG64(4242))
+    reads = []
+    for p in (90, 130, 200, 260, 400, 520, 700, 1100, 1600):
+        for L in (1500, 3000, 6000):
+            tm = rng.integers(0, 4, p, dtype=np.int8)
+            reads.append(synth.rolling_circle_read(rng, tm, L))
+    unit = rng.integers(0, 4, 35, dtype=np.int8)
+    reads.append(np.tile(unit, 40))                                   # exact repeat at the minimum-offset scale
+    reads.append(synth.mutate(np.tile(unit, 60), rng))
+    reads.append(np.zeros(700, dtype=np.int8))                        # homopolymer: one chain holds every position
+    reads.append(np.tile(np.array([0, 1], dtype=np.int8), 400))
+    reads.append(synth.mutate(np.tile(rng.integers(0, 4, 64, dtype=np.int8), 70), rng, sub=0.1, ins=0.1, dele=0.1))
+    nrich = synth.rolling_circle_read(rng, rng.integers(0, 4, 300, dtype=np.int8), 2000).copy()
+    nrich[rng.integers(0, len(nrich), 150)] = 4
+    reads.append(nrich)
+    got = pyccs.find_consensus_batch(reads)
+    found = 0
+    for k, r in enumerate(reads):
+        want = oracle_lib.oracle_find_consensus(r)
+        assert got[k] == want[:2], (k, len(r), got[k][0], want[0])
+        found += got[k][0] is not None
+    assert found >= 25
+
+
 def test_spoa_call_shape():
     from ciri_long_amd import spoa
     cons, msa = spoa.poa(SEGMENTS, 0, True, 10, -4, -8, -2, -24, -1)     # tests/test_poa.py:30

@@ -105,11 +105,20 @@ def main():
     wl = args.workload
     nreads = args.reads or (100000 if wl == 'c3' else 10000)
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # The CPU leg spawns one process per host core.  It runs BEFORE this process touches the GPU (a child of a process
+    # that has initialised the GPU must not exec), and not at all under rocprofv3, whose preloaded library initialises
+    # the GPU before Python starts (and again in every child).
+    profiled = any('rocprof' in os.environ.get(k, '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB')) \
+        or any(k.startswith('ROCPROF') for k in os.environ)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu and not profiled:
+        cpu = cpu_baseline(args.cpu_seconds, wl)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -271,10 +280,7 @@ def main():
     }
     if wl == 'c3':
         out['config']['reads_with_consensus'] = int(len(has))
-    if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline(args.cpu_seconds, wl)
-    else:
-        out['cpu_baseline'] = None
+    out['cpu_baseline'] = cpu      # rank 0 at N=1 only; None under a profiler or with --no-cpu
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -32,6 +32,7 @@ static constexpr int POA_MAXP = 12;
 static constexpr int POA_MATCH = 10;
 static constexpr int POA_MISMATCH = -4;
 static constexpr int POA_GAP = -8;
+static constexpr int POA_MAX_COPY = 3200;            // longest copy: 10 * 3200 < 32767 (H rows are int16)
 
 // Phase boundary inside one wave that exchanges data between lanes through HBM: complete the stores, then drop the
 // CU's L1 so that no line read before the stores can be served stale (buffer_inv sc1; a few microseconds, used a
@@ -843,6 +844,7 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
         }
         const int ncap = total + 8, mcap = maxlen + 1;
         if (poa_slot_bytes(ncap, mcap) > p.slot_bytes) { res.status = 1; if (lane == 0) p.results[rd] = res; continue; }
+        if (maxlen > POA_MAX_COPY) { res.status = 4; if (lane == 0) p.results[rd] = res; continue; }   // H is int16: |H| <= 10 * copy length
         const PoaWs w = carve(slot, ncap, mcap);
         phase_sync();
         unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};

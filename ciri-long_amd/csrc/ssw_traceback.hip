@@ -3,8 +3,12 @@
 // Replaces banded_sw (reference: libs/striped_smith_waterman/ssw.c:548-735) bit for bit on every input whose
 // traceback stays inside the band (the reference reads unrelated memory otherwise).  The reference sweeps the
 // band row by row with a scalar loop; here the cells of one anti-diagonal (row + column = a) are independent,
-// so the 64 lanes take consecutive rows of the anti-diagonal and the H/E/F values of the two previous
-// anti-diagonals sit in an LDS window indexed by row modulo the window size.
+// so the threads of the workgroup take consecutive rows of the anti-diagonal and the H/E/F values of the two previous
+// anti-diagonals sit in an LDS window indexed by row modulo the window size.  An alignment is a chain of ~2000
+// dependent anti-diagonal steps per band iteration, so its latency -- and with it the tail of a batch -- is set by the
+// time of one step: several wavefronts per alignment cut a wide band's step from (band/64) chunk passes to one pass
+// plus an LDS-only barrier (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would also wait for the direction-byte
+// stores, an HBM round trip per step).
 //
 // Reference behaviour that is kept on purpose (oracle/ssw_oracle.c:banded_traceback states the same rules):
 //   * out-of-band neighbours read as H = E = F = 0 through the sentinel slots of ssw.c:596;
@@ -18,6 +22,7 @@
 // stored anti-diagonal-major so that a wave's stores are contiguous.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "clh_device.h"
 
 namespace clh {
@@ -39,6 +44,9 @@ __device__ __forceinline__ int wave_max(int v)
     return v;
 }
 
+// workgroup barrier that orders LDS traffic only (outstanding global stores keep flying)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // first row of anti-diagonal a inside the band: ceil((a - w) / 2), not clamped
 __device__ __forceinline__ int ad_first_row(int a, int w) { int t = a - w; return t >= 0 ? (t + 1) >> 1 : -((-t) >> 1); }
 // storage of one band iteration: anti-diagonal a holds its active rows [ad_lo, ...] in ad_stride consecutive bytes.
@@ -59,7 +67,7 @@ __device__ __forceinline__ int ad_stride(int w, int readLen, int refLen)
 
 // big = 0: first attempt with a small LDS window (high occupancy); alignments whose band outgrows it are marked
 // CLH_STATUS_NEED_BIG.  big = 1: only the marked ones, with a window sized for the launch's read-length class.
-__global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp, int big, int seq_cap)
+__global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp, int big, int seq_cap)
 {
     extern __shared__ __attribute__((aligned(16))) short tb_lds[];
     short* const H0 = tb_lds;                 // H[3][ws]
@@ -70,7 +78,10 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     __shared__ int smat[32];
     __shared__ unsigned long long hist_at[24];   // every band iteration keeps its direction bytes (see hist_lookup)
     __shared__ int hist_w[24];
-    const int lane = threadIdx.x & 63;
+    __shared__ unsigned long long s_at;
+    __shared__ int s_max[16];
+    const int lane = threadIdx.x;            // "lane" = thread of the workgroup; thread 0 does the scalar stores
+    const int nt = blockDim.x;
     if (lane < 25) smat[lane] = p.mat[lane];
     __syncthreads();
     const SswTask task = p.tasks[blockIdx.x];
@@ -105,8 +116,8 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
         if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | (big ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG); }
         return;
     }
-    for (int k = lane; k < readLen; k += 64) sseq[k] = read[k];
-    for (int k = lane; k < refLen; k += 64) sseq[readLen + k] = ref[k];
+    for (int k = lane; k < readLen; k += nt) sseq[k] = read[k];
+    for (int k = lane; k < refLen; k += nt) sseq[readLen + k] = ref[k];
     __syncthreads();
     const int8_t* const sread = sseq;
     const int8_t* const sref = sseq + readLen;
@@ -135,8 +146,10 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
         const int imask = ring ? wsp - 1 : -1;
         unsigned long long need = ((unsigned long long)nAD * (unsigned long long)stride_w + 63ull) & ~63ull;
         unsigned long long at = 0;
-        if (lane == 0) at = atomicAdd(pool.head, need);
-        at = __shfl(at, 0);
+        __syncthreads();
+        if (lane == 0) s_at = atomicAdd(pool.head, need);
+        __syncthreads();
+        at = s_at;
         if (at + need > pool.size) { status = CLH_STATUS_CIGAR_TRUNC; break; }
         dir = pool.base + at;
         last_at = at;
@@ -150,7 +163,7 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
             int ihi = (a + w) >> 1;
             if (ihi > readLen - 1) ihi = readLen - 1;
             if (ihi > a) ihi = a;
-            for (int i0 = ilo; i0 <= ihi; i0 += 64) {
+            for (int i0 = ilo; i0 <= ihi; i0 += nt) {
                 const int i = i0 + lane;
                 if (i <= ihi) {
                     const int j = a - i;
@@ -179,11 +192,13 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
                     dir[(size_t)a * stride_w + (i - ilo)] = (uint8_t)(dh | (de == 3 ? 8 : 0) | (df == 5 ? 16 : 0));
                 }
             }
-            // one wave per workgroup: LDS operations of a wave execute in order, so the next anti-diagonal's reads see
-            // these writes; only the compiler has to be told not to move them.
-            asm volatile("" ::: "memory");
+            // the next anti-diagonal reads what this one wrote
+            lds_barrier();
         }
         itmax = wave_max(itmax);
+        if ((lane & 63) == 0) s_max[lane >> 6] = itmax;
+        __syncthreads();
+        for (int k = 0; k < (nt >> 6); ++k) itmax = s_max[k] > itmax ? s_max[k] : itmax;
         maxv = itmax > maxv ? itmax : maxv;
         w *= 2;
         if (!(maxv < score && w < 2 * readLen)) break;
@@ -205,26 +220,26 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     int i = readLen - 1, j = refLen - 1, state = 2, run = 0, nops = 0, fail = 0;
     int op = 0, prev_op = 0;             // 0 M, 1 I, 2 D
     const int stride = ad_stride(w, readLen, refLen);
-    const int srow = stride < 66 ? stride : 0;      // staging only when an anti-diagonal fits 66 bytes
-    int staged_lo = 1 << 30, staged_hi = -1;
+    // A step moves to anti-diagonal a-1 or a-2 and changes the slot (row minus first row of the anti-diagonal) by at
+    // most one, so a 64 x 64 patch (anti-diagonals a-63..a, slots slot-32..slot+31) serves >= 32 steps per refill; a
+    // dependent HBM read per step (~1.5 us each, ~2000 steps) was most of an alignment's latency.
+    int st_lo = 1 << 30, st_hi = -1, st_base = 0;
     const long long wd_final = 2ll * w + 1;
     while (i > 0) {
         int code = 0;
         if (j >= 0 && j <= i + w && j >= i - w && j < refLen) {
             const int a = i + j;
             const int slot = i - ad_lo(a, w, refLen);
-            if (srow) {
-                if (a < staged_lo || a > staged_hi) {
-                    staged_hi = a; staged_lo = a - 63 > 0 ? a - 63 : 0;
-                    const int nbytes = (staged_hi - staged_lo + 1) * stride;
-                    __syncthreads();
-                    for (int b = lane; b < nbytes; b += 64) stage[b] = dir[(size_t)staged_lo * stride + b];
-                    __syncthreads();
+            if (a < st_lo || a > st_hi || slot < st_base || slot >= st_base + 64) {
+                st_hi = a; st_lo = a - 63 > 0 ? a - 63 : 0; st_base = slot - 32;
+                __syncthreads();
+                for (int b = lane; b < 64 * 64; b += nt) {
+                    const int aa = st_lo + (b >> 6), t = st_base + (b & 63);
+                    stage[b] = (aa <= st_hi && t >= 0 && t < stride) ? dir[(size_t)aa * stride + t] : (uint8_t)0;
                 }
-                code = stage[(a - staged_lo) * stride + slot];
-            } else {
-                code = dir[(size_t)a * stride + slot];
+                __syncthreads();
             }
+            code = stage[(a - st_lo) * 64 + (slot - st_base)];
         } else {
             const long long xi = i - w > 0 ? i - w : 0;
             const long long C = (long long)i * wd_final + ((long long)j - xi);   // cell index in the final layout
@@ -279,7 +294,7 @@ __global__ void __launch_bounds__(64) ssw_traceback_kernel(const SswParams p, Tb
     }
     __threadfence_block();
     __syncthreads();
-    for (int k = lane; k < nops / 2; k += 64) {      // reverse in place, ssw.c:716-725
+    for (int k = lane; k < nops / 2; k += nt) {      // reverse in place, ssw.c:716-725
         const uint32_t x = cig[k], y = cig[nops - 1 - k];
         cig[k] = y; cig[nops - 1 - k] = x;
     }
@@ -297,7 +312,12 @@ hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t
     while (wsp * 2 <= ws) wsp *= 2;
     const int seq_cap = rv > 0 ? 128 * rv * 3 + 64 : 6144;
     const size_t lds = (size_t)7 * ws * sizeof(short) + (size_t)seq_cap;
-    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(ntasks), dim3(64), lds, stream, p, pool, ws, wsp, rv > 0 ? 1 : 0, seq_cap);
+    static int nt_small = 0, nt_big = 0;
+    if (!nt_small) {   // tuning hooks (multiples of 64, <= 1024)
+        const char* a = getenv("CLH_TB_SMALL_NT"); const char* b = getenv("CLH_TB_BIG_NT");
+        nt_small = a ? atoi(a) : 128; nt_big = b ? atoi(b) : 1024;
+    }
+    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(ntasks), dim3(rv > 0 ? nt_big : nt_small), lds, stream, p, pool, ws, wsp, rv > 0 ? 1 : 0, seq_cap);
     return hipGetLastError();
 }
 

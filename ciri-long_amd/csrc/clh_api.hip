@@ -432,6 +432,76 @@ extern "C" int clh_ssw_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K4: unit-cost edit distance of n pairs of byte strings (utils.py:153-159 `distance`)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int clh_edit_distance_batch(clh_ctx* ctx, int32_t n, const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off,
+                                       int32_t* out)
+{
+    if (!ctx || n < 0 || !a_off || !b_off || !out || (n > 0 && (!a || !b))) return fail(CLH_E_ARG, "clh_edit_distance_batch: null argument");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t ta = a_off[n] - a_off[0], tb = b_off[n] - b_off[0];
+    if (ta < 0 || tb < 0) return fail(CLH_E_ARG, "clh_edit_distance_batch: offsets must ascend");
+    // the batch's alphabet -> dense codes; the kernel builds match vectors from 3 bit planes (<= 8 symbols: DNA) or 8
+    int code[256];
+    for (int& c : code) c = -1;
+    int nsym = 0;
+    auto learn = [&](const uint8_t* p, int64_t len) { for (int64_t i = 0; i < len; ++i) if (code[p[i]] < 0) code[p[i]] = nsym++; };
+    learn(a + a_off[0], ta); learn(b + b_off[0], tb);
+    const int planes = nsym <= 8 ? 3 : 8;
+    std::vector<uint8_t> sym((size_t)(ta + tb) + 32, 0);
+    for (int64_t i = 0; i < ta; ++i) sym[(size_t)i] = (uint8_t)code[a[a_off[0] + i]];
+    for (int64_t i = 0; i < tb; ++i) sym[(size_t)(ta + i)] = (uint8_t)code[b[b_off[0] + i]];
+    std::vector<clh::EdTask> tasks;
+    tasks.reserve((size_t)n);
+    std::vector<int> cls;
+    for (int k = 0; k < n; ++k) {
+        const int64_t la = a_off[k + 1] - a_off[k], lb = b_off[k + 1] - b_off[k];
+        if (la < 0 || lb < 0) return fail(CLH_E_ARG, "clh_edit_distance_batch: offsets must ascend");
+        if (la == 0 || lb == 0) { out[k] = (int32_t)(la + lb); continue; }
+        clh::EdTask t;
+        const bool a_is_pat = la <= lb;
+        t.pat_off = a_is_pat ? a_off[k] - a_off[0] : ta + (b_off[k] - b_off[0]);
+        t.txt_off = a_is_pat ? ta + (b_off[k] - b_off[0]) : a_off[k] - a_off[0];
+        t.pat_len = (int32_t)(a_is_pat ? la : lb); t.txt_len = (int32_t)(a_is_pat ? lb : la);
+        t.out_index = k; t.pad = 0;
+        if (t.pat_len > 4096) return fail(CLH_E_UNSUPPORTED, "clh_edit_distance_batch: the shorter string of a pair is longer than 4096 symbols");
+        tasks.push_back(t);
+    }
+    const int nt = (int)tasks.size();
+    if (nt == 0) return 0;
+    auto group = [](const clh::EdTask& t) { int B = (t.pat_len + 63) >> 6, G = 1; while (G < B) G <<= 1; return G; };
+    std::stable_sort(tasks.begin(), tasks.end(), [&](const clh::EdTask& x, const clh::EdTask& y) {
+        const int gx = group(x), gy = group(y);
+        if (gx != gy) return gx < gy;
+        return x.txt_len > y.txt_len;                 // similar step counts share a wave
+    });
+    void* d_sym = ctx->alloc(sym.size());
+    void* d_tasks = ctx->alloc(sizeof(clh::EdTask) * (size_t)nt);
+    void* d_out = ctx->alloc(sizeof(int32_t) * (size_t)n);
+    int rc = 0;
+    if (!d_sym || !d_tasks || !d_out) rc = fail(CLH_E_HIP, "out of device memory");
+    if (!rc && (hipMemcpyAsync(d_sym, sym.data(), sym.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(d_tasks, tasks.data(), sizeof(clh::EdTask) * (size_t)nt, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
+        rc = fail(CLH_E_HIP, "H2D failed");
+    for (int i = 0; i < nt && !rc;) {
+        const int G = group(tasks[i]);
+        int j = i;
+        while (j < nt && group(tasks[j]) == G) ++j;
+        if (clh::launch_edit_distance((const uint8_t*)d_sym, (const clh::EdTask*)d_tasks + i, j - i, G, planes, (int32_t*)d_out, ctx->stream) != hipSuccess)
+            rc = fail(CLH_E_HIP, "edit distance launch failed");
+        i = j;
+    }
+    std::vector<int32_t> res((size_t)n);
+    if (!rc && (hipMemcpyAsync(res.data(), d_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = fail(CLH_E_HIP, "edit distance kernel or D2H failed");
+    if (!rc) for (const clh::EdTask& t : tasks) out[t.out_index] = res[(size_t)t.out_index];
+    ctx->release(d_sym); ctx->release(d_tasks); ctx->release(d_out);
+    return rc;
+}
+
 extern "C" void clh_encode_dna(const char* seq, int64_t len, int8_t* out)
 {
     static int8_t lut[256];

@@ -83,6 +83,13 @@ hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream);
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream);
 size_t poa_slot_bytes_host(int ncap, int mcap);
 
+struct EdTask {            // K4: one pair; the pattern is the shorter string
+    int64_t pat_off, txt_off;   // into the packed symbol array (codes 0..nsym-1, one per byte)
+    int32_t pat_len, txt_len;
+    int32_t out_index, pad;
+};
+hipError_t launch_edit_distance(const uint8_t* seqs, const EdTask* tasks, int ntasks, int G, int planes, int32_t* out, hipStream_t stream);
+
 static constexpr int kRvStrips = 1000;   // pseudo class: RV = 32 with row strips (reads longer than 4096 bases)
 extern const int kRvClasses[];
 extern const int kNumRvClasses;

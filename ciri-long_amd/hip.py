@@ -77,6 +77,8 @@ def lib():
         L.clh_ccs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_plan_timing.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_edit_distance_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_edit_distance_batch.restype = C.c_int
         L.clh_poa_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -208,6 +210,24 @@ class Context(object):
                 o = int(seq_off[group_off[k]])
                 res.append(bases[np.minimum(out[o:o + lens[k]], 4)].tobytes().decode())
         return res
+
+    def edit_distance_batch(self, xs, ys):
+        """Unit-cost edit distance of the pairs (xs[k], ys[k]) (str or bytes) -> int32 array.  K4 through the C ABI."""
+        n = len(xs)
+        if n != len(ys):
+            raise ValueError('edit_distance_batch: the two lists differ in length')
+        ba = [x.encode() if isinstance(x, str) else bytes(x) for x in xs]
+        bb = [y.encode() if isinstance(y, str) else bytes(y) for y in ys]
+        a_off = np.zeros(n + 1, dtype=np.int64); b_off = np.zeros(n + 1, dtype=np.int64)
+        if n:
+            a_off[1:] = np.cumsum([len(x) for x in ba]); b_off[1:] = np.cumsum([len(y) for y in bb])
+        a = np.frombuffer(b''.join(ba) + b'\0', dtype=np.uint8)
+        b = np.frombuffer(b''.join(bb) + b'\0', dtype=np.uint8)
+        out = np.zeros(n, dtype=np.int32)
+        rc = lib().clh_edit_distance_batch(self._h, n, a.ctypes.data, a_off.ctypes.data, b.ctypes.data, b_off.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise ClhError('clh_edit_distance_batch failed (%d): %s' % (rc, last_error()))
+        return out
 
     def ccs_plan(self, read_off):
         return CcsPlan(self, read_off)

@@ -1,4 +1,4 @@
-"""Small helpers of the `call` path (counterparts of CIRI_long/utils.py:52-58, 78-86, 118-124)."""
+"""Small helpers of the `call` and `collapse` paths (counterparts of CIRI_long/utils.py:52-58, 78-86, 118-124, 153-167)."""
 from itertools import zip_longest
 
 _COMPLEMENT = str.maketrans('ATCG', 'TAGC')   # upper-case ACGT only; N and lower case pass through (utils.py:118-120)
@@ -20,3 +20,39 @@ def grouper(iterable, n, fillvalue=None):
 
 def transform_seq(seq, bsj):
     return seq[bsj:] + seq[:bsj]
+
+
+def distance(x, y):
+    """Unit-cost edit distance of two strings (utils.py:153-159: python-Levenshtein / edlib, the same integer), on the GPU."""
+    from . import hip
+    return int(hip.default_context().edit_distance_batch([x], [y])[0])
+
+
+def distance_batch(xs, ys):
+    """distance(xs[k], ys[k]) for every k in one launch per size class."""
+    from . import hip
+    return hip.default_context().edit_distance_batch(xs, ys)
+
+
+def pairwise_distance(seqs):
+    """The matrix cluster_sequence builds (collapse.py:466-473): dist[i][j] = distance(s_i, s_j) / max(len(s_i), len(s_j)),
+    symmetric, zero diagonal; all i < j pairs go to the GPU as one batch."""
+    import numpy as np
+    n = len(seqs)
+    dist = np.zeros((n, n))
+    ii, jj = np.triu_indices(n, 1)
+    if len(ii):
+        d = distance_batch([seqs[i] for i in ii], [seqs[j] for j in jj])
+        norm = np.array([max(len(seqs[i]), len(seqs[j])) for i, j in zip(ii, jj)], dtype=np.float64)
+        # the reference also divides the (zero) diagonal distances by the length; an empty pair would raise there too
+        dist[ii, jj] = d / norm
+    return dist + dist.T
+
+
+def compress_seq(seq):
+    """Homopolymer compression (utils.py:162-167)."""
+    hpc = [seq[0], ]
+    for i, j in zip(seq[:-1], seq[1:]):
+        if i != j:
+            hpc.append(j)
+    return ''.join(hpc)

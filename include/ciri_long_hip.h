@@ -130,6 +130,14 @@ int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* r
 int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64_t* seq_off, const int64_t* group_off,
                   int32_t* out_len, int8_t* out_ccs);
 
+/* Unit-cost edit distance of n pairs of byte strings: what the reference's distance(x, y) returns (CIRI_long/utils.py:
+ * 153-159; python-Levenshtein for <= 50 characters, edlib otherwise -- the same integer), used pairwise by
+ * cluster_sequence (collapse.py:466-473) and per candidate by avg_score (collapse.py:156-158).  Strings are compared
+ * byte for byte (case-sensitive, like the reference); pair k is a[a_off[k]..a_off[k+1]) against b[b_off[k]..b_off[k+1]).
+ * Limit: the shorter string of a pair at most 4096 bytes (CLH_E_UNSUPPORTED otherwise). */
+int clh_edit_distance_batch(clh_ctx* ctx, int32_t n, const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off,
+                            int32_t* out);
+
 /* ASCII -> codes exactly as ssw_wrap.py:234-252 (A/a C/c G/g T/t N/n, anything else 4), on the host. */
 void clh_encode_dna(const char* seq, int64_t len, int8_t* out);
 

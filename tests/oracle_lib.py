@@ -200,3 +200,13 @@ def oracle_poa(seqs):
     out = np.zeros(int(off[-1]) + 8, dtype=np.int8)
     n = _ccs_lib().clo_poa_consensus(len(arrs), data.ctypes.data, off.ctypes.data, out.ctypes.data, len(out))
     return None if n < 0 else decode(out[:n])
+
+
+def oracle_edit_distance(x, y):
+    """oracle/edit_oracle.c: unit-cost edit distance of two str/bytes"""
+    L = oracle()
+    bx = x.encode() if isinstance(x, str) else bytes(x)
+    by = y.encode() if isinstance(y, str) else bytes(y)
+    L.clo_edit_distance.restype = C.c_int32
+    L.clo_edit_distance.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
+    return int(L.clo_edit_distance(bx, len(bx), by, len(by)))

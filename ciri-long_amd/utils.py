@@ -22,6 +22,38 @@ def transform_seq(seq, bsj):
     return seq[bsj:] + seq[:bsj]
 
 
+def pairwise(iterable):
+    """s -> (s0, s1), (s1, s2), ... (utils.py:89-94)"""
+    from itertools import tee
+    a, b = tee(iterable)
+    next(b, None)
+    return zip(a, b)
+
+
+def flatten(x):
+    import itertools
+    return list(itertools.chain(*x))
+
+
+def min_sorted_items(iters, key, reverse=False):
+    """every item that shares the best value of field `key` (utils.py:112-115)"""
+    from operator import itemgetter
+    x = sorted(iters, key=itemgetter(key), reverse=reverse)
+    return [i for i in x if i[key] == x[0][key]]
+
+
+def get_junc_seq(seq, bsj, width=25):
+    """2*width bases around position bsj of a circular sequence (utils.py:127-140)"""
+    st, en = bsj - width, bsj + width
+    if len(seq) <= 2 * width:
+        return seq[bsj - len(seq) // 2:] + seq[:bsj - len(seq) // 2]
+    if st < 0:
+        return seq[st:en] if en < 0 else seq[st:] + seq[:en]
+    if en > len(seq):
+        return seq[st:] + seq[:en - len(seq)]
+    return seq[st:en]
+
+
 def distance(x, y):
     """Unit-cost edit distance of two strings (utils.py:153-159: python-Levenshtein / edlib, the same integer), on the GPU."""
     from . import hip

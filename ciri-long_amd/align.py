@@ -145,6 +145,22 @@ class Fasta(object):
 # ---------------------------------------------------------------------------------------------------------------
 # CIGAR -> blocks on the reference
 # ---------------------------------------------------------------------------------------------------------------
+class DeviceGenome(object):
+    """`env.GENOME` with a copy of the contigs resident on the GPU: `seq()` keeps serving the host-side steps (splice
+    signals, junction sequences), while the Smith-Waterman windows of the BSJ step are read in place from HBM
+    (find_bsj._run_clip_jobs).  `host` is any object with the Fasta contract
+    (`seq(ctg, start, end)`, `contig_len`); `contigs` the sequences to upload ({name: str})."""
+
+    def __init__(self, host, contigs, context=None):
+        from . import hip
+        self.host = host
+        self.contig_len = dict(host.contig_len) if hasattr(host, 'contig_len') else {k: len(v) for k, v in contigs.items()}
+        self.device = hip.Genome(context or hip.default_context(), contigs)
+
+    def seq(self, ctg, start, end):
+        return self.host.seq(ctg, start, end)
+
+
 def get_blocks(hit):
     """[start, end, length] of every N-separated stretch of the hit (align.py:319-343; length is end-start+1)."""
     blocks, st, en = [], hit.r_st, hit.r_st

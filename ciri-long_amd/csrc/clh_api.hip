@@ -149,10 +149,13 @@ static int rv_class_for(int rows)
     return clh::kRvStrips;      // longer than 4096 rows: RV = 32 kernel with row strips
 }
 
-extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
-                                  const int32_t* mask_len, const clh_ssw_opts* o)
+// ref_off != nullptr: packed references, alignment a against [ref_off[a], ref_off[a+1]).  Otherwise windows of a resident
+// genome: win_off[a], win_len[a], win_rc[a] (1 = read backwards and complemented).
+static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
+                                const int64_t* win_off, const int32_t* win_len, const uint8_t* win_rc,
+                                const int32_t* mask_len, const clh_ssw_opts* o)
 {
-    if (!ctx || n < 0 || !read_off || !ref_off || !o || !o->mat) { fail(CLH_E_ARG, "clh_ssw_plan: null argument"); return nullptr; }
+    if (!ctx || n < 0 || !read_off || (!ref_off && (!win_off || !win_len)) || !o || !o->mat) { fail(CLH_E_ARG, "clh_ssw_plan: null argument"); return nullptr; }
     if (o->n_mat < 1 || o->n_mat > 5) { fail(CLH_E_UNSUPPORTED, "substitution matrix edge must be 1..5"); return nullptr; }
     if (o->gap_open < o->gap_extend) {
         fail(CLH_E_UNSUPPORTED, "gap_open < gap_extend: the reference's 8-bit lazy-F loop is not a plain recurrence there; not implemented");
@@ -186,13 +189,15 @@ extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_o
     size_t colmax = 0, cig = 0;
     unsigned long long pool = 0;
     for (int a = 0; a < n; ++a) {
-        const int64_t L = read_off[a + 1] - read_off[a], R = ref_off[a + 1] - ref_off[a];
+        const int64_t L = read_off[a + 1] - read_off[a], R = ref_off ? ref_off[a + 1] - ref_off[a] : (int64_t)win_len[a];
         if (L < 1 || R < 0 || L > 0x7fffffff || R > 0x7fffffff) { fail(CLH_E_ARG, "empty read or negative length in batch"); delete pl; return nullptr; }
+        const int rc = (!ref_off && win_rc && win_rc[a]) ? 1 : 0;
         const int rows = (int)((L + 15) / 16) * 16;
         const int rv = rv_class_for(rows);
         cls[a] = rv;
         clh::SswTask& t = pl->tasks[a];
-        t.read_off = read_off[a]; t.ref_off = ref_off[a];
+        t.read_off = read_off[a]; t.ref_off = ref_off ? ref_off[a] : (rc ? win_off[a] + R - 1 : win_off[a]);
+        t.ref_rc = rc; t.pad = 0;
         t.read_len = (int)L; t.ref_len = (int)R;
         t.mask_len = mask_len ? mask_len[a] : (L > 30 ? (int)(L / 2) : 15);
         t.out_index = a;
@@ -252,6 +257,94 @@ extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_o
         clh_plan_destroy(pl); return nullptr;
     }
     return pl;
+}
+
+extern "C" clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
+                                  const int32_t* mask_len, const clh_ssw_opts* o)
+{
+    if (!ref_off) { fail(CLH_E_ARG, "clh_ssw_plan: null argument"); return nullptr; }
+    return ssw_plan_build(ctx, n, read_off, ref_off, nullptr, nullptr, nullptr, mask_len, o);
+}
+
+extern "C" clh_plan* clh_ssw_plan_windows(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* win_off, const int32_t* win_len,
+                                          const uint8_t* win_rc, const int32_t* mask_len, const clh_ssw_opts* o)
+{
+    if (!win_off || !win_len) { fail(CLH_E_ARG, "clh_ssw_plan_windows: null argument"); return nullptr; }
+    return ssw_plan_build(ctx, n, read_off, nullptr, win_off, win_len, win_rc, mask_len, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5: resident genome
+// ---------------------------------------------------------------------------------------------------------------
+struct clh_genome {
+    clh_ctx* ctx = nullptr;
+    int64_t len = 0;
+    void *d_codes = nullptr, *d_pre = nullptr;
+};
+
+extern "C" void clh_genome_destroy(clh_genome* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    g->ctx->release(g->d_codes); g->ctx->release(g->d_pre);
+    delete g;
+}
+
+extern "C" clh_genome* clh_genome_create(clh_ctx* ctx, const char* ascii, int64_t len)
+{
+    if (!ctx || len < 0 || (len > 0 && !ascii)) { fail(CLH_E_ARG, "clh_genome_create: null argument"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail(CLH_E_HIP, "hipSetDevice failed"); return nullptr; }
+    clh_genome* g = new clh_genome();
+    g->ctx = ctx; g->len = len;
+    const size_t nblk = (size_t)(len / clh::kGenomeBlock) + 2;
+    g->d_codes = ctx->alloc((size_t)len + 64);
+    g->d_pre = ctx->alloc(sizeof(unsigned int) * nblk);
+    void* d_ascii = ctx->alloc((size_t)len + 64);
+    bool ok = g->d_codes && g->d_pre && d_ascii;
+    if (!ok) fail(CLH_E_HIP, "out of device memory for the genome");
+    std::vector<unsigned int> pre(nblk, 0);
+    if (ok && len > 0) {
+        ok = hipMemsetAsync(g->d_pre, 0, sizeof(unsigned int) * nblk, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(d_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+             clh::launch_genome_encode((const char*)d_ascii, (uint8_t*)g->d_codes, (unsigned int*)g->d_pre, len, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(pre.data(), g->d_pre, sizeof(unsigned int) * nblk, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (!ok) fail(CLH_E_HIP, "genome encode failed");
+    }
+    if (ok) {   // exclusive prefix: pre[b] = upper-case N before base b * kGenomeBlock
+        unsigned int run = 0;
+        for (size_t b = 0; b < nblk; ++b) { const unsigned int c = pre[b]; pre[b] = run; run += c; }
+        ok = hipMemcpyAsync(g->d_pre, pre.data(), sizeof(unsigned int) * nblk, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (!ok) fail(CLH_E_HIP, "genome prefix upload failed");
+    }
+    ctx->release(d_ascii);
+    if (!ok) { clh_genome_destroy(g); return nullptr; }
+    return g;
+}
+
+extern "C" const void* clh_genome_codes(const clh_genome* g) { return g ? g->d_codes : nullptr; }
+extern "C" int64_t clh_genome_length(const clh_genome* g) { return g ? g->len : 0; }
+
+extern "C" int clh_genome_count_n(clh_genome* g, int32_t n, const int64_t* off, const int64_t* len, int64_t* out)
+{
+    if (!g || n < 0 || (n > 0 && (!off || !len || !out))) return fail(CLH_E_ARG, "clh_genome_count_n: null argument");
+    if (n == 0) return 0;
+    for (int i = 0; i < n; ++i) if (off[i] < 0 || len[i] < 0 || off[i] + len[i] > g->len) return fail(CLH_E_ARG, "clh_genome_count_n: window outside the genome");
+    clh_ctx* ctx = g->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    void* d_off = ctx->alloc(sizeof(int64_t) * (size_t)n); void* d_len = ctx->alloc(sizeof(int64_t) * (size_t)n); void* d_out = ctx->alloc(sizeof(int64_t) * (size_t)n);
+    int rc = 0;
+    if (!d_off || !d_len || !d_out) rc = fail(CLH_E_HIP, "out of device memory");
+    if (!rc && (hipMemcpyAsync(d_off, off, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(d_len, len, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                clh::launch_genome_count_n((const uint8_t*)g->d_codes, (const unsigned int*)g->d_pre, (const long long*)d_off, (const long long*)d_len,
+                                           (long long*)d_out, n, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(out, d_out, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = fail(CLH_E_HIP, "N count failed");
+    ctx->release(d_off); ctx->release(d_len); ctx->release(d_out);
+    return rc;
 }
 
 extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs, void* stream_)
@@ -427,6 +520,28 @@ extern "C" int clh_ssw_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const
     if (!rc && hipMemcpyAsync(pl->d_reads, reads, rb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D reads failed");
     if (!rc && hipMemcpyAsync(pl->d_refs, refs, fb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D refs failed");
     if (!rc) rc = clh_ssw_run(pl, pl->d_reads, pl->d_refs, nullptr);
+    if (!rc) rc = clh_ssw_fetch(pl, out, cigar_buf, cigar_cap, cigar_used);
+    clh_plan_destroy(pl);
+    return rc;
+}
+
+// clh_ssw_batch with the references given as windows of a resident genome: only the reads cross PCIe
+extern "C" int clh_ssw_windows_batch(clh_genome* genome, int32_t n, const int8_t* reads, const int64_t* read_off, const int64_t* win_off,
+                                     const int32_t* win_len, const uint8_t* win_rc, const int32_t* mask_len, const clh_ssw_opts* opts,
+                                     clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used)
+{
+    if (!genome || !reads || !read_off || !win_off || !win_len) return fail(CLH_E_ARG, "clh_ssw_windows_batch: null argument");
+    for (int i = 0; i < n; ++i)
+        if (win_off[i] < 0 || win_len[i] < 0 || win_off[i] + win_len[i] > genome->len) return fail(CLH_E_ARG, "clh_ssw_windows_batch: window outside the genome");
+    clh_ctx* ctx = genome->ctx;
+    clh_plan* pl = clh_ssw_plan_windows(ctx, n, read_off, win_off, win_len, win_rc, mask_len, opts);
+    if (!pl) return g_err.empty() ? CLH_E_ARG : (g_err.find("not implemented") != std::string::npos ? CLH_E_UNSUPPORTED : CLH_E_ARG);
+    int rc = 0;
+    const size_t rb = (size_t)read_off[n];
+    pl->d_reads = ctx->alloc(rb + 64);
+    if (!pl->d_reads) { rc = fail(CLH_E_HIP, "out of device memory for the batch"); }
+    if (!rc && hipMemcpyAsync(pl->d_reads, reads, rb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D reads failed");
+    if (!rc) rc = clh_ssw_run(pl, pl->d_reads, genome->d_codes, nullptr);
     if (!rc) rc = clh_ssw_fetch(pl, out, cigar_buf, cigar_cap, cigar_used);
     clh_plan_destroy(pl);
     return rc;

@@ -18,7 +18,7 @@ enum {
 // One alignment = one workgroup of one wavefront.  Offsets are into the packed batch arrays.
 struct SswTask {
     int64_t read_off;     // into reads (int8 codes)
-    int64_t ref_off;      // into refs (int8 codes)
+    int64_t ref_off;      // into refs: first base of the reference; for a reverse-complemented genome window (ref_rc) its LAST byte
     int64_t colmax_off;   // into the column-maximum workspace (u16), one slot per reference base
     int64_t dir_off;      // strip-boundary workspace of this task inside `dirs` (bytes; reads longer than 4096 bases only)
     int32_t read_len;
@@ -27,7 +27,18 @@ struct SswTask {
     int32_t out_index;    // row of the result / cigar tables this task fills
     int32_t cigar_off;    // first u32 of this task's share of the CIGAR buffer
     int32_t cigar_cap;    // u32 slots in that share
+    int32_t ref_rc;       // 1: the reference is read backwards and complemented on the fly (minus-strand window of a resident genome)
+    int32_t pad;
 };
+
+// A reference byte is a base code in bits 0-2 (A0 C1 G2 T3, anything else 4).  Bytes of a resident genome also carry
+// bit 3 = lower-case letter (the reference's revcomp() leaves lower case uncomplemented, utils.py:118-120) and bit 4 =
+// upper-case 'N' (what Counter(window)['N'] counts, find_bsj.py:199).
+__device__ __forceinline__ int ref_code(int byte, int rc) {
+    int c = byte & 7;
+    c = c > 4 ? 4 : c;
+    return (rc && !(byte & 8) && c < 4) ? 3 - c : c;
+}
 
 struct SswResult {        // 32 bytes; the s_align fields of ssw.h:42-52 minus the pointer
     int32_t score1, score2, ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, status;
@@ -88,6 +99,9 @@ struct EdTask {            // K4: one pair; the pattern is the shorter string
     int32_t pat_len, txt_len;
     int32_t out_index, pad;
 };
+hipError_t launch_genome_encode(const char* ascii, uint8_t* codes, unsigned int* block_n, long long len, hipStream_t stream);
+hipError_t launch_genome_count_n(const uint8_t* codes, const unsigned int* pre_n, const long long* off, const long long* len, long long* out, int n, hipStream_t stream);
+static constexpr int kGenomeBlock = 256;     // bases per entry of the N prefix table
 hipError_t launch_edit_distance(const uint8_t* seqs, const EdTask* tasks, int ntasks, int G, int planes, int32_t* out, hipStream_t stream);
 
 static constexpr int kRvStrips = 1000;   // pseudo class: RV = 32 with row strips (reads longer than 4096 bases)

@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
         if (lane == 0) { cig[0] = (1u << 4); *cig_len = 1; }
         return;
     }
-    const int8_t* ref = p.refs + task.ref_off + res.ref_begin1;
+    const int rdir = task.ref_rc ? -1 : 1;
+    const int8_t* ref = p.refs + task.ref_off + (int64_t)res.ref_begin1 * rdir;
     const int8_t* read = p.reads + task.read_off + res.read_begin1;
     const int refLen = res.ref_end1 - res.ref_begin1 + 1, readLen = res.read_end1 - res.read_begin1 + 1;
     const int score = res.score1, gO = p.gapO, gE = p.gapE, n = p.n;
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
         return;
     }
     for (int k = lane; k < readLen; k += nt) sseq[k] = read[k];
-    for (int k = lane; k < refLen; k += nt) sseq[readLen + k] = ref[k];
+    for (int k = lane; k < refLen; k += nt) sseq[readLen + k] = (int8_t)ref_code((int)ref[(int64_t)k * rdir], task.ref_rc);
     __syncthreads();
     const int8_t* const sread = sseq;
     const int8_t* const sref = sseq + readLen;

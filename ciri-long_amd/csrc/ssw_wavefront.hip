@@ -63,6 +63,7 @@ struct PassIn {
     int L;                // rows of the read
     const int8_t* ref;    // first column's base
     int cstep;            // +1 / -1
+    int comp;             // reference bytes are complemented as they are read (reverse-complemented genome window)
     int ncols;
     int terminate;        // column maximum that ends the pass (ssw.c:296,499); > 32767 = never
     uint16_t* colmax;     // per-column maxima in processing order, or nullptr
@@ -143,7 +144,7 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
 
     auto load_chunk = [&](int t0) -> int {
         int j = t0 + lane;
-        return j < ncols ? (int)in.ref[(int64_t)j * in.cstep] : CODE_NULL;
+        return j < ncols ? ref_code((int)in.ref[(int64_t)j * in.cstep], in.comp) : CODE_NULL;
     };
     int term_col = -1, stop = 0;
     const int nsteps = ncols > 0 ? ncols + 127 : 0;
@@ -392,7 +393,8 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
     bool byte_overflowed = false;
     int job_word = (p.score_size == 1 || (p.score_size == 2 && p.max_match * L + bias >= 255)) ? 1 : 0;
     PassIn in;
-    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = 1; in.ncols = refLen; in.terminate = 1 << 30;
+    const int rdir = task.ref_rc ? -1 : 1;       // physical direction of the reference in memory
+    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = task.ref_rc; in.ncols = refLen; in.terminate = 1 << 30;
     in.colmax = colmax;
     while (regime < 0) {
         if (job_word) {
@@ -418,7 +420,7 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
     if (want_begin) {
         PassIn rv;
         rv.L = res.read_end1 + 1; rv.read = read + res.read_end1; rv.rstep = -1;
-        rv.ncols = res.ref_end1 + 1; rv.ref = ref + res.ref_end1; rv.cstep = -1;
+        rv.ncols = res.ref_end1 + 1; rv.ref = ref + (int64_t)res.ref_end1 * rdir; rv.cstep = -rdir; rv.comp = task.ref_rc;
         rv.terminate = res.score1; rv.colmax = nullptr;
         PassOut r;
         for (;;) {

@@ -78,6 +78,10 @@ def _clip_prepare(circ, hit):
         return _REJECT
     win_start = max(hit.r_st - WINDOW_FLANK, 0)
     win_end = min(hit.r_en + WINDOW_FLANK, env.CONTIG_LEN[hit.ctg])
+    if getattr(env.GENOME, 'device', None) is not None:
+        # genome resident on the GPU: the window stays a coordinate triple; its N count, reverse complement and encoding
+        # happen on the device in _run_clip_jobs
+        return _ClipJob(circ, hit, clip_seq, None, win_start, win_end)
     window = env.GENOME.seq(hit.ctg, win_start, win_end)
     if window.count('N') >= WINDOW_MAX_N * (win_end - win_start):
         return _REJECT
@@ -106,6 +110,21 @@ def _run_clip_jobs(jobs):
     """Phase 2: all pending clip alignments of a chunk in ONE GPU call (scoring 1/1/1/1, find_bsj.py:204,214)."""
     if not jobs:
         return []
+    device = getattr(env.GENOME, 'device', None)
+    if device is not None:
+        from .ssw_wrap import align_windows
+        wins = [(j.hit.ctg, j.win_start, j.win_end) for j in jobs]
+        n_cnt = device.count_n(wins)
+        keep = [k for k, j in enumerate(jobs) if not n_cnt[k] >= WINDOW_MAX_N * (j.win_end - j.win_start)]   # find_bsj.py:199
+        res = [None] * len(jobs)        # None = rejected by the N filter
+        if keep:
+            got = align_windows(device, [wins[k] for k in keep], [jobs[k].hit.strand <= 0 for k in keep],
+                                [jobs[k].clip_seq for k in keep], match=1, mismatch=1, gap_open=1, gap_extend=1)
+            for k, r in zip(keep, got):
+                if r is None:
+                    raise RuntimeError('Smith-Waterman of clipped bases returned no result')
+                res[k] = r
+        return res
     from .ssw_wrap import align_pairs
     res = align_pairs([j.window for j in jobs], [j.clip_seq for j in jobs], match=1, mismatch=1, gap_open=1, gap_extend=1)
     for r in res:
@@ -119,7 +138,8 @@ def align_clip_segments(circ, hit):
     job = _clip_prepare(circ, hit)
     if not isinstance(job, _ClipJob):
         return job
-    return _clip_finish(job, _run_clip_jobs([job])[0])
+    res = _run_clip_jobs([job])[0]
+    return _REJECT if res is None else _clip_finish(job, res)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -200,7 +220,8 @@ def _scan_chunk(chunk, raw_filters, min_circ_fraction):
     ret = []
     for read_id, segments, ccs, circ, junc, circ_hit, prep in pending:
         if isinstance(prep, _ClipJob):
-            prep = _clip_finish(prep, next(results))
+            res = next(results)
+            prep = _REJECT if res is None else _clip_finish(prep, res)
         clipped_circ, circ_start, circ_end, clip_info = prep
         if circ_start is None or circ_end is None:
             continue

@@ -77,6 +77,19 @@ def lib():
         L.clh_ccs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_plan_timing.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_genome_create.restype = C.c_void_p
+        L.clh_genome_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.clh_genome_destroy.restype = None
+        L.clh_genome_destroy.argtypes = [C.c_void_p]
+        L.clh_genome_codes.restype = C.c_void_p
+        L.clh_genome_codes.argtypes = [C.c_void_p]
+        L.clh_genome_length.restype = C.c_int64
+        L.clh_genome_length.argtypes = [C.c_void_p]
+        L.clh_genome_count_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_ssw_plan_windows.restype = C.c_void_p
+        L.clh_ssw_plan_windows.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_ssw_windows_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.clh_edit_distance_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_edit_distance_batch.restype = C.c_int
         L.clh_poa_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -235,6 +248,75 @@ class Context(object):
     def plan(self, read_off, ref_off, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,
              want_cigar=True, mask_len=None):
         return Plan(self, read_off, ref_off, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, mask_len)
+
+
+class Genome(object):
+    """Contigs resident in HBM as base codes (K5).  A Smith-Waterman reference is then a window (contig, start, end,
+    minus-strand flag) read in place: no window string, no reverse complement, no per-base encode on the host."""
+
+    def __init__(self, ctx, contigs):
+        """contigs: {name: str} (or an iterable of (name, str)); they are concatenated in iteration order"""
+        items = list(contigs.items()) if hasattr(contigs, 'items') else list(contigs)
+        self.ctx = ctx
+        self.offset, self.length = {}, {}
+        pos = 0
+        for name, seq in items:
+            self.offset[name] = pos; self.length[name] = len(seq); pos += len(seq)
+        blob = ''.join(seq for _, seq in items).encode('latin-1')
+        self._h = lib().clh_genome_create(ctx._h, blob, len(blob))
+        if not self._h:
+            raise ClhError('clh_genome_create failed: %s' % last_error())
+
+    def close(self):
+        if self._h:
+            lib().clh_genome_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def codes_ptr(self):
+        return lib().clh_genome_codes(self._h)
+
+    def _spans(self, windows):
+        off = np.array([self.offset[c] + s for c, s, e in windows], dtype=np.int64)
+        ln = np.array([e - s for c, s, e in windows], dtype=np.int64)
+        return off, ln
+
+    def count_n(self, windows):
+        """upper-case 'N' per window [(contig, start, end)] -- Counter(window)['N'] of find_bsj.py:199"""
+        n = len(windows)
+        off, ln = self._spans(windows)
+        out = np.zeros(n, dtype=np.int64)
+        rc = lib().clh_genome_count_n(self._h, n, off.ctypes.data, ln.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise ClhError('clh_genome_count_n failed (%d): %s' % (rc, last_error()))
+        return out
+
+    def ssw_windows(self, reads, read_off, windows, minus, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,
+                    want_cigar=True, mask_len=None):
+        """ssw_batch with reference k = windows[k] = (contig, start, end), reverse-complemented where minus[k]."""
+        reads = np.ascontiguousarray(reads, dtype=np.int8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        n = len(read_off) - 1
+        off, ln = self._spans(windows)
+        ln32 = ln.astype(np.int32)
+        rcf = np.ascontiguousarray(np.asarray(minus, dtype=np.uint8))
+        o, _keep = self.ctx._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar)
+        out = np.zeros(n, dtype=ALIGN_DTYPE)
+        cap = int(2 * (read_off[-1] if n else 0) + 2 * n + 8) if want_cigar else 1
+        cig = np.zeros(cap, dtype=np.uint32)
+        used = C.c_int64(0)
+        ml = np.ascontiguousarray(mask_len, dtype=np.int32) if mask_len is not None else None
+        rc = lib().clh_ssw_windows_batch(self._h, n, reads.ctypes.data, read_off.ctypes.data, off.ctypes.data, ln32.ctypes.data, rcf.ctypes.data,
+                                         ml.ctypes.data if ml is not None else None, C.byref(o), out.ctypes.data,
+                                         cig.ctypes.data if want_cigar else None, cap, C.byref(used))
+        if rc != 0:
+            raise ClhError('clh_ssw_windows_batch failed (%d): %s' % (rc, last_error()))
+        return out, cig[:used.value]
 
 
 class Plan(object):

@@ -123,6 +123,26 @@ def align_pairs(ref_seqs, query_seqs, match=2, mismatch=2, gap_open=3, gap_exten
     return out
 
 
+def align_windows(genome, windows, minus, query_seqs, match=2, mismatch=2, gap_open=3, gap_extend=1, report_secondary=False,
+                  report_cigar=False, min_score=0, min_len=0):
+    """align_pairs with reference k = window (contig, start, end) of a genome resident on the GPU (hip.Genome),
+    reverse-complemented the reference's way where minus[k]: element k equals
+    ``Aligner(revcomp(seq) if minus[k] else seq, ...).align(query_seqs[k])`` for seq = the window's string."""
+    if len(windows) != len(query_seqs):
+        raise ValueError('align_windows: %d windows vs %d queries' % (len(windows), len(query_seqs)))
+    if not windows:
+        return []
+    qd, qo = hip.pack(query_seqs)
+    rows, cig = genome.ssw_windows(qd, qo, windows, minus, hip.score_matrix(match, mismatch), gap_open, gap_extend, flag=1, score_size=2,
+                                   want_score2=bool(report_secondary), want_cigar=bool(report_cigar))
+    out = []
+    for k in range(len(rows)):
+        r = rows[k]
+        c = cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']] if r['cigar_len'] > 0 else ()
+        out.append(_filter(r, c, int(qo[k + 1] - qo[k]), min_score, min_len, report_secondary, report_cigar))
+    return out
+
+
 class Aligner(object):
     """One reference sequence, many queries (ssw_wrap.py:40-264)."""
 

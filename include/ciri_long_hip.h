@@ -130,6 +130,29 @@ int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* r
 int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64_t* seq_off, const int64_t* group_off,
                   int32_t* out_len, int8_t* out_ccs);
 
+/* ---- Resident genome ---------------------------------------------------------------------
+ * The reference builds, per clipped read, a window string of hit +- 200 kb, counts its 'N', reverse-complements it for
+ * minus-strand hits and encodes it base by base in Python (CIRI_long/find_bsj.py:196-201,214;
+ * libs/striped_smith_waterman/ssw_wrap.py:234-252).  Here the genome (all contigs concatenated by the caller, who keeps
+ * the contig offsets) is encoded once into HBM and a window is (offset, length, strand): clh_ssw_plan_windows +
+ * clh_ssw_run(plan, d_reads, clh_genome_codes(genome), stream) give the results clh_ssw_plan/clh_ssw_run give for the
+ * window strings built the reference's way -- including its handling of lower-case bases (reversed, not complemented). */
+typedef struct clh_genome clh_genome;
+clh_genome* clh_genome_create(clh_ctx* ctx, const char* ascii, int64_t len);
+void clh_genome_destroy(clh_genome* genome);
+const void* clh_genome_codes(const clh_genome* genome);      /* device pointer */
+int64_t clh_genome_length(const clh_genome* genome);
+/* out[k] = number of upper-case 'N' in [off[k], off[k]+len[k]) -- Counter(window)['N'] of find_bsj.py:199 */
+int clh_genome_count_n(clh_genome* genome, int32_t n, const int64_t* off, const int64_t* len, int64_t* out);
+/* like clh_ssw_plan, references given as windows of the resident genome; win_rc[k] != 0: minus strand */
+clh_plan* clh_ssw_plan_windows(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* win_off, const int32_t* win_len,
+                               const uint8_t* win_rc, const int32_t* mask_len, const clh_ssw_opts* opts);
+
+/* one call: reads from the host, references = windows of the resident genome (same outputs as clh_ssw_batch) */
+int clh_ssw_windows_batch(clh_genome* genome, int32_t n, const int8_t* reads, const int64_t* read_off, const int64_t* win_off,
+                          const int32_t* win_len, const uint8_t* win_rc, const int32_t* mask_len, const clh_ssw_opts* opts,
+                          clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used);
+
 /* Unit-cost edit distance of n pairs of byte strings: what the reference's distance(x, y) returns (CIRI_long/utils.py:
  * 153-159; python-Levenshtein for <= 50 characters, edlib otherwise -- the same integer), used pairwise by
  * cluster_sequence (collapse.py:466-473) and per candidate by avg_score (collapse.py:156-158).  Strings are compared

@@ -89,7 +89,10 @@ struct StripIo {
     int last;              // last strip: owns the finished column maxima (terminate test, colmax output)
 };
 
-template <int RV, bool WORD, bool GEQ, bool STRIPS>
+// LEAN = a pass that neither reports column maxima nor ends at a terminate score (the forward pass of the call path,
+// want_score2 off): the column-maximum chain down the lanes, the finished-column bookkeeping and the terminate test
+// are compiled out -- about a fifth of the per-step instructions of the short-read classes.
+template <int RV, bool WORD, bool GEQ, bool STRIPS, bool LEAN>
 __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __restrict__ lds_prof, const int* __restrict__ lds_mat,
                              int gapO, int gapE, int bias, const int null_code, int& exceeded_out)
 {
@@ -156,8 +159,9 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
         RB = hand_down(RB, (uint32_t)sb);
         const uint32_t aLo = (RB & 0xffffu) * BASE_STRIDE + lane * 16;
         const uint32_t aHi = (RB >> 16) * BASE_STRIDE + lane * 16;
-        const uint32_t inH = hand_down(outH, STRIPS ? (bHC & 0xffffu) : 0u), inC = hand_down(outC, STRIPS ? (bHC >> 16) : 0u),
-                       inM = hand_down(outM, STRIPS ? bM : 0u);
+        const uint32_t inH = hand_down(outH, STRIPS ? (bHC & 0xffffu) : 0u), inC = hand_down(outC, STRIPS ? (bHC >> 16) : 0u);
+        uint32_t inM = 0;
+        if constexpr (!LEAN) inM = hand_down(outM, STRIPS ? bM : 0u);
         uint32_t F = inC, diag = diagIn, cm = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -197,17 +201,20 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
         diagIn = inH;
         outH = HW[RV - 1];
         outC = F;
-        outM = pk_max(inM, cm);
+        if constexpr (!LEAN) outM = pk_max(inM, cm);
 
         // per-lane best (first column wins, strict >) and a snapshot of that column
         const int jLo = t - 2 * lane, jHi = jLo - 1;
-        const uint32_t vm = ((uint32_t)jLo < (uint32_t)ncols ? 0x0000ffffu : 0u) | ((uint32_t)jHi < (uint32_t)ncols ? 0xffff0000u : 0u);
-        const uint32_t cmv = cm & vm;
+        uint32_t cmv = cm;
+        if (t < 127 || t >= ncols) {     // some virtual lane is outside the matrix (wave-uniform test: only the ramps pay)
+            const uint32_t vm = ((uint32_t)jLo < (uint32_t)ncols ? 0x0000ffffu : 0u) | ((uint32_t)jHi < (uint32_t)ncols ? 0xffff0000u : 0u);
+            cmv = cm & vm;
+        }
         const uint32_t nb = pk_max(best, cmv);
         const uint32_t ch = nb ^ best;
         best = nb;
         if (!WORD) flags |= (pk_subus(cmv, ovf2) != 0u) ? 1u : 0u;
-        flags |= (pk_subus(cmv, term2) != 0u) ? 2u : 0u;
+        if constexpr (!LEAN) flags |= (pk_subus(cmv, term2) != 0u) ? 2u : 0u;
         if (__builtin_amdgcn_ballot_w64(ch != 0u)) {
             const uint32_t m = ((ch & 0xffffu) ? 0x0000ffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
             colLo = (ch & 0xffffu) ? jLo : colLo;
@@ -220,7 +227,7 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
         }
         // the last virtual lane has the finished column maximum of column t-127
         const int jl = t - 127;
-        if (jl >= 0 && jl < ncols) {
+        if (!LEAN && jl >= 0 && jl < ncols) {
             const int cmLast = (int)((uint32_t)__builtin_amdgcn_readlane((int)outM, 63) >> 16);
             ring = lane == (t & 63) ? cmLast : ring;
             if (STRIPS) {
@@ -315,8 +322,12 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
     int exceeded = 0;
     if (!STRIPS || rows <= CAP) {
         StripIo io; io.row_base = rows - CAP; io.bnd_in = nullptr; io.bnd_out = nullptr; io.last = 1;
-        PassOut o = run_strip<RV, WORD, GEQ, false>(in, io, lds_prof, lds_mat, gapO, gapE, bias, null_code, exceeded);
-        return o;
+        // not in the row-strip kernel (reads above 4096 bases): with a third inlined variant of the pass that kernel stops
+        // terminating on gfx950 (ROCm 7.2 code generation; the same source without this call runs) -- and it has no use for it
+        if constexpr (!STRIPS) {
+            if (!in.colmax && in.terminate > 32767) return run_strip<RV, WORD, GEQ, false, true>(in, io, lds_prof, lds_mat, gapO, gapE, bias, null_code, exceeded);
+        }
+        return run_strip<RV, WORD, GEQ, false, false>(in, io, lds_prof, lds_mat, gapO, gapE, bias, null_code, exceeded);
     }
     const int ns = (rows + CAP - 1) / CAP;
     uint2* buf[2] = {bnd, bnd + ((in.ncols + 63) & ~63)};
@@ -324,7 +335,7 @@ __device__ PassOut run_pass(const PassIn& in, uint32_t* __restrict__ lds_prof, c
     for (int s = 0; s < ns; ++s) {
         StripIo io;
         io.row_base = s * CAP; io.bnd_in = s > 0 ? buf[(s - 1) & 1] : nullptr; io.bnd_out = s < ns - 1 ? buf[s & 1] : nullptr; io.last = s == ns - 1;
-        const PassOut o = run_strip<RV, WORD, GEQ, true>(in, io, lds_prof, lds_mat, gapO, gapE, bias, null_code, exceeded);
+        const PassOut o = run_strip<RV, WORD, GEQ, true, false>(in, io, lds_prof, lds_mat, gapO, gapE, bias, null_code, exceeded);
         if (o.overflow) return o;
         if (io.last) best.term_col = o.term_col;
         // strips are in row order: on a full tie the earlier strip (smaller rows) stays
@@ -463,7 +474,9 @@ static hipError_t launch_rv(int rv, const SswParams& p, int ntasks, hipStream_t 
     if (rv == kRvStrips) return launch_one<32, GEQ, true>(p, ntasks, stream);   // reads longer than 4096 bases: row strips
     switch (rv) {
 #define CLH_CASE(R) case R: return launch_one<R, GEQ>(p, ntasks, stream);
-#ifdef CLH_PROBE_BUILD
+#if defined(CLH_STRIPS_BUILD)      // debugging builds with one class: seconds instead of minutes
+        CLH_CASE(1)
+#elif defined(CLH_PROBE_BUILD)
         CLH_CASE(8)
 #else
         CLH_CASE(1) CLH_CASE(2) CLH_CASE(3) CLH_CASE(4) CLH_CASE(5) CLH_CASE(6) CLH_CASE(7) CLH_CASE(8)

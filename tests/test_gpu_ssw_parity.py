@@ -148,6 +148,31 @@ def test_reference_test_ssw_orientation_430kb_query(ctx, testfa):
     assert [int(x) for x in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar']
 
 
+@pytest.mark.parametrize('score2', [True, False])
+def test_every_row_class_up_to_4096_vs_oracle(ctx, score2):
+    """read lengths that land in each launch class (rows per lane 1..32), with and without the column maxima
+    (want_score2 off selects the lean forward pass)"""
+    from ciri_long_amd import hip
+    rng = np.random.default_rng(31)
+    reads, refs = [], []
+    for L in (60, 200, 330, 470, 600, 730, 860, 1000, 1200, 1500, 1900, 2400, 3000, 3500, 4090):
+        ref = rng.integers(0, 4, int(rng.integers(300, 2200)), dtype=np.int8)
+        core = ref[50:50 + min(L, len(ref) - 60)]
+        read = np.concatenate([rng.integers(0, 4, (L - len(core)) // 2, dtype=np.int8), core, rng.integers(0, 4, L - len(core) - (L - len(core)) // 2, dtype=np.int8)])
+        flip = rng.random(len(read)) < 0.08
+        read = np.where(flip, rng.integers(0, 4, len(read), dtype=np.int8), read).astype(np.int8)
+        reads.append(read); refs.append(ref)
+    for scheme in ((1, 1, 1, 1), (10, 4, 8, 2)):
+        rd, ro = hip.pack(reads); fd, fo = hip.pack(refs)
+        rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(scheme[0], scheme[1]), scheme[2], scheme[3], want_score2=score2, want_cigar=False)
+        for k in range(len(reads)):
+            want = oracle_align(refs[k], reads[k], *scheme)
+            got = (int(rows[k]['score1']), int(rows[k]['ref_begin1']), int(rows[k]['ref_end1']), int(rows[k]['read_begin1']), int(rows[k]['read_end1']))
+            assert got == (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end']), (k, len(reads[k]), scheme)
+            if score2:
+                assert (int(rows[k]['score2']), int(rows[k]['ref_end2'])) == (want['score2'], want['ref_end2'])
+
+
 @pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (10, 4, 8, 2)])
 def test_long_reads_row_strips_vs_oracle(ctx, scheme):
     """Reads of 4 097 ... 13 000 bases (2-4 row strips), mutated copies and unrelated pairs, both regimes."""

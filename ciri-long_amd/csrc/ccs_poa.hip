@@ -32,7 +32,7 @@ static constexpr int POA_MAXP = 12;
 static constexpr int POA_MATCH = 10;
 static constexpr int POA_MISMATCH = -4;
 static constexpr int POA_GAP = -8;
-static constexpr int POA_MAX_COPY = 3200;            // longest copy: 10 * 3200 < 32767 (H rows are int16)
+static constexpr int POA_MAX_COPY = 2800;            // longest copy: cells are int16 and hold H - jl*gap <= 10*2800 + 8*512
 
 // Phase boundary inside one wave that exchanges data between lanes through HBM: complete the stores, then drop the
 // CU's L1 so that no line read before the stores can be served stale (buffer_inv sc1; a few microseconds, used a
@@ -355,12 +355,21 @@ __device__ __forceinline__ void far_row(const short* ptr, int (&h)[C], int& hpre
 // max-plus scan, one cross-lane DPP scan, one wide LDS write, one wide direction-byte store.  Copies longer than W are
 // swept in passes of W columns (passes outer, rows inner); the value that leaves a row on the right is handed to the next
 // pass through a per-row carry array in HBM.  The graph rows (w.ri) and the carries are streamed 64 rows at a time into
-// one register per lane and read with v_readlane, so LDS holds nothing but the ring of the last RING rows of H.
+// one register per lane and read with v_readlane, so LDS holds nothing but the ring of the last RING rows.
+//
+// Cells are kept as X[r][j] = H[r][j] - jl*gap, jl = column within the pass (gap < 0): the horizontal move then costs
+// nothing (X[j] = max(A[j], X[j-1]): a plain prefix maximum), the diagonal move adds (match|mismatch) - gap, the vertical
+// move adds gap, the row-0 diagonal is one constant per pass -- no per-column term anywhere.  Carries between passes
+// are H values (X at local column 0 equals H).  A candidate is (X << 8) | (255 - ordinal); for the horizontal chain the
+// low byte of what a cell offers to its right neighbours is replaced by the horizontal code, the lowest of all, so the
+// plain signed max also implements "horizontal only if strictly larger" and the winner's low byte is the direction.
 template <int C>
 __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out)
 {
-    constexpr int NEG = -(1 << 28);
+    constexpr int NEG = -(1 << 30);
     constexpr int W = 64 * C;
+    constexpr int HCODE = 255 - POA_ORD_HORIZ;
+    constexpr int DIAG_MATCH = (POA_MATCH - POA_GAP) * 256, DIAG_MIS = (POA_MISMATCH - POA_GAP) * 256;
     const int npass = (m + W - 1) / W;
     const int gp = poa_pitch(m);                                 // row pitch of H and dir in HBM
     const int lp = poa_pitch(m < W ? m : W);                     // row pitch of the LDS ring (one pass wide)
@@ -370,13 +379,14 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
     for (int pass = 0; pass < npass; ++pass) {
         const int col0 = pass * W + C * lane;                    // cell k is column col0+k+1, element col0+k+8 of an HBM row
         const bool more = pass + 1 < npass, last = !more;
-        uint32_t sbm = 0;                                        // bit 8*b+k: cell k of this lane holds base b
+        int sb[C];                                               // this lane's bases of the copy (100: none / not ACGT)
 #pragma unroll
         for (int k = 0; k < C; ++k) {
             const int j = col0 + k + 1;
-            const int sb = j <= m ? (int)seq[j - 1] : 4;
-            if (sb >= 0 && sb < 4) sbm |= 1u << (8 * sb + k);
+            const int c = j <= m ? (int)seq[j - 1] : 100;
+            sb[k] = (c >= 0 && c < 4) ? c : 100;
         }
+        const int row0 = (pass * W) * (POA_GAP * 256) + (255 - POA_ORD_ROW0);   // row-0 diagonal: X = (j-1) gap + s - jl gap
         const short* cprev = w.carry + (size_t)(pass & 1) * w.cpitch;
         short* cnext = w.carry + (size_t)((pass + 1) & 1) * w.cpitch;
         uint2 blk = 1 + lane <= N ? w.ri[1 + lane] : make_uint2(0, 0);
@@ -390,17 +400,16 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
             for (int i = 0; i < cnt; ++i) {
                 const int r = rb + i;
                 const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
-                const int cin = __builtin_amdgcn_readlane(cblk, i);             // H[r][pass*W]; 0 in the first pass
+                const int cin = __builtin_amdgcn_readlane(cblk, i);             // H[r][pass*W] = X at local column 0; 0 in the first pass
                 const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0x7f);
                 const bool keep = (d0 & 0x8000u) != 0;           // read later from HBM by a far successor
                 const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
-                const uint32_t mk = vb >= 0 && vb < 4 ? (sbm >> (8 * vb)) & 0xffu : 0u;
                 short* cur = lds_ring + (r & rmask) * lp;
                 int best[C], ss[C];
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
-                    ss[k] = ((mk >> k) & 1u) ? (POA_MATCH * 256) : (POA_MISMATCH * 256);
-                    best[k] = (col0 + k) * (POA_GAP * 256) + ss[k] + (255 - POA_ORD_ROW0);
+                    ss[k] = sb[k] == vb ? DIAG_MATCH : DIAG_MIS;
+                    best[k] = ss[k] + row0;
                 }
                 auto source = [&](int e, int q) {
                     int h[C], hprev;
@@ -416,6 +425,7 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                         else { const uint32_t t = *(const uint32_t*)src; h[0] = (int)(short)(t & 0xffff); h[1] = (int)t >> 16; }
                     } else {
                         far_row<C>(w.H + (size_t)q * gp + col0 + 7, h, hprev);
+                        if (lane == 0 && pass > 0) hprev += W * POA_GAP;     // that element was stored in the previous pass's frame
                     }
                     const int cd = 255 - e, cv = POA_GAP * 256 + 255 - POA_ORD_VERT - e;
 #pragma unroll
@@ -434,62 +444,63 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                     const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
                     for (int e = 3; e < np; ++e) source(e, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + e]]));
                 }
-                // horizontal chain H[j] = max(A[j], H[j-1]+g) == max over k<=j of A[k] + (j-k) g: prefix max of
-                // X[k] = A[k] - k g (g < 0), in the packed domain (the low byte rides along and never matters)
-                int x[C];
+                // horizontal chain = prefix maximum: what the cells to the left offer (their value, horizontal code)
+                int run[C];                                      // in-lane exclusive running maximum
+                run[0] = NEG;
 #pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    x[k] = best[k] + (col0 + k + 1) * (-POA_GAP * 256);
-                    if (k) x[k] = x[k - 1] > x[k] ? x[k - 1] : x[k];
+                for (int k = 1; k < C; ++k) {
+                    const int y = (best[k - 1] & ~0xff) | HCODE;
+                    run[k] = run[k - 1] > y ? run[k - 1] : y;
                 }
-                const int incl = wave_prefix_max(x[C - 1]);
-                int excl = __builtin_amdgcn_update_dpp(NEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1
-                const int xc = (cin + (pass * W) * (-POA_GAP)) * 256;
+                const int ylast = (best[C - 1] & ~0xff) | HCODE;
+                const int incl = wave_prefix_max(run[C - 1] > ylast ? run[C - 1] : ylast);
+                int excl = __builtin_amdgcn_update_dpp(NEG, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1
+                const int xc = (cin << 8) | HCODE;
                 excl = xc > excl ? xc : excl;
-                int hv[C];
-                uint32_t db[C];
+                int fin[C];
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
-                    const int pk = excl > x[k] ? excl : x[k];
-                    hv[k] = (pk >> 8) + (col0 + k + 1) * POA_GAP;
-                    db[k] = hv[k] > (best[k] >> 8) ? (uint32_t)(255 - POA_ORD_HORIZ) : ((uint32_t)best[k] & 0xffu);
+                    const int a = run[k] > excl ? run[k] : excl;
+                    fin[k] = best[k] > a ? best[k] : a;
                 }
-                if (lane == 0) cur[7] = (short)cin;              // element of column pass*W: the left neighbour of cell 0
+                if (lane == 0) cur[7] = (short)cin;              // element of local column 0: the left neighbour of cell 0
                 if (col0 + 1 <= m) {
                     short* dst = cur + C * lane + 8;
                     uint8_t* dd = w.dir + (size_t)r * gp + col0 + 8;
                     short* hd = w.H + (size_t)r * gp + col0 + 8;
                     if constexpr (C == 8) {
                         uint4 t;
-                        t.x = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16); t.y = ((uint32_t)hv[2] & 0xffffu) | ((uint32_t)hv[3] << 16);
-                        t.z = ((uint32_t)hv[4] & 0xffffu) | ((uint32_t)hv[5] << 16); t.w = ((uint32_t)hv[6] & 0xffffu) | ((uint32_t)hv[7] << 16);
+                        t.x = ((uint32_t)fin[0] >> 8 & 0xffffu) | ((uint32_t)(fin[1] >> 8) << 16); t.y = ((uint32_t)fin[2] >> 8 & 0xffffu) | ((uint32_t)(fin[3] >> 8) << 16);
+                        t.z = ((uint32_t)fin[4] >> 8 & 0xffffu) | ((uint32_t)(fin[5] >> 8) << 16); t.w = ((uint32_t)fin[6] >> 8 & 0xffffu) | ((uint32_t)(fin[7] >> 8) << 16);
                         *(uint4*)dst = t;
                         uint2 bb;
-                        bb.x = db[0] | (db[1] << 8) | (db[2] << 16) | (db[3] << 24); bb.y = db[4] | (db[5] << 8) | (db[6] << 16) | (db[7] << 24);
+                        bb.x = ((uint32_t)fin[0] & 0xffu) | (((uint32_t)fin[1] & 0xffu) << 8) | (((uint32_t)fin[2] & 0xffu) << 16) | ((uint32_t)fin[3] << 24);
+                        bb.y = ((uint32_t)fin[4] & 0xffu) | (((uint32_t)fin[5] & 0xffu) << 8) | (((uint32_t)fin[6] & 0xffu) << 16) | ((uint32_t)fin[7] << 24);
                         *(uint2*)dd = bb;
                         if (keep) *(uint4*)hd = t;
                     } else if constexpr (C == 4) {
                         uint2 t;
-                        t.x = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16); t.y = ((uint32_t)hv[2] & 0xffffu) | ((uint32_t)hv[3] << 16);
+                        t.x = ((uint32_t)fin[0] >> 8 & 0xffffu) | ((uint32_t)(fin[1] >> 8) << 16); t.y = ((uint32_t)fin[2] >> 8 & 0xffffu) | ((uint32_t)(fin[3] >> 8) << 16);
                         *(uint2*)dst = t;
-                        *(uint32_t*)dd = db[0] | (db[1] << 8) | (db[2] << 16) | (db[3] << 24);
+                        *(uint32_t*)dd = ((uint32_t)fin[0] & 0xffu) | (((uint32_t)fin[1] & 0xffu) << 8) | (((uint32_t)fin[2] & 0xffu) << 16) | ((uint32_t)fin[3] << 24);
                         if (keep) *(uint2*)hd = t;
                     } else {
-                        const uint32_t t = ((uint32_t)hv[0] & 0xffffu) | ((uint32_t)hv[1] << 16);
+                        const uint32_t t = ((uint32_t)fin[0] >> 8 & 0xffffu) | ((uint32_t)(fin[1] >> 8) << 16);
                         *(uint32_t*)dst = t;
-                        *(uint16_t*)dd = (uint16_t)(db[0] | (db[1] << 8));
+                        *(uint16_t*)dd = (uint16_t)(((uint32_t)fin[0] & 0xffu) | (((uint32_t)fin[1] & 0xffu) << 8));
                         if (keep) *(uint32_t*)hd = t;
                     }
                 }
                 if (keep && pass == 0 && lane == 0) w.H[(size_t)r * gp + 7] = 0;
                 if (last) {
-                    int hm = hv[0];
+                    int hm = fin[0];
 #pragma unroll
-                    for (int k = 1; k < C; ++k) hm = km == k ? hv[k] : hm;
+                    for (int k = 1; k < C; ++k) hm = km == k ? fin[k] : hm;
+                    hm >>= 8;                                    // same column for every row: X compares like H
                     if (lane == lm && hm > bs) { bs = hm; br = r; }          // strict >: lowest rank on ties
                 } else {
-                    const int right = __builtin_amdgcn_readlane(hv[C - 1], 63);
-                    cob = lane == i ? right : cob;
+                    const int right = __builtin_amdgcn_readlane(fin[C - 1], 63) >> 8;
+                    cob = lane == i ? right + W * POA_GAP : cob;             // as an H value: X at local column W is H - W gap
                 }
                 asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
             }

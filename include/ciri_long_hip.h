@@ -114,7 +114,7 @@ typedef struct {
     int32_t nseg;      /* 0: no tandem repeat / no consensus (find_consensus would return (None, None)) */
     int32_t ccs_len;
     int32_t period;
-    int32_t status;    /* 0 ok; >0 treated as no consensus: 1 workspace, 2 graph capacity/in-degree, 3 output, 4 copy longer than 3200 bases */
+    int32_t status;    /* 0 ok; >0 treated as no consensus: 1 workspace, 2 graph capacity/in-degree, 3 output, 4 copy longer than 2800 bases */
 } clh_ccs_t;
 typedef struct clh_ccs_plan clh_ccs_plan;
 clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off);

@@ -513,8 +513,10 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
 }
 
 // returns the new node count, or -1 on overflow
-__device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* seq, int m, int lane, unsigned long long* tacc)
+__device__ int poa_add(const PoaWs& w, int N_, int ncap, int mcap, const int8_t* seq, int m_, int lane, unsigned long long* tacc)
 {
+    // wave-uniform by construction; say so, or every quantity derived from them lives in VGPRs behind exec-mask branches
+    const int N = __builtin_amdgcn_readfirstlane(N_), m = __builtin_amdgcn_readfirstlane(m_);
     unsigned long long tlast = 0;
 #ifdef CLH_DEBUG_POA
     tlast = __builtin_amdgcn_s_memtime();
@@ -726,8 +728,9 @@ __device__ int poa_add(const PoaWs& w, int N, int ncap, int mcap, const int8_t* 
 // the scores in LDS and the previous row's score forwarded in a register, so the chain never waits for HBM.  Rows with
 // more than 3 in-edges or a weight above 255 fetch their lists from HBM (rare).  Back pointers leave through a lane
 // buffer; the final chase reads them back 64 ranks at a time.
-__device__ int poa_consensus(const PoaWs& w, int N, int8_t* out, int cap, int lane)
+__device__ int poa_consensus(const PoaWs& w, int N_, int8_t* out, int cap, int lane)
 {
+    const int N = __builtin_amdgcn_readfirstlane(N_);
     if (N <= POA_LDS_SCORES) {
         int* score = (int*)poa_lds;
 #pragma unroll 4
@@ -837,17 +840,20 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
         const int8_t* seq = p.reads + off;
         const CcsScan sc = p.scan[rd];
         CcsResult res;
-        res.nseg = 0; res.ccs_len = 0; res.period = sc.period; res.status = 0;
-        if (sc.period == 0) { if (lane == 0) p.results[rd] = res; continue; }
+        const int period = __builtin_amdgcn_readfirstlane(sc.period);
+        res.nseg = 0; res.ccs_len = 0; res.period = period; res.status = 0;
+        if (period == 0) { if (lane == 0) p.results[rd] = res; continue; }
         // copies
         int nseg = 0, b = 0, maxlen = 0, total = 0;
-        for (int i = 0; i < sc.ncuts; ++i) {
-            if (lane == 0) { p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg] = b; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg + 1] = sc.cuts[i]; }
-            const int len = sc.cuts[i] - b;
+        const int ncuts = __builtin_amdgcn_readfirstlane(sc.ncuts);
+        for (int i = 0; i < ncuts; ++i) {
+            const int cut = __builtin_amdgcn_readfirstlane(sc.cuts[i]);
+            if (lane == 0) { p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg] = b; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg + 1] = cut; }
+            const int len = cut - b;
             maxlen = len > maxlen ? len : maxlen; total += len;
-            b = sc.cuts[i]; ++nseg;
+            b = cut; ++nseg;
         }
-        if (L - b >= CCS_MIN_TAIL || (sc.period < 0 && L > b)) {   // period < 0: explicit copies (poa API), keep any tail
+        if (L - b >= CCS_MIN_TAIL || (period < 0 && L > b)) {   // period < 0: explicit copies (poa API), keep any tail
             if (lane == 0) { p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg] = b; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg + 1] = L; }
             const int len = L - b;
             maxlen = len > maxlen ? len : maxlen; total += len;
@@ -862,7 +868,7 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
         int N = 0;
         b = 0;
         for (int s = 0; s < nseg && N >= 0; ++s) {
-            const int e = s < sc.ncuts ? sc.cuts[s] : L;
+            const int e = s < ncuts ? __builtin_amdgcn_readfirstlane(sc.cuts[s]) : L;
             N = poa_add(w, N, ncap, mcap, seq + b, e - b, lane, tacc);
 #ifdef CLH_DEBUG_POA
             if (lane == 0 && 40 + s < CCS_SEG_CAP) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (40 + s)] = N;

@@ -1,0 +1,178 @@
+// fastx_ccs.hip -- stage 1 of `CIRI-long call` from file to file in native code (host side).
+//
+// What it replaces: the read loop of find_ccs_reads (CIRI_long/find_ccs.py:29-96): open FASTA/FASTQ(.gz) by suffix, one
+// header line + one sequence line per record (FASTQ: two more lines skipped), header = first space-separated token
+// without its leading '>' / '@' characters, consensus of every read, and the two tmp files in the reference's format
+// (find_ccs.py:94-95):  tmp/{prefix}.ccs.fa  ">{header}\t{segments}\t{len(ccs)}\n{ccs}\n"   and
+//                       tmp/{prefix}.raw.fa  ">{header}\n{raw sequence}\n"   -- reads with a consensus only, input order.
+// The Python loop handles ~10^5 reads/s; K2+K3 handle ~7*10^6.  Here a reader thread parses and encodes the next batch
+// (zlib's gzread serves plain and gzip files alike) while the calling thread runs the previous one on the GPU and writes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ciri_long_hip.h"
+
+namespace {
+
+struct Batch {
+    std::vector<char> text;            // headers and raw sequences, back to back
+    std::vector<int64_t> hdr_off, hdr_len, seq_off, seq_len;   // into text
+    std::vector<int8_t> codes;         // packed base codes of the reads handed to the GPU
+    std::vector<int64_t> read_off;     // n_gpu + 1
+    std::vector<int32_t> gpu_index;    // record -> row of the GPU batch, -1 = skipped (longer than the kernel's limit)
+    bool last = false;
+    void clear() { text.clear(); hdr_off.clear(); hdr_len.clear(); seq_off.clear(); seq_len.clear(); codes.clear(); read_off.assign(1, 0); gpu_index.clear(); last = false; }
+};
+
+struct LineReader {
+    gzFile f;
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+    bool eof = false;
+    explicit LineReader(gzFile f_) : f(f_), buf(1 << 22) {}
+    // next line without its terminator; false at end of file
+    bool next(std::string& line) {
+        line.clear();
+        for (;;) {
+            if (pos == end) {
+                if (eof) return !line.empty();
+                const int got = gzread(f, buf.data(), (unsigned)buf.size());
+                if (got <= 0) { eof = true; return !line.empty(); }
+                pos = 0; end = (size_t)got;
+            }
+            const char* nl = (const char*)memchr(buf.data() + pos, '\n', end - pos);
+            if (nl) { line.append(buf.data() + pos, nl - (buf.data() + pos)); pos = (size_t)(nl - buf.data()) + 1; return true; }
+            line.append(buf.data() + pos, end - pos);
+            pos = end;
+        }
+    }
+};
+
+inline void rstrip(std::string& s) { while (!s.empty() && (s.back() == ' ' || s.back() == '\t' || s.back() == '\r' || s.back() == '\n' || s.back() == '\v' || s.back() == '\f')) s.pop_back(); }
+
+const int kMaxRead = 18000;            // K2's LDS capacity (clh_ccs_plan_create refuses longer reads)
+
+}  // namespace
+
+extern "C" int clh_ccs_file(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
+                            int32_t batch_reads, clh_ccs_file_stats* stats)
+{
+    if (!ctx || !in_path || !ccs_fa_path || !raw_fa_path || !stats) return CLH_E_ARG;
+    if (batch_reads <= 0) batch_reads = 65536;
+    memset(stats, 0, sizeof(*stats));
+    gzFile in = gzopen(in_path, "rb");
+    if (!in) return CLH_E_ARG;
+    gzbuffer(in, 1 << 20);
+    FILE* fc = fopen(ccs_fa_path, "w");
+    FILE* fr = fopen(raw_fa_path, "w");
+    if (!fc || !fr) { if (fc) fclose(fc); if (fr) fclose(fr); gzclose(in); return CLH_E_ARG; }
+    std::vector<char> wbuf1(1 << 22), wbuf2(1 << 22);
+    setvbuf(fc, wbuf1.data(), _IOFBF, wbuf1.size());
+    setvbuf(fr, wbuf2.data(), _IOFBF, wbuf2.size());
+
+    int8_t lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = 4;                       // ssw_wrap.py:50,243-250: A/a C/c G/g T/t, anything else 4
+    lut['A'] = lut['a'] = 0; lut['C'] = lut['c'] = 1; lut['G'] = lut['g'] = 2; lut['T'] = lut['t'] = 3;
+
+    // two batches ping-pong between the reader thread and this one
+    Batch slot[2];
+    std::mutex mu;
+    std::condition_variable cv;
+    int filled[2] = {0, 0};              // 0 = free for the reader, 1 = ready for the consumer
+    auto reader = [&]() {
+        LineReader lr(in);
+        std::string header, seq, skip;
+        int s = 0;
+        bool done = false;
+        while (!done) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[s] == 0; }); }
+            Batch& b = slot[s];
+            b.clear();
+            while ((int)b.hdr_off.size() < batch_reads && b.codes.size() < (size_t)256 << 20) {
+                if (!lr.next(header)) { done = true; break; }
+                const bool have_seq = lr.next(seq);
+                if (is_fastq) { lr.next(skip); lr.next(skip); }
+                rstrip(header); rstrip(seq);
+                (void)have_seq;     // a header line without a sequence line is a record with an empty sequence (as in the reference's loop)
+                size_t sp = header.find(' ');
+                if (sp != std::string::npos) header.resize(sp);
+                size_t lead = 0;
+                const char mark = is_fastq ? '@' : '>';
+                while (lead < header.size() && header[lead] == mark) ++lead;   // str.lstrip: every leading marker character
+                b.hdr_off.push_back((int64_t)b.text.size()); b.hdr_len.push_back((int64_t)(header.size() - lead));
+                b.text.insert(b.text.end(), header.begin() + (long)lead, header.end());
+                b.seq_off.push_back((int64_t)b.text.size()); b.seq_len.push_back((int64_t)seq.size());
+                b.text.insert(b.text.end(), seq.begin(), seq.end());
+                if (seq.empty() || (int)seq.size() > kMaxRead) { b.gpu_index.push_back(-1); continue; }
+                b.gpu_index.push_back((int32_t)(b.read_off.size() - 1));
+                const size_t o = b.codes.size();
+                b.codes.resize(o + seq.size());
+                for (size_t i = 0; i < seq.size(); ++i) b.codes[o + i] = lut[(unsigned char)seq[i]];
+                b.read_off.push_back((int64_t)b.codes.size());
+            }
+            b.last = done;
+            { std::lock_guard<std::mutex> lk(mu); filled[s] = 1; }
+            cv.notify_all();
+            s ^= 1;
+        }
+    };
+    std::thread th(reader);
+
+    int rc = 0;
+    std::vector<clh_ccs_t> rows;
+    std::vector<int32_t> segs;
+    std::vector<int8_t> ccs;
+    std::string line;
+    static const char BASES[] = "ACGTN";
+    for (int s = 0;; s ^= 1) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[s] == 1; }); }
+        Batch& b = slot[s];
+        const int nrec = (int)b.hdr_off.size(), ngpu = (int)b.read_off.size() - 1;
+        if (!rc && ngpu > 0) {
+            rows.resize((size_t)ngpu); segs.resize((size_t)ngpu * 2 * 65); ccs.resize(b.codes.size() + 64);
+            rc = clh_ccs_batch(ctx, ngpu, b.codes.data(), b.read_off.data(), rows.data(), segs.data(), ccs.data());
+        }
+        if (!rc) {
+            for (int k = 0; k < nrec; ++k) {
+                stats->total_reads += 1;
+                const int g = b.gpu_index[(size_t)k];
+                if (g < 0) { if (b.seq_len[(size_t)k] > kMaxRead) stats->too_long += 1; continue; }
+                const clh_ccs_t& r = rows[(size_t)g];
+                if (r.nseg <= 0 || r.status != 0) continue;
+                stats->ro_reads += 1;
+                const char* hdr = b.text.data() + b.hdr_off[(size_t)k];
+                line.assign(">"); line.append(hdr, (size_t)b.hdr_len[(size_t)k]); line.push_back('\t');
+                char num[48];
+                for (int i = 0; i < r.nseg; ++i) {
+                    const int n = snprintf(num, sizeof(num), i ? ";%d-%d" : "%d-%d", segs[((size_t)g * 65 + (size_t)i) * 2], segs[((size_t)g * 65 + (size_t)i) * 2 + 1]);
+                    line.append(num, (size_t)n);
+                }
+                const int n = snprintf(num, sizeof(num), "\t%d\n", r.ccs_len);
+                line.append(num, (size_t)n);
+                const int8_t* c = ccs.data() + b.read_off[(size_t)g];
+                for (int i = 0; i < r.ccs_len; ++i) line.push_back(BASES[c[i] < 0 || c[i] > 4 ? 4 : c[i]]);
+                line.push_back('\n');
+                fwrite(line.data(), 1, line.size(), fc);
+                fputc('>', fr); fwrite(hdr, 1, (size_t)b.hdr_len[(size_t)k], fr); fputc('\n', fr);
+                fwrite(b.text.data() + b.seq_off[(size_t)k], 1, (size_t)b.seq_len[(size_t)k], fr); fputc('\n', fr);
+            }
+        }
+        const bool last = b.last;
+        { std::lock_guard<std::mutex> lk(mu); filled[s] = 0; }
+        cv.notify_all();
+        if (last) break;
+    }
+    th.join();
+    gzclose(in);
+    if (fclose(fc) != 0 || fclose(fr) != 0) rc = rc ? rc : CLH_E_ARG;
+    return rc;
+}

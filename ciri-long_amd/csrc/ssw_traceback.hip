@@ -86,6 +86,11 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
     __syncthreads();
     const SswTask task = p.tasks[blockIdx.x];
     SswResult res = p.results[task.out_index];
+    // the result row is read with a vector load (this kernel also writes it): tell the compiler it is wave-uniform, or
+    // every loop bound below sits in a VGPR behind exec-mask control flow
+    res.score1 = __builtin_amdgcn_readfirstlane(res.score1); res.status = __builtin_amdgcn_readfirstlane(res.status);
+    res.ref_begin1 = __builtin_amdgcn_readfirstlane(res.ref_begin1); res.ref_end1 = __builtin_amdgcn_readfirstlane(res.ref_end1);
+    res.read_begin1 = __builtin_amdgcn_readfirstlane(res.read_begin1); res.read_end1 = __builtin_amdgcn_readfirstlane(res.read_end1);
     uint32_t* cig = p.cigars + task.cigar_off;
     int* cig_len = p.cigar_len + task.out_index;
     if (big) {
@@ -150,7 +155,7 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
         __syncthreads();
         if (lane == 0) s_at = atomicAdd(pool.head, need);
         __syncthreads();
-        at = s_at;
+        at = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(s_at & 0xffffffffull)) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(s_at >> 32)) << 32);
         if (at + need > pool.size) { status = CLH_STATUS_CIGAR_TRUNC; break; }
         dir = pool.base + at;
         last_at = at;
@@ -200,6 +205,7 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
         if ((lane & 63) == 0) s_max[lane >> 6] = itmax;
         __syncthreads();
         for (int k = 0; k < (nt >> 6); ++k) itmax = s_max[k] > itmax ? s_max[k] : itmax;
+        itmax = __builtin_amdgcn_readfirstlane(itmax);
         maxv = itmax > maxv ? itmax : maxv;
         w *= 2;
         if (!(maxv < score && w < 2 * readLen)) break;

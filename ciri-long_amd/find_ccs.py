@@ -54,7 +54,27 @@ def iter_reads(in_file):
 
 
 def find_ccs_reads(in_file, out_dir, prefix, threads, debugging):
-    """-> (total_reads, ro_reads, {header: [segments, ccs, raw]}); writes the two tmp FASTA files (find_ccs.py:21-103)."""
+    """-> (total_reads, ro_reads, {header: [segments, ccs, raw]}); writes the two tmp FASTA files (find_ccs.py:21-103).
+    Parsing, encoding, the kernels and the two output files are native code (`clh_ccs_file`: a reader thread keeps the
+    GPU fed); the returned dict is read back from the files the way the reference's own resume path does."""
+    from . import hip
+    from .logger import ProgressBar
+    prog = ProgressBar()
+    prog.update(0)
+    fq, is_fastq, _ = _open_reads(in_file)      # suffix check and exit message of find_ccs.py:29-46
+    fq.close()
+    total_reads, ro_reads, too_long = hip.default_context().ccs_file(
+        in_file, is_fastq, '{}/tmp/{}.ccs.fa'.format(out_dir, prefix), '{}/tmp/{}.raw.fa'.format(out_dir, prefix))
+    if too_long:
+        import logging
+        logging.getLogger('CIRI-long').warning('%d reads longer than 18000 bases were not scanned for a consensus', too_long)
+    prog.update(100)
+    return total_reads, ro_reads, load_ccs_reads(out_dir, prefix)
+
+
+def find_ccs_reads_py(in_file, out_dir, prefix, threads, debugging):
+    """The same stage with the record loop in Python (the shape of find_ccs.py:21-103); kept as the cross-check of the
+    native route."""
     from .logger import ProgressBar
     prog = ProgressBar()
     prog.update(0)

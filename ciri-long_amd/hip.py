@@ -77,6 +77,8 @@ def lib():
         L.clh_ccs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_plan_timing.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_ccs_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p]
+        L.clh_ccs_file.restype = C.c_int
         L.clh_genome_create.restype = C.c_void_p
         L.clh_genome_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.clh_genome_destroy.restype = None
@@ -241,6 +243,15 @@ class Context(object):
         if rc != 0:
             raise ClhError('clh_edit_distance_batch failed (%d): %s' % (rc, last_error()))
         return out
+
+    def ccs_file(self, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads=0):
+        """Stage 1 from file to file in native code -> (total_reads, reads_with_consensus, reads_too_long)"""
+        st = (C.c_int64 * 3)()
+        rc = lib().clh_ccs_file(self._h, os.fsencode(in_path), int(bool(is_fastq)), os.fsencode(ccs_fa_path), os.fsencode(raw_fa_path),
+                                int(batch_reads), C.byref(st))
+        if rc != 0:
+            raise ClhError('clh_ccs_file failed (%d): %s' % (rc, last_error()))
+        return int(st[0]), int(st[1]), int(st[2])
 
     def ccs_plan(self, read_off):
         return CcsPlan(self, read_off)

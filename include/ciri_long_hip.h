@@ -130,6 +130,15 @@ int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* r
 int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64_t* seq_off, const int64_t* group_off,
                   int32_t* out_len, int8_t* out_ccs);
 
+/* ---- Stage 1 from file to file -------------------------------------------------------------
+ * The read loop of find_ccs_reads (CIRI_long/find_ccs.py:29-96) in native code: FASTA/FASTQ, plain or gzip, one header and
+ * one sequence line per record; writes tmp/{prefix}.ccs.fa and tmp/{prefix}.raw.fa in the reference's format
+ * (find_ccs.py:94-95), reads with a consensus only, input order.  batch_reads <= 0 selects 65536.  Reads longer than the
+ * repeat scan's limit (18 000 bases) are counted in too_long and get no consensus. */
+typedef struct { int64_t total_reads, ro_reads, too_long; } clh_ccs_file_stats;
+int clh_ccs_file(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
+                 int32_t batch_reads, clh_ccs_file_stats* stats);
+
 /* ---- Resident genome ---------------------------------------------------------------------
  * The reference builds, per clipped read, a window string of hit +- 200 kb, counts its 'N', reverse-complements it for
  * minus-strand hits and encodes it base by base in Python (CIRI_long/find_bsj.py:196-201,214;

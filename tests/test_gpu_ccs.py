@@ -124,3 +124,41 @@ def test_find_ccs_reads_files_and_resume(tmp_path):
     fa = tmp_path / 'in.fa'
     fa.write_text(''.join('>%s\n%s\n' % hs for hs in reads))
     assert find_ccs.find_ccs_reads(str(fa), str(tmp_path), 'q', 1, False)[2] == ccs_seq
+
+
+def test_native_file_stage_equals_the_python_loop(tmp_path):
+    """clh_ccs_file (reader thread + kernels + writers in native code) against the record loop in Python: byte-identical
+    tmp files and counts on FASTA and gzipped FASTQ, incl. CRLF line ends, '>>' / '@@' markers, lower case, N, an empty
+    sequence, several batches."""
+    import gzip
+    from ciri_long_amd import find_ccs, synth
+    rng = np.random.Generator(np.random.PCG64(17))
+    recs = []
+    for k in range(700):
+        tm = synth.template(rng)
+        r = synth.rolling_circle_read(rng, tm, int(rng.integers(300, 1400))) if k % 3 else synth.mutate(rng.integers(0, 4, 700, dtype=np.int8), rng)
+        s = oracle_lib.decode(r)
+        if k % 50 == 7:
+            s = s.lower()
+        if k % 50 == 9:
+            s = s[:100] + 'NNNN' + s[100:]
+        recs.append(('r%04d desc %d' % (k, k), s))
+    recs[5] = ('empty_seq', '')
+    recs[6] = ('>double_marker x', recs[6][1])
+    for sub in ('a', 'b'):
+        (tmp_path / sub / 'tmp').mkdir(parents=True)
+    fa = tmp_path / 'in.fa'
+    fa.write_bytes(''.join('>%s\r\n%s\r\n' % hs for hs in recs).encode())
+    fq = tmp_path / 'in.fastq.gz'
+    with gzip.open(fq, 'wt') as f:
+        for h, s in recs:
+            f.write('@%s\n%s\n+\n%s\n' % (h.replace('>', '@'), s, 'I' * len(s)))
+    from ciri_long_amd import hip
+    for path, is_fq in ((fa, 0), (fq, 1)):
+        tot_n, ro_n, long_n = hip.default_context().ccs_file(str(path), is_fq, str(tmp_path / 'a' / 'tmp' / 'x.ccs.fa'), str(tmp_path / 'a' / 'tmp' / 'x.raw.fa'), 256)
+        tot_p, ro_p, d_p = find_ccs.find_ccs_reads_py(str(path), str(tmp_path / 'b'), 'x', 1, False)
+        assert (tot_n, ro_n, long_n) == (tot_p, ro_p, 0) and tot_n == 700 and ro_n > 200
+        for name in ('x.ccs.fa', 'x.raw.fa'):
+            assert (tmp_path / 'a' / 'tmp' / name).read_bytes() == (tmp_path / 'b' / 'tmp' / name).read_bytes(), (str(path), name)
+        tot_d, ro_d, d_d = find_ccs.find_ccs_reads(str(path), str(tmp_path / 'a'), 'x', 1, False)
+        assert (tot_d, ro_d) == (tot_p, ro_p) and d_d == d_p

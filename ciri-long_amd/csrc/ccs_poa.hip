@@ -11,7 +11,8 @@
 //     maximum, the harmonic test and the per-copy boundary search (same chains, a histogram over the candidate offsets)
 //     are lane-parallel with shuffle reductions.
 // K3: persistent waves pull reads from an atomic counter; each owns a workspace slot in HBM (graph arrays, int16 DP
-//     matrix, direction bytes).  A DP row (one graph node) is computed by the 64 lanes over the sequence positions: the
+//     matrix, direction bytes; slots are sized for the common case, the few reads that need more run in a second
+//     launch over a handful of large slots).  A DP row (one graph node) is computed by the 64 lanes over the sequence positions: the
 //     diagonal/vertical maxima over the node's in-edges are independent per position, the horizontal gap chain
 //     H[j] = max(A[j], H[j-1]+g) is a max-plus prefix scan (linear gap cost), done with DPP-free shuffles per 64-wide
 //     chunk and a carried running maximum.  The walk-back, the graph update and the heaviest-path pass are sequential by
@@ -838,6 +839,7 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
         const int64_t off = p.read_off[rd];
         const int L = (int)(p.read_off[rd + 1] - off);
         const int8_t* seq = p.reads + off;
+        if (p.tier == 1 && __builtin_amdgcn_readfirstlane(p.results[rd].status) != 1) continue;   // second tier: only what did not fit a first-tier slot
         const CcsScan sc = p.scan[rd];
         CcsResult res;
         const int period = __builtin_amdgcn_readfirstlane(sc.period);

@@ -727,10 +727,10 @@ extern "C" clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int6
 
 struct clh_ccs_plan {
     clh_ctx* ctx = nullptr;
-    int n = 0, lcap = 0, nslots = 0;
+    int n = 0, lcap = 0, nslots = 0, nslots_big = 0;
     int64_t total = 0;
-    size_t slot_bytes = 0;
-    void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr,
+    size_t slot_bytes = 0, slot_bytes_big = 0;      // second tier: a few slots sized for the worst case of the batch
+    void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr, *d_ws_big = nullptr,
          *d_counter = nullptr, *d_order = nullptr, *d_reads = nullptr;
     hipStream_t last_stream = nullptr;
     bool ran = false;
@@ -742,7 +742,7 @@ extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
-    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_counter, pl->d_order, pl->d_reads};
+    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_reads};
     for (void* b : bufs) pl->ctx->release(b);
     for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
     delete pl;
@@ -764,20 +764,32 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     }
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return read_off[x + 1] - read_off[x] > read_off[y + 1] - read_off[y]; });
     pl->lcap = (lmax + 63) & ~63;
-    // workspace slot: graph of at most L+8 nodes, copies of at most L/2 + L/16 + 1 bases (period <= L/2, tolerance period/8)
-    pl->slot_bytes = clh::poa_slot_bytes_host(lmax + 8, mcap_hint > 0 ? mcap_hint + 1 : lmax / 2 + lmax / 16 + 8);
-    const unsigned long long budget = 24ull << 30;
-    long long slots = (long long)(budget / pl->slot_bytes);
-    pl->nslots = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(slots, 4096), std::max(n, 1))   /* K3 runs 16 waves per CU (8 KiB of LDS, <=128 VGPRs) x 256 CUs */);
+    // Workspace.  The worst case of a read of L bases is a graph of L+8 nodes against copies of L/2 + L/16 bases (period
+    // <= L/2, tolerance period/8; copies above 2800 bases are refused by the kernel) -- ~L^2 bytes, while the common case
+    // (period of a few hundred bases) needs a small fraction of that.  So: 4096 first-tier slots (16 waves per CU x 256
+    // CUs) share a fixed budget, and the reads that do not fit one (status 1 after the first launch) run in a second
+    // launch over a few slots of worst-case size.
+    const int mcap_worst = mcap_hint > 0 ? mcap_hint + 1 : std::min(lmax / 2 + lmax / 16 + 8, 2801);
+    const size_t need_worst = clh::poa_slot_bytes_host(lmax + 8, mcap_worst);
+    pl->nslots = (int)std::max<long long>(1, std::min<long long>(4096, std::max(n, 1)));
+    unsigned long long budget = 32ull << 30;
+    if (const char* e = getenv("CLH_POA_BUDGET_MB")) budget = std::max(1ull, strtoull(e, nullptr, 10)) << 20;     // tests: force the second tier
+    pl->slot_bytes = std::min<size_t>(need_worst, (size_t)((budget / (unsigned long long)pl->nslots) & ~255ull));
+    if (pl->slot_bytes < need_worst) {
+        pl->slot_bytes_big = need_worst;
+        pl->nslots_big = (int)std::max<unsigned long long>(2, std::min<unsigned long long>(64, (12ull << 30) / need_worst));
+        pl->nslots_big = std::min(pl->nslots_big, std::max(n, 1));
+    }
     pl->d_off = ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));
     pl->d_scan = ctx->alloc(sizeof(clh::CcsScan) * (size_t)std::max(n, 1));
     pl->d_res = ctx->alloc(sizeof(clh::CcsResult) * (size_t)std::max(n, 1));
     pl->d_segs = ctx->alloc(sizeof(int32_t) * 2 * clh::CCS_SEG_CAP * (size_t)std::max(n, 1));
     pl->d_ccs = ctx->alloc((size_t)std::max<int64_t>(pl->total, 1) + 64);
     pl->d_ws = ctx->alloc(pl->slot_bytes * (size_t)pl->nslots);
+    if (pl->nslots_big) pl->d_ws_big = ctx->alloc(pl->slot_bytes_big * (size_t)pl->nslots_big);
     pl->d_counter = ctx->alloc(256);
     pl->d_order = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
-    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || !pl->d_counter || !pl->d_order) {
+    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || (pl->nslots_big && !pl->d_ws_big) || !pl->d_counter || !pl->d_order) {
         fail(CLH_E_HIP, "out of device memory while building the consensus plan");
         clh_ccs_plan_destroy(pl); return nullptr;
     }
@@ -802,11 +814,16 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
     P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
     if (!pl->ev[0]) for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipMemsetAsync(pl->d_counter, 0, 4, st));
+    HIPCHK(hipMemsetAsync(pl->d_counter, 0, 8, st));
     HIPCHK(hipEventRecord(pl->ev[0], st));
     HIPCHK(clh::launch_ccs_scan(P, st));
     HIPCHK(hipEventRecord(pl->ev[1], st));
     HIPCHK(clh::launch_poa(P, pl->nslots, st));
+    if (pl->nslots_big) {       // the reads the first tier left with status 1
+        clh::CcsParams Q = P;
+        Q.poa_ws = (uint8_t*)pl->d_ws_big; Q.slot_bytes = pl->slot_bytes_big; Q.work_counter = (int*)pl->d_counter + 1; Q.tier = 1;
+        HIPCHK(clh::launch_poa(Q, pl->nslots_big, st));
+    }
     HIPCHK(hipEventRecord(pl->ev[2], st));
     pl->last_stream = st; pl->ran = true;
     return 0;
@@ -889,8 +906,13 @@ extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, 
         P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
         P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
         P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
-        if (hipMemsetAsync(pl->d_counter, 0, 4, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
+        if (hipMemsetAsync(pl->d_counter, 0, 8, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
         if (!rc && clh::launch_poa(P, pl->nslots, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "launch failed");
+        if (!rc && pl->nslots_big) {
+            clh::CcsParams Q = P;
+            Q.poa_ws = (uint8_t*)pl->d_ws_big; Q.slot_bytes = pl->slot_bytes_big; Q.work_counter = (int*)pl->d_counter + 1; Q.tier = 1;
+            if (clh::launch_poa(Q, pl->nslots_big, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "launch failed");
+        }
         pl->ran = true; pl->last_stream = ctx->stream;
     }
     if (!rc && ngroups) {

@@ -88,6 +88,7 @@ struct CcsParams {
     unsigned long long slot_bytes;
     int32_t n;
     int32_t lcap;              // >= longest read of the batch
+    int32_t tier;              // K3: 0 = every read (too large for the slot: status 1); 1 = only the reads left with status 1
 };
 
 hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream);

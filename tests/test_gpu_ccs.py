@@ -85,6 +85,24 @@ def test_shapes_that_exercise_every_kernel_path_vs_oracle():
     assert found >= 25
 
 
+def test_reads_that_overflow_a_first_tier_slot_run_in_the_second_tier(monkeypatch):
+    """K3's workspace slots are sized for the common case; with the budget squeezed, the long-period reads of this batch
+    do not fit one and must come back identical from the second launch (large slots)."""
+    from ciri_long_amd import pyccs, synth
+    monkeypatch.setenv('CLH_POA_BUDGET_MB', '48')
+    rng = np.random.Generator(np.random.PCG64(8))
+    reads = []
+    for p, L in ((120, 1500), (300, 2500), (900, 5000), (1300, 6000), (200, 4000), (1500, 5500)) * 4:
+        reads.append(synth.rolling_circle_read(rng, rng.integers(0, 4, p, dtype=np.int8), L))
+    got = pyccs.find_consensus_batch(reads)
+    found = 0
+    for k, r in enumerate(reads):
+        want = oracle_lib.oracle_find_consensus(r)
+        assert got[k] == want[:2], (k, len(r))
+        found += got[k][0] is not None
+    assert found >= 20
+
+
 def test_spoa_call_shape():
     from ciri_long_amd import spoa
     cons, msa = spoa.poa(SEGMENTS, 0, True, 10, -4, -8, -2, -24, -1)     # tests/test_poa.py:30

@@ -35,12 +35,17 @@ PK_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0       # SIMDs x Hz / 4 cycles: packed-16 o
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (spawned processes; never fork a process that has initialised HIP)
 # ------------------------------------------------------------------------------------------------------------------
+def make_batch(synth, workload, n, rank):
+    if workload == 'c4':
+        return synth.c4_batch(n, seed=synth.SEEDS['C4'], rank=rank)
+    return synth.c2_batch(n, seed=synth.SEEDS['C3' if workload == 'c3' else 'C2'], rank=rank)
+
+
 def _cpu_worker(arg):
     tid, nproc, seconds, nsample, workload = arg
     import oracle_lib
     from ciri_long_amd import synth
-    seed = synth.SEEDS['C3'] if workload == 'c3' else synth.SEEDS['C2']
-    reads, wins = synth.c2_batch(nsample, seed=seed, rank=0)
+    reads, wins = make_batch(synth, workload, nsample, 0)
     have_ref = oracle_lib.have_ref()
     mat = oracle_lib.make_mat(1, 1)
     ref = oracle_lib.ref_lib() if have_ref else None
@@ -51,7 +56,7 @@ def _cpu_worker(arg):
     if tid == 0:
         expect = []
         for i in range(min(NCHECK, nsample)):
-            if workload == 'c3':
+            if workload != 'c2':
                 seg, ccs, _ = oracle_lib.oracle_find_consensus(reads[i])
                 row = None
                 if seg is not None:
@@ -76,7 +81,7 @@ def _cpu_worker(arg):
 
     while time.time() < deadline:
         q, r = reads[k % nsample], wins[k % nsample]
-        if workload == 'c3':
+        if workload != 'c2':
             seg, ccs, _ = oracle_lib.oracle_find_consensus(q)
             if seg is not None:
                 c = oracle_lib.encode(ccs)
@@ -98,7 +103,7 @@ def cpu_baseline(seconds, workload, nsample=2048):
         res = pool.map(_cpu_worker, [(i, ncores, seconds, nsample, workload) for i in range(ncores)])
     total = sum(r[0] for r in res)
     el = max(r[1] for r in res)
-    if workload == 'c3':
+    if workload != 'c2':
         kind = 'port'
         what = ('consensus by the CPU statement of this project\'s own specification (oracle/ccs_oracle.c; pyccs/spoa are '
                 'not available) + clip re-alignment by ' + ('the reference\'s libssw.so' if res[0][2] == 'reference' else 'the scalar port'))
@@ -115,13 +120,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=('c3', 'c2'), default='c3')
+    ap.add_argument('--workload', choices=('c3', 'c2', 'c4'), default='c3')
     ap.add_argument('--reads', type=int, default=0, help='reads per GPU (default: 100000 for c3, 10000 for c2)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
     wl = args.workload
-    nreads = args.reads or (100000 if wl == 'c3' else 10000)
+    full = wl != 'c2'            # c3 / c4: consensus + clip re-alignment; c2: Smith-Waterman only
+    nreads = args.reads or {'c3': 100000, 'c2': 10000, 'c4': 125000}[wl]
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -146,7 +152,7 @@ def main():
 
     from ciri_long_amd import hip, synth
     expect = cpu.pop('_expect') if cpu else None     # None: no CPU leg in this run (multi-GPU, --no-cpu, profiler): no spot check
-    reads, wins = synth.c2_batch(nreads, seed=synth.SEEDS['C3' if wl == 'c3' else 'C2'], rank=rank)
+    reads, wins = make_batch(synth, wl, nreads, rank)
     rd, ro = hip.pack(reads)
     d_reads = torch.from_numpy(rd.view(np.uint8)).cuda()
     ctx = hip.Context(local_rank)
@@ -154,7 +160,7 @@ def main():
     mat = hip.score_matrix(1, 1)
     launches = []
 
-    if wl == 'c3':
+    if full:
         ccs_plan = ctx.ccs_plan(ro)
         ccs_plan.run(d_reads.data_ptr(), stream)
         crow, csegs, ccs = ccs_plan.fetch()
@@ -224,7 +230,7 @@ def main():
 
     # ---- per-launch durations (HIP events on the stream the kernels run on), outside the timed region ----
     PROF = 3
-    if wl == 'c3':
+    if full:
         k2 = k3 = 0.0
         for _ in range(PROF):
             ccs_plan.run(d_reads.data_ptr(), stream)
@@ -237,7 +243,7 @@ def main():
     ssw_plan.set_profiling(True)
     acc, accb = None, [0.0, 0.0]
     for _ in range(PROF):
-        if wl == 'c3':
+        if full:
             ssw_plan.run(d_clips.data_ptr(), d_wins.data_ptr(), stream)
         else:
             ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
@@ -245,7 +251,7 @@ def main():
         acc = tm if acc is None else [x + y for x, y in zip(acc, tm)]
         accb = [accb[0] + tb[0], accb[1] + tb[1]]
     srow, _c = ssw_plan.fetch()
-    qoff, woff = (co, fo) if wl == 'c3' else (ro, fo)
+    qoff, woff = (co, fo) if full else (ro, fo)
     qlen, wlen = np.diff(qoff), np.diff(woff)
     b_alg = qlen + wlen + 40 + 4 * srow['cigar_len'].astype(np.int64)
     classes = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32]
@@ -285,16 +291,16 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic',
         'config': {
-            'workload': ('C3: %d NanoSim-shaped ~1 kb reads per GPU through the GPU stages of the call path: cyclic consensus '
+            'workload': (('C4 (per-GPU share of 1 M reads, lengths 500-4000): ' if wl == 'c4' else 'C3: ') + '%d NanoSim-shaped reads per GPU (~1 kb for C3) through the GPU stages of the call path: cyclic consensus '
                          '(K2+K3) of every read, then Smith-Waterman re-alignment (K1) of each consensus\' clipped part against '
-                         'its 2 kb window; the external mapper between them is not part of the step' % nreads) if wl == 'c3' else
+                         'its 2 kb window; the external mapper between them is not part of the step' % nreads) if full else
                         ('C2: %d NanoSim-shaped ~1 kb reads per GPU, SSW step only, complete s_align (second best, begin/end, '
                          'CIGAR) vs own 2 kb window' % nreads),
             'reads_per_gpu': nreads, 'window': 2000, 'scoring': '1/1/1/1', 'parallelism': 'reads sharded x%d, no data-path collective' % world,
-            'consensus_parity': 'unpinned (pyccs/spoa absent; own specification, oracle/ccs_oracle.c)' if wl == 'c3' else None},
+            'consensus_parity': 'unpinned (pyccs/spoa absent; own specification, oracle/ccs_oracle.c)' if full else None},
         'roofline': roofline, 'valu_roofline': valu, 'launches': launches,
     }
-    if wl == 'c3':
+    if full:
         out['config']['reads_with_consensus'] = int(len(has))
     out['cpu_baseline'] = cpu      # rank 0 at N=1 only; None under a profiler or with --no-cpu
     if rank == 0:

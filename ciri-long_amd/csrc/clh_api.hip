@@ -768,7 +768,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     // <= L/2, tolerance period/8; copies above 2800 bases are refused by the kernel) -- ~L^2 bytes, while the common case
     // (period of a few hundred bases) needs a small fraction of that.  So: 4096 first-tier slots (16 waves per CU x 256
     // CUs) share a fixed budget, and the reads that do not fit one (status 1 after the first launch) run in a second
-    // launch over a few slots of worst-case size.
+    // launch over up to 1024 slots of worst-case size (64 GB at most: HBM is 288 GB).
     const int mcap_worst = mcap_hint > 0 ? mcap_hint + 1 : std::min(lmax / 2 + lmax / 16 + 8, 2801);
     const size_t need_worst = clh::poa_slot_bytes_host(lmax + 8, mcap_worst);
     pl->nslots = (int)std::max<long long>(1, std::min<long long>(4096, std::max(n, 1)));
@@ -777,7 +777,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->slot_bytes = std::min<size_t>(need_worst, (size_t)((budget / (unsigned long long)pl->nslots) & ~255ull));
     if (pl->slot_bytes < need_worst) {
         pl->slot_bytes_big = need_worst;
-        pl->nslots_big = (int)std::max<unsigned long long>(2, std::min<unsigned long long>(64, (12ull << 30) / need_worst));
+        pl->nslots_big = (int)std::max<unsigned long long>(2, std::min<unsigned long long>(1024, (64ull << 30) / need_worst));
         pl->nslots_big = std::min(pl->nslots_big, std::max(n, 1));
     }
     pl->d_off = ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));

@@ -62,6 +62,28 @@ def c2_batch(n, seed=SEEDS['C2'], rank=0, window=2000, mean_len=1000, sd_len=100
     return reads, wins
 
 
+def c4_batch(n, seed=SEEDS['C4'], rank=0, window=2000):
+    """BASELINE config 4: read lengths a uniform mix of {500, 1000, 2000, 4000} +- 10 %, otherwise as c2_batch."""
+    rng = np.random.Generator(np.random.PCG64([seed, rank]))
+    reads, wins = [], []
+    for _ in range(n):
+        base = (500, 1000, 2000, 4000)[int(rng.integers(0, 4))]
+        L = int(round(base * (0.9 + 0.2 * rng.random())))
+        tm = template(rng)
+        if rng.random() < 0.5:
+            read = rolling_circle_read(rng, tm, L)
+        else:
+            read = mutate(rng.integers(0, 4, L, dtype=np.int8), rng)
+        read = read[:4096]
+        w = rng.integers(0, 4, window, dtype=np.int8)
+        emb = tm[:window]
+        off = int(rng.integers(0, window - len(emb) + 1))
+        w[off:off + len(emb)] = emb
+        reads.append(read)
+        wins.append(w)
+    return reads, wins
+
+
 def clip_batch(n, seed=SEEDS['C3'], rank=0, window=400000, shared_window=True):
     """Production shape of align_clip_segments (find_bsj.py:191-205): 20..300-nt clips against a +-200 kb window."""
     rng = np.random.Generator(np.random.PCG64([seed, rank, 7]))

@@ -73,23 +73,21 @@ __device__ __forceinline__ int wmax_i(int v) {
 // LDS layout for a batch whose longest read has lcap bases (lcap a multiple of 64):
 //   head[K2_BUCKETS] int32 | cnt[lcap/2+2] int32 | sm[lcap/2+2] int32 | code[lcap] uint16 | next[lcap] int16
 static constexpr int K2_BUCKETS = 2048;
+static constexpr int K2_LDS_MAX = 16000;       // longest read scanned out of LDS (8 bytes per base + 8 KiB of 160 KiB)
 __host__ __device__ inline size_t k2_lds_bytes(int lcap) { return 4 * (size_t)K2_BUCKETS + 8 * ((size_t)lcap / 2 + 2) + 4 * (size_t)lcap; }
 
-__global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
+// The scan of one read.  NextT = int16_t with every array in LDS (reads up to K2_LDS_MAX bases), int32_t with cnt/sm/
+// code/next in an HBM workspace (longer reads: rare, so the slower memory does not matter; no length limit).
+template <typename NextT>
+__device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, int32_t* head, int32_t* cnt, int32_t* sm, uint16_t* code, NextT* next)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t k2_lds[];
-    const int lane = threadIdx.x & 63;
-    const int rd = blockIdx.x;
     const int64_t off = p.read_off[rd];
     const int L = (int)(p.read_off[rd + 1] - off);
     const int8_t* seq = p.reads + off;
     CcsScan out;
     out.period = 0; out.ncuts = 0; out.support = 0;
-    int32_t* head = k2_lds;                         // bucket -> last inserted position, -1 = empty
-    int32_t* cnt = head + K2_BUCKETS;               // matches per offset, [lcap/2 + 2]
-    int32_t* sm = cnt + p.lcap / 2 + 2;             // smoothed counts; later the per-cut histogram of offsets
-    uint16_t* code = (uint16_t*)(sm + p.lcap / 2 + 2);
-    int16_t* next = (int16_t*)(code + p.lcap);      // chain of the positions of a bucket; -1 = end (invalid k-mers are in no chain)
+    // lanes exchange data through the arrays: LDS needs a barrier, the HBM workspace also a cache invalidate
+    auto sync = [&]() { if constexpr (sizeof(NextT) == 4) phase_sync(); else __syncthreads(); };
     if (L < 2 * CCS_DMIN) { if (lane == 0) p.scan[rd] = out; return; }
 
     // The specification counts, per offset d, the positions i with equal valid k-mers at i and i+d: that is one count per
@@ -98,7 +96,7 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
     const int dmax = L / 2;
     for (int i = lane; i < K2_BUCKETS; i += 64) head[i] = -1;
     for (int d = lane; d <= dmax + 1; d += 64) cnt[d] = 0;
-    __syncthreads();
+    sync();
     for (int i = lane; i < L; i += 64) {
         int32_t c = 0, ok = i + CCS_K <= L;
         if (ok)
@@ -108,9 +106,9 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
                 c = (c << 2) | (b & 3);
             }
         code[i] = (uint16_t)c;
-        next[i] = ok ? (int16_t)atomicExch(&head[(c ^ (c >> 5)) & (K2_BUCKETS - 1)], i) : (int16_t)-2;
+        next[i] = ok ? (NextT)atomicExch(&head[(c ^ (c >> 5)) & (K2_BUCKETS - 1)], i) : (NextT)-2;
     }
-    __syncthreads();
+    sync();
     for (int i = lane; i < L; i += 64) {
         int j = next[i];
         if (j == -2) continue;
@@ -123,7 +121,7 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
             j = next[j];
         }
     }
-    __syncthreads();
+    sync();
     int best = -1, bestd = 0x7fffffff;
     for (int d = CCS_DMIN + lane; d <= dmax; d += 64) {
         int s = 0;
@@ -137,7 +135,7 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
         const int b2 = __shfl_xor(best, d), d2 = __shfl_xor(bestd, d);
         if (b2 > best || (b2 == best && d2 < bestd)) { best = b2; bestd = d2; }
     }
-    __syncthreads();
+    sync();
     if (best < CCS_MIN_SUPPORT) { if (lane == 0) p.scan[rd] = out; return; }
     int p0 = bestd;
     for (int q = 2; q <= 8; ++q) {
@@ -155,11 +153,11 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
     const int tol = p0 / 8 > 4 ? p0 / 8 : 4, W = p0 < 96 ? p0 : 96;
     const int dlo = p0 - tol, nd = 2 * tol + 1;
     int32_t* dh = sm;
-    __syncthreads();
+    sync();
     int b = 0, prev = p0, n = 0;
     while (n < CCS_MAX_CUTS) {
         for (int t = lane; t < nd; t += 64) dh[t] = 0;
-        __syncthreads();
+        sync();
         for (int i = b + lane; i < b + W && i < L; i += 64) {
             if (next[i] == -2) continue;
             const int ci = code[i];
@@ -170,7 +168,7 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
                 j = next[j];
             }
         }
-        __syncthreads();
+        sync();
         int bs = -1, bdel = 0, bdist = 0x7fffffff;
         for (int t = lane; t < nd; t += 64) {
             const int delta = dlo + t;
@@ -185,7 +183,7 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
             const int s2 = __shfl_xor(bs, d), e2 = __shfl_xor(bdel, d), t2 = __shfl_xor(bdist, d);
             if (s2 > bs || (s2 == bs && (t2 < bdist || (t2 == bdist && e2 < bdel)))) { bs = s2; bdel = e2; bdist = t2; }
         }
-        __syncthreads();
+        sync();
         if (bs < 0) break;
         b += bdel;
         prev = bdel;
@@ -194,6 +192,34 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
     }
     if (n >= 2) { out.period = p0; out.ncuts = n; out.support = best; }
     if (lane == 0) p.scan[rd] = out;
+}
+
+__global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t k2_lds[];
+    const int lane = threadIdx.x & 63;
+    const int rd = blockIdx.x;
+    if ((int)(p.read_off[rd + 1] - p.read_off[rd]) > p.k2_lds_max) return;        // ccs_scan_long_kernel takes it
+    int32_t* head = k2_lds;                         // bucket -> last inserted position, -1 = empty
+    int32_t* cnt = head + K2_BUCKETS;               // matches per offset, [lcap/2 + 2]
+    int32_t* sm = cnt + p.lcap / 2 + 2;             // smoothed counts; later the per-cut histogram of offsets
+    uint16_t* code = (uint16_t*)(sm + p.lcap / 2 + 2);
+    int16_t* next = (int16_t*)(code + p.lcap);      // chain of the positions of a bucket; -1 = end (invalid k-mers are in no chain)
+    ccs_scan_read<int16_t>(p, rd, lane, head, cnt, sm, code, next);
+}
+
+__global__ void __launch_bounds__(64) ccs_scan_long_kernel(const CcsParams p)
+{
+    __shared__ int32_t head[K2_BUCKETS];
+    const int lane = threadIdx.x & 63;
+    const int rd = p.long_idx[blockIdx.x];
+    uint8_t* ws = p.k2_ws + (size_t)blockIdx.x * p.k2_slot;       // cnt | sm | next (int32) | code (uint16), sized for the longest read
+    const size_t half = (size_t)p.k2_lmax / 2 + 2;
+    int32_t* cnt = (int32_t*)ws;
+    int32_t* sm = cnt + half;
+    int32_t* next = sm + half;
+    uint16_t* code = (uint16_t*)(next + p.k2_lmax);
+    ccs_scan_read<int32_t>(p, rd, lane, head, cnt, sm, code, next);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -855,7 +881,8 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
             maxlen = len > maxlen ? len : maxlen; total += len;
             b = cut; ++nseg;
         }
-        if (L - b >= CCS_MIN_TAIL || (period < 0 && L > b)) {   // period < 0: explicit copies (poa API), keep any tail
+        // period < 0: explicit copies (poa API), keep any tail.  A scan that stopped at its cap leaves the rest of the read out.
+        if ((L - b >= CCS_MIN_TAIL && (period < 0 || ncuts < CCS_MAX_CUTS)) || (period < 0 && L > b)) {
             if (lane == 0) { p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg] = b; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg + 1] = L; }
             const int len = L - b;
             maxlen = len > maxlen ? len : maxlen; total += len;
@@ -910,6 +937,7 @@ hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream)
         attr = true;
     }
     hipLaunchKernelGGL(ccs_scan_kernel, dim3(p.n), dim3(64), lds, stream, p);
+    if (p.n_long > 0) hipLaunchKernelGGL(ccs_scan_long_kernel, dim3(p.n_long), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

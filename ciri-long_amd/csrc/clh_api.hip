@@ -727,7 +727,8 @@ extern "C" clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int6
 
 struct clh_ccs_plan {
     clh_ctx* ctx = nullptr;
-    int n = 0, lcap = 0, nslots = 0, nslots_big = 0;
+    int n = 0, lcap = 0, lmax = 0, n_long = 0, nslots = 0, nslots_big = 0;
+    void *d_long = nullptr, *d_k2ws = nullptr;
     int64_t total = 0;
     size_t slot_bytes = 0, slot_bytes_big = 0;      // second tier: a few slots sized for the worst case of the batch
     void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr, *d_ws_big = nullptr,
@@ -742,7 +743,7 @@ extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
-    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_reads};
+    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_reads, pl->d_long, pl->d_k2ws};
     for (void* b : bufs) pl->ctx->release(b);
     for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
     delete pl;
@@ -755,15 +756,17 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     clh_ccs_plan* pl = new clh_ccs_plan();
     pl->ctx = ctx; pl->n = n; pl->total = read_off[n];
     int lmax = 1;
-    std::vector<int32_t> order(n);
+    std::vector<int32_t> order(n), long_idx;
     for (int i = 0; i < n; ++i) {
         const int64_t L = read_off[i + 1] - read_off[i];
-        if (L < 0 || L > 18000) { fail(CLH_E_UNSUPPORTED, "read longer than 18000 bases (LDS capacity of the repeat scan: 8 bytes per base + 8 KiB)"); delete pl; return nullptr; }
+        if (L < 0 || L > (1 << 24)) { fail(CLH_E_UNSUPPORTED, "read longer than 16 M bases"); delete pl; return nullptr; }
         lmax = std::max(lmax, (int)L);
+        if (L > clh::kK2LdsMax) long_idx.push_back(i);     // scanned out of an HBM workspace (ccs_scan_long_kernel)
         order[i] = i;
     }
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return read_off[x + 1] - read_off[x] > read_off[y + 1] - read_off[y]; });
-    pl->lcap = (lmax + 63) & ~63;
+    pl->lcap = (std::min(lmax, clh::kK2LdsMax) + 63) & ~63;
+    pl->lmax = lmax; pl->n_long = (int)long_idx.size();
     // Workspace.  The worst case of a read of L bases is a graph of L+8 nodes against copies of L/2 + L/16 bases (period
     // <= L/2, tolerance period/8; copies above 2800 bases are refused by the kernel) -- ~L^2 bytes, while the common case
     // (period of a few hundred bases) needs a small fraction of that.  So: 4096 first-tier slots (16 waves per CU x 256
@@ -787,6 +790,14 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->d_ccs = ctx->alloc((size_t)std::max<int64_t>(pl->total, 1) + 64);
     pl->d_ws = ctx->alloc(pl->slot_bytes * (size_t)pl->nslots);
     if (pl->nslots_big) pl->d_ws_big = ctx->alloc(pl->slot_bytes_big * (size_t)pl->nslots_big);
+    if (pl->n_long) {
+        pl->d_long = ctx->alloc(sizeof(int32_t) * (size_t)pl->n_long);
+        pl->d_k2ws = ctx->alloc(clh::k2_long_slot_bytes(lmax) * (size_t)pl->n_long);
+        if (!pl->d_long || !pl->d_k2ws || hipMemcpy(pl->d_long, long_idx.data(), sizeof(int32_t) * (size_t)pl->n_long, hipMemcpyHostToDevice) != hipSuccess) {
+            fail(CLH_E_HIP, "out of device memory for the long-read scan workspace");
+            clh_ccs_plan_destroy(pl); return nullptr;
+        }
+    }
     pl->d_counter = ctx->alloc(256);
     pl->d_order = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
     if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || (pl->nslots_big && !pl->d_ws_big) || !pl->d_counter || !pl->d_order) {
@@ -813,6 +824,8 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
     P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
     P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
+    P.long_idx = (const int32_t*)pl->d_long; P.k2_ws = (uint8_t*)pl->d_k2ws; P.k2_slot = clh::k2_long_slot_bytes(pl->lmax);
+    P.n_long = pl->n_long; P.k2_lmax = pl->lmax; P.k2_lds_max = clh::kK2LdsMax;
     if (!pl->ev[0]) for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMemsetAsync(pl->d_counter, 0, 8, st));
     HIPCHK(hipEventRecord(pl->ev[0], st));

@@ -88,12 +88,18 @@ struct CcsParams {
     unsigned long long slot_bytes;
     int32_t n;
     int32_t lcap;              // >= longest read of the batch
+    const int32_t* long_idx;   // K2: reads above k2_lds_max bases (scanned out of an HBM workspace)
+    uint8_t* k2_ws;
+    unsigned long long k2_slot;
+    int32_t n_long, k2_lmax, k2_lds_max;
     int32_t tier;              // K3: 0 = every read (too large for the slot: status 1); 1 = only the reads left with status 1
 };
 
 hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream);
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream);
 size_t poa_slot_bytes_host(int ncap, int mcap);
+static constexpr int kK2LdsMax = 16000;
+inline size_t k2_long_slot_bytes(int lmax) { return ((size_t)8 * ((size_t)lmax / 2 + 2) + (size_t)6 * (size_t)lmax + 255) & ~(size_t)255; }
 
 struct EdTask {            // K4: one pair; the pattern is the shorter string
     int64_t pat_off, txt_off;   // into the packed symbol array (codes 0..nsym-1, one per byte)

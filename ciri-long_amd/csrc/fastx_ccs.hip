@@ -59,7 +59,7 @@ struct LineReader {
 
 inline void rstrip(std::string& s) { while (!s.empty() && (s.back() == ' ' || s.back() == '\t' || s.back() == '\r' || s.back() == '\n' || s.back() == '\v' || s.back() == '\f')) s.pop_back(); }
 
-const int kMaxRead = 18000;            // K2's LDS capacity (clh_ccs_plan_create refuses longer reads)
+const int kMaxRead = 1 << 24;          // sanity bound of clh_ccs_plan_create
 
 }  // namespace
 

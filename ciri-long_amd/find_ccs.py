@@ -67,7 +67,7 @@ def find_ccs_reads(in_file, out_dir, prefix, threads, debugging):
         in_file, is_fastq, '{}/tmp/{}.ccs.fa'.format(out_dir, prefix), '{}/tmp/{}.raw.fa'.format(out_dir, prefix))
     if too_long:
         import logging
-        logging.getLogger('CIRI-long').warning('%d reads longer than 18000 bases were not scanned for a consensus', too_long)
+        logging.getLogger('CIRI-long').warning('%d reads longer than 16 M bases were not scanned for a consensus', too_long)
     prog.update(100)
     return total_reads, ro_reads, load_ccs_reads(out_dir, prefix)
 

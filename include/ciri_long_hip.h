@@ -133,8 +133,8 @@ int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64
 /* ---- Stage 1 from file to file -------------------------------------------------------------
  * The read loop of find_ccs_reads (CIRI_long/find_ccs.py:29-96) in native code: FASTA/FASTQ, plain or gzip, one header and
  * one sequence line per record; writes tmp/{prefix}.ccs.fa and tmp/{prefix}.raw.fa in the reference's format
- * (find_ccs.py:94-95), reads with a consensus only, input order.  batch_reads <= 0 selects 65536.  Reads longer than the
- * repeat scan's limit (18 000 bases) are counted in too_long and get no consensus. */
+ * (find_ccs.py:94-95), reads with a consensus only, input order.  batch_reads <= 0 selects 65536.  too_long counts reads
+ * above 16 M bases (not scanned). */
 typedef struct { int64_t total_reads, ro_reads, too_long; } clh_ccs_file_stats;
 int clh_ccs_file(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
                  int32_t batch_reads, clh_ccs_file_stats* stats);

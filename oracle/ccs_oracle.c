@@ -26,7 +26,9 @@
  *    [p0-tol, p0+tol] with b+delta <= L; none -> stop.  score(delta) = #{ i in [b, b+W) : kmer(i), kmer(i+delta) valid
  *    and equal } (same k as step 1).  Take the best score; ties: smallest |delta-prev|, then smallest delta; a best
  *    score of 0 takes the candidate closest to prev.  Cut at b+delta, prev = delta.  At most 64 cuts.
- *    Fewer than 2 full copies -> no repeat.  A tail of >= 20 bases after the last cut is kept as a partial copy.
+ *    Fewer than 2 full copies -> no repeat.  A tail of >= 20 bases after the last cut is kept as a partial copy, unless
+ *    the 64-cut cap ended the search (the rest of the read is then an unscanned stretch of copies and is left out).
+ *    A copy longer than 2800 bases -> no consensus (limit of v1: 16-bit cells of the alignment kernel).
  * 3. consensus.  Partial-order alignment of the copies in read order ("clh-poa v1", below), heaviest path.
  *
  * Specification "clh-poa v1" (scores from the reference's call sites: match 10, mismatch -4, gap -8; tests/test_poa.py:30)
@@ -59,6 +61,7 @@
 #define CCS_SMOOTH 3
 #define CCS_MAX_CUTS 64
 #define CCS_MIN_TAIL 20
+#define POA_MAX_COPY 2800
 #define POA_MAXP 12
 #define POA_MATCH 10
 #define POA_MISMATCH (-4)
@@ -384,7 +387,11 @@ int clo_find_consensus(const int8_t *seq, int32_t L, int32_t *segs, int32_t *nse
     *period = p0;
     int n = 0, b = 0;
     for (int i = 0; i < nc; ++i) { segs[2 * n] = b; segs[2 * n + 1] = cuts[i]; b = cuts[i]; ++n; }
-    if (L - b >= CCS_MIN_TAIL) { segs[2 * n] = b; segs[2 * n + 1] = L; ++n; }
+    /* the rest of the read is a (partial) last copy -- unless the boundary search stopped at its cap, in which case the rest
+       is an unscanned stretch of many copies and is left out */
+    if (L - b >= CCS_MIN_TAIL && nc < CCS_MAX_CUTS) { segs[2 * n] = b; segs[2 * n + 1] = L; ++n; }
+    /* limit of specification v1: a copy longer than POA_MAX_COPY bases (a period above ~2.5 kb) yields no consensus */
+    for (int i = 0; i < n; ++i) if (segs[2 * i + 1] - segs[2 * i] > POA_MAX_COPY) return 0;
     *nseg = n;
     int32_t *off = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
     int8_t *buf = (int8_t *)malloc((size_t)L + 1);

@@ -103,6 +103,23 @@ def test_reads_that_overflow_a_first_tier_slot_run_in_the_second_tier(monkeypatc
     assert found >= 20
 
 
+def test_reads_longer_than_the_lds_scan_limit():
+    """above 16 000 bases the repeat scan runs out of an HBM workspace; same results as the oracle, mixed in one batch
+    with ordinary reads"""
+    from ciri_long_amd import pyccs, synth
+    rng = np.random.Generator(np.random.PCG64(12))
+    reads = [synth.rolling_circle_read(rng, rng.integers(0, 4, 400, dtype=np.int8), 1200),
+             synth.rolling_circle_read(rng, rng.integers(0, 4, 700, dtype=np.int8), 17000),
+             synth.mutate(rng.integers(0, 4, 21000, dtype=np.int8), rng),
+             synth.rolling_circle_read(rng, rng.integers(0, 4, 1500, dtype=np.int8), 30000),
+             synth.rolling_circle_read(rng, rng.integers(0, 4, 250, dtype=np.int8), 40000)]
+    got = pyccs.find_consensus_batch(reads)
+    for k, r in enumerate(reads):
+        want = oracle_lib.oracle_find_consensus(r)
+        assert got[k] == want[:2], (k, len(r), got[k][0] and got[k][0][:60], want[0] and want[0][:60])
+    assert got[1][0] is not None and got[2][0] is None and got[4][0] is not None
+
+
 def test_spoa_call_shape():
     from ciri_long_amd import spoa
     cons, msa = spoa.poa(SEGMENTS, 0, True, 10, -4, -8, -2, -24, -1)     # tests/test_poa.py:30

@@ -23,16 +23,14 @@ def transform_seq(seq, bsj):
 
 
 def pairwise(iterable):
-    """s -> (s0, s1), (s1, s2), ... (utils.py:89-94)"""
-    from itertools import tee
-    a, b = tee(iterable)
-    next(b, None)
-    return zip(a, b)
+    """neighbouring pairs (s0, s1), (s1, s2), ... (utils.py:89-94)"""
+    items = list(iterable)
+    return zip(items, items[1:])
 
 
 def flatten(x):
-    import itertools
-    return list(itertools.chain(*x))
+    """one level of nesting removed (utils.py:102-109)"""
+    return [item for sub in x for item in sub]
 
 
 def min_sorted_items(iters, key, reverse=False):
@@ -82,9 +80,6 @@ def pairwise_distance(seqs):
 
 
 def compress_seq(seq):
-    """Homopolymer compression (utils.py:162-167)."""
-    hpc = [seq[0], ]
-    for i, j in zip(seq[:-1], seq[1:]):
-        if i != j:
-            hpc.append(j)
-    return ''.join(hpc)
+    """Homopolymer compression: every run of equal characters becomes one (utils.py:162-167)."""
+    from itertools import groupby
+    return ''.join(ch for ch, _ in groupby(seq))

@@ -359,9 +359,9 @@ __device__ __forceinline__ int poa_ring(int m) {
     return ring;
 }
 
-// direction byte of the fast path = 255 - ordinal of the winning candidate in the specification's evaluation order:
+// direction byte = POA_ORD_HORIZ - ordinal of the winning candidate in the specification's evaluation order:
 // diagonal from in-edge e (ordinal e), diagonal from row 0 (12), vertical from in-edge e (13+e), horizontal (25).
-// A candidate is carried as (value << 8) | (255 - ordinal), so one signed max per candidate both takes the larger
+// A candidate is carried as (value << 8) | (25 - ordinal) (horizontal = 0), so one signed max per candidate both takes the larger
 // value and, between equal values, keeps the earlier candidate -- the strict '>' chain of the specification.
 static constexpr int POA_ORD_ROW0 = 12, POA_ORD_VERT = 13, POA_ORD_HORIZ = 25;
 
@@ -387,7 +387,7 @@ __device__ __forceinline__ void far_row(const short* ptr, int (&h)[C], int& hpre
 // Cells are kept as X[r][j] = H[r][j] - jl*gap, jl = column within the pass (gap < 0): the horizontal move then costs
 // nothing (X[j] = max(A[j], X[j-1]): a plain prefix maximum), the diagonal move adds (match|mismatch) - gap, the vertical
 // move adds gap, the row-0 diagonal is one constant per pass -- no per-column term anywhere.  Carries between passes
-// are H values (X at local column 0 equals H).  A candidate is (X << 8) | (255 - ordinal); for the horizontal chain the
+// are H values (X at local column 0 equals H).  A candidate is (X << 8) | (25 - ordinal); for the horizontal chain the
 // low byte of what a cell offers to its right neighbours is replaced by the horizontal code, the lowest of all, so the
 // plain signed max also implements "horizontal only if strictly larger" and the winner's low byte is the direction.
 template <int C>
@@ -395,7 +395,7 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
 {
     constexpr int NEG = -(1 << 30);
     constexpr int W = 64 * C;
-    constexpr int HCODE = 255 - POA_ORD_HORIZ;
+    constexpr int HCODE = 0;                                     // POA_ORD_HORIZ - POA_ORD_HORIZ: clearing the low byte makes a horizontal offer
     constexpr int DIAG_MATCH = (POA_MATCH - POA_GAP) * 256, DIAG_MIS = (POA_MISMATCH - POA_GAP) * 256;
     const int npass = (m + W - 1) / W;
     const int gp = poa_pitch(m);                                 // row pitch of H and dir in HBM
@@ -413,7 +413,7 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
             const int c = j <= m ? (int)seq[j - 1] : 100;
             sb[k] = (c >= 0 && c < 4) ? c : 100;
         }
-        const int row0 = (pass * W) * (POA_GAP * 256) + (255 - POA_ORD_ROW0);   // row-0 diagonal: X = (j-1) gap + s - jl gap
+        const int row0 = (pass * W) * (POA_GAP * 256) + (POA_ORD_HORIZ - POA_ORD_ROW0);   // row-0 diagonal: X = (j-1) gap + s - jl gap
         const short* cprev = w.carry + (size_t)(pass & 1) * w.cpitch;
         short* cnext = w.carry + (size_t)((pass + 1) & 1) * w.cpitch;
         uint2 blk = 1 + lane <= N ? w.ri[1 + lane] : make_uint2(0, 0);
@@ -454,7 +454,7 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                         far_row<C>(w.H + (size_t)q * gp + col0 + 7, h, hprev);
                         if (lane == 0 && pass > 0) hprev += W * POA_GAP;     // that element was stored in the previous pass's frame
                     }
-                    const int cd = 255 - e, cv = POA_GAP * 256 + 255 - POA_ORD_VERT - e;
+                    const int cd = POA_ORD_HORIZ - e, cv = POA_GAP * 256 + POA_ORD_HORIZ - POA_ORD_VERT - e;
 #pragma unroll
                     for (int k = 0; k < C; ++k) {
                         const int up = k == 0 ? hprev : h[k - 1];
@@ -476,13 +476,13 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                 run[0] = NEG;
 #pragma unroll
                 for (int k = 1; k < C; ++k) {
-                    const int y = (best[k - 1] & ~0xff) | HCODE;
+                    const int y = best[k - 1] & ~0xff;
                     run[k] = run[k - 1] > y ? run[k - 1] : y;
                 }
-                const int ylast = (best[C - 1] & ~0xff) | HCODE;
+                const int ylast = best[C - 1] & ~0xff;
                 const int incl = wave_prefix_max(run[C - 1] > ylast ? run[C - 1] : ylast);
                 int excl = __builtin_amdgcn_update_dpp(NEG, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1
-                const int xc = (cin << 8) | HCODE;
+                const int xc = cin << 8;
                 excl = xc > excl ? xc : excl;
                 int fin[C];
 #pragma unroll
@@ -627,8 +627,8 @@ __device__ int poa_add(const PoaWs& w, int N_, int ncap, int mcap, const int8_t*
             const uint32_t sel = (byte >> 2) == 0 ? pw0 : ((byte >> 2) == 1 ? pw1 : ((byte >> 2) == 2 ? pw2 : pw3));
             const int d = (__builtin_amdgcn_readlane((int)sel, src_lane) >> ((byte & 3) * 8)) & 0xff;
             int kind = d & 3, e = d >> 4;
-            {                                             // bytes are 255 - ordinal (see dp_rows)
-                const int ord = 255 - d;
+            {                                             // bytes are POA_ORD_HORIZ - ordinal (see dp_rows)
+                const int ord = POA_ORD_HORIZ - d;
                 kind = ord <= POA_ORD_ROW0 ? 1 : (ord < POA_ORD_HORIZ ? 2 : 3);
                 e = ord < POA_ORD_ROW0 ? ord : (ord == POA_ORD_ROW0 ? 15 : ord - POA_ORD_VERT);
             }

@@ -889,9 +889,25 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
             ++nseg;
         }
         const int ncap = total + 8, mcap = maxlen + 1;
-        if (poa_slot_bytes(ncap, mcap) > p.slot_bytes) { res.status = 1; if (lane == 0) p.results[rd] = res; continue; }
-        if (maxlen > POA_MAX_COPY) { res.status = 4; if (lane == 0) p.results[rd] = res; continue; }   // H is int16: |H| <= 10 * copy length
-        const PoaWs w = carve(slot, ncap, mcap);
+        if (maxlen > POA_MAX_COPY) { res.status = 4; if (lane == 0) p.results[rd] = res; continue; }   // cells are int16
+        // workspace: this wave's slot, or -- a read that needs more -- one of the large slots, claimed for the duration of
+        // the read; none free (or none large enough): status 1, the second launch over the large slots takes the read
+        uint8_t* ws = slot;
+        int big = -1;
+        const size_t need = poa_slot_bytes(ncap, mcap);
+        if (need > p.slot_bytes) {
+            if (p.tier == 0 && p.n_big > 0 && need <= p.big_slot_bytes) {
+                if (lane == 0)
+                    for (int t = 0; t < 64 && big < 0; ++t) {
+                        const int cand = (int)((blockIdx.x * 7u + (unsigned)t * 131u + (unsigned)rd) % (unsigned)p.n_big);
+                        if (atomicCAS(&p.big_busy[cand], 0, 1) == 0) big = cand;
+                    }
+                big = __builtin_amdgcn_readfirstlane(big);
+            }
+            if (big < 0) { res.status = 1; if (lane == 0) p.results[rd] = res; continue; }
+            ws = p.big_ws + (size_t)big * p.big_slot_bytes;
+        }
+        const PoaWs w = carve(ws, ncap, mcap);
         phase_sync();
         unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int N = 0;
@@ -899,31 +915,28 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
         for (int s = 0; s < nseg && N >= 0; ++s) {
             const int e = s < ncuts ? __builtin_amdgcn_readfirstlane(sc.cuts[s]) : L;
             N = poa_add(w, N, ncap, mcap, seq + b, e - b, lane, tacc);
-#ifdef CLH_DEBUG_POA
-            if (lane == 0 && 40 + s < CCS_SEG_CAP) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (40 + s)] = N;
-#endif
             b = e;
         }
-        if (N < 0) { res.status = 2; if (lane == 0) p.results[rd] = res; continue; }
+        int len = -1;
+        if (N < 0) res.status = 2;
+        else {
 #ifdef CLH_DEBUG_POA
-        if (lane == 0) {
-            long long snp = 0, spw = 0, hsh = 0;
-            for (int v = 0; v < N; ++v) { snp += w.np[v]; for (int e = 0; e < w.np[v]; ++e) { spw += w.pw[v * POA_MAXP + e]; hsh = hsh * 31 + w.pred[v * POA_MAXP + e] * 7 + w.pw[v * POA_MAXP + e]; } hsh = hsh * 131 + w.rank[v]; }
-            p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * 50] = (int)snp; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * 51] = (int)spw; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * 52] = (int)(hsh & 0x7fffffff);
+            unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
+            len = poa_consensus(w, N, p.ccs + off, L, lane);
+#ifdef CLH_DEBUG_POA
+            tacc[4] += __builtin_amdgcn_s_memtime() - tc0;
+            if (lane == 0) for (int k = 0; k < 5; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
+#endif
+            if (len < 0) res.status = 3;
+            else { res.nseg = nseg; res.ccs_len = len; }
         }
-#endif
-#ifdef CLH_DEBUG_POA
-        unsigned long long tc0 = __builtin_amdgcn_s_memtime();
-#endif
-        const int len = poa_consensus(w, N, p.ccs + off, L, lane);
-#ifdef CLH_DEBUG_POA
-        tacc[4] += __builtin_amdgcn_s_memtime() - tc0;
-        if (lane == 0) for (int k = 0; k < 5; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
-#endif
-        if (len < 0) { res.status = 3; if (lane == 0) p.results[rd] = res; continue; }
-        res.nseg = nseg; res.ccs_len = len;
         if (lane == 0) p.results[rd] = res;
         __syncthreads();
+        if (big >= 0) {                      // every store into the large slot has landed before another wave may claim it
+            __threadfence();
+            if (lane == 0) atomicExch(&p.big_busy[big], 0);
+        }
     }
 }
 

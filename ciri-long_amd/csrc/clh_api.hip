@@ -728,7 +728,7 @@ extern "C" clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int6
 struct clh_ccs_plan {
     clh_ctx* ctx = nullptr;
     int n = 0, lcap = 0, lmax = 0, n_long = 0, nslots = 0, nslots_big = 0;
-    void *d_long = nullptr, *d_k2ws = nullptr;
+    void *d_long = nullptr, *d_k2ws = nullptr, *d_busy = nullptr;
     int64_t total = 0;
     size_t slot_bytes = 0, slot_bytes_big = 0;      // second tier: a few slots sized for the worst case of the batch
     void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr, *d_ws_big = nullptr,
@@ -743,7 +743,7 @@ extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
-    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_reads, pl->d_long, pl->d_k2ws};
+    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_reads, pl->d_long, pl->d_k2ws, pl->d_busy};
     for (void* b : bufs) pl->ctx->release(b);
     for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
     delete pl;
@@ -789,7 +789,11 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->d_segs = ctx->alloc(sizeof(int32_t) * 2 * clh::CCS_SEG_CAP * (size_t)std::max(n, 1));
     pl->d_ccs = ctx->alloc((size_t)std::max<int64_t>(pl->total, 1) + 64);
     pl->d_ws = ctx->alloc(pl->slot_bytes * (size_t)pl->nslots);
-    if (pl->nslots_big) pl->d_ws_big = ctx->alloc(pl->slot_bytes_big * (size_t)pl->nslots_big);
+    if (pl->nslots_big) {
+        pl->d_ws_big = ctx->alloc(pl->slot_bytes_big * (size_t)pl->nslots_big);
+        pl->d_busy = ctx->alloc(sizeof(int) * (size_t)pl->nslots_big);
+        if (pl->d_busy && hipMemset(pl->d_busy, 0, sizeof(int) * (size_t)pl->nslots_big) != hipSuccess) { ctx->release(pl->d_busy); pl->d_busy = nullptr; }
+    }
     if (pl->n_long) {
         pl->d_long = ctx->alloc(sizeof(int32_t) * (size_t)pl->n_long);
         pl->d_k2ws = ctx->alloc(clh::k2_long_slot_bytes(lmax) * (size_t)pl->n_long);
@@ -800,7 +804,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     }
     pl->d_counter = ctx->alloc(256);
     pl->d_order = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
-    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || (pl->nslots_big && !pl->d_ws_big) || !pl->d_counter || !pl->d_order) {
+    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || (pl->nslots_big && (!pl->d_ws_big || !pl->d_busy)) || !pl->d_counter || !pl->d_order) {
         fail(CLH_E_HIP, "out of device memory while building the consensus plan");
         clh_ccs_plan_destroy(pl); return nullptr;
     }
@@ -831,6 +835,7 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     HIPCHK(hipEventRecord(pl->ev[0], st));
     HIPCHK(clh::launch_ccs_scan(P, st));
     HIPCHK(hipEventRecord(pl->ev[1], st));
+    if (pl->nslots_big) { P.big_ws = (uint8_t*)pl->d_ws_big; P.big_slot_bytes = pl->slot_bytes_big; P.big_busy = (int*)pl->d_busy; P.n_big = pl->nslots_big; }
     HIPCHK(clh::launch_poa(P, pl->nslots, st));
     if (pl->nslots_big) {       // the reads the first tier left with status 1
         clh::CcsParams Q = P;
@@ -920,6 +925,7 @@ extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, 
         P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
         P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
         if (hipMemsetAsync(pl->d_counter, 0, 8, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
+        if (pl->nslots_big) { P.big_ws = (uint8_t*)pl->d_ws_big; P.big_slot_bytes = pl->slot_bytes_big; P.big_busy = (int*)pl->d_busy; P.n_big = pl->nslots_big; }
         if (!rc && clh::launch_poa(P, pl->nslots, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "launch failed");
         if (!rc && pl->nslots_big) {
             clh::CcsParams Q = P;

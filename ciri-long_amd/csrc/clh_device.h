@@ -92,6 +92,10 @@ struct CcsParams {
     uint8_t* k2_ws;
     unsigned long long k2_slot;
     int32_t n_long, k2_lmax, k2_lds_max;
+    uint8_t* big_ws;           // K3: large slots that first-tier waves may claim for a read that does not fit their own
+    unsigned long long big_slot_bytes;
+    int* big_busy;
+    int32_t n_big;
     int32_t tier;              // K3: 0 = every read (too large for the slot: status 1); 1 = only the reads left with status 1
 };
 

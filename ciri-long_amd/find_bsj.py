@@ -248,6 +248,18 @@ def _write_records(out, records):
         out.write('>{}\t{}\t{}\t{}\t{}\t{}\t{}\n{}\n'.format(*rec))
 
 
+GPU_CHUNKS = 16           # chunks of 250 reads whose clip re-alignments share one GPU call (results do not depend on it)
+
+
+def _resident(genome):
+    """Wrap a genome that exposes its sequences ({name: str} in `.genome`, as align.Fasta does) so that the Smith-Waterman
+    windows are read from a copy resident on the GPU; anything else (e.g. a mappy index) is used as it is."""
+    from .align import DeviceGenome
+    if getattr(genome, 'device', None) is not None or not isinstance(getattr(genome, 'genome', None), dict):
+        return genome
+    return DeviceGenome(genome, genome.genome)
+
+
 def scan_ccs_reads(ccs_seq, ref_fasta, ss_index, gtf_index, intron_index, is_canonical, out_dir, prefix, threads,
                    aligner=None, genome=None, contig_len=None):
     """Stage driver (find_bsj.py:328-372).  The reference forks a process pool per stage; here the calling process
@@ -261,12 +273,12 @@ def scan_ccs_reads(ccs_seq, ref_fasta, ss_index, gtf_index, intron_index, is_can
     if contig_len is None:
         from .align import Fasta
         contig_len = Fasta(ref_fasta).contig_len
-    env.initializer(aligner, contig_len, genome, gtf_index, intron_index, ss_index)
+    env.initializer(aligner, contig_len, _resident(genome), gtf_index, intron_index, ss_index)
 
     reads_count = defaultdict(int)
     short_reads = []
     with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'w') as out:
-        for reads in grouper(list(ccs_seq), 250):
+        for reads in grouper(list(ccs_seq), 250 * GPU_CHUNKS):
             chunk = [[i, ] + ccs_seq[i] for i in reads if i is not None]
             cnt, short, ret = scan_ccs_chunk(chunk, is_canonical)
             for key, value in cnt.items():
@@ -285,11 +297,11 @@ def recover_ccs_reads(short_reads, ref_fasta, ss_index, gtf_index, intron_index,
     if aligner is None:
         from bwapy import BwaAligner
         aligner = Aligner(BwaAligner(ref_fasta, options='-x ont2d -T 19'))
-    env.initializer(aligner, genome.contig_len, genome, gtf_index, intron_index, ss_index)
+    env.initializer(aligner, genome.contig_len, _resident(genome), gtf_index, intron_index, ss_index)
 
     reads_count = defaultdict(int)
     with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'a') as out:
-        for reads in grouper(short_reads, 250):
+        for reads in grouper(short_reads, 250 * GPU_CHUNKS):
             chunk = [i for i in reads if i is not None]
             cnt, ret = recover_ccs_chunk(chunk, is_canonical)
             for key, value in cnt.items():

@@ -83,3 +83,33 @@ def test_scan_ccs_chunk_with_resident_genome_matches_reference_golden():
     env.initializer(mapper, w['genome'].contig_len, w['genome'], w['gtf_index'], None, w['ss_index'])
     cnt2, short2, ret2 = find_bsj.scan_ccs_chunk(reads, True)
     assert [list(r) for r in ret] == [list(r) for r in ret2] and dict(cnt) == dict(cnt2)
+
+
+def test_stage_drivers_write_the_reference_records(tmp_path):
+    """scan_ccs_reads / recover_ccs_reads (find_bsj.py:328-372, 451-490) with the mapper double: 16 chunks per GPU call,
+    genome wrapped into a resident copy automatically; cand_circ.fa holds the reference's records in input order."""
+    from ciri_long_amd import find_bsj
+    with gzip.open(os.path.join(HERE, 'golden', 'bsj_golden.json.gz'), 'rt') as f:
+        golden = json.load(f)
+    w = fm.build_world()
+    mapper = fm.FakeMapper(w['genome'])
+    reads = fm.build_reads(w, 64)
+    ccs_seq = {r[0]: [r[1], r[2], r[3]] for r in reads}
+    cnt, short = find_bsj.scan_ccs_reads(ccs_seq, None, w['ss_index'], w['gtf_index'], None, True, str(tmp_path), 'p', 1,
+                                         aligner=mapper, genome=w['genome'], contig_len=w['genome'].contig_len)
+    from ciri_long_amd import env
+    assert getattr(env.GENOME, 'device', None) is not None                # the windows came from HBM
+    g = golden['scan_ccs_chunk']
+    assert dict(cnt) == g['counters'] and json.loads(json.dumps([list(x) for x in short])) == g['short']
+    tied = set(golden['tied_reads'])
+    lines = (tmp_path / 'p.cand_circ.fa').read_text().split('\n')
+    want = [r for r in g['records']]
+    assert len(lines) == 2 * len(want) + 1
+    for k, r in enumerate(want):
+        if r[0] not in tied:
+            assert lines[2 * k] == '>{}\t{}\t{}\t{}\t{}\t{}\t{}'.format(*r[:7]) and lines[2 * k + 1] == r[7], r[0]
+    cnt2 = find_bsj.recover_ccs_reads(reads, None, w['ss_index'], w['gtf_index'], None, True, str(tmp_path), 'p', 1,
+                                      aligner=mapper, genome=w['genome'])
+    assert dict(cnt2) == golden['recover_ccs_chunk']['counters']
+    lines2 = (tmp_path / 'p.cand_circ.fa').read_text().split('\n')
+    assert len(lines2) == len(lines) + 2 * len(golden['recover_ccs_chunk']['records'])

@@ -808,6 +808,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
         fail(CLH_E_HIP, "out of device memory while building the consensus plan");
         clh_ccs_plan_destroy(pl); return nullptr;
     }
+    (void)hipMemset(pl->d_segs, 0, sizeof(int32_t) * 2 * clh::CCS_SEG_CAP * (size_t)std::max(n, 1));   // entries beyond nseg read as 0
     if (hipMemcpy(pl->d_off, read_off, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice) != hipSuccess ||
         (n > 0 && hipMemcpy(pl->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)) {
         fail(CLH_E_HIP, "plan upload failed");

@@ -468,31 +468,70 @@ static hipError_t launch_one(const SswParams& p, int ntasks, hipStream_t stream)
     return hipGetLastError();
 }
 
+// The 30 kernel instantiations take minutes to compile, so the file is built as four objects (Makefile: -DCLH_K1_PART=0..3),
+// each with a quarter of the row classes; part 0 owns the dispatcher.  Without the macro everything is in one object.
+#ifndef CLH_K1_PART
+#define CLH_K1_PART (-1)
+#endif
+#define CLH_K1_HAS(part) (CLH_K1_PART < 0 || CLH_K1_PART == (part))
+
 template <bool GEQ>
 static hipError_t launch_rv(int rv, const SswParams& p, int ntasks, hipStream_t stream)
 {
-    if (rv == kRvStrips) return launch_one<32, GEQ, true>(p, ntasks, stream);   // reads longer than 4096 bases: row strips
-    switch (rv) {
 #define CLH_CASE(R) case R: return launch_one<R, GEQ>(p, ntasks, stream);
 #if defined(CLH_STRIPS_BUILD)      // debugging builds with one class: seconds instead of minutes
-        CLH_CASE(1)
+    if (rv == kRvStrips) return launch_one<32, GEQ, true>(p, ntasks, stream);
+    switch (rv) { CLH_CASE(1) default: return hipErrorInvalidValue; }
 #elif defined(CLH_PROBE_BUILD)
-        CLH_CASE(8)
+    switch (rv) { CLH_CASE(8) default: return hipErrorInvalidValue; }
 #else
-        CLH_CASE(1) CLH_CASE(2) CLH_CASE(3) CLH_CASE(4) CLH_CASE(5) CLH_CASE(6) CLH_CASE(7) CLH_CASE(8)
-        CLH_CASE(10) CLH_CASE(12) CLH_CASE(16) CLH_CASE(20) CLH_CASE(24) CLH_CASE(32)
+#if CLH_K1_HAS(3)
+    if (rv == kRvStrips) return launch_one<32, GEQ, true>(p, ntasks, stream);   // reads longer than 4096 bases: row strips
 #endif
-#undef CLH_CASE
+    switch (rv) {
+#if CLH_K1_HAS(0)
+        CLH_CASE(1) CLH_CASE(2) CLH_CASE(3) CLH_CASE(4) CLH_CASE(5)
+#endif
+#if CLH_K1_HAS(1)
+        CLH_CASE(6) CLH_CASE(7) CLH_CASE(8) CLH_CASE(10)
+#endif
+#if CLH_K1_HAS(2)
+        CLH_CASE(12) CLH_CASE(16) CLH_CASE(20)
+#endif
+#if CLH_K1_HAS(3)
+        CLH_CASE(24) CLH_CASE(32)
+#endif
         default: return hipErrorInvalidValue;
     }
+#endif
+#undef CLH_CASE
 }
 
+#if CLH_K1_PART == 1
+hipError_t launch_ssw_part1(int rv, bool geq, const SswParams& p, int ntasks, hipStream_t stream) { return geq ? launch_rv<true>(rv, p, ntasks, stream) : launch_rv<false>(rv, p, ntasks, stream); }
+#elif CLH_K1_PART == 2
+hipError_t launch_ssw_part2(int rv, bool geq, const SswParams& p, int ntasks, hipStream_t stream) { return geq ? launch_rv<true>(rv, p, ntasks, stream) : launch_rv<false>(rv, p, ntasks, stream); }
+#elif CLH_K1_PART == 3
+hipError_t launch_ssw_part3(int rv, bool geq, const SswParams& p, int ntasks, hipStream_t stream) { return geq ? launch_rv<true>(rv, p, ntasks, stream) : launch_rv<false>(rv, p, ntasks, stream); }
+#else
 const int kRvClasses[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32};
 const int kNumRvClasses = sizeof(kRvClasses) / sizeof(kRvClasses[0]);
 
+#if CLH_K1_PART == 0
+hipError_t launch_ssw_part1(int rv, bool geq, const SswParams& p, int ntasks, hipStream_t stream);
+hipError_t launch_ssw_part2(int rv, bool geq, const SswParams& p, int ntasks, hipStream_t stream);
+hipError_t launch_ssw_part3(int rv, bool geq, const SswParams& p, int ntasks, hipStream_t stream);
+#endif
+
 hipError_t launch_ssw(int rv, bool geq, const SswParams& p, int ntasks, hipStream_t stream)
 {
+#if CLH_K1_PART == 0
+    if (rv == kRvStrips || rv >= 24) return launch_ssw_part3(rv, geq, p, ntasks, stream);
+    if (rv >= 12) return launch_ssw_part2(rv, geq, p, ntasks, stream);
+    if (rv >= 6) return launch_ssw_part1(rv, geq, p, ntasks, stream);
+#endif
     return geq ? launch_rv<true>(rv, p, ntasks, stream) : launch_rv<false>(rv, p, ntasks, stream);
 }
+#endif
 
 }  // namespace clh

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) edit_distance_kernel(const uint8_t* __rest
             if (t) cur = nxt;
             if (feeder && t + 16 < n) { __builtin_memcpy(&nxt, txt + t + 16, 16); }
         }
-        const int prev = __builtin_amdgcn_update_dpp(0, carry, 0x138, 0xf, 0xf, false);    // wave_shr:1
+        const int prev = __builtin_amdgcn_update_dpp(0, carry, 0x138, 0xf, 0xf, true);     // wave_shr:1, lane 0 reads 0
         int c, hin;
         if (bl == 0) {
             const int k = (t >> 2) & 3;

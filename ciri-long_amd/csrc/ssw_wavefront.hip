@@ -47,6 +47,12 @@ __device__ __forceinline__ uint32_t hand_down(uint32_t v, uint32_t lane0_lo) {
     return __builtin_amdgcn_alignbit(v, x, 16);
 }
 
+// the same with 0 entering lane 0's low half: bound_ctrl supplies the zero, no v_mov to seed the destination
+__device__ __forceinline__ uint32_t hand_down0(uint32_t v) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    return __builtin_amdgcn_alignbit(v, x, 16);
+}
+
 static constexpr int NEG16 = -32768;
 
 struct PassOut {
@@ -159,9 +165,9 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
         RB = hand_down(RB, (uint32_t)sb);
         const uint32_t aLo = (RB & 0xffffu) * BASE_STRIDE + lane * 16;
         const uint32_t aHi = (RB >> 16) * BASE_STRIDE + lane * 16;
-        const uint32_t inH = hand_down(outH, STRIPS ? (bHC & 0xffffu) : 0u), inC = hand_down(outC, STRIPS ? (bHC >> 16) : 0u);
-        uint32_t inM = 0;
-        if constexpr (!LEAN) inM = hand_down(outM, STRIPS ? bM : 0u);
+        uint32_t inH, inC, inM = 0;
+        if constexpr (STRIPS) { inH = hand_down(outH, bHC & 0xffffu); inC = hand_down(outC, bHC >> 16); inM = hand_down(outM, bM); }
+        else { inH = hand_down0(outH); inC = hand_down0(outC); if constexpr (!LEAN) inM = hand_down0(outM); }
         uint32_t F = inC, diag = diagIn, cm = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {

@@ -550,70 +550,131 @@ extern "C" int clh_ssw_windows_batch(clh_genome* genome, int32_t n, const int8_t
 // ---------------------------------------------------------------------------------------------------------------
 // K4: unit-cost edit distance of n pairs of byte strings (utils.py:153-159 `distance`)
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int clh_edit_distance_batch(clh_ctx* ctx, int32_t n, const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off,
-                                       int32_t* out)
+struct clh_edit_plan {
+    clh_ctx* ctx = nullptr;
+    int n = 0, planes = 3;
+    std::vector<clh::EdTask> tasks;          // launch order (by lane-group class, longest text first)
+    std::vector<int32_t> trivial;            // out[k] for pairs with an empty side, -1 otherwise
+    void *d_sym = nullptr, *d_tasks = nullptr, *d_out = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool ran = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+static int ed_group(const clh::EdTask& t) { int B = (t.pat_len + 63) >> 6, G = 1; while (G < B) G <<= 1; return G; }
+
+extern "C" void clh_edit_plan_destroy(clh_edit_plan* pl)
 {
-    if (!ctx || n < 0 || !a_off || !b_off || !out || (n > 0 && (!a || !b))) return fail(CLH_E_ARG, "clh_edit_distance_batch: null argument");
-    if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
-    const int64_t ta = a_off[n] - a_off[0], tb = b_off[n] - b_off[0];
-    if (ta < 0 || tb < 0) return fail(CLH_E_ARG, "clh_edit_distance_batch: offsets must ascend");
+    if (!pl) return;
+    (void)hipSetDevice(pl->ctx->device);
+    if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
+    pl->ctx->release(pl->d_sym); pl->ctx->release(pl->d_tasks); pl->ctx->release(pl->d_out);
+    for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
+    delete pl;
+}
+
+// uploads the strings (as dense symbol codes) and the task table; the plan then runs any number of times
+extern "C" clh_edit_plan* clh_edit_plan_create(clh_ctx* ctx, int32_t n, const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off)
+{
+    if (!ctx || n < 0 || !a_off || !b_off || (n > 0 && (!a || !b))) { fail(CLH_E_ARG, "clh_edit_plan_create: null argument"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail(CLH_E_HIP, "hipSetDevice failed"); return nullptr; }
+    const int64_t ta = n ? a_off[n] - a_off[0] : 0, tb = n ? b_off[n] - b_off[0] : 0;
+    if (ta < 0 || tb < 0) { fail(CLH_E_ARG, "clh_edit_plan_create: offsets must ascend"); return nullptr; }
+    clh_edit_plan* pl = new clh_edit_plan();
+    pl->ctx = ctx; pl->n = n;
     // the batch's alphabet -> dense codes; the kernel builds match vectors from 3 bit planes (<= 8 symbols: DNA) or 8
     int code[256];
     for (int& c : code) c = -1;
     int nsym = 0;
     auto learn = [&](const uint8_t* p, int64_t len) { for (int64_t i = 0; i < len; ++i) if (code[p[i]] < 0) code[p[i]] = nsym++; };
-    learn(a + a_off[0], ta); learn(b + b_off[0], tb);
-    const int planes = nsym <= 8 ? 3 : 8;
+    if (n) { learn(a + a_off[0], ta); learn(b + b_off[0], tb); }
+    pl->planes = nsym <= 8 ? 3 : 8;
     std::vector<uint8_t> sym((size_t)(ta + tb) + 32, 0);
     for (int64_t i = 0; i < ta; ++i) sym[(size_t)i] = (uint8_t)code[a[a_off[0] + i]];
     for (int64_t i = 0; i < tb; ++i) sym[(size_t)(ta + i)] = (uint8_t)code[b[b_off[0] + i]];
-    std::vector<clh::EdTask> tasks;
-    tasks.reserve((size_t)n);
-    std::vector<int> cls;
+    pl->trivial.assign((size_t)n, -1);
+    pl->tasks.reserve((size_t)n);
     for (int k = 0; k < n; ++k) {
         const int64_t la = a_off[k + 1] - a_off[k], lb = b_off[k + 1] - b_off[k];
-        if (la < 0 || lb < 0) return fail(CLH_E_ARG, "clh_edit_distance_batch: offsets must ascend");
-        if (la == 0 || lb == 0) { out[k] = (int32_t)(la + lb); continue; }
+        if (la < 0 || lb < 0) { fail(CLH_E_ARG, "clh_edit_plan_create: offsets must ascend"); delete pl; return nullptr; }
+        if (la == 0 || lb == 0) { pl->trivial[(size_t)k] = (int32_t)(la + lb); continue; }
         clh::EdTask t;
         const bool a_is_pat = la <= lb;
         t.pat_off = a_is_pat ? a_off[k] - a_off[0] : ta + (b_off[k] - b_off[0]);
         t.txt_off = a_is_pat ? ta + (b_off[k] - b_off[0]) : a_off[k] - a_off[0];
         t.pat_len = (int32_t)(a_is_pat ? la : lb); t.txt_len = (int32_t)(a_is_pat ? lb : la);
         t.out_index = k; t.pad = 0;
-        if (t.pat_len > 4096) return fail(CLH_E_UNSUPPORTED, "clh_edit_distance_batch: the shorter string of a pair is longer than 4096 symbols");
-        tasks.push_back(t);
+        if (t.pat_len > 4096) { fail(CLH_E_UNSUPPORTED, "edit distance: the shorter string of a pair is longer than 4096 symbols"); delete pl; return nullptr; }
+        pl->tasks.push_back(t);
     }
-    const int nt = (int)tasks.size();
-    if (nt == 0) return 0;
-    auto group = [](const clh::EdTask& t) { int B = (t.pat_len + 63) >> 6, G = 1; while (G < B) G <<= 1; return G; };
-    std::stable_sort(tasks.begin(), tasks.end(), [&](const clh::EdTask& x, const clh::EdTask& y) {
-        const int gx = group(x), gy = group(y);
+    std::stable_sort(pl->tasks.begin(), pl->tasks.end(), [&](const clh::EdTask& x, const clh::EdTask& y) {
+        const int gx = ed_group(x), gy = ed_group(y);
         if (gx != gy) return gx < gy;
         return x.txt_len > y.txt_len;                 // similar step counts share a wave
     });
-    void* d_sym = ctx->alloc(sym.size());
-    void* d_tasks = ctx->alloc(sizeof(clh::EdTask) * (size_t)nt);
-    void* d_out = ctx->alloc(sizeof(int32_t) * (size_t)n);
-    int rc = 0;
-    if (!d_sym || !d_tasks || !d_out) rc = fail(CLH_E_HIP, "out of device memory");
-    if (!rc && (hipMemcpyAsync(d_sym, sym.data(), sym.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                hipMemcpyAsync(d_tasks, tasks.data(), sizeof(clh::EdTask) * (size_t)nt, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
-        rc = fail(CLH_E_HIP, "H2D failed");
-    for (int i = 0; i < nt && !rc;) {
-        const int G = group(tasks[i]);
+    const size_t nt = pl->tasks.size();
+    pl->d_sym = ctx->alloc(sym.size());
+    pl->d_tasks = ctx->alloc(sizeof(clh::EdTask) * std::max<size_t>(nt, 1));
+    pl->d_out = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
+    if (!pl->d_sym || !pl->d_tasks || !pl->d_out ||
+        hipMemcpy(pl->d_sym, sym.data(), sym.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        (nt && hipMemcpy(pl->d_tasks, pl->tasks.data(), sizeof(clh::EdTask) * nt, hipMemcpyHostToDevice) != hipSuccess)) {
+        fail(CLH_E_HIP, "out of device memory or upload failed while building the edit-distance plan");
+        clh_edit_plan_destroy(pl); return nullptr;
+    }
+    return pl;
+}
+
+extern "C" int clh_edit_plan_run(clh_edit_plan* pl, void* stream_)
+{
+    if (!pl) return fail(CLH_E_ARG, "clh_edit_plan_run: null argument");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : pl->ctx->stream;
+    if (!pl->ev[0]) for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventRecord(pl->ev[0], st));
+    const int nt = (int)pl->tasks.size();
+    for (int i = 0; i < nt;) {
+        const int G = ed_group(pl->tasks[(size_t)i]);
         int j = i;
-        while (j < nt && group(tasks[j]) == G) ++j;
-        if (clh::launch_edit_distance((const uint8_t*)d_sym, (const clh::EdTask*)d_tasks + i, j - i, G, planes, (int32_t*)d_out, ctx->stream) != hipSuccess)
-            rc = fail(CLH_E_HIP, "edit distance launch failed");
+        while (j < nt && ed_group(pl->tasks[(size_t)j]) == G) ++j;
+        HIPCHK(clh::launch_edit_distance((const uint8_t*)pl->d_sym, (const clh::EdTask*)pl->d_tasks + i, j - i, G, pl->planes, (int32_t*)pl->d_out, st));
         i = j;
     }
-    std::vector<int32_t> res((size_t)n);
-    if (!rc && (hipMemcpyAsync(res.data(), d_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess))
-        rc = fail(CLH_E_HIP, "edit distance kernel or D2H failed");
-    if (!rc) for (const clh::EdTask& t : tasks) out[t.out_index] = res[(size_t)t.out_index];
-    ctx->release(d_sym); ctx->release(d_tasks); ctx->release(d_out);
+    HIPCHK(hipEventRecord(pl->ev[1], st));
+    pl->last_stream = st; pl->ran = true;
+    return 0;
+}
+
+extern "C" int clh_edit_plan_fetch(clh_edit_plan* pl, int32_t* out)
+{
+    if (!pl || !out) return fail(CLH_E_ARG, "clh_edit_plan_fetch: null argument");
+    if (!pl->ran) return fail(CLH_E_ARG, "clh_edit_plan_fetch before clh_edit_plan_run");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    std::vector<int32_t> res((size_t)std::max(pl->n, 1));
+    if (pl->n) HIPCHK(hipMemcpy(res.data(), pl->d_out, sizeof(int32_t) * (size_t)pl->n, hipMemcpyDeviceToHost));
+    for (int k = 0; k < pl->n; ++k) out[k] = pl->trivial[(size_t)k] >= 0 ? pl->trivial[(size_t)k] : res[(size_t)k];
+    return 0;
+}
+
+extern "C" int clh_edit_plan_timing(clh_edit_plan* pl, float* ms)
+{
+    if (!pl || !ms || !pl->ran) return fail(CLH_E_ARG, "clh_edit_plan_timing: no run to time");
+    HIPCHK(hipEventSynchronize(pl->ev[1]));
+    HIPCHK(hipEventElapsedTime(ms, pl->ev[0], pl->ev[1]));
+    return 0;
+}
+
+extern "C" int clh_edit_distance_batch(clh_ctx* ctx, int32_t n, const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off,
+                                       int32_t* out)
+{
+    if (!out) return fail(CLH_E_ARG, "clh_edit_distance_batch: null argument");
+    if (n == 0) return 0;
+    clh_edit_plan* pl = clh_edit_plan_create(ctx, n, a, a_off, b, b_off);
+    if (!pl) return g_err.find("longer than 4096") != std::string::npos ? CLH_E_UNSUPPORTED : CLH_E_ARG;
+    int rc = clh_edit_plan_run(pl, nullptr);
+    if (!rc) rc = clh_edit_plan_fetch(pl, out);
+    clh_edit_plan_destroy(pl);
     return rc;
 }
 

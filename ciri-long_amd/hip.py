@@ -92,6 +92,13 @@ def lib():
         L.clh_ssw_plan_windows.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ssw_windows_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.clh_edit_plan_create.restype = C.c_void_p
+        L.clh_edit_plan_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_edit_plan_destroy.restype = None
+        L.clh_edit_plan_destroy.argtypes = [C.c_void_p]
+        L.clh_edit_plan_run.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_edit_plan_fetch.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_edit_plan_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_edit_distance_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_edit_distance_batch.restype = C.c_int
         L.clh_poa_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -244,6 +251,9 @@ class Context(object):
             raise ClhError('clh_edit_distance_batch failed (%d): %s' % (rc, last_error()))
         return out
 
+    def edit_plan(self, xs, ys):
+        return EditPlan(self, xs, ys)
+
     def ccs_file(self, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads=0):
         """Stage 1 from file to file in native code -> (total_reads, reads_with_consensus, reads_too_long)"""
         st = (C.c_int64 * 3)()
@@ -259,6 +269,56 @@ class Context(object):
     def plan(self, read_off, ref_off, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,
              want_cigar=True, mask_len=None):
         return Plan(self, read_off, ref_off, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, mask_len)
+
+
+def _pack_bytes(items):
+    bs = [x.encode() if isinstance(x, str) else bytes(x) for x in items]
+    off = np.zeros(len(bs) + 1, dtype=np.int64)
+    if bs:
+        off[1:] = np.cumsum([len(x) for x in bs])
+    return np.frombuffer(b''.join(bs) + b'\0', dtype=np.uint8), off
+
+
+class EditPlan(object):
+    """Pairs of strings resident on the GPU: run() the edit distances any number of times, fetch() the int32 array."""
+
+    def __init__(self, ctx, xs, ys):
+        if len(xs) != len(ys):
+            raise ValueError('EditPlan: the two lists differ in length')
+        self.n = len(xs)
+        a, a_off = _pack_bytes(xs)
+        b, b_off = _pack_bytes(ys)
+        self._h = lib().clh_edit_plan_create(ctx._h, self.n, a.ctypes.data, a_off.ctypes.data, b.ctypes.data, b_off.ctypes.data)
+        if not self._h:
+            raise ClhError('clh_edit_plan_create failed: %s' % last_error())
+
+    def run(self, stream=0):
+        rc = lib().clh_edit_plan_run(self._h, C.c_void_p(stream))
+        if rc != 0:
+            raise ClhError('clh_edit_plan_run failed (%d): %s' % (rc, last_error()))
+
+    def fetch(self):
+        out = np.zeros(self.n, dtype=np.int32)
+        rc = lib().clh_edit_plan_fetch(self._h, out.ctypes.data)
+        if rc != 0:
+            raise ClhError('clh_edit_plan_fetch failed (%d): %s' % (rc, last_error()))
+        return out
+
+    def timing(self):
+        ms = C.c_float(0)
+        if lib().clh_edit_plan_timing(self._h, C.byref(ms)) != 0:
+            raise ClhError('clh_edit_plan_timing: %s' % last_error())
+        return float(ms.value)
+
+    def close(self):
+        if self._h:
+            lib().clh_edit_plan_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Genome(object):

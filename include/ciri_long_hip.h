@@ -170,6 +170,14 @@ int clh_ssw_windows_batch(clh_genome* genome, int32_t n, const int8_t* reads, co
 int clh_edit_distance_batch(clh_ctx* ctx, int32_t n, const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off,
                             int32_t* out);
 
+/* the same in three steps, for batches that stay resident (strings uploaded once, any number of runs) */
+typedef struct clh_edit_plan clh_edit_plan;
+clh_edit_plan* clh_edit_plan_create(clh_ctx* ctx, int32_t n, const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off);
+void clh_edit_plan_destroy(clh_edit_plan* plan);
+int clh_edit_plan_run(clh_edit_plan* plan, void* stream);
+int clh_edit_plan_fetch(clh_edit_plan* plan, int32_t* out);
+int clh_edit_plan_timing(clh_edit_plan* plan, float* ms);       /* HIP-event duration of the last run */
+
 /* ASCII -> codes exactly as ssw_wrap.py:234-252 (A/a C/c G/g T/t N/n, anything else 4), on the host. */
 void clh_encode_dna(const char* seq, int64_t len, int8_t* out);
 

@@ -555,20 +555,20 @@ struct clh_edit_plan {
     int n = 0, planes = 3;
     std::vector<clh::EdTask> tasks;          // launch order (by lane-group class, longest text first)
     std::vector<int32_t> trivial;            // out[k] for pairs with an empty side, -1 otherwise
-    void *d_sym = nullptr, *d_tasks = nullptr, *d_out = nullptr;
+    void *d_sym = nullptr, *d_tasks = nullptr, *d_out = nullptr, *d_carry = nullptr;
     hipStream_t last_stream = nullptr;
     bool ran = false;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
-static int ed_group(const clh::EdTask& t) { int B = (t.pat_len + 63) >> 6, G = 1; while (G < B) G <<= 1; return G; }
+static int ed_group(const clh::EdTask& t) { int B = (t.pat_len + 63) >> 6, G = 1; while (G < B && G < 64) G <<= 1; return G; }   // above 64 blocks: passes
 
 extern "C" void clh_edit_plan_destroy(clh_edit_plan* pl)
 {
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
-    pl->ctx->release(pl->d_sym); pl->ctx->release(pl->d_tasks); pl->ctx->release(pl->d_out);
+    pl->ctx->release(pl->d_sym); pl->ctx->release(pl->d_tasks); pl->ctx->release(pl->d_out); pl->ctx->release(pl->d_carry);
     for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
     delete pl;
 }
@@ -594,6 +594,7 @@ extern "C" clh_edit_plan* clh_edit_plan_create(clh_ctx* ctx, int32_t n, const ui
     for (int64_t i = 0; i < tb; ++i) sym[(size_t)(ta + i)] = (uint8_t)code[b[b_off[0] + i]];
     pl->trivial.assign((size_t)n, -1);
     pl->tasks.reserve((size_t)n);
+    size_t carry_bytes = 0;
     for (int k = 0; k < n; ++k) {
         const int64_t la = a_off[k + 1] - a_off[k], lb = b_off[k + 1] - b_off[k];
         if (la < 0 || lb < 0) { fail(CLH_E_ARG, "clh_edit_plan_create: offsets must ascend"); delete pl; return nullptr; }
@@ -603,8 +604,11 @@ extern "C" clh_edit_plan* clh_edit_plan_create(clh_ctx* ctx, int32_t n, const ui
         t.pat_off = a_is_pat ? a_off[k] - a_off[0] : ta + (b_off[k] - b_off[0]);
         t.txt_off = a_is_pat ? ta + (b_off[k] - b_off[0]) : a_off[k] - a_off[0];
         t.pat_len = (int32_t)(a_is_pat ? la : lb); t.txt_len = (int32_t)(a_is_pat ? lb : la);
-        t.out_index = k; t.pad = 0;
-        if (t.pat_len > 4096) { fail(CLH_E_UNSUPPORTED, "edit distance: the shorter string of a pair is longer than 4096 symbols"); delete pl; return nullptr; }
+        t.out_index = k; t.carry_off64 = -1;
+        if (t.pat_len > 4096) {      // swept in passes of 64 blocks: two buffers of one byte per text column (+ slack for 16-byte reads)
+            t.carry_off64 = (int32_t)(carry_bytes / 64);
+            carry_bytes += 2 * ((((size_t)t.txt_len + 63) & ~(size_t)63) + 64);
+        }
         pl->tasks.push_back(t);
     }
     std::stable_sort(pl->tasks.begin(), pl->tasks.end(), [&](const clh::EdTask& x, const clh::EdTask& y) {
@@ -616,7 +620,8 @@ extern "C" clh_edit_plan* clh_edit_plan_create(clh_ctx* ctx, int32_t n, const ui
     pl->d_sym = ctx->alloc(sym.size());
     pl->d_tasks = ctx->alloc(sizeof(clh::EdTask) * std::max<size_t>(nt, 1));
     pl->d_out = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
-    if (!pl->d_sym || !pl->d_tasks || !pl->d_out ||
+    if (carry_bytes) pl->d_carry = ctx->alloc(carry_bytes + 64);
+    if (!pl->d_sym || !pl->d_tasks || !pl->d_out || (carry_bytes && !pl->d_carry) ||
         hipMemcpy(pl->d_sym, sym.data(), sym.size(), hipMemcpyHostToDevice) != hipSuccess ||
         (nt && hipMemcpy(pl->d_tasks, pl->tasks.data(), sizeof(clh::EdTask) * nt, hipMemcpyHostToDevice) != hipSuccess)) {
         fail(CLH_E_HIP, "out of device memory or upload failed while building the edit-distance plan");
@@ -637,7 +642,7 @@ extern "C" int clh_edit_plan_run(clh_edit_plan* pl, void* stream_)
         const int G = ed_group(pl->tasks[(size_t)i]);
         int j = i;
         while (j < nt && ed_group(pl->tasks[(size_t)j]) == G) ++j;
-        HIPCHK(clh::launch_edit_distance((const uint8_t*)pl->d_sym, (const clh::EdTask*)pl->d_tasks + i, j - i, G, pl->planes, (int32_t*)pl->d_out, st));
+        HIPCHK(clh::launch_edit_distance((const uint8_t*)pl->d_sym, (const clh::EdTask*)pl->d_tasks + i, j - i, G, pl->planes, (int32_t*)pl->d_out, (int8_t*)pl->d_carry, st));
         i = j;
     }
     HIPCHK(hipEventRecord(pl->ev[1], st));
@@ -671,7 +676,7 @@ extern "C" int clh_edit_distance_batch(clh_ctx* ctx, int32_t n, const uint8_t* a
     if (!out) return fail(CLH_E_ARG, "clh_edit_distance_batch: null argument");
     if (n == 0) return 0;
     clh_edit_plan* pl = clh_edit_plan_create(ctx, n, a, a_off, b, b_off);
-    if (!pl) return g_err.find("longer than 4096") != std::string::npos ? CLH_E_UNSUPPORTED : CLH_E_ARG;
+    if (!pl) return CLH_E_ARG;
     int rc = clh_edit_plan_run(pl, nullptr);
     if (!rc) rc = clh_edit_plan_fetch(pl, out);
     clh_edit_plan_destroy(pl);

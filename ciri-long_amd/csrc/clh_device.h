@@ -108,12 +108,13 @@ inline size_t k2_long_slot_bytes(int lmax) { return ((size_t)8 * ((size_t)lmax /
 struct EdTask {            // K4: one pair; the pattern is the shorter string
     int64_t pat_off, txt_off;   // into the packed symbol array (codes 0..nsym-1, one per byte)
     int32_t pat_len, txt_len;
-    int32_t out_index, pad;
+    int32_t out_index;
+    int32_t carry_off64;        // pattern above 4096 symbols: its two between-pass delta buffers, in units of 64 bytes; else -1
 };
 hipError_t launch_genome_encode(const char* ascii, uint8_t* codes, unsigned int* block_n, long long len, hipStream_t stream);
 hipError_t launch_genome_count_n(const uint8_t* codes, const unsigned int* pre_n, const long long* off, const long long* len, long long* out, int n, hipStream_t stream);
 static constexpr int kGenomeBlock = 256;     // bases per entry of the N prefix table
-hipError_t launch_edit_distance(const uint8_t* seqs, const EdTask* tasks, int ntasks, int G, int planes, int32_t* out, hipStream_t stream);
+hipError_t launch_edit_distance(const uint8_t* seqs, const EdTask* tasks, int ntasks, int G, int planes, int32_t* out, int8_t* carry_ws, hipStream_t stream);
 
 static constexpr int kRvStrips = 1000;   // pseudo class: RV = 32 with row strips (reads longer than 4096 bases)
 extern const int kRvClasses[];

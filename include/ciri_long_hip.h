@@ -166,7 +166,7 @@ int clh_ssw_windows_batch(clh_genome* genome, int32_t n, const int8_t* reads, co
  * 153-159; python-Levenshtein for <= 50 characters, edlib otherwise -- the same integer), used pairwise by
  * cluster_sequence (collapse.py:466-473) and per candidate by avg_score (collapse.py:156-158).  Strings are compared
  * byte for byte (case-sensitive, like the reference); pair k is a[a_off[k]..a_off[k+1]) against b[b_off[k]..b_off[k+1]).
- * Limit: the shorter string of a pair at most 4096 bytes (CLH_E_UNSUPPORTED otherwise). */
+ * No length limit (a shorter string above 4096 bytes is swept in passes). */
 int clh_edit_distance_batch(clh_ctx* ctx, int32_t n, const uint8_t* a, const int64_t* a_off, const uint8_t* b, const int64_t* b_off,
                             int32_t* out);
 

@@ -95,9 +95,16 @@ def test_pairwise_matrix_as_cluster_sequence_builds_it():
 
 
 @pytest.mark.gpu
-def test_limits_fail_loudly():
+def test_many_symbols_and_long_strings():
     from ciri_long_amd import hip, utils
     assert utils.distance('ABCDEFGHI', 'ABCDEFGHJ') == 1                # more than 8 distinct symbols: 8 bit planes
-    with pytest.raises(hip.ClhError):
-        utils.distance('A' * 5000, 'C' * 5000)                      # shorter string above 4096
+    assert utils.distance('A' * 5000, 'C' * 5000) == 5000              # shorter string above 4096: passes of 64 blocks
     assert utils.distance('A' * 5000, 'C' * 100) == 5000
+    rng = random.Random(77)
+    xs, ys = [], []
+    for la in (4097, 5000, 8192, 8193, 12000):
+        a, b = _rand_pair(rng, la, related=True)
+        xs += [a, a]; ys += [b, ''.join(rng.choice('ACGT') for _ in range(la + 300))]
+    got = utils.distance_batch(xs + ['ACGT'], ys + ['AGGT'])
+    for x, y, d in zip(xs + ['ACGT'], ys + ['AGGT'], got):
+        assert int(d) == oracle_lib.oracle_edit_distance(x, y), (len(x), len(y))

@@ -274,16 +274,27 @@ __host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)
     return o + 64;
 }
 
+extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];     // K3's dynamic LDS block (POA_LDS_BYTES, declared below)
+static constexpr int POA_RERANK_LDS_KEYS = 1024;                       // new-node keys staged in LDS for the merge (8 KiB)
+
 // merge the nodes created by the last sequence ([n_old, n_new), keys ascending in creation order) into the rank order
 __device__ void poa_rerank(const PoaWs& w, int n_old, int n_new, int lane)
 {
     const int added = n_new - n_old;
-    // old node at rank r (key r<<20): new rank = r + #{new nodes with key < its key}
+    // old node at rank r (key r<<20): new rank = r + #{new nodes with key < its key}.  The binary search runs over the new
+    // keys in LDS (the H ring is idle here) instead of a chain of dependent HBM loads per probe.
+    long long* lkeys = (long long*)poa_lds;
+    const bool in_lds = added <= POA_RERANK_LDS_KEYS;
+    if (in_lds) {
+        for (int i = lane; i < added; i += 64) lkeys[i] = w.key[n_old + i];
+        __syncthreads();
+    }
     for (int r = 1 + lane; r <= n_old; r += 64) {
         const int v = w.order[r - 1];
         const long long k = (long long)r << 20;
         int lo = 0, hi = added;                      // lower_bound over new keys
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.key[n_old + mid] < k) lo = mid + 1; else hi = mid; }
+        if (in_lds) while (lo < hi) { const int mid = (lo + hi) >> 1; if (lkeys[mid] < k) lo = mid + 1; else hi = mid; }
+        else while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.key[n_old + mid] < k) lo = mid + 1; else hi = mid; }
         w.rank[v] = r + lo;
     }
     // new node i: new rank = 1 + i + #{old nodes with key <= its key} = 1 + i + clamp(key >> 20, 0, n_old)
@@ -346,7 +357,7 @@ __device__ unsigned long long g_t[8];
 static constexpr int POA_LDS_BYTES = 8192;           // ring of recent H rows (DP) / score per rank (heaviest path)
 static constexpr int POA_RING_SHORTS = POA_LDS_BYTES / 2;
 static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whose scores fit the LDS block
-extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];
+static_assert(POA_RERANK_LDS_KEYS * 8 <= POA_LDS_BYTES, "rerank keys must fit the K3 LDS block");
 #define lds_ring ((short*)poa_lds)
 
 // columns per lane, LDS row pitch and ring depth for a copy of m bases

@@ -1,3 +1,5 @@
+"""Debugging aid: one long-read alignment (row strips) through a debug build of the library (tools/strips_build.sh),
+printed for every combination of the CIGAR / second-best switches.  CLH_DBG_LIB names the library file."""
 import sys, os
 sys.path.insert(0, os.path.join(os.getcwd(), 'tests')); sys.path.insert(0, os.getcwd())
 import numpy as np

@@ -361,7 +361,7 @@ static_assert(POA_RERANK_LDS_KEYS * 8 <= POA_LDS_BYTES, "rerank keys must fit th
 #define lds_ring ((short*)poa_lds)
 
 // columns per lane, LDS row pitch and ring depth for a copy of m bases
-__device__ __forceinline__ int poa_cols(int m) { return m <= 128 ? 2 : (m <= 256 ? 4 : 8); }
+__device__ __forceinline__ int poa_cols(int m) { const int c = (m + 63) >> 6; return c < 2 ? 2 : (c > 8 ? 8 : c); }   // columns per lane
 __device__ __forceinline__ int poa_ring(int m) {
     const int W = 64 * poa_cols(m);
     const int lp = poa_pitch(m < W ? m : W);
@@ -388,7 +388,7 @@ __device__ __forceinline__ void far_row(const short* ptr, int (&h)[C], int& hpre
     asm volatile("" : "+v"(hprev));
 }
 
-// DP rows of one copy against the graph.  Lane l owns C adjacent columns (C = 2, 4, 8 by copy length), so a row of up to
+// DP rows of one copy against the graph.  Lane l owns C adjacent columns (C = 2..8: ceil(copy length / 64)), so a row of up to
 // W = 64*C columns is ONE step: one wide LDS read per source row, the candidates of the C cells in registers, an in-lane
 // max-plus scan, one cross-lane DPP scan, one wide LDS write, one wide direction-byte store.  Copies longer than W are
 // swept in passes of W columns (passes outer, rows inner); the value that leaves a row on the right is handed to the next
@@ -454,13 +454,10 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                     if (r - q < RING) {
                         const short* src = lds_ring + (q & rmask) * lp + C * lane + 8;
                         hprev = src[-1];
-                        if constexpr (C == 8) { const uint4 t = *(const uint4*)src; const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+                        // element-wise 16-bit LDS reads: sign extension comes with the load, and LDS instructions do not
+                        // occupy the VALU (a 128-bit read would cost one unpack instruction per cell)
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) h[k] = (k & 1) ? (int)u[k >> 1] >> 16 : (int)(short)(u[k >> 1] & 0xffff); }
-                        else if constexpr (C == 4) { const uint2 t = *(const uint2*)src; const uint32_t u[2] = {t.x, t.y};
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) h[k] = (k & 1) ? (int)u[k >> 1] >> 16 : (int)(short)(u[k >> 1] & 0xffff); }
-                        else { const uint32_t t = *(const uint32_t*)src; h[0] = (int)(short)(t & 0xffff); h[1] = (int)t >> 16; }
+                        for (int k = 0; k < C; ++k) h[k] = src[k];
                     } else {
                         far_row<C>(w.H + (size_t)q * gp + col0 + 7, h, hprev);
                         if (lane == 0 && pass > 0) hprev += W * POA_GAP;     // that element was stored in the previous pass's frame
@@ -505,28 +502,29 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                 if (col0 + 1 <= m) {
                     short* dst = cur + C * lane + 8;
                     uint8_t* dd = w.dir + (size_t)r * gp + col0 + 8;
-                    short* hd = w.H + (size_t)r * gp + col0 + 8;
-                    if constexpr (C == 8) {
-                        uint4 t;
-                        t.x = ((uint32_t)fin[0] >> 8 & 0xffffu) | ((uint32_t)(fin[1] >> 8) << 16); t.y = ((uint32_t)fin[2] >> 8 & 0xffffu) | ((uint32_t)(fin[3] >> 8) << 16);
-                        t.z = ((uint32_t)fin[4] >> 8 & 0xffffu) | ((uint32_t)(fin[5] >> 8) << 16); t.w = ((uint32_t)fin[6] >> 8 & 0xffffu) | ((uint32_t)(fin[7] >> 8) << 16);
-                        *(uint4*)dst = t;
-                        uint2 bb;
-                        bb.x = ((uint32_t)fin[0] & 0xffu) | (((uint32_t)fin[1] & 0xffu) << 8) | (((uint32_t)fin[2] & 0xffu) << 16) | ((uint32_t)fin[3] << 24);
-                        bb.y = ((uint32_t)fin[4] & 0xffu) | (((uint32_t)fin[5] & 0xffu) << 8) | (((uint32_t)fin[6] & 0xffu) << 16) | ((uint32_t)fin[7] << 24);
-                        *(uint2*)dd = bb;
-                        if (keep) *(uint4*)hd = t;
-                    } else if constexpr (C == 4) {
-                        uint2 t;
-                        t.x = ((uint32_t)fin[0] >> 8 & 0xffffu) | ((uint32_t)(fin[1] >> 8) << 16); t.y = ((uint32_t)fin[2] >> 8 & 0xffffu) | ((uint32_t)(fin[3] >> 8) << 16);
-                        *(uint2*)dst = t;
-                        *(uint32_t*)dd = ((uint32_t)fin[0] & 0xffu) | (((uint32_t)fin[1] & 0xffu) << 8) | (((uint32_t)fin[2] & 0xffu) << 16) | ((uint32_t)fin[3] << 24);
-                        if (keep) *(uint2*)hd = t;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) dst[k] = (short)(fin[k] >> 8);        // ds_write_b16 takes the low half: no packing
+                    // direction bytes: C contiguous bytes per lane, as the widest stores their count allows
+                    uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+                    for (int k = 0; k < C && k < 4; ++k) d0 |= ((uint32_t)fin[k] & 0xffu) << (8 * k);
+#pragma unroll
+                    for (int k = 4; k < C; ++k) d1 |= ((uint32_t)fin[k] & 0xffu) << (8 * (k - 4));
+                    if constexpr (C == 8) *(uint2*)dd = make_uint2(d0, d1);
+                    else if constexpr (C >= 4) {
+                        __builtin_memcpy(dd, &d0, 4);
+                        if constexpr (C == 5) dd[4] = (uint8_t)d1;
+                        if constexpr (C >= 6) { const uint16_t lo = (uint16_t)d1; __builtin_memcpy(dd + 4, &lo, 2); }
+                        if constexpr (C == 7) dd[6] = (uint8_t)(d1 >> 16);
                     } else {
-                        const uint32_t t = ((uint32_t)fin[0] >> 8 & 0xffffu) | ((uint32_t)(fin[1] >> 8) << 16);
-                        *(uint32_t*)dst = t;
-                        *(uint16_t*)dd = (uint16_t)(((uint32_t)fin[0] & 0xffu) | (((uint32_t)fin[1] & 0xffu) << 8));
-                        if (keep) *(uint32_t*)hd = t;
+                        const uint16_t lo = (uint16_t)d0;
+                        __builtin_memcpy(dd, &lo, 2);
+                        if constexpr (C == 3) dd[2] = (uint8_t)(d0 >> 16);
+                    }
+                    if (keep) {
+                        short* hd = w.H + (size_t)r * gp + col0 + 8;
+#pragma unroll
+                        for (int k = 0; k < C; ++k) hd[k] = (short)(fin[k] >> 8);
                     }
                 }
                 if (keep && pass == 0 && lane == 0) w.H[(size_t)r * gp + 7] = 0;
@@ -599,9 +597,15 @@ __device__ int poa_add(const PoaWs& w, int N_, int ncap, int mcap, const int8_t*
             if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) { const int q = w.rank[w.pred[v * POA_MAXP + e]]; if (r - q >= RING) atomicOr(&ri32[q * 2], 0x8000u); } }
         }
         phase_sync();
-        if (m <= 128) dp_rows<2>(w, N, m, seq, lane, bs, br);
-        else if (m <= 256) dp_rows<4>(w, N, m, seq, lane, bs, br);
-        else dp_rows<8>(w, N, m, seq, lane, bs, br);
+        switch (poa_cols(m)) {            // columns per lane: the smallest that covers the copy in one pass (8 beyond 512)
+            case 2: dp_rows<2>(w, N, m, seq, lane, bs, br); break;
+            case 3: dp_rows<3>(w, N, m, seq, lane, bs, br); break;
+            case 4: dp_rows<4>(w, N, m, seq, lane, bs, br); break;
+            case 5: dp_rows<5>(w, N, m, seq, lane, bs, br); break;
+            case 6: dp_rows<6>(w, N, m, seq, lane, bs, br); break;
+            case 7: dp_rows<7>(w, N, m, seq, lane, bs, br); break;
+            default: dp_rows<8>(w, N, m, seq, lane, bs, br); break;
+        }
     }
     phase_sync();
     TSTAMP(0);

@@ -429,6 +429,9 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
         short* cnext = w.carry + (size_t)((pass + 1) & 1) * w.cpitch;
         uint2 blk = 1 + lane <= N ? w.ri[1 + lane] : make_uint2(0, 0);
         int cblk = pass > 0 && 1 + lane <= N ? (int)cprev[1 + lane] : 0;
+        int px[C], pcin = 0;                                     // the previous row of this pass, still in registers (see source())
+#pragma unroll
+        for (int k = 0; k < C; ++k) px[k] = 0;
         for (int rb = 1; rb <= N; rb += 64) {
             const int nr = rb + 64 + lane;
             const uint2 nxt = nr <= N ? w.ri[nr] : make_uint2(0, 0);           // next 64 graph rows, consumed after this block
@@ -451,7 +454,14 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                 }
                 auto source = [&](int e, int q) {
                     int h[C], hprev;
-                    if (r - q < RING) {
+                    if (q == r - 1) {
+                        // the row just computed (the usual source: a chain) is forwarded from registers; going through the
+                        // LDS ring would put a write->read round trip on every row's critical path
+#pragma unroll
+                        for (int k = 0; k < C; ++k) h[k] = px[k];
+                        hprev = __builtin_amdgcn_update_dpp(0, px[C - 1], 0x138, 0xf, 0xf, true);     // wave_shr:1
+                        hprev = lane == 0 ? pcin : hprev;
+                    } else if (r - q < RING) {
                         const short* src = lds_ring + (q & rmask) * lp + C * lane + 8;
                         hprev = src[-1];
                         // element-wise 16-bit LDS reads: sign extension comes with the load, and LDS instructions do not
@@ -498,12 +508,15 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                     const int a = run[k] > excl ? run[k] : excl;
                     fin[k] = best[k] > a ? best[k] : a;
                 }
+#pragma unroll
+                for (int k = 0; k < C; ++k) px[k] = fin[k] >> 8;
+                pcin = cin;
                 if (lane == 0) cur[7] = (short)cin;              // element of local column 0: the left neighbour of cell 0
                 if (col0 + 1 <= m) {
                     short* dst = cur + C * lane + 8;
                     uint8_t* dd = w.dir + (size_t)r * gp + col0 + 8;
 #pragma unroll
-                    for (int k = 0; k < C; ++k) dst[k] = (short)(fin[k] >> 8);        // ds_write_b16 takes the low half: no packing
+                    for (int k = 0; k < C; ++k) dst[k] = (short)px[k];                 // ds_write_b16 takes the low half: no packing
                     // direction bytes: C contiguous bytes per lane, as the widest stores their count allows
                     uint32_t d0 = 0, d1 = 0;
 #pragma unroll
@@ -524,7 +537,7 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                     if (keep) {
                         short* hd = w.H + (size_t)r * gp + col0 + 8;
 #pragma unroll
-                        for (int k = 0; k < C; ++k) hd[k] = (short)(fin[k] >> 8);
+                        for (int k = 0; k < C; ++k) hd[k] = (short)px[k];
                     }
                 }
                 if (keep && pass == 0 && lane == 0) w.H[(size_t)r * gp + 7] = 0;

@@ -12,8 +12,8 @@ The mapper stays external and pluggable: ``env.ALIGNER.map(seq)`` (mappy, bwapy 
 from collections import defaultdict
 
 from . import env
-from .align import (find_annotated_signal, find_denovo_signal, find_host_gene, get_blocks, get_primary_alignment,
-                    merge_clip_exon)
+from .align import (find_annotated_signal, find_denovo_signal, find_host_gene, get_blocks, get_parital_blocks,
+                    get_primary_alignment, merge_clip_exon, merge_exons, remove_long_insert)
 from .utils import grouper, revcomp
 
 CLIP_MIN = 20            # find_bsj.py:191
@@ -308,3 +308,134 @@ def recover_ccs_reads(short_reads, ref_fasta, ss_index, gtf_index, intron_index,
                 reads_count[key] += value
             _write_records(out, ret)
     return reads_count
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# third stage of `call`: reads without a cyclic consensus that still span one junction ("partial" candidates).
+# Mapper logic only -- no alignment kernel is involved; kept so that the module offers every stage of the reference's.
+# ---------------------------------------------------------------------------------------------------------------
+def _primary_hits(seq):
+    return sorted([h for h in env.ALIGNER.map(seq) if h.is_primary], key=lambda h: [h.q_st, h.q_en])
+
+
+def _raw_junction(seq, raw_hits):
+    """(circ, junc) when the raw read's primary hits look like one pass over a junction (find_bsj.py:512-541)"""
+    n = len(seq)
+    if len(raw_hits) == 1:
+        hit = remove_long_insert(raw_hits[0])
+        if hit.mlen < n * .45 or hit.mlen > n - 50:
+            return None
+        if hit.q_st < 50 and hit.q_en > n - 50:
+            return None
+        circ, junc = find_bsj(seq)
+        return None if junc is None else (circ, junc)
+    if len(raw_hits) == 2:
+        head, tail = remove_long_insert(raw_hits[0]), remove_long_insert(raw_hits[1])
+        if head.ctg != tail.ctg or not head.q_st + head.mlen * 0.45 < tail.q_st:
+            return None
+        if head.r_en - 20 < tail.r_st or head.q_en < tail.q_st - 50:
+            return None
+        circ, junc = find_bsj(seq)
+        if junc is None or junc < head.q_en - 10 or junc > tail.q_st + 10:
+            return None
+        return circ, junc
+    return None
+
+
+def _raw_layout(seq, circ, junc, raw_hits):
+    """(ctg, start, end, strand, clip_base, exons, circ) from the hits of the rotated read (find_bsj.py:543-579)"""
+    n = len(seq)
+    circ_hits = sorted([remove_long_insert(h) for h in env.ALIGNER.map(circ) if h.is_primary], key=lambda h: [h.q_st, h.q_en])
+    if len(circ_hits) == 1:
+        hit = circ_hits[0]
+        if hit.mlen <= max(h.mlen for h in raw_hits) or min(junc, n - junc) < 30:
+            return None
+        if not junc + hit.q_st < n < junc + hit.q_en:
+            return None
+        return hit.ctg, hit.r_st, hit.r_en, hit.strand, hit.q_st + n - hit.q_en, get_parital_blocks(hit, n - junc), circ
+    if len(circ_hits) == 2:
+        head, tail = circ_hits
+        if head.ctg != tail.ctg or head.strand != tail.strand:
+            return None
+        if not head.q_st + (head.q_en - head.q_st) * 0.5 < tail.q_st:
+            return None
+        if head.r_en - 20 < tail.r_st or head.q_en < tail.q_st - 20:
+            return None
+        exons = merge_exons(get_blocks(tail), get_blocks(head))
+        return head.ctg, tail.r_st, head.r_en, head.strand, abs(tail.q_st - head.q_en), exons, circ[tail.q_st:] + circ[:tail.q_st]
+    return None
+
+
+def scan_raw_chunk(chunk, is_canonical, circ_reads):
+    """[(read_id, seq)] -> (counters, 'partial' records, short reads) (find_bsj.py:499-620)"""
+    reads_cnt = defaultdict(int)
+    ret, short_reads = [], []
+    for read_id, seq in chunk:
+        if read_id in circ_reads:
+            continue
+        if len(seq) < 300:
+            short_reads.append((read_id, seq))
+            continue
+        raw_hits = _primary_hits(seq)
+        if not raw_hits:
+            continue
+        cand = _raw_junction(seq, raw_hits)
+        if cand is None:
+            continue
+        circ, junc = cand
+        layout = _raw_layout(seq, circ, junc, raw_hits)
+        if layout is None:
+            continue
+        ctg, start, end, circ_strand, clip_base, exons, circ = layout
+        if clip_base > 20:
+            continue
+        host_strand = find_host_gene(ctg, start, end)
+        ss_site, us_free, ds_free, tmp_signal = find_annotated_signal(ctg, start, end, clip_base, clip_base + 10)
+        if ss_site is None:
+            ss_site = find_denovo_signal(ctg, start, end, host_strand, tmp_signal, us_free, ds_free, clip_base, clip_base + 10, 3, True)
+        if ss_site is None:
+            ss_id, strand, shift = 'NA', 'NA', 0
+        else:
+            ss_id, strand, us_shift, ds_shift = ss_site
+            start += us_shift
+            end += ds_shift
+            shift = min(max(us_shift, -us_free), ds_free)       # sign of us_free as in find_bsj.py:598 (differs from :300)
+        exons[0][0] = start
+        exons[-1][1] = end
+        exon_tag = ','.join('{}-{}|{}'.format(a, b, length) for a, b, length in exons)     # 0-based starts here (find_bsj.py:606)
+        out_seq = circ if circ_strand > 0 else revcomp(circ)
+        out_seq = out_seq[shift:] + out_seq[:shift]
+        ret.append((read_id, '{}:{}-{}'.format(ctg, start + 1, end), strand, exon_tag, ss_id, '{}|{}-NA'.format(junc, clip_base),
+                    'partial', out_seq))
+        reads_cnt['partial'] += 1
+    return reads_cnt, ret, short_reads
+
+
+def scan_raw_reads(in_file, ref_fasta, gtf_index, intron_index, ss_index, is_canonical, out_dir, prefix, threads,
+                   aligner=None, genome=None, contig_len=None):
+    """Stage driver (find_bsj.py:623-720): every read of the input that is not already in cand_circ.fa, chunks of 1000,
+    records to {prefix}.low_confidence.fa.  ``aligner``/``genome``/``contig_len`` may be injected as in scan_ccs_reads
+    (the reference serves sequences from the mappy index itself)."""
+    from .find_ccs import iter_reads
+    circ_reads = {}
+    with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'r') as f:
+        for line in f:
+            circ_reads[line.rstrip().split()[0].lstrip('>')] = 1
+            f.readline()
+    if aligner is None:
+        import mappy as mp
+        aligner = mp.Aligner(ref_fasta, n_threads=threads, preset='splice')
+    if contig_len is None:
+        from .align import Fasta
+        contig_len = Fasta(ref_fasta).contig_len
+    env.initializer(aligner, contig_len, aligner if genome is None else genome, gtf_index, intron_index, ss_index)
+    reads_cnt = defaultdict(int)
+    short_reads = []
+    with open('{}/{}.low_confidence.fa'.format(out_dir, prefix), 'w') as out:
+        for reads in grouper(iter_reads(in_file), 1000):
+            cnt, ret, short = scan_raw_chunk([r for r in reads if r is not None], is_canonical, circ_reads)
+            for key, value in cnt.items():
+                reads_cnt[key] += value
+            short_reads += short
+            _write_records(out, ret)
+    return reads_cnt, short_reads

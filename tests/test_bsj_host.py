@@ -160,3 +160,32 @@ def test_scan_ccs_chunk_on_gpu(golden, world):
     _same_records(ret, g['records'], set(golden['tied_reads']))
     cnt, ret = find_bsj.recover_ccs_chunk(world['reads'], True)
     _same_records(ret, golden['recover_ccs_chunk']['records'], set(golden['tied_reads']))
+
+
+def test_scan_raw_chunk_matches_reference(world):
+    """third stage of `call` (find_bsj.py:499-620): mapper logic only, golden from the reference's own function"""
+    from ciri_long_amd import find_bsj
+    with gzip.open(os.path.join(HERE, 'golden', 'raw_golden.json.gz'), 'rt') as f:
+        g = json.load(f)
+    assert not g['any_tie']
+    reads = [tuple(r) for r in g['reads']]
+    cnt, ret, short = find_bsj.scan_raw_chunk(reads, True, {k: 1 for k in g['skip']})
+    assert dict(cnt) == g['counters'] and g['counters'].get('partial', 0) >= 5
+    assert _tolist([list(r) for r in ret]) == g['records']
+    assert _tolist([list(s) for s in short]) == g['short']
+
+
+def test_scan_raw_reads_driver(world, tmp_path):
+    from ciri_long_amd import find_bsj
+    with gzip.open(os.path.join(HERE, 'golden', 'raw_golden.json.gz'), 'rt') as f:
+        g = json.load(f)
+    fa = tmp_path / 'reads.fa'
+    fa.write_text(''.join('>%s extra\n%s\n' % (h, s) for h, s in g['reads']))
+    (tmp_path / 'p.cand_circ.fa').write_text(''.join('>%s\tx\n%s\n' % (k, 'ACGT') for k in g['skip']))
+    cnt, short = find_bsj.scan_raw_reads(str(fa), None, world['gtf_index'], None, world['ss_index'], True, str(tmp_path), 'p', 1,
+                                         aligner=world['mapper'], genome=world['genome'], contig_len=world['genome'].contig_len)
+    assert dict(cnt) == g['counters'] and _tolist([list(x) for x in short]) == g['short']
+    lines = (tmp_path / 'p.low_confidence.fa').read_text().split('\n')
+    assert len(lines) == 2 * len(g['records']) + 1
+    for k, r in enumerate(g['records']):
+        assert lines[2 * k] == '>{}\t{}\t{}\t{}\t{}\t{}\t{}'.format(*r[:7]) and lines[2 * k + 1] == r[7]

@@ -189,3 +189,38 @@ def test_scan_raw_reads_driver(world, tmp_path):
     assert len(lines) == 2 * len(g['records']) + 1
     for k, r in enumerate(g['records']):
         assert lines[2 * k] == '>{}\t{}\t{}\t{}\t{}\t{}\t{}'.format(*r[:7]) and lines[2 * k + 1] == r[7]
+
+
+def test_window_route_host_logic_on_cpu(golden, world, monkeypatch):
+    """find_bsj with a resident genome (windows as coordinates): the host side of that route -- deferred N filter, strand
+    flags, None for rejected windows -- with the two device calls replaced by CPU stand-ins (test infrastructure)."""
+    from ciri_long_amd import env, find_bsj, ssw_wrap, utils
+
+    class FakeDevice(object):
+        def __init__(self, genome):
+            self.genome = genome
+
+        def count_n(self, wins):
+            return [self.genome.seq(c, s, e).count('N') for c, s, e in wins]
+
+    class Wrapped(object):
+        def __init__(self, genome):
+            self.host, self.device, self.contig_len = genome, FakeDevice(genome), genome.contig_len
+
+        def seq(self, ctg, start, end):
+            return self.host.seq(ctg, start, end)
+
+    def align_windows(device, wins, minus, queries, match=2, mismatch=2, gap_open=3, gap_extend=1, **kw):
+        refs = [device.genome.seq(c, s, e) for c, s, e in wins]
+        refs = [utils.revcomp(r) if m else r for r, m in zip(refs, minus)]
+        return _oracle_pairs(refs, queries, match, mismatch, gap_open, gap_extend)
+
+    monkeypatch.setattr(ssw_wrap, 'align_windows', align_windows)
+    env.initializer(world['mapper'], world['genome'].contig_len, Wrapped(world['genome']), world['gtf_index'], None, world['ss_index'])
+    try:
+        cnt, short, ret = find_bsj.scan_ccs_chunk(world['reads'], True)
+    finally:
+        env.initializer(world['mapper'], world['genome'].contig_len, world['genome'], world['gtf_index'], None, world['ss_index'])
+    g = golden['scan_ccs_chunk']
+    assert dict(cnt) == g['counters']
+    _same_records(ret, g['records'], set(golden['tied_reads']))

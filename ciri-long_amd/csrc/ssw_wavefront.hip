@@ -161,7 +161,7 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
     // one step of the wavefront: reads the previous column from HR, writes the current one to HW.
     // Returns 1 when the pass must end (8-bit overflow or terminate score met).
     auto step = [&](const int t, const int sb, const uint32_t bHC, const uint32_t bM, uint32_t (&HR)[RV], uint32_t (&HW)[RV],
-                    int& ring, int& ringHC) -> int {
+                    int& ring, int& ringHC, uint32_t& cmOut) -> int {
         RB = hand_down(RB, (uint32_t)sb);
         const uint32_t aLo = (RB & 0xffffu) * BASE_STRIDE + lane * 16;
         const uint32_t aHi = (RB >> 16) * BASE_STRIDE + lane * 16;
@@ -216,6 +216,7 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
             const uint32_t vm = ((uint32_t)jLo < (uint32_t)ncols ? 0x0000ffffu : 0u) | ((uint32_t)jHi < (uint32_t)ncols ? 0xffff0000u : 0u);
             cmv = cm & vm;
         }
+        if constexpr (LEAN) { cmOut = cmv; return 0; }     // the lean pass resolves the best cell once per pair of steps (below)
         const uint32_t nb = pk_max(best, cmv);
         const uint32_t ch = nb ^ best;
         best = nb;
@@ -262,13 +263,33 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
         nxtb = load_bnd(t0 + 64);
         int ring = 0, ringHC = 0;
         int done = 64;
+        // per-lane best (first column wins, strict >) and a snapshot of that column, for the step that wrote Hst
+        auto resolve = [&](const uint32_t cmv, const int t, const uint32_t (&Hst)[RV]) {
+            const uint32_t nb = pk_max(best, cmv);
+            const uint32_t ch = nb ^ best;
+            best = nb;
+            const int jLo = t - 2 * lane, jHi = jLo - 1;
+            const uint32_t m = ((ch & 0xffffu) ? 0x0000ffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
+            colLo = (ch & 0xffffu) ? jLo : colLo;
+            colHi = (ch >> 16) ? jHi : colHi;
+#pragma unroll
+            for (int k = 0; k < RV; ++k) SH[k] = (Hst[k] & m) | (SH[k] & ~m);
+        };
         for (int u = 0; u < 64; u += 2) {
+            uint32_t cmA = 0, cmB = 0;
             int r = step(t0 + u, __builtin_amdgcn_readlane(chunk, u), STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.x, u) : 0u,
-                         STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u) : 0u, HA, HB, ring, ringHC);
+                         STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u) : 0u, HA, HB, ring, ringHC, cmA);
             if (r) { stop = r; done = u + 1; break; }
             r = step(t0 + u + 1, __builtin_amdgcn_readlane(chunk, u + 1), STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.x, u + 1) : 0u,
-                     STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u + 1) : 0u, HB, HA, ring, ringHC);
+                     STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u + 1) : 0u, HB, HA, ring, ringHC, cmB);
             if (r) { stop = r; done = u + 2; break; }
+            if constexpr (LEAN) {
+                // both steps at once: overflow test and "did any lane improve"; the order of the two columns matters only
+                // inside the rare branch (HB holds the first step's column, HA the second's)
+                const uint32_t cm2 = pk_max(cmA, cmB);
+                if (!WORD) { if (__builtin_amdgcn_ballot_w64(pk_subus(cm2, ovf2) != 0u)) { stop = 2; break; } }
+                if (__builtin_amdgcn_ballot_w64(pk_max(best, cm2) != best)) { resolve(cmA, t0 + u, HB); resolve(cmB, t0 + u + 1, HA); }
+            }
         }
         const int col = t0 - 127 + lane;
         if (in.colmax && io.last) {

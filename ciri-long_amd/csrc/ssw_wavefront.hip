@@ -161,7 +161,7 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
     // one step of the wavefront: reads the previous column from HR, writes the current one to HW.
     // Returns 1 when the pass must end (8-bit overflow or terminate score met).
     auto step = [&](const int t, const int sb, const uint32_t bHC, const uint32_t bM, uint32_t (&HR)[RV], uint32_t (&HW)[RV],
-                    int& ring, int& ringHC, uint32_t& cmOut) -> int {
+                    int& ring, int& ringHC, uint32_t& cmOut, int& cmLastOut) -> int {
         RB = hand_down(RB, (uint32_t)sb);
         const uint32_t aLo = (RB & 0xffffu) * BASE_STRIDE + lane * 16;
         const uint32_t aHi = (RB >> 16) * BASE_STRIDE + lane * 16;
@@ -216,24 +216,10 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
             const uint32_t vm = ((uint32_t)jLo < (uint32_t)ncols ? 0x0000ffffu : 0u) | ((uint32_t)jHi < (uint32_t)ncols ? 0xffff0000u : 0u);
             cmv = cm & vm;
         }
-        if constexpr (LEAN) { cmOut = cmv; return 0; }     // the lean pass resolves the best cell once per pair of steps (below)
-        const uint32_t nb = pk_max(best, cmv);
-        const uint32_t ch = nb ^ best;
-        best = nb;
-        if (!WORD) flags |= (pk_subus(cmv, ovf2) != 0u) ? 1u : 0u;
-        if constexpr (!LEAN) flags |= (pk_subus(cmv, term2) != 0u) ? 2u : 0u;
-        if (__builtin_amdgcn_ballot_w64(ch != 0u)) {
-            const uint32_t m = ((ch & 0xffffu) ? 0x0000ffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
-            colLo = (ch & 0xffffu) ? jLo : colLo;
-            colHi = (ch >> 16) ? jHi : colHi;
-#pragma unroll
-            for (int k = 0; k < RV; ++k) SH[k] = (HW[k] & m) | (SH[k] & ~m);
-        }
-        if (!WORD) {
-            if (__builtin_amdgcn_ballot_w64((flags & 1u) != 0u)) return 2;
-        }
+        cmOut = cmv;                 // best cell, overflow and terminate are resolved once per pair of steps (below)
         // the last virtual lane has the finished column maximum of column t-127
         const int jl = t - 127;
+        cmLastOut = -1;
         if (!LEAN && jl >= 0 && jl < ncols) {
             const int cmLast = (int)((uint32_t)__builtin_amdgcn_readlane((int)outM, 63) >> 16);
             ring = lane == (t & 63) ? cmLast : ring;
@@ -241,7 +227,7 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
                 const uint32_t hL = (uint32_t)__builtin_amdgcn_readlane((int)outH, 63) >> 16, cL = (uint32_t)__builtin_amdgcn_readlane((int)outC, 63) >> 16;
                 ringHC = lane == (t & 63) ? (int)(hL | (cL << 16)) : ringHC;
             }
-            if (io.last && cmLast == in.terminate) { term_col = jl; return 1; }
+            cmLastOut = cmLast;
         }
         return 0;
     };
@@ -277,18 +263,24 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
         };
         for (int u = 0; u < 64; u += 2) {
             uint32_t cmA = 0, cmB = 0;
-            int r = step(t0 + u, __builtin_amdgcn_readlane(chunk, u), STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.x, u) : 0u,
-                         STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u) : 0u, HA, HB, ring, ringHC, cmA);
-            if (r) { stop = r; done = u + 1; break; }
-            r = step(t0 + u + 1, __builtin_amdgcn_readlane(chunk, u + 1), STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.x, u + 1) : 0u,
-                     STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u + 1) : 0u, HB, HA, ring, ringHC, cmB);
-            if (r) { stop = r; done = u + 2; break; }
-            if constexpr (LEAN) {
-                // both steps at once: overflow test and "did any lane improve"; the order of the two columns matters only
-                // inside the rare branch (HB holds the first step's column, HA the second's)
-                const uint32_t cm2 = pk_max(cmA, cmB);
-                if (!WORD) { if (__builtin_amdgcn_ballot_w64(pk_subus(cm2, ovf2) != 0u)) { stop = 2; break; } }
-                if (__builtin_amdgcn_ballot_w64(pk_max(best, cm2) != best)) { resolve(cmA, t0 + u, HB); resolve(cmB, t0 + u + 1, HA); }
+            int lastA = -1, lastB = -1;
+            step(t0 + u, __builtin_amdgcn_readlane(chunk, u), STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.x, u) : 0u,
+                 STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u) : 0u, HA, HB, ring, ringHC, cmA, lastA);
+            step(t0 + u + 1, __builtin_amdgcn_readlane(chunk, u + 1), STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.x, u + 1) : 0u,
+                 STRIPS ? (uint32_t)__builtin_amdgcn_readlane((int)cb.y, u + 1) : 0u, HB, HA, ring, ringHC, cmB, lastB);
+            // both steps at once: overflow, terminate and "did any lane improve".  The order of the two columns matters only
+            // inside the rare branches (HB holds the first step's column, HA the second's).  A pass that ends at the first
+            // step has computed one column too many: nothing of it is kept (done excludes it from the column-maximum
+            // stores; the exceeded flag may see it, which at worst triggers the exact re-run).
+            const uint32_t cm2 = pk_max(cmA, cmB);
+            if (!WORD) { if (__builtin_amdgcn_ballot_w64(pk_subus(cm2, ovf2) != 0u)) { stop = 2; done = u + 1; break; } }
+            if constexpr (!LEAN) {
+                flags |= (pk_subus(cm2, term2) != 0u) ? 2u : 0u;
+                if (io.last && lastA == in.terminate) { resolve(cmA, t0 + u, HB); term_col = t0 + u - 127; stop = 1; done = u + 1; break; }
+            }
+            if (__builtin_amdgcn_ballot_w64(pk_max(best, cm2) != best)) { resolve(cmA, t0 + u, HB); resolve(cmB, t0 + u + 1, HA); }
+            if constexpr (!LEAN) {
+                if (io.last && lastB == in.terminate) { term_col = t0 + u + 1 - 127; stop = 1; done = u + 2; break; }
             }
         }
         const int col = t0 - 127 + lane;

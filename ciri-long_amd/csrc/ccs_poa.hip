@@ -43,14 +43,19 @@ __device__ __forceinline__ void phase_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-// inclusive prefix maximum over the 64 lanes with DPP (row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 and
-// 31 to carry the row totals): 12 VALU instructions instead of 6 dependent ds_bpermute round trips through the LDS
+// inclusive prefix maximum over the 64 lanes: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 and 31 carry
+// the row totals.  The DPP modifier sits on the max itself (v_max_i32_dpp: dst = max(dpp(src), src)); a lane without a
+// valid DPP source is simply not written, so no fill value and no separate v_mov_dpp are needed -- 6 VALU instructions
+// (plus the 2 wait states a DPP read needs after a VALU write) instead of 24.
 __device__ __forceinline__ int wave_prefix_max(int v) {
-    constexpr int NEG = -(1 << 28);
-#define CLH_DPP_MAX(ctrl, rowmask) { const int o = __builtin_amdgcn_update_dpp(NEG, v, ctrl, rowmask, 0xf, false); v = o > v ? o : v; }
-    CLH_DPP_MAX(0x111, 0xf) CLH_DPP_MAX(0x112, 0xf) CLH_DPP_MAX(0x114, 0xf) CLH_DPP_MAX(0x118, 0xf)
-    CLH_DPP_MAX(0x142, 0xa) CLH_DPP_MAX(0x143, 0xc)
-#undef CLH_DPP_MAX
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
     return v;
 }
 

@@ -375,11 +375,12 @@ __device__ __forceinline__ int poa_ring(int m) {
     return ring;
 }
 
-// direction byte = POA_ORD_HORIZ - ordinal of the winning candidate in the specification's evaluation order:
-// diagonal from in-edge e (ordinal e), diagonal from row 0 (12), vertical from in-edge e (13+e), horizontal (25).
-// A candidate is carried as (value << 8) | (25 - ordinal) (horizontal = 0), so one signed max per candidate both takes the larger
-// value and, between equal values, keeps the earlier candidate -- the strict '>' chain of the specification.
-static constexpr int POA_ORD_ROW0 = 12, POA_ORD_VERT = 13, POA_ORD_HORIZ = 25;
+// direction byte: a code that DEcreases along the specification's evaluation order -- diagonal from in-edge e: 0x3F - e,
+// diagonal from row 0: 0x20, vertical from in-edge e: 0x1F - e, horizontal: 0 -- so that a candidate carried as
+// (value << 8) | code needs one signed max to take the larger value and, between equal values, keep the earlier candidate
+// (the strict '>' chain of the specification).  The layout (move group in bits 4-5, 15 - slot in bits 0-3) makes the
+// decode of the walk-back two shifts and a subtraction.
+static constexpr int POA_CODE_DIAG = 0x3F, POA_CODE_ROW0 = 0x20, POA_CODE_VERT = 0x1F;
 
 // C+1 H values (columns first-1 .. first+C-1) of a far source row from HBM; assembly for the reason given at far_h
 template <int C>
@@ -411,7 +412,7 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
 {
     constexpr int NEG = -(1 << 30);
     constexpr int W = 64 * C;
-    constexpr int HCODE = 0;                                     // POA_ORD_HORIZ - POA_ORD_HORIZ: clearing the low byte makes a horizontal offer
+    constexpr int HCODE = 0;                                     // horizontal: clearing the low byte makes a horizontal offer
     constexpr int DIAG_MATCH = (POA_MATCH - POA_GAP) * 256, DIAG_MIS = (POA_MISMATCH - POA_GAP) * 256;
     const int npass = (m + W - 1) / W;
     const int gp = poa_pitch(m);                                 // row pitch of H and dir in HBM
@@ -429,7 +430,7 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
             const int c = j <= m ? (int)seq[j - 1] : 100;
             sb[k] = (c >= 0 && c < 4) ? c : 100;
         }
-        const int row0 = (pass * W) * (POA_GAP * 256) + (POA_ORD_HORIZ - POA_ORD_ROW0);   // row-0 diagonal: X = (j-1) gap + s - jl gap
+        const int row0 = (pass * W) * (POA_GAP * 256) + POA_CODE_ROW0;   // row-0 diagonal: X = (j-1) gap + s - jl gap
         const short* cprev = w.carry + (size_t)(pass & 1) * w.cpitch;
         short* cnext = w.carry + (size_t)((pass + 1) & 1) * w.cpitch;
         uint2 blk = 1 + lane <= N ? w.ri[1 + lane] : make_uint2(0, 0);
@@ -477,7 +478,7 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                         far_row<C>(w.H + (size_t)q * gp + col0 + 7, h, hprev);
                         if (lane == 0 && pass > 0) hprev += W * POA_GAP;     // that element was stored in the previous pass's frame
                     }
-                    const int cd = POA_ORD_HORIZ - e, cv = POA_GAP * 256 + POA_ORD_HORIZ - POA_ORD_VERT - e;
+                    const int cd = POA_CODE_DIAG - e, cv = POA_GAP * 256 + POA_CODE_VERT - e;
 #pragma unroll
                     for (int k = 0; k < C; ++k) {
                         const int up = k == 0 ? hprev : h[k - 1];
@@ -659,24 +660,21 @@ __device__ int poa_add(const PoaWs& w, int N_, int ncap, int mcap, const int8_t*
             const int byte = 15 - (b & 15), src_lane = a * 2 + (b >> 4);
             const uint32_t sel = (byte >> 2) == 0 ? pw0 : ((byte >> 2) == 1 ? pw1 : ((byte >> 2) == 2 ? pw2 : pw3));
             const int d = (__builtin_amdgcn_readlane((int)sel, src_lane) >> ((byte & 3) * 8)) & 0xff;
-            int kind = d & 3, e = d >> 4;
-            {                                             // bytes are POA_ORD_HORIZ - ordinal (see dp_rows)
-                const int ord = POA_ORD_HORIZ - d;
-                kind = ord <= POA_ORD_ROW0 ? 1 : (ord < POA_ORD_HORIZ ? 2 : 3);
-                e = ord < POA_ORD_ROW0 ? ord : (ord == POA_ORD_ROW0 ? 15 : ord - POA_ORD_VERT);
-            }
+            // code -> move: group 3 diagonal from in-edge e, 2 diagonal from row 0, 1 vertical from in-edge e, 0 horizontal
+            const int grp = d >> 4, e = 15 - (d & 15);
+            const int kind = grp == 0 ? 3 : (grp == 1 ? 2 : 1);
             int pre = 0;
-            if (kind != 3 && e != 15) {
-                if (e < 3) {
-                    const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2), q1 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2 + 1);
-                    pre = e == 0 ? (int)(q0 >> 16) : (e == 1 ? (int)(q1 & 0xffff) : (int)(q1 >> 16));
+            if (grp & 1) {                                // an in-edge slot (groups 3 and 1): rank of that source
+                if (e == 0) pre = (int)((uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2) >> 16);
+                else if (e < 3) {
+                    const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2 + 1);
+                    pre = e == 1 ? (int)(q1 & 0xffff) : (int)(q1 >> 16);
                 } else {
                     const int v = w.order[r - 1];
                     pre = __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + e]]);
                 }
             }
             if (kind == 2) { r = pre; continue; }
-            if (kind == 0) break;
             --j;
             buf = lane == (j & 63) ? (kind == 1 ? r : 0) : buf;
             if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }

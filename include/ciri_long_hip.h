@@ -24,6 +24,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)     /* the library itself is built with -fvisibility=hidden: only the C ABI is exported */
 
 #define CLH_E_HIP        (-1)   /* HIP runtime error (no device, launch failure, out of memory) */
 #define CLH_E_ARG        (-2)   /* invalid argument */
@@ -181,6 +182,7 @@ int clh_edit_plan_timing(clh_edit_plan* plan, float* ms);       /* HIP-event dur
 /* ASCII -> codes exactly as ssw_wrap.py:234-252 (A/a C/c G/g T/t N/n, anything else 4), on the host. */
 void clh_encode_dna(const char* seq, int64_t len, int8_t* out);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

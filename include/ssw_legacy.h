@@ -25,6 +25,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)     /* the library itself is built with -fvisibility=hidden: only the C ABI is exported */
 
 struct _profile;
 typedef struct _profile s_profile;
@@ -50,6 +51,7 @@ void align_destroy(s_align* a);
 char cigar_int_to_op(uint32_t cigar_int);
 uint32_t cigar_int_to_len(uint32_t cigar_int);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -448,8 +448,9 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
                 const int r = rb + i;
                 const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
                 const int cin = __builtin_amdgcn_readlane(cblk, i);             // H[r][pass*W] = X at local column 0; 0 in the first pass
-                const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0x7f);
+                const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0xf);
                 const bool keep = (d0 & 0x8000u) != 0;           // read later from HBM by a far successor
+                const bool tolds = (d0 & 0x4000u) != 0;          // read later from the LDS ring (a near source that is not the next row)
                 const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
                 short* cur = lds_ring + (r & rmask) * lp;
                 int best[C], ss[C];
@@ -517,12 +518,14 @@ __device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lan
 #pragma unroll
                 for (int k = 0; k < C; ++k) px[k] = fin[k] >> 8;
                 pcin = cin;
-                if (lane == 0) cur[7] = (short)cin;              // element of local column 0: the left neighbour of cell 0
+                if (tolds && lane == 0) cur[7] = (short)cin;     // element of local column 0: the left neighbour of cell 0
                 if (col0 + 1 <= m) {
                     short* dst = cur + C * lane + 8;
                     uint8_t* dd = w.dir + (size_t)r * gp + col0 + 8;
+                    if (tolds) {
 #pragma unroll
-                    for (int k = 0; k < C; ++k) dst[k] = (short)px[k];                 // ds_write_b16 takes the low half: no packing
+                        for (int k = 0; k < C; ++k) dst[k] = (short)px[k];             // ds_write_b16 takes the low half: no packing
+                    }
                     // direction bytes: C contiguous bytes per lane, as the widest stores their count allows
                     uint32_t d0 = 0, d1 = 0;
 #pragma unroll
@@ -605,15 +608,18 @@ __device__ int poa_add(const PoaWs& w, int N_, int ncap, int mcap, const int8_t*
         }
         phase_sync();
         // a row's H values go to HBM only if some later row reads them from there, i.e. it is a source of a row at
-        // least RING ranks further on (bit 15 of the in-degree byte field is free: in-degree <= 12)
+        // least RING ranks further on (bits 14 and 15 of the in-degree byte field are free: in-degree <= 12)
         for (int r = 1 + lane; r <= N; r += 64) {
             const uint2 d = w.ri[r];
-            const int np = (int)((d.x >> 8) & 0x7f);
+            const int np = (int)((d.x >> 8) & 0xf);
             const int p0 = (int)(d.x >> 16), p1 = (int)(d.y & 0xffff), p2 = (int)(d.y >> 16);
-            if (np > 0 && r - p0 >= RING) atomicOr(&ri32[p0 * 2], 0x8000u);
-            if (np > 1 && r - p1 >= RING) atomicOr(&ri32[p1 * 2], 0x8000u);
-            if (np > 2 && r - p2 >= RING) atomicOr(&ri32[p2 * 2], 0x8000u);
-            if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) { const int q = w.rank[w.pred[v * POA_MAXP + e]]; if (r - q >= RING) atomicOr(&ri32[q * 2], 0x8000u); } }
+            // where will row r read source p from?  the row before it: registers; another recent row: the LDS ring (0x4000);
+            // an older one: its row in HBM (0x8000).  Rows nobody reads from memory store nothing but direction bytes.
+            auto mark = [&](int q) { if (r - q >= RING) atomicOr(&ri32[q * 2], 0x8000u); else if (r - q >= 2) atomicOr(&ri32[q * 2], 0x4000u); };
+            if (np > 0) mark(p0);
+            if (np > 1) mark(p1);
+            if (np > 2) mark(p2);
+            if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) mark(w.rank[w.pred[v * POA_MAXP + e]]); }
         }
         phase_sync();
         switch (poa_cols(m)) {            // columns per lane: the smallest that covers the copy in one pass (8 beyond 512)

@@ -140,6 +140,8 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
     // H of the previous column is kept twice (HA/HB) and the step body is instantiated for both roles, so that the
     // "previous column" registers never have to be rotated at the loop back-edge.
     uint32_t HA[RV], HB[RV], E[RV], SH[RV];
+    constexpr bool QUAD = LEAN && RV <= 4;      // short-read classes of the lean pass: four steps per resolution (two more H files)
+    uint32_t HC[QUAD ? RV : 1], HD[QUAD ? RV : 1];
 #pragma unroll
     for (int k = 0; k < RV; ++k) { HA[k] = 0; HB[k] = 0; E[k] = 0; SH[k] = 0; }
     uint32_t outH = 0, outC = 0, outM = 0, diagIn = 0, best = 0, RB = dup16(CODE_NULL);
@@ -261,6 +263,22 @@ __device__ PassOut run_strip(const PassIn& in, const StripIo io, uint32_t* __res
 #pragma unroll
             for (int k = 0; k < RV; ++k) SH[k] = (Hst[k] & m) | (SH[k] & ~m);
         };
+        if constexpr (QUAD) {
+            // four steps back to back through four H register files (HA->HB->HC->HD->HA), one vote for the four columns
+            for (int u = 0; u < 64; u += 4) {
+                uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                int l0 = -1;
+                step(t0 + u, __builtin_amdgcn_readlane(chunk, u), 0u, 0u, HA, HB, ring, ringHC, c0, l0);
+                step(t0 + u + 1, __builtin_amdgcn_readlane(chunk, u + 1), 0u, 0u, HB, HC, ring, ringHC, c1, l0);
+                step(t0 + u + 2, __builtin_amdgcn_readlane(chunk, u + 2), 0u, 0u, HC, HD, ring, ringHC, c2, l0);
+                step(t0 + u + 3, __builtin_amdgcn_readlane(chunk, u + 3), 0u, 0u, HD, HA, ring, ringHC, c3, l0);
+                const uint32_t cm4 = pk_max(pk_max(c0, c1), pk_max(c2, c3));
+                if (!WORD) { if (__builtin_amdgcn_ballot_w64(pk_subus(cm4, ovf2) != 0u)) { stop = 2; done = u + 1; break; } }
+                if (__builtin_amdgcn_ballot_w64(pk_max(best, cm4) != best)) {
+                    resolve(c0, t0 + u, HB); resolve(c1, t0 + u + 1, HC); resolve(c2, t0 + u + 2, HD); resolve(c3, t0 + u + 3, HA);
+                }
+            }
+        } else
         for (int u = 0; u < 64; u += 2) {
             uint32_t cmA = 0, cmB = 0;
             int lastA = -1, lastB = -1;

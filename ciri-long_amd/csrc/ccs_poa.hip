@@ -280,7 +280,7 @@ __host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)
 }
 
 extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];     // K3's dynamic LDS block (POA_LDS_BYTES, declared below)
-static constexpr int POA_RERANK_LDS_KEYS = 1024;                       // new-node keys staged in LDS for the merge (8 KiB)
+static constexpr int POA_RERANK_LDS_KEYS = 768;                        // new-node keys staged in LDS for the merge (6 KiB)
 
 // merge the nodes created by the last sequence ([n_old, n_new), keys ascending in creation order) into the rank order
 __device__ void poa_rerank(const PoaWs& w, int n_old, int n_new, int lane)
@@ -359,7 +359,7 @@ __device__ unsigned long long g_t[8];
 #else
 #define TSTAMP(k) do {} while (0)
 #endif
-static constexpr int POA_LDS_BYTES = 8192;           // ring of recent H rows (DP) / score per rank (heaviest path)
+static constexpr int POA_LDS_BYTES = 6144;           // ring of recent H rows (DP) / score per rank (heaviest path)
 static constexpr int POA_RING_SHORTS = POA_LDS_BYTES / 2;
 static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whose scores fit the LDS block
 static_assert(POA_RERANK_LDS_KEYS * 8 <= POA_LDS_BYTES, "rerank keys must fit the K3 LDS block");
@@ -889,7 +889,7 @@ __device__ int poa_consensus(const PoaWs& w, int N_, int8_t* out, int cap, int l
     return len;
 }
 
-__global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
+__global__ void __launch_bounds__(64, 5) poa_consensus_kernel(const CcsParams p)
 {
     const int lane = threadIdx.x & 63;
     uint8_t* slot = p.poa_ws + (size_t)blockIdx.x * p.slot_bytes;

@@ -835,13 +835,13 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->lmax = lmax; pl->n_long = (int)long_idx.size();
     // Workspace.  The worst case of a read of L bases is a graph of L+8 nodes against copies of L/2 + L/16 bases (period
     // <= L/2, tolerance period/8; copies above 2800 bases are refused by the kernel) -- ~L^2 bytes, while the common case
-    // (period of a few hundred bases) needs a small fraction of that.  So: 4096 first-tier slots (16 waves per CU x 256
+    // (period of a few hundred bases) needs a small fraction of that.  So: 5120 first-tier slots (20 waves per CU x 256
     // CUs) share a fixed budget, and the reads that do not fit one (status 1 after the first launch) run in a second
     // launch over up to 1024 slots of worst-case size (64 GB at most: HBM is 288 GB).
     const int mcap_worst = mcap_hint > 0 ? mcap_hint + 1 : std::min(lmax / 2 + lmax / 16 + 8, 2801);
     const size_t need_worst = clh::poa_slot_bytes_host(lmax + 8, mcap_worst);
-    pl->nslots = (int)std::max<long long>(1, std::min<long long>(4096, std::max(n, 1)));
-    unsigned long long budget = 32ull << 30;
+    pl->nslots = (int)std::max<long long>(1, std::min<long long>(5120, std::max(n, 1)));
+    unsigned long long budget = 40ull << 30;
     if (const char* e = getenv("CLH_POA_BUDGET_MB")) budget = std::max(1ull, strtoull(e, nullptr, 10)) << 20;     // tests: force the second tier
     pl->slot_bytes = std::min<size_t>(need_worst, (size_t)((budget / (unsigned long long)pl->nslots) & ~255ull));
     if (pl->slot_bytes < need_worst) {

@@ -418,6 +418,47 @@ def find_denovo_signal(contig, start, end, host_strand, tmp_signal, us_free, ds_
     return None
 
 
+_MOTIFS = list(SPLICE_SIGNAL)      # K6 reports the motif as an index into this order
+
+
+def find_signal_batch(cands, is_canonical=True):
+    """The splice-signal step of find_bsj.py:286-301 for many candidates at once:
+    cands = [(contig, start, end, clip_base, host_strand)] -> [(ss_site | None, us_free, ds_free)], each entry what
+    find_annotated_signal followed (when it finds nothing) by find_denovo_signal(..., clip_base + 10, 3, is_canonical)
+    gives.  Candidates on contigs without annotated splice sites are scanned on the GPU when env.GENOME is resident
+    there (K6, splice_scan.hip); annotated contigs, and the candidates the kernel hands back (contig ends, characters
+    other than ACGTN), go through the functions above."""
+    out = [None] * len(cands)
+    dev = getattr(env.GENOME, 'device', None)
+    if not hasattr(dev, 'splice_signals'):
+        dev = None
+    on_gpu = []
+    for k, (ctg, start, end, clip_base, host) in enumerate(cands):
+        if dev is not None and ctg in dev.offset and (env.SS_INDEX is None or ctg not in env.SS_INDEX):
+            on_gpu.append(k)
+    if on_gpu:
+        rows = dev.splice_signals([(cands[k][0], cands[k][1], cands[k][2], cands[k][3],
+                                    (1 if cands[k][4] and '+' in cands[k][4] else 0) | (2 if cands[k][4] and '-' in cands[k][4] else 0))
+                                   for k in on_gpu], 10, 3, is_canonical)
+        for k, r in zip(on_gpu, rows.tolist()):
+            status, us_free, ds_free, found, strand, i, j, motif = r
+            if status != 0:
+                continue
+            site = None
+            if found:
+                donor, acceptor = _MOTIFS[motif]
+                site = ('{}-{}*|{}-{}'.format(acceptor, donor, i, j), '-' if strand else '+', i, j)
+            out[k] = (site, us_free, ds_free)
+    for k, (ctg, start, end, clip_base, host) in enumerate(cands):
+        if out[k] is not None:
+            continue
+        site, us_free, ds_free, tmp_signal = find_annotated_signal(ctg, start, end, clip_base, clip_base + 10)
+        if site is None:
+            site = find_denovo_signal(ctg, start, end, host, tmp_signal, us_free, ds_free, clip_base, clip_base + 10, 3, is_canonical)
+        out[k] = (site, us_free, ds_free)
+    return out
+
+
 def sort_ss(sites, us, ds, clip_base):
     """Rank candidate sites (id, strand, us_shift, ds_shift, weight, altered_len, clip_altered, altered_total) in four
     tiers (align.py:705-733) and return (id, strand, us_shift, ds_shift) of the winner.

@@ -347,6 +347,38 @@ extern "C" int clh_genome_count_n(clh_genome* g, int32_t n, const int64_t* off, 
     return rc;
 }
 
+// K6: splice signals around n candidate junctions of the resident genome (align.py:474-733 without annotation)
+extern "C" int clh_splice_signal_batch(clh_genome* g, int32_t n, const int64_t* ctg_off, const int64_t* ctg_len, const int64_t* start,
+                                       const int64_t* end, const int32_t* clip_base, const int32_t* host_mask, int32_t search_extra,
+                                       int32_t shift_threshold, int32_t is_canonical, int32_t* out)
+{
+    if (!g || n < 0 || (n > 0 && (!ctg_off || !ctg_len || !start || !end || !clip_base || !host_mask || !out)))
+        return fail(CLH_E_ARG, "clh_splice_signal_batch: null argument");
+    if (n == 0) return 0;
+    if (search_extra < 0 || shift_threshold < 0) return fail(CLH_E_ARG, "clh_splice_signal_batch: negative search length");
+    std::vector<clh::SpliceTask> tasks((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (ctg_off[i] < 0 || ctg_len[i] < 0 || ctg_off[i] + ctg_len[i] > g->len) return fail(CLH_E_ARG, "clh_splice_signal_batch: contig outside the genome");
+        if (clip_base[i] < 0 || clip_base[i] > 4096) return fail(CLH_E_ARG, "clh_splice_signal_batch: clip_base out of range");
+        clh::SpliceTask& t = tasks[(size_t)i];
+        t.ctg_off = ctg_off[i]; t.ctg_len = ctg_len[i]; t.start = start[i]; t.end = end[i]; t.clip_base = clip_base[i]; t.host_mask = host_mask[i];
+    }
+    clh_ctx* ctx = g->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t tb = sizeof(clh::SpliceTask) * (size_t)n, ob = sizeof(int32_t) * 8 * (size_t)n;
+    void* d_t = ctx->alloc(tb); void* d_o = ctx->alloc(ob);
+    int rc = 0;
+    if (!d_t || !d_o) rc = fail(CLH_E_HIP, "out of device memory");
+    if (!rc && (hipMemcpyAsync(d_t, tasks.data(), tb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                clh::launch_splice_scan((const uint8_t*)g->d_codes, (const clh::SpliceTask*)d_t, n, search_extra, shift_threshold, is_canonical ? 1 : 0,
+                                        (int32_t*)d_o, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(out, d_o, ob, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = fail(CLH_E_HIP, "splice-signal scan failed");
+    ctx->release(d_t); ctx->release(d_o);
+    return rc;
+}
+
 extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs, void* stream_)
 {
     if (!pl || !d_reads || !d_refs) return fail(CLH_E_ARG, "clh_ssw_run: null argument");

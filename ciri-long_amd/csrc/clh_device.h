@@ -112,6 +112,16 @@ struct EdTask {            // K4: one pair; the pattern is the shorter string
     int32_t carry_off64;        // pattern above 4096 symbols: its two between-pass delta buffers, in units of 64 bytes; else -1
 };
 hipError_t launch_genome_encode(const char* ascii, uint8_t* codes, unsigned int* block_n, long long len, hipStream_t stream);
+// K6: one candidate junction [start, end) of a contig of the resident genome (splice_scan.hip)
+struct SpliceTask {
+    int64_t ctg_off;      // first byte of the contig in the genome codes
+    int64_t ctg_len;
+    int64_t start, end;   // 0-based, end exclusive (circ_start, circ_end of find_bsj.py:279-301)
+    int32_t clip_base;
+    int32_t host_mask;    // strands of the host gene(s): bit 0 '+', bit 1 '-' (align.find_host_gene), 0 = none
+};
+hipError_t launch_splice_scan(const uint8_t* codes, const SpliceTask* tasks, int n, int search_extra, int shift_threshold, int canonical,
+                              int32_t* out, hipStream_t stream);
 hipError_t launch_genome_count_n(const uint8_t* codes, const unsigned int* pre_n, const long long* off, const long long* len, long long* out, int n, hipStream_t stream);
 static constexpr int kGenomeBlock = 256;     // bases per entry of the N prefix table
 hipError_t launch_edit_distance(const uint8_t* seqs, const EdTask* tasks, int ntasks, int G, int planes, int32_t* out, int8_t* carry_ws, hipStream_t stream);

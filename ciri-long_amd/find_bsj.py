@@ -12,7 +12,7 @@ The mapper stays external and pluggable: ``env.ALIGNER.map(seq)`` (mappy, bwapy 
 from collections import defaultdict
 
 from . import env
-from .align import (find_annotated_signal, find_denovo_signal, find_host_gene, get_blocks, get_parital_blocks,
+from .align import (find_signal_batch, find_host_gene, get_blocks, get_parital_blocks,
                     get_primary_alignment, merge_clip_exon, merge_exons, remove_long_insert)
 from .utils import grouper, revcomp
 
@@ -150,18 +150,23 @@ def _segment_span(segments):
     return int(parts[0].split('-')[0]), int(parts[-1].split('-')[1])
 
 
-def _assemble(read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_start, circ_end, clip_info, reads_cnt):
-    """Phase 3 for one read: splice signal, coordinates, exon tags, sequence rotation (find_bsj.py:279-323)."""
+def _signals(cands):
+    """[(contig, start, end, clip_base)] -> [(ss_site | None, us_free, ds_free)]: host gene, annotated sites, then the
+    de-novo search (find_bsj.py:286-301), one GPU batch where the genome is resident (align.find_signal_batch)."""
+    return find_signal_batch([(ctg, st, en, cb, find_host_gene(ctg, st, en)) for ctg, st, en, cb in cands], True)
+
+
+def _assemble(read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_start, circ_end, clip_info, reads_cnt, signal=None):
+    """Phase 3 for one read: splice signal, coordinates, exon tags, sequence rotation (find_bsj.py:279-323).
+    `signal`: this read's entry of _signals() when the caller batched that step."""
     clip_base = clip_info[2]
     if clip_base > 0.15 * len(ccs) or clip_base > 20:
         return None
     reads_cnt['bsj'] += 1
 
-    host_strand = find_host_gene(circ_hit.ctg, circ_start, circ_end)
-    ss_site, us_free, ds_free, tmp_signal = find_annotated_signal(circ_hit.ctg, circ_start, circ_end, clip_base, clip_base + 10)
-    if ss_site is None:
-        ss_site = find_denovo_signal(circ_hit.ctg, circ_start, circ_end, host_strand, tmp_signal, us_free, ds_free,
-                                     clip_base, clip_base + 10, 3, True)
+    if signal is None:
+        signal = _signals([(circ_hit.ctg, circ_start, circ_end, clip_base)])[0]
+    ss_site, us_free, ds_free = signal
     if ss_site is None:
         ss_id, strand, shift = 'NA', 'NA', 0
     else:
@@ -217,7 +222,7 @@ def _scan_chunk(chunk, raw_filters, min_circ_fraction):
         pending.append((read_id, segments, ccs, circ, junc, circ_hit, prep))
 
     results = iter(_run_clip_jobs(jobs))
-    ret = []
+    ready = []
     for read_id, segments, ccs, circ, junc, circ_hit, prep in pending:
         if isinstance(prep, _ClipJob):
             res = next(results)
@@ -225,7 +230,13 @@ def _scan_chunk(chunk, raw_filters, min_circ_fraction):
         clipped_circ, circ_start, circ_end, clip_info = prep
         if circ_start is None or circ_end is None:
             continue
-        rec = _assemble(read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_start, circ_end, clip_info, reads_cnt)
+        ready.append((read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_start, circ_end, clip_info))
+    # the splice-signal step of every read that will reach it, as one batch
+    live = [r for r in ready if not (r[9][2] > 0.15 * len(r[2]) or r[9][2] > 20)]
+    signals = dict(zip((id(r) for r in live), _signals([(r[5].ctg, r[7], r[8], r[9][2]) for r in live])))
+    ret = []
+    for r in ready:
+        rec = _assemble(*r, reads_cnt, signals.get(id(r)))
         if rec is not None:
             ret.append(rec)
     return reads_cnt, short_reads, ret
@@ -369,7 +380,7 @@ def _raw_layout(seq, circ, junc, raw_hits):
 def scan_raw_chunk(chunk, is_canonical, circ_reads):
     """[(read_id, seq)] -> (counters, 'partial' records, short reads) (find_bsj.py:499-620)"""
     reads_cnt = defaultdict(int)
-    ret, short_reads = [], []
+    ret, short_reads, laid = [], [], []
     for read_id, seq in chunk:
         if read_id in circ_reads:
             continue
@@ -386,13 +397,12 @@ def scan_raw_chunk(chunk, is_canonical, circ_reads):
         layout = _raw_layout(seq, circ, junc, raw_hits)
         if layout is None:
             continue
-        ctg, start, end, circ_strand, clip_base, exons, circ = layout
-        if clip_base > 20:
+        if layout[4] > 20:
             continue
-        host_strand = find_host_gene(ctg, start, end)
-        ss_site, us_free, ds_free, tmp_signal = find_annotated_signal(ctg, start, end, clip_base, clip_base + 10)
-        if ss_site is None:
-            ss_site = find_denovo_signal(ctg, start, end, host_strand, tmp_signal, us_free, ds_free, clip_base, clip_base + 10, 3, True)
+        laid.append((read_id, junc, layout))
+    signals = _signals([(lay[0], lay[1], lay[2], lay[4]) for _, _, lay in laid])
+    for (read_id, junc, layout), (ss_site, us_free, ds_free) in zip(laid, signals):
+        ctg, start, end, circ_strand, clip_base, exons, circ = layout
         if ss_site is None:
             ss_id, strand, shift = 'NA', 'NA', 0
         else:

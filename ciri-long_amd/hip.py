@@ -88,6 +88,8 @@ def lib():
         L.clh_genome_length.restype = C.c_int64
         L.clh_genome_length.argtypes = [C.c_void_p]
         L.clh_genome_count_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_splice_signal_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.clh_ssw_plan_windows.restype = C.c_void_p
         L.clh_ssw_plan_windows.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ssw_windows_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -365,6 +367,25 @@ class Genome(object):
         rc = lib().clh_genome_count_n(self._h, n, off.ctypes.data, ln.ctypes.data, out.ctypes.data)
         if rc != 0:
             raise ClhError('clh_genome_count_n failed (%d): %s' % (rc, last_error()))
+        return out
+
+    def splice_signals(self, cands, search_extra=10, shift_threshold=3, is_canonical=True):
+        """K6: cands = [(contig, start, end, clip_base, host_mask)] -> int32 array [n, 8]:
+        status, us_free, ds_free, found, strand, us_shift, ds_shift, motif (see include/ciri_long_hip.h)"""
+        n = len(cands)
+        out = np.zeros((n, 8), dtype=np.int32)
+        if n == 0:
+            return out
+        off = np.array([self.offset[c[0]] for c in cands], dtype=np.int64)
+        ln = np.array([self.length[c[0]] for c in cands], dtype=np.int64)
+        st = np.array([c[1] for c in cands], dtype=np.int64)
+        en = np.array([c[2] for c in cands], dtype=np.int64)
+        cb = np.array([c[3] for c in cands], dtype=np.int32)
+        hm = np.array([c[4] for c in cands], dtype=np.int32)
+        rc = lib().clh_splice_signal_batch(self._h, n, off.ctypes.data, ln.ctypes.data, st.ctypes.data, en.ctypes.data, cb.ctypes.data,
+                                           hm.ctypes.data, search_extra, shift_threshold, 1 if is_canonical else 0, out.ctypes.data)
+        if rc != 0:
+            raise ClhError('clh_splice_signal_batch failed (%d): %s' % (rc, last_error()))
         return out
 
     def ssw_windows(self, reads, read_off, windows, minus, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,

@@ -13,7 +13,7 @@ ctx = hip.default_context()
 B = 'ACGT'
 seed = int(time.time()) & 0xffff
 print('seed base', seed, flush=True)
-n_ssw = n_ccs = n_ed = n_null = 0
+n_ssw = n_ccs = n_ed = n_null = n_ss = 0
 it = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed + it)
@@ -83,5 +83,20 @@ while time.time() < t_end:
         if int(d[k]) != oracle_lib.oracle_edit_distance(xs[k], ys[k]):
             print('EDIT MISMATCH seed', seed + it - 1, 'k', k, len(xs[k]), len(ys[k]), int(d[k])); sys.exit(1)
     n_ed += len(xs)
-    print('round', it, 'ok: ssw', n_ssw, 'ccs', n_ccs, 'edit', n_ed, flush=True)
-print('fuzz ok:', n_ssw, 'alignments (%d where the reference returns NULL: TRACE_ERR),' % n_null, n_ccs, 'consensus calls,', n_ed, 'edit distances')
+    # ---- splice signals (K6) against the Python statement of the step ----
+    import test_gpu_splice as tgs
+    from ciri_long_amd import align, env
+    contigs, cands = tgs._world(seed + it, 1200)
+    host = tgs._Genome(contigs)
+    canon = bool(it & 1)
+    env.initializer(None, host.contig_len, host, None, None, None)
+    want = [tgs._host_answer(align, c, canon) for c in cands]
+    env.initializer(None, host.contig_len, align.DeviceGenome(host, contigs, ctx), None, None, None)
+    got = align.find_signal_batch(cands, canon)
+    env.GENOME.device.close()
+    for k in range(len(cands)):
+        if got[k] != want[k]:
+            print('SPLICE MISMATCH seed', seed + it, 'k', k, cands[k][1:4], got[k], want[k]); sys.exit(1)
+    n_ss += len(cands)
+    print('round', it, 'ok: ssw', n_ssw, 'ccs', n_ccs, 'edit', n_ed, 'splice', n_ss, flush=True)
+print('fuzz ok:', n_ssw, 'alignments (%d where the reference returns NULL: TRACE_ERR),' % n_null, n_ccs, 'consensus calls,', n_ed, 'edit distances,', n_ss, 'splice-signal searches')

@@ -425,18 +425,17 @@ def find_signal_batch(cands, is_canonical=True):
     """The splice-signal step of find_bsj.py:286-301 for many candidates at once:
     cands = [(contig, start, end, clip_base, host_strand)] -> [(ss_site | None, us_free, ds_free)], each entry what
     find_annotated_signal followed (when it finds nothing) by find_denovo_signal(..., clip_base + 10, 3, is_canonical)
-    gives.  Candidates on contigs without annotated splice sites are scanned on the GPU when env.GENOME is resident
-    there (K6, splice_scan.hip); annotated contigs, and the candidates the kernel hands back (contig ends, characters
-    other than ACGTN), go through the functions above."""
+    gives.  When env.GENOME is resident on the GPU the candidates are scanned there (K6, splice_scan.hip; env.SS_INDEX
+    is uploaded once as sorted position runs); the candidates the kernel hands back (contig ends, characters other than
+    ACGTN) go through the functions above."""
     out = [None] * len(cands)
     dev = getattr(env.GENOME, 'device', None)
     if not hasattr(dev, 'splice_signals'):
         dev = None
-    on_gpu = []
-    for k, (ctg, start, end, clip_base, host) in enumerate(cands):
-        if dev is not None and ctg in dev.offset and (env.SS_INDEX is None or ctg not in env.SS_INDEX):
-            on_gpu.append(k)
+    on_gpu = [k for k, c in enumerate(cands) if dev is not None and c[0] in dev.offset]
     if on_gpu:
+        if dev._sites_of is not env.SS_INDEX:
+            dev.set_splice_sites(env.SS_INDEX)
         rows = dev.splice_signals([(cands[k][0], cands[k][1], cands[k][2], cands[k][3],
                                     (1 if cands[k][4] and '+' in cands[k][4] else 0) | (2 if cands[k][4] and '-' in cands[k][4] else 0))
                                    for k in on_gpu], 10, 3, is_canonical)
@@ -445,9 +444,16 @@ def find_signal_batch(cands, is_canonical=True):
             if status != 0:
                 continue
             site = None
-            if found:
+            if found == 1:
                 donor, acceptor = _MOTIFS[motif]
                 site = ('{}-{}*|{}-{}'.format(acceptor, donor, i, j), '-' if strand else '+', i, j)
+            elif found == 2:          # a pair of annotated sites: the id shows the genome's own dinucleotides (align.py:549-556)
+                ctg, start, end = cands[k][:3]
+                us_ss = env.GENOME.seq(ctg, start + i - 2, start + i)
+                ds_ss = env.GENOME.seq(ctg, end + j, end + j + 2)
+                if strand:
+                    us_ss, ds_ss = revcomp(ds_ss), revcomp(us_ss)
+                site = ('{}-{}|{}-{}'.format(us_ss, ds_ss, i, j), '-' if strand else '+', i, j)
             out[k] = (site, us_free, ds_free)
     for k, (ctg, start, end, clip_base, host) in enumerate(cands):
         if out[k] is not None:

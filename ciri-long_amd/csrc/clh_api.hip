@@ -280,13 +280,15 @@ struct clh_genome {
     clh_ctx* ctx = nullptr;
     int64_t len = 0;
     void *d_codes = nullptr, *d_pre = nullptr;
+    void* d_sites = nullptr;                    // annotated splice sites (K6): four sorted runs of int64 in one buffer
+    int64_t n_sites[4] = {0, 0, 0, 0};
 };
 
 extern "C" void clh_genome_destroy(clh_genome* g)
 {
     if (!g) return;
     (void)hipSetDevice(g->ctx->device);
-    g->ctx->release(g->d_codes); g->ctx->release(g->d_pre);
+    g->ctx->release(g->d_codes); g->ctx->release(g->d_pre); g->ctx->release(g->d_sites);
     delete g;
 }
 
@@ -347,7 +349,38 @@ extern "C" int clh_genome_count_n(clh_genome* g, int32_t n, const int64_t* off, 
     return rc;
 }
 
-// K6: splice signals around n candidate junctions of the resident genome (align.py:474-733 without annotation)
+// K6: annotated splice sites of the resident genome (the SS_INDEX of align.py:235-252, 275-316) as four sorted runs
+extern "C" int clh_genome_set_splice_sites(clh_genome* g, const int64_t* pos, const int64_t* count4)
+{
+    if (!g || !count4) return fail(CLH_E_ARG, "clh_genome_set_splice_sites: null argument");
+    int64_t tot = 0;
+    for (int k = 0; k < 4; ++k) { if (count4[k] < 0) return fail(CLH_E_ARG, "clh_genome_set_splice_sites: negative count"); tot += count4[k]; }
+    if (tot > 0 && !pos) return fail(CLH_E_ARG, "clh_genome_set_splice_sites: null argument");
+    int64_t at = 0;
+    for (int k = 0; k < 4; ++k) {
+        for (int64_t i = 0; i < count4[k]; ++i) {
+            const int64_t v = pos[at + i];
+            if (v < 0 || v > g->len || (i > 0 && v <= pos[at + i - 1])) return fail(CLH_E_ARG, "clh_genome_set_splice_sites: positions must be strictly ascending and inside the genome");
+        }
+        at += count4[k];
+    }
+    clh_ctx* ctx = g->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->release(g->d_sites); g->d_sites = nullptr;
+    for (int k = 0; k < 4; ++k) g->n_sites[k] = 0;
+    if (tot == 0) return 0;
+    g->d_sites = ctx->alloc(sizeof(int64_t) * (size_t)tot);
+    if (!g->d_sites) return fail(CLH_E_HIP, "out of device memory");
+    if (hipMemcpyAsync(g->d_sites, pos, sizeof(int64_t) * (size_t)tot, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ctx->release(g->d_sites); g->d_sites = nullptr;
+        return fail(CLH_E_HIP, "splice-site upload failed");
+    }
+    for (int k = 0; k < 4; ++k) g->n_sites[k] = count4[k];
+    return 0;
+}
+
+// K6: splice signals around n candidate junctions of the resident genome (align.py:474-733)
 extern "C" int clh_splice_signal_batch(clh_genome* g, int32_t n, const int64_t* ctg_off, const int64_t* ctg_len, const int64_t* start,
                                        const int64_t* end, const int32_t* clip_base, const int32_t* host_mask, int32_t search_extra,
                                        int32_t shift_threshold, int32_t is_canonical, int32_t* out)
@@ -367,11 +400,14 @@ extern "C" int clh_splice_signal_batch(clh_genome* g, int32_t n, const int64_t* 
     HIPCHK(hipSetDevice(ctx->device));
     const size_t tb = sizeof(clh::SpliceTask) * (size_t)n, ob = sizeof(int32_t) * 8 * (size_t)n;
     void* d_t = ctx->alloc(tb); void* d_o = ctx->alloc(ob);
+    clh::SpliceSites sites;
+    int64_t at = 0;
+    for (int k = 0; k < 4; ++k) { sites.pos[k] = (const int64_t*)g->d_sites + at; sites.n[k] = g->n_sites[k]; at += g->n_sites[k]; }
     int rc = 0;
     if (!d_t || !d_o) rc = fail(CLH_E_HIP, "out of device memory");
     if (!rc && (hipMemcpyAsync(d_t, tasks.data(), tb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
                 clh::launch_splice_scan((const uint8_t*)g->d_codes, (const clh::SpliceTask*)d_t, n, search_extra, shift_threshold, is_canonical ? 1 : 0,
-                                        (int32_t*)d_o, ctx->stream) != hipSuccess ||
+                                        sites, (int32_t*)d_o, ctx->stream) != hipSuccess ||
                 hipMemcpyAsync(out, d_o, ob, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess))
         rc = fail(CLH_E_HIP, "splice-signal scan failed");

@@ -120,8 +120,14 @@ struct SpliceTask {
     int32_t clip_base;
     int32_t host_mask;    // strands of the host gene(s): bit 0 '+', bit 1 '-' (align.find_host_gene), 0 = none
 };
+// annotated splice sites: sorted genome-wide positions (contig offset + 1-based position of align.py:251-252), device
+// pointers; 0: '+' exon starts, 1: '+' exon ends, 2: '-' starts, 3: '-' ends
+struct SpliceSites {
+    const int64_t* pos[4];
+    int64_t n[4];
+};
 hipError_t launch_splice_scan(const uint8_t* codes, const SpliceTask* tasks, int n, int search_extra, int shift_threshold, int canonical,
-                              int32_t* out, hipStream_t stream);
+                              const SpliceSites& sites, int32_t* out, hipStream_t stream);
 hipError_t launch_genome_count_n(const uint8_t* codes, const unsigned int* pre_n, const long long* off, const long long* len, long long* out, int n, hipStream_t stream);
 static constexpr int kGenomeBlock = 256;     // bases per entry of the N prefix table
 hipError_t launch_edit_distance(const uint8_t* seqs, const EdTask* tasks, int ntasks, int G, int planes, int32_t* out, int8_t* carry_ws, hipStream_t stream);

@@ -8,6 +8,11 @@
 // tests/golden/make_bsj_golden.py); where the reference's own choice depends on the hash order of a Python set (ties
 // in sort_ss) the rule is first-seen order, as in the mirror.
 //
+// Annotated splice sites (align.py:474-568, the GTF/BED-derived SS_INDEX) are four sorted arrays of genome-wide
+// positions (strand x start/end) in HBM; a candidate finds the annotated shifts near its two ends by binary search, as
+// 64-bit masks over the 2 x search_length shifts.  Pairs of annotated sites are ranked first (weight from the genome's
+// own dinucleotides); if there is none, the annotated shifts join the motif occurrences of the de-novo search.
+//
 // One candidate per lane: the work is a few hundred byte reads in two 262-base neighbourhoods of a genome that is
 // already in HBM (K5), so there is nothing to stage -- consecutive lanes are consecutive candidates and the reads go
 // through L2.  The candidates are independent; the launch is bound by the latency of those reads, not by bandwidth.
@@ -30,8 +35,37 @@ __device__ __forceinline__ int iabs(int x) { return x < 0 ? -x : x; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
+// bit k: the sorted array holds g0 + k (0 <= k < span <= 64)
+__device__ __forceinline__ unsigned long long site_mask(const int64_t* __restrict__ a, long long n, long long g0, int span)
+{
+    long long lo = 0, hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (a[mid] < g0) lo = mid + 1; else hi = mid; }
+    unsigned long long m = 0;
+    for (; lo < n; ++lo) { const long long d = a[lo] - g0; if (d >= span) break; m |= 1ull << d; }
+    return m;
+}
+
+// sort_ss (align.py:705-733): first tier that accepts the site, that tier's key order, in one integer
+__device__ __forceinline__ unsigned long long site_key(int i, int j, int w, int cb, int us_free, int ds_free)
+{
+    // get_ss_altered_length (align.py:698-702)
+    const int alt = iabs(i - j);
+    const int clip_alt = imin(iabs(j - i - cb), iabs(j - i + cb));
+    const int tot = imin(iabs(i + us_free), iabs(i - ds_free)) + imin(iabs(j + us_free), iabs(j - ds_free));
+    unsigned long long key;
+    if (alt <= cb) key = (0ull << 60) | ((unsigned long long)clip_alt << 45) | ((unsigned long long)alt << 30) | ((unsigned long long)w << 15);
+    else if (-us_free <= i && i <= ds_free && -us_free <= j && j <= ds_free)
+        key = (1ull << 60) | ((unsigned long long)alt << 45) | ((unsigned long long)w << 30) | ((unsigned long long)clip_alt << 15);
+    else {
+        const unsigned long long tier = (-cb <= i && i <= 0 && 0 <= j && j <= cb) ? 2ull : 3ull;
+        key = (tier << 60) | ((unsigned long long)w << 45) | ((unsigned long long)alt << 30) | ((unsigned long long)clip_alt << 15);
+    }
+    return key | (unsigned long long)tot;
+}
+
 __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restrict__ codes, const SpliceTask* __restrict__ tasks, int n,
-                                                          int search_extra, int shift_threshold, int canonical, int32_t* __restrict__ out)
+                                                          int search_extra, int shift_threshold, int canonical, SpliceSites sites,
+                                                          int32_t* __restrict__ out)
 {
     const int tid = blockIdx.x * 256 + threadIdx.x;
     if (tid >= n) return;
@@ -62,13 +96,52 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
     const int sl = cb + search_extra;
     const int us_len = sl + us_free, ds_len = sl + ds_free;
     if (!status && (S - us_len - 2 < 0 || E + ds_len + 2 > L)) status = 1;
-    o[0] = status; o[1] = us_free; o[2] = ds_free;
+    o[1] = us_free; o[2] = ds_free;
     int found = 0, b_strand = 0, b_i = 0, b_j = 0, b_motif = 0;
+    const bool anno = sites.n[0] + sites.n[1] + sites.n[2] + sites.n[3] > 0;
+    if (!status && anno && 2 * sl > 64) status = 1;
+    o[0] = status;
     if (!status) {
-        const int lo = 1 - us_len, hi = ds_len;           // shifts whose dinucleotide lies inside the two windows
         const int T = cb + shift_threshold;
-        const int host = t.host_mask & 3;
         unsigned long long best = ~0ull;
+        // annotated shifts in [-sl, sl): exon starts are looked up one base further (align.py:507-546); [strand][kind]
+        unsigned long long mu[2][2] = {{0, 0}, {0, 0}}, md[2][2] = {{0, 0}, {0, 0}};
+        if (anno) {
+            const long long gs = t.ctg_off + S - sl, ge = t.ctg_off + E - sl;
+            for (int strand = 0; strand < 2; ++strand) {
+                mu[strand][0] = site_mask(sites.pos[2 * strand], sites.n[2 * strand], gs + 1, 2 * sl);
+                mu[strand][1] = site_mask(sites.pos[2 * strand + 1], sites.n[2 * strand + 1], gs, 2 * sl);
+                md[strand][0] = site_mask(sites.pos[2 * strand], sites.n[2 * strand], ge + 1, 2 * sl);
+                md[strand][1] = site_mask(sites.pos[2 * strand + 1], sites.n[2 * strand + 1], ge, 2 * sl);
+            }
+            // pairs of annotated sites, '+' first, each list = starts then ends, ascending (align.py:520-556)
+            for (int strand = 0; strand < 2; ++strand)
+                for (int pi = 0; pi < 2; ++pi)
+                    for (unsigned long long mi = mu[strand][pi]; mi; mi &= mi - 1) {
+                        const int i = __builtin_ctzll(mi) - sl;
+                        const uint32_t u0 = g[S + i - 2], u1 = g[S + i - 1];
+                        for (int pj = 0; pj < 2; ++pj)
+                            for (unsigned long long mj = md[strand][pj]; mj; mj &= mj - 1) {
+                                const int j = __builtin_ctzll(mj) - sl;
+                                if (iabs(i - j) > T) continue;
+                                const uint32_t d0 = g[E + j], d1 = g[E + j + 1];
+                                // the genome's own dinucleotides; minus strand: reverse complements, sides swapped
+                                // (revcomp() leaves anything but upper-case ACGT as it is: no motif then)
+                                int w = 3;
+                                if (u0 < 4 && u1 < 4 && d0 < 4 && d1 < 4) {
+                                    const uint32_t n0 = strand ? 3u - u1 : d0, n1 = strand ? 3u - u0 : d1;      // donor
+                                    const uint32_t a0 = strand ? 3u - d1 : u0, a1 = strand ? 3u - d0 : u1;      // acceptor
+                                    for (int m = 0; m < 5; ++m)
+                                        if (kDonor[m][0] == n0 && kDonor[m][1] == n1 && kAcceptor[m][0] == a0 && kAcceptor[m][1] == a1) w = kWeight[m];
+                                }
+                                const unsigned long long key = site_key(i, j, w, cb, us_free, ds_free);
+                                if (key < best) { best = key; found = 2; b_strand = strand; b_i = i; b_j = j; b_motif = 0; }
+                            }
+                    }
+        }
+        const int lo = 1 - us_len, hi = ds_len;           // shifts whose dinucleotide lies inside the two windows
+        const int lo0 = imin(lo, -sl);                    // annotated shifts start at -search_length
+        const int host = t.host_mask & 3;
         for (int round = 0; round < 2 && !found; ++round) {
             // host-gene strands first, the other strand(s) only if that finds nothing (align.py:640-695)
             // without a host gene both strands are searched at once
@@ -76,6 +149,7 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
             if (round == 1 && host == 0) break;
             for (int strand = 0; strand < 2; ++strand) {    // '+' sorts before '-'
                 if (!((mask >> strand) & 1)) continue;
+                const unsigned long long au = mu[strand][0] | mu[strand][1], ad = md[strand][0] | md[strand][1];
                 const int nm = canonical ? 1 : 5;
                 for (int m = 0; m < nm; ++m) {
                     // plus: acceptor upstream, donor downstream; minus: the reverse complements, sides swapped
@@ -83,25 +157,15 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
                     if (strand == 0) { u0 = kAcceptor[m][0]; u1 = kAcceptor[m][1]; d0 = kDonor[m][0]; d1 = kDonor[m][1]; }
                     else { u0 = 3u - kDonor[m][1]; u1 = 3u - kDonor[m][0]; d0 = 3u - kAcceptor[m][1]; d1 = 3u - kAcceptor[m][0]; }
                     const int w = kWeight[m];
-                    for (int i = lo; i <= hi; ++i) {
-                        if (g[S + i - 2] != u0 || g[S + i - 1] != u1) continue;
-                        const int jlo = imax(lo, i - T), jhi = imin(hi, i + T);
+                    for (int i = lo0; i <= hi; ++i) {
+                        // a site: an occurrence of the motif, or an annotated shift of this strand (align.py:612-621)
+                        const bool ai = i >= -sl && i < sl && ((au >> (i + sl)) & 1);
+                        if (!ai && (i < lo || g[S + i - 2] != u0 || g[S + i - 1] != u1)) continue;
+                        const int jlo = imax(lo0, i - T), jhi = imin(hi, i + T);
                         for (int j = jlo; j <= jhi; ++j) {
-                            if (g[E + j] != d0 || g[E + j + 1] != d1) continue;
-                            // get_ss_altered_length (align.py:698-702)
-                            const int alt = iabs(i - j);
-                            const int clip_alt = imin(iabs(j - i - cb), iabs(j - i + cb));
-                            const int tot = imin(iabs(i + us_free), iabs(i - ds_free)) + imin(iabs(j + us_free), iabs(j - ds_free));
-                            // sort_ss (align.py:705-733): first tier that accepts the site, that tier's key order
-                            unsigned long long key;
-                            if (alt <= cb) key = (0ull << 60) | ((unsigned long long)clip_alt << 45) | ((unsigned long long)alt << 30) | ((unsigned long long)w << 15);
-                            else if (-us_free <= i && i <= ds_free && -us_free <= j && j <= ds_free)
-                                key = (1ull << 60) | ((unsigned long long)alt << 45) | ((unsigned long long)w << 30) | ((unsigned long long)clip_alt << 15);
-                            else {
-                                const unsigned long long tier = (-cb <= i && i <= 0 && 0 <= j && j <= cb) ? 2ull : 3ull;
-                                key = (tier << 60) | ((unsigned long long)w << 45) | ((unsigned long long)alt << 30) | ((unsigned long long)clip_alt << 15);
-                            }
-                            key |= (unsigned long long)tot;
+                            const bool aj = j >= -sl && j < sl && ((ad >> (j + sl)) & 1);
+                            if (!aj && (j < lo || g[E + j] != d0 || g[E + j + 1] != d1)) continue;
+                            const unsigned long long key = site_key(i, j, w, cb, us_free, ds_free);
                             if (key < best) { best = key; found = 1; b_strand = strand; b_i = i; b_j = j; b_motif = m; }
                         }
                     }
@@ -113,10 +177,10 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
 }
 
 hipError_t launch_splice_scan(const uint8_t* codes, const SpliceTask* tasks, int n, int search_extra, int shift_threshold, int canonical,
-                              int32_t* out, hipStream_t stream)
+                              const SpliceSites& sites, int32_t* out, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(splice_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, codes, tasks, n, search_extra, shift_threshold, canonical, out);
+    hipLaunchKernelGGL(splice_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, codes, tasks, n, search_extra, shift_threshold, canonical, sites, out);
     return hipGetLastError();
 }
 

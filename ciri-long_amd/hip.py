@@ -88,6 +88,7 @@ def lib():
         L.clh_genome_length.restype = C.c_int64
         L.clh_genome_length.argtypes = [C.c_void_p]
         L.clh_genome_count_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_genome_set_splice_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_splice_signal_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.clh_ssw_plan_windows.restype = C.c_void_p
@@ -336,6 +337,7 @@ class Genome(object):
         for name, seq in items:
             self.offset[name] = pos; self.length[name] = len(seq); pos += len(seq)
         blob = ''.join(seq for _, seq in items).encode('latin-1')
+        self._sites_of = None
         self._h = lib().clh_genome_create(ctx._h, blob, len(blob))
         if not self._h:
             raise ClhError('clh_genome_create failed: %s' % last_error())
@@ -368,6 +370,33 @@ class Genome(object):
         if rc != 0:
             raise ClhError('clh_genome_count_n failed (%d): %s' % (rc, last_error()))
         return out
+
+    def set_splice_sites(self, ss_index):
+        """Annotated splice sites for splice_signals(): ss_index = {contig: {pos: {strand: {'start'|'end': 1}}}} (the
+        reference's splice_site_index, align.py:235-252) or None.  Contigs that are not resident are ignored."""
+        runs = [[], [], [], []]
+        for ctg, by_pos in (ss_index or {}).items():
+            if ctg not in self.offset:
+                continue
+            off, ln = self.offset[ctg], self.length[ctg]
+            for pos, by_strand in by_pos.items():
+                if not 1 <= pos <= ln:         # outside the contig: no candidate can look it up (and it must not alias a neighbour)
+                    continue
+                for k, strand in enumerate('+-'):
+                    kinds = by_strand.get(strand) if hasattr(by_strand, 'get') else None
+                    if not kinds:
+                        continue
+                    if 'start' in kinds:
+                        runs[2 * k].append(off + pos)
+                    if 'end' in kinds:
+                        runs[2 * k + 1].append(off + pos)
+        runs = [np.unique(np.array(r, dtype=np.int64)) for r in runs]
+        cnt = np.array([len(r) for r in runs], dtype=np.int64)
+        flat = np.ascontiguousarray(np.concatenate(runs)) if cnt.sum() else np.zeros(1, dtype=np.int64)
+        rc = lib().clh_genome_set_splice_sites(self._h, flat.ctypes.data, cnt.ctypes.data)
+        if rc != 0:
+            raise ClhError('clh_genome_set_splice_sites failed (%d): %s' % (rc, last_error()))
+        self._sites_of = ss_index
 
     def splice_signals(self, cands, search_extra=10, shift_threshold=3, is_canonical=True):
         """K6: cands = [(contig, start, end, clip_base, host_mask)] -> int32 array [n, 8]:

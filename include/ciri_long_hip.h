@@ -154,12 +154,19 @@ const void* clh_genome_codes(const clh_genome* genome);      /* device pointer *
 int64_t clh_genome_length(const clh_genome* genome);
 /* out[k] = number of upper-case 'N' in [off[k], off[k]+len[k]) -- Counter(window)['N'] of find_bsj.py:199 */
 int clh_genome_count_n(clh_genome* genome, int32_t n, const int64_t* off, const int64_t* len, int64_t* out);
+/* Annotated splice sites for clh_splice_signal_batch: the reference's splice_site_index / circ_ss_idx
+ * (CIRI_long/align.py:235-252, 275-316: index[contig][pos][strand]['start'|'end']) flattened to four runs of genome-wide
+ * positions (contig offset in the resident genome + pos), each strictly ascending, concatenated in `pos` in the order
+ * '+' starts, '+' ends, '-' starts, '-' ends; count4 = their lengths.  Replaces any earlier set; all zero = none. */
+int clh_genome_set_splice_sites(clh_genome* genome, const int64_t* pos, const int64_t* count4);
 /* Splice signals around n candidate back-splice junctions [start, end) (0-based) of contigs of the resident genome --
- * CIRI_long/align.py:477-493 (free sliding), :571-695 (find_denovo_signal, no annotated sites) and :698-733 (ranking),
- * as called from find_bsj.py:286-301 with search_length = clip_base + search_extra (10), shift_threshold (3).
+ * CIRI_long/align.py:477-493 (free sliding), :495-568 (pairs of annotated sites, if sites were set), :571-695
+ * (find_denovo_signal, annotated shifts joining the motif occurrences) and :698-733 (ranking), as called from
+ * find_bsj.py:286-301 with search_length = clip_base + search_extra (10), shift_threshold (3).
  * host_mask: strands of the host gene, bit 0 '+', bit 1 '-'.  out[8k..8k+7] = status (0 done, 1 = outside this kernel's
  * domain: the neighbourhood leaves the contig or holds non-ACGTN characters; run the Python statement), us_free,
- * ds_free, found, strand (0 '+', 1 '-'), us_shift, ds_shift, motif (index into GT-AG, GC-AG, AT-AC, GT-AC, AT-AG). */
+ * ds_free, found (0 none, 1 de novo, 2 annotated pair), strand (0 '+', 1 '-'), us_shift, ds_shift, motif (de novo:
+ * index into GT-AG, GC-AG, AT-AC, GT-AC, AT-AG). */
 int clh_splice_signal_batch(clh_genome* genome, int32_t n, const int64_t* ctg_off, const int64_t* ctg_len, const int64_t* start,
                             const int64_t* end, const int32_t* clip_base, const int32_t* host_mask, int32_t search_extra,
                             int32_t shift_threshold, int32_t is_canonical, int32_t* out);

@@ -70,6 +70,26 @@ def _world(seed, n_cand):
     return contigs, cands
 
 
+def _annotation(contigs, cands, seed):
+    """A splice-site index in the reference's layout, with sites at and around the candidates' ends: both kinds, both
+    strands, sometimes only one side, sometimes several within the search range."""
+    rng = random.Random(seed)
+    idx = {}
+    for ctg, st, en, cb, host in cands:
+        if rng.random() < 0.35:
+            continue
+        d = idx.setdefault(ctg, {})
+        for anchor in (st, en):
+            if rng.random() < 0.25:
+                continue
+            for _ in range(rng.choice([1, 1, 2, 4])):
+                pos = anchor + rng.randint(-14, 14) + rng.choice([0, 1])
+                if pos < 1:
+                    continue
+                d.setdefault(pos, {}).setdefault(rng.choice('+-'), {})[rng.choice(['start', 'end'])] = 1
+    return idx
+
+
 def _host_answer(align, cand, is_canonical):
     ctg, st, en, cb, host = cand
     site, us_free, ds_free, sig = align.find_annotated_signal(ctg, st, en, cb, cb + 10)
@@ -78,18 +98,21 @@ def _host_answer(align, cand, is_canonical):
     return site, us_free, ds_free
 
 
-@pytest.mark.parametrize('is_canonical', [True, False])
-def test_kernel_rows_match_python_statement(is_canonical):
+@pytest.mark.parametrize('is_canonical,annotated', [(True, False), (False, False), (True, True), (False, True)])
+def test_kernel_rows_match_python_statement(is_canonical, annotated):
     from ciri_long_amd import align, env, hip
-    contigs, cands = _world(77 + is_canonical, 4000)
+    from ciri_long_amd.utils import revcomp
+    contigs, cands = _world(77 + is_canonical + 2 * annotated, 4000)
     host = _Genome(contigs)
-    env.initializer(None, host.contig_len, host, None, None, None)
+    ss_index = _annotation(contigs, cands, 99) if annotated else None
+    env.initializer(None, host.contig_len, host, None, None, ss_index)
     ctx = hip.Context(0)
     dev = hip.Genome(ctx, contigs)
+    dev.set_splice_sites(ss_index)
     rows = dev.splice_signals([(c[0], c[1], c[2], c[3], (1 if c[4] and '+' in c[4] else 0) | (2 if c[4] and '-' in c[4] else 0)) for c in cands],
                               10, 3, is_canonical).tolist()
     motifs = list(align.SPLICE_SIGNAL)
-    n_dev = n_found = n_slide = n_minus = 0
+    n_dev = n_found = n_slide = n_minus = n_anno = 0
     for cand, r in zip(cands, rows):
         status, us_free, ds_free, found, strand, i, j, m = r
         want = _host_answer(align, cand, is_canonical)
@@ -103,57 +126,62 @@ def test_kernel_rows_match_python_statement(is_canonical):
             continue
         n_dev += 1
         got = None
-        if found:
+        if found == 1:
             d, a = motifs[m]
             got = ('{}-{}*|{}-{}'.format(a, d, i, j), '-' if strand else '+', i, j)
+        elif found == 2:
+            us_ss, ds_ss = host.seq(cand[0], cand[1] + i - 2, cand[1] + i), host.seq(cand[0], cand[2] + j, cand[2] + j + 2)
+            if strand:
+                us_ss, ds_ss = revcomp(ds_ss), revcomp(us_ss)
+            got = ('{}-{}|{}-{}'.format(us_ss, ds_ss, i, j), '-' if strand else '+', i, j)
+            n_anno += 1
+        if found:
             n_found += 1
             n_minus += strand
         assert (got, us_free, ds_free) == want, (cand, r, want)
         n_slide += (us_free + ds_free) > 0
     # the cases are really exercised
     assert n_dev > 0.8 * len(cands) and n_found > 0.4 * n_dev and n_slide > 0.3 * n_dev and n_minus > 0.1 * n_found
+    assert (n_anno > 0.1 * n_dev) if annotated else n_anno == 0
     dev.close(); ctx.close()
 
 
-def test_find_signal_batch_equals_per_read_path():
+@pytest.mark.parametrize('annotated', [False, True])
+def test_find_signal_batch_equals_per_read_path(annotated):
     """align.find_signal_batch (GPU rows + the Python statement for what the kernel hands back) == the per-read calls."""
     from ciri_long_amd import align, env, hip
     contigs, cands = _world(5, 2000)
     host = _Genome(contigs)
-    env.initializer(None, host.contig_len, host, None, None, None)
+    ss_index = _annotation(contigs, cands, 7) if annotated else None
+    env.initializer(None, host.contig_len, host, None, None, ss_index)
     want = [_host_answer(align, c, True) for c in cands]
-    env.initializer(None, host.contig_len, align.DeviceGenome(host, contigs), None, None, None)
+    env.initializer(None, host.contig_len, align.DeviceGenome(host, contigs), None, None, ss_index)
     got = align.find_signal_batch(cands, True)
     assert got == want
     env.GENOME.device.close()
 
 
-def test_reference_goldens_without_annotation():
-    """Candidates of the reference-made fixture whose annotated search found nothing and added no annotated shifts: the
-    kernel must return what the REFERENCE returned (ties in the reference's set order excluded)."""
+def test_reference_goldens():
+    """Every splice-signal case of the reference-made fixture (annotated index of the fixture world loaded): the kernel must
+    return what the REFERENCE returned, for the annotated search and for the de-novo search after it (cases whose
+    ranking is tied in the reference's set order excluded)."""
     import gzip
     import fake_mapper
-    from ciri_long_amd import align, hip
+    from ciri_long_amd import align, env
     with gzip.open(os.path.join(HERE, 'golden', 'bsj_golden.json.gz'), 'rt') as f:
         golden = json.load(f)
     world = fake_mapper.build_world()
-    contigs = world['genome'].genome
-    ctx = hip.Context(0)
-    dev = hip.Genome(ctx, contigs)
-    motifs = list(align.SPLICE_SIGNAL)
-    n = 0
-    for s in golden['signals']:
-        if s['tie'] or s['annotated'][0] is not None or any(v[0] or v[1] for v in s['annotated'][3].values()):
-            continue
-        hm = (1 if s['host'] and '+' in s['host'] else 0) | (2 if s['host'] and '-' in s['host'] else 0)
-        r = dev.splice_signals([(s['ctg'], s['start'], s['end'], s['clip_base'], hm)], 10, 3, True).tolist()[0]
-        if r[0]:
-            continue
-        got = None
-        if r[3]:
-            d, a = motifs[r[7]]
-            got = ['{}-{}*|{}-{}'.format(a, d, r[5], r[6]), '-' if r[4] else '+', r[5], r[6]]
-        assert got == s['denovo'] and r[1:3] == s['annotated'][1:3], s
-        n += 1
-    dev.close(); ctx.close()
-    assert n >= 100
+    g = world['genome']
+    env.initializer(None, g.contig_len, align.DeviceGenome(g, g.genome), world['gtf_index'], None, world['ss_index'])
+    cases = [s for s in golden['signals'] if not s['tie']]
+    got = align.find_signal_batch([(s['ctg'], s['start'], s['end'], s['clip_base'], s['host']) for s in cases], True)
+    rows = env.GENOME.device.splice_signals([(s['ctg'], s['start'], s['end'], s['clip_base'], 0) for s in cases])
+    n_anno = n_denovo = 0
+    for s, (site, us_free, ds_free) in zip(cases, got):
+        want = s['annotated'][0] if s['annotated'][0] is not None else s['denovo']
+        assert (list(site) if site else None) == want and [us_free, ds_free] == s['annotated'][1:3], s
+        n_anno += s['annotated'][0] is not None
+        n_denovo += s['annotated'][0] is None and s['denovo'] is not None
+    env.GENOME.device.close()
+    assert int((rows[:, 0] == 0).sum()) > 0.8 * len(cases)       # answered by the kernel, not handed back
+    assert n_anno >= 20 and n_denovo >= 20

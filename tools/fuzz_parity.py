@@ -89,9 +89,10 @@ while time.time() < t_end:
     contigs, cands = tgs._world(seed + it, 1200)
     host = tgs._Genome(contigs)
     canon = bool(it & 1)
-    env.initializer(None, host.contig_len, host, None, None, None)
+    ss_index = tgs._annotation(contigs, cands, seed + it) if it % 3 else None        # two rounds of three with annotated sites
+    env.initializer(None, host.contig_len, host, None, None, ss_index)
     want = [tgs._host_answer(align, c, canon) for c in cands]
-    env.initializer(None, host.contig_len, align.DeviceGenome(host, contigs, ctx), None, None, None)
+    env.initializer(None, host.contig_len, align.DeviceGenome(host, contigs, ctx), None, None, ss_index)
     got = align.find_signal_batch(cands, canon)
     env.GENOME.device.close()
     for k in range(len(cands)):

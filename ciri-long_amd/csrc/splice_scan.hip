@@ -63,6 +63,8 @@ __device__ __forceinline__ unsigned long long site_key(int i, int j, int w, int 
     return key | (unsigned long long)tot;
 }
 
+// ANNO: annotated sites are loaded (the search without them keeps its smaller register file)
+template <bool ANNO>
 __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restrict__ codes, const SpliceTask* __restrict__ tasks, int n,
                                                           int search_extra, int shift_threshold, int canonical, SpliceSites sites,
                                                           int32_t* __restrict__ out)
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
     if (!status && (S - us_len - 2 < 0 || E + ds_len + 2 > L)) status = 1;
     o[1] = us_free; o[2] = ds_free;
     int found = 0, b_strand = 0, b_i = 0, b_j = 0, b_motif = 0;
-    const bool anno = sites.n[0] + sites.n[1] + sites.n[2] + sites.n[3] > 0;
+    constexpr bool anno = ANNO;
     if (!status && anno && 2 * sl > 64) status = 1;
     o[0] = status;
     if (!status) {
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
         unsigned long long best = ~0ull;
         // annotated shifts in [-sl, sl): exon starts are looked up one base further (align.py:507-546); [strand][kind]
         unsigned long long mu[2][2] = {{0, 0}, {0, 0}}, md[2][2] = {{0, 0}, {0, 0}};
-        if (anno) {
+        if constexpr (ANNO) {
             const long long gs = t.ctg_off + S - sl, ge = t.ctg_off + E - sl;
             for (int strand = 0; strand < 2; ++strand) {
                 mu[strand][0] = site_mask(sites.pos[2 * strand], sites.n[2 * strand], gs + 1, 2 * sl);
@@ -180,7 +182,10 @@ hipError_t launch_splice_scan(const uint8_t* codes, const SpliceTask* tasks, int
                               const SpliceSites& sites, int32_t* out, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(splice_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, codes, tasks, n, search_extra, shift_threshold, canonical, sites, out);
+    if (sites.n[0] + sites.n[1] + sites.n[2] + sites.n[3] > 0)
+        hipLaunchKernelGGL(splice_scan_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, codes, tasks, n, search_extra, shift_threshold, canonical, sites, out);
+    else
+        hipLaunchKernelGGL(splice_scan_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, codes, tasks, n, search_extra, shift_threshold, canonical, sites, out);
     return hipGetLastError();
 }
 

@@ -399,18 +399,23 @@ class Genome(object):
         self._sites_of = ss_index
 
     def splice_signals(self, cands, search_extra=10, shift_threshold=3, is_canonical=True):
-        """K6: cands = [(contig, start, end, clip_base, host_mask)] -> int32 array [n, 8]:
+        """K6: cands = [(contig, start, end, clip_base, host_mask)] (or a dict of columns, see below) -> int32 array [n, 8]:
         status, us_free, ds_free, found, strand, us_shift, ds_shift, motif (see include/ciri_long_hip.h)"""
-        n = len(cands)
+        if isinstance(cands, dict):       # columns: ctg_off, ctg_len, start, end (int64), clip_base, host_mask (int32)
+            off, ln, st, en = (np.ascontiguousarray(cands[k], dtype=np.int64) for k in ('ctg_off', 'ctg_len', 'start', 'end'))
+            cb, hm = (np.ascontiguousarray(cands[k], dtype=np.int32) for k in ('clip_base', 'host_mask'))
+            n = len(st)
+        else:
+            n = len(cands)
+            off = np.array([self.offset[c[0]] for c in cands], dtype=np.int64)
+            ln = np.array([self.length[c[0]] for c in cands], dtype=np.int64)
+            st = np.array([c[1] for c in cands], dtype=np.int64)
+            en = np.array([c[2] for c in cands], dtype=np.int64)
+            cb = np.array([c[3] for c in cands], dtype=np.int32)
+            hm = np.array([c[4] for c in cands], dtype=np.int32)
         out = np.zeros((n, 8), dtype=np.int32)
         if n == 0:
             return out
-        off = np.array([self.offset[c[0]] for c in cands], dtype=np.int64)
-        ln = np.array([self.length[c[0]] for c in cands], dtype=np.int64)
-        st = np.array([c[1] for c in cands], dtype=np.int64)
-        en = np.array([c[2] for c in cands], dtype=np.int64)
-        cb = np.array([c[3] for c in cands], dtype=np.int32)
-        hm = np.array([c[4] for c in cands], dtype=np.int32)
         rc = lib().clh_splice_signal_batch(self._h, n, off.ctypes.data, ln.ctypes.data, st.ctypes.data, en.ctypes.data, cb.ctypes.data,
                                            hm.ctypes.data, search_extra, shift_threshold, 1 if is_canonical else 0, out.ctypes.data)
         if rc != 0:

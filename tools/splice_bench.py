@@ -53,7 +53,26 @@ def main():
                                                hm32.ctypes.data, 10, 3, 1, out.ctypes.data)
         t_abi = min(t_abi, time.time() - t0)
     assert rc == 0 and (out == rows).all()
+    cols = dict(ctg_off=off, ctg_len=lnn, start=st64, end=en64, clip_base=cb32, host_mask=hm32)
+    assert (dev.splice_signals(cols) == rows).all()
     print('C-ABI call alone: %.1f ms = %.1f M candidates/s' % (t_abi * 1e3, n / t_abi / 1e6))
+    # the same with an annotation loaded: 2 M sites, half of them at the candidates' own ends
+    ss = {}
+    for k in range(0, n, 2):
+        d = ss.setdefault(names[k], {})
+        d.setdefault(int(st[k]) + 1, {}).setdefault('+-'[k & 2 > 0], {})['start'] = 1
+        d.setdefault(int(st[k] + ln[k]), {}).setdefault('+-'[k & 2 > 0], {})['end'] = 1
+    for c in range(4):
+        d = ss.setdefault('chr%d' % c, {})
+        for p in rng.integers(1, L, size=250000):
+            d.setdefault(int(p), {}).setdefault('+', {})['start'] = 1
+    t0 = time.time(); dev.set_splice_sites(ss); t_ss = time.time() - t0
+    t_an = 1e9
+    for _ in range(3):
+        t0 = time.time(); rows_a = dev.splice_signals(cols); t_an = min(t_an, time.time() - t0)
+    print('with %d annotated sites (flatten+upload %.1f s): %.1f ms per call = %.1f M candidates/s; %d annotated pairs, %d de novo'
+          % (sum(len(v) for v in ss.values()), t_ss, t_an * 1e3, n / t_an / 1e6, int((rows_a[:, 3] == 2).sum()), int((rows_a[:, 3] == 1).sum())))
+    dev.set_splice_sites(None)
     # the Python statement on a sample
     m = min(n, 3000)
     masks = {0: None, 1: {'+': 1}, 2: {'-': 1}, 3: {'+': 1, '-': 1}}

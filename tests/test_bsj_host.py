@@ -224,3 +224,69 @@ def test_window_route_host_logic_on_cpu(golden, world, monkeypatch):
     g = golden['scan_ccs_chunk']
     assert dict(cnt) == g['counters']
     _same_records(ret, g['records'], set(golden['tied_reads']))
+
+
+def test_find_signal_batch_host_logic_on_cpu(golden, world):
+    """align.find_signal_batch with the device call replaced by a CPU stand-in that answers in the kernel's row format:
+    the routing (status 1 -> Python statement), the annotated / de-novo ids and the upload-once of the site index."""
+    from ciri_long_amd import align, env
+
+    motifs = list(align.SPLICE_SIGNAL)
+
+    class FakeDevice(object):
+        def __init__(self, genome):
+            self.offset = {c: 0 for c in genome.genome}
+            self._sites_of = None
+            self.uploads = 0
+            self.handed_back = 0
+
+        def set_splice_sites(self, ss_index):
+            self._sites_of = ss_index
+            self.uploads += 1
+
+        def splice_signals(self, cands, search_extra, shift_threshold, is_canonical):
+            import numpy as np
+            rows = np.zeros((len(cands), 8), dtype=np.int32)
+            for k, (ctg, st, en, cb, hm) in enumerate(cands):
+                if k % 5 == 4:                      # as the kernel does for contig ends / odd characters
+                    rows[k, 0] = 1
+                    self.handed_back += 1
+                    continue
+                host = [s for b, s in ((1, '+'), (2, '-')) if hm & b] or None
+                a = align.find_annotated_signal(ctg, st, en, cb, cb + search_extra)
+                site, found = a[0], 2
+                if site is None:
+                    site, found = align.find_denovo_signal(ctg, st, en, host, a[3], a[1], a[2], cb, cb + search_extra, shift_threshold, is_canonical), 1
+                rows[k, 1:3] = a[1:3]
+                if site is not None:
+                    m = 0
+                    if found == 1:
+                        acc, don = site[0].split('*')[0].split('-')
+                        m = motifs.index((don, acc))
+                    rows[k, 3:] = [found, site[1] == '-', site[2], site[3], m]
+            return rows
+
+    class Wrapped(object):
+        def __init__(self, genome):
+            self.host, self.device, self.contig_len = genome, FakeDevice(genome), genome.contig_len
+
+        def seq(self, ctg, start, end):
+            return self.host.seq(ctg, start, end)
+
+    cases = golden['signals']
+    cands = [(s['ctg'], s['start'], s['end'], s['clip_base'], s['host']) for s in cases]
+    want = []
+    for ctg, st, en, cb, host in cands:
+        a = align.find_annotated_signal(ctg, st, en, cb, cb + 10)
+        site = a[0] if a[0] is not None else align.find_denovo_signal(ctg, st, en, host, a[3], a[1], a[2], cb, cb + 10, 3, True)
+        want.append((site, a[1], a[2]))
+    wrapped = Wrapped(world['genome'])
+    env.initializer(world['mapper'], world['genome'].contig_len, wrapped, world['gtf_index'], None, world['ss_index'])
+    try:
+        got = align.find_signal_batch(cands, True)
+        got2 = align.find_signal_batch(cands[:10], True)
+    finally:
+        env.initializer(world['mapper'], world['genome'].contig_len, world['genome'], world['gtf_index'], None, world['ss_index'])
+    assert got == want and got2 == want[:10]
+    assert wrapped.device.uploads == 1 and wrapped.device.handed_back > 0
+    assert sum(1 for s, _, _ in got if s and '*' not in s[0]) >= 20 and sum(1 for s, _, _ in got if s and '*' in s[0]) >= 20

@@ -432,7 +432,10 @@ def find_signal_batch(cands, is_canonical=True):
     dev = getattr(env.GENOME, 'device', None)
     if not hasattr(dev, 'splice_signals'):
         dev = None
-    on_gpu = [k for k, c in enumerate(cands) if dev is not None and c[0] in dev.offset]
+    # a host gene on a strand other than '+'/'-' (a '.' in the GTF) is searched under that label by the reference: not a
+    # case of the kernel's two-bit strand mask
+    on_gpu = [k for k, c in enumerate(cands)
+              if dev is not None and c[0] in dev.offset and not (c[4] and any(st not in ('+', '-') for st in c[4]))]
     if on_gpu:
         if dev._sites_of is not env.SS_INDEX:
             dev.set_splice_sites(env.SS_INDEX)

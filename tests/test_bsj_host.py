@@ -239,6 +239,7 @@ def test_find_signal_batch_host_logic_on_cpu(golden, world):
             self._sites_of = None
             self.uploads = 0
             self.handed_back = 0
+            self.seen = 0
 
         def set_splice_sites(self, ss_index):
             self._sites_of = ss_index
@@ -247,6 +248,7 @@ def test_find_signal_batch_host_logic_on_cpu(golden, world):
         def splice_signals(self, cands, search_extra, shift_threshold, is_canonical):
             import numpy as np
             rows = np.zeros((len(cands), 8), dtype=np.int32)
+            self.seen += len(cands)
             for k, (ctg, st, en, cb, hm) in enumerate(cands):
                 if k % 5 == 4:                      # as the kernel does for contig ends / odd characters
                     rows[k, 0] = 1
@@ -285,6 +287,12 @@ def test_find_signal_batch_host_logic_on_cpu(golden, world):
     try:
         got = align.find_signal_batch(cands, True)
         got2 = align.find_signal_batch(cands[:10], True)
+        seen = wrapped.device.seen
+        # a host gene on strand '.' is searched under that label by the reference: stays with the Python statement
+        odd = cands[0][:4] + ({'.': [1]},)
+        a = align.find_annotated_signal(*odd[:4], odd[3] + 10)
+        want_odd = a[0] if a[0] is not None else align.find_denovo_signal(*odd[:3], odd[4], a[3], a[1], a[2], odd[3], odd[3] + 10, 3, True)
+        assert align.find_signal_batch([odd], True) == [(want_odd, a[1], a[2])] and wrapped.device.seen == seen
     finally:
         env.initializer(world['mapper'], world['genome'].contig_len, world['genome'], world['gtf_index'], None, world['ss_index'])
     assert got == want and got2 == want[:10]

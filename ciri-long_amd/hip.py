@@ -324,6 +324,33 @@ class EditPlan(object):
             pass
 
 
+def flatten_splice_sites(ss_index, offset, length):
+    """{contig: {pos: {strand: {'start'|'end': 1}}}} -> (positions int64, counts int64[4]): four strictly ascending runs
+    of contig offset + pos in the order '+' starts, '+' ends, '-' starts, '-' ends (clh_genome_set_splice_sites).
+    Contigs without an offset, positions outside their contig and strands other than '+'/'-' are left out: no candidate
+    can look them up, and a position past the end of a contig must not alias its neighbour."""
+    runs = [[], [], [], []]
+    for ctg, by_pos in (ss_index or {}).items():
+        if ctg not in offset:
+            continue
+        off, ln = offset[ctg], length[ctg]
+        for pos, by_strand in by_pos.items():
+            if not 1 <= pos <= ln:
+                continue
+            for k, strand in enumerate('+-'):
+                kinds = by_strand.get(strand) if hasattr(by_strand, 'get') else None
+                if not kinds:
+                    continue
+                if 'start' in kinds:
+                    runs[2 * k].append(off + pos)
+                if 'end' in kinds:
+                    runs[2 * k + 1].append(off + pos)
+    runs = [np.unique(np.array(r, dtype=np.int64)) for r in runs]
+    cnt = np.array([len(r) for r in runs], dtype=np.int64)
+    flat = np.ascontiguousarray(np.concatenate(runs)) if cnt.sum() else np.zeros(1, dtype=np.int64)
+    return flat, cnt
+
+
 class Genome(object):
     """Contigs resident in HBM as base codes (K5).  A Smith-Waterman reference is then a window (contig, start, end,
     minus-strand flag) read in place: no window string, no reverse complement, no per-base encode on the host."""
@@ -374,25 +401,7 @@ class Genome(object):
     def set_splice_sites(self, ss_index):
         """Annotated splice sites for splice_signals(): ss_index = {contig: {pos: {strand: {'start'|'end': 1}}}} (the
         reference's splice_site_index, align.py:235-252) or None.  Contigs that are not resident are ignored."""
-        runs = [[], [], [], []]
-        for ctg, by_pos in (ss_index or {}).items():
-            if ctg not in self.offset:
-                continue
-            off, ln = self.offset[ctg], self.length[ctg]
-            for pos, by_strand in by_pos.items():
-                if not 1 <= pos <= ln:         # outside the contig: no candidate can look it up (and it must not alias a neighbour)
-                    continue
-                for k, strand in enumerate('+-'):
-                    kinds = by_strand.get(strand) if hasattr(by_strand, 'get') else None
-                    if not kinds:
-                        continue
-                    if 'start' in kinds:
-                        runs[2 * k].append(off + pos)
-                    if 'end' in kinds:
-                        runs[2 * k + 1].append(off + pos)
-        runs = [np.unique(np.array(r, dtype=np.int64)) for r in runs]
-        cnt = np.array([len(r) for r in runs], dtype=np.int64)
-        flat = np.ascontiguousarray(np.concatenate(runs)) if cnt.sum() else np.zeros(1, dtype=np.int64)
+        flat, cnt = flatten_splice_sites(ss_index, self.offset, self.length)
         rc = lib().clh_genome_set_splice_sites(self._h, flat.ctypes.data, cnt.ctypes.data)
         if rc != 0:
             raise ClhError('clh_genome_set_splice_sites failed (%d): %s' % (rc, last_error()))

@@ -298,3 +298,44 @@ def test_find_signal_batch_host_logic_on_cpu(golden, world):
     assert got == want and got2 == want[:10]
     assert wrapped.device.uploads == 1 and wrapped.device.handed_back > 0
     assert sum(1 for s, _, _ in got if s and '*' not in s[0]) >= 20 and sum(1 for s, _, _ in got if s and '*' in s[0]) >= 20
+
+
+def test_flatten_splice_sites():
+    """The host side of clh_genome_set_splice_sites: four strictly ascending runs of genome-wide positions."""
+    import collections
+    import numpy as np
+    from ciri_long_amd import hip
+    tree = lambda: collections.defaultdict(tree)       # the reference's index is such a tree (align.py:235)
+    idx = tree()
+    idx['b'][10]['+']['start'] = 1
+    idx['b'][10]['+']['end'] = 1
+    idx['b'][10]['-']['end'] = 1
+    idx['a'][7]['-']['start'] = 1
+    idx['a'][7]['.']['start'] = 1          # unstranded: never looked up
+    idx['a'][100]['+']['end'] = 1          # == contig length: kept
+    idx['a'][101]['+']['end'] = 1          # past the contig: would alias b's position 1
+    idx['a'][0]['+']['start'] = 1
+    idx['zz'][5]['+']['start'] = 1         # contig not resident
+    idx['b'][3]['+']['start'] = 1
+    flat, cnt = hip.flatten_splice_sites(idx, {'a': 0, 'b': 100}, {'a': 100, 'b': 50})
+    assert cnt.tolist() == [2, 2, 1, 1] and flat.dtype == np.int64 and flat.flags['C_CONTIGUOUS']
+    assert flat.tolist() == [103, 110, 100, 110, 7, 110]
+    flat, cnt = hip.flatten_splice_sites(None, {'a': 0}, {'a': 100})
+    assert cnt.tolist() == [0, 0, 0, 0] and len(flat) >= 1
+
+    class FakeLib(object):
+        def clh_genome_set_splice_sites(self, h, pos, count4):
+            import ctypes
+            c = np.ctypeslib.as_array(ctypes.cast(count4, ctypes.POINTER(ctypes.c_int64)), (4,)).copy()
+            self.got = (np.ctypeslib.as_array(ctypes.cast(pos, ctypes.POINTER(ctypes.c_int64)), (int(c.sum()),)).copy(), c)
+            return 0
+    g = hip.Genome.__new__(hip.Genome)
+    g._h, g.offset, g.length, g._sites_of = 1, {'a': 0, 'b': 100}, {'a': 100, 'b': 50}, None
+    fake, real = FakeLib(), hip.lib
+    hip.lib = lambda: fake
+    try:
+        g.set_splice_sites(idx)
+    finally:
+        hip.lib = real
+        g._h = None
+    assert fake.got[0].tolist() == [103, 110, 100, 110, 7, 110] and fake.got[1].tolist() == [2, 2, 1, 1] and g._sites_of is idx

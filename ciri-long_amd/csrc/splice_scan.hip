@@ -3,10 +3,10 @@
 // What it replaces: per candidate read, CIRI_long/align.py:477-493 (how far the junction slides between identical
 // flanks: up to 2 x 100 string slices and comparisons in Python), align.py:571-695 (find_denovo_signal: str.find of
 // the donor/acceptor dinucleotides over two windows of <= 262 bases, all pairs of occurrences) and align.py:698-733
-// (get_ss_altered_length, sort_ss: four tiers, sorted by four keys) -- SURVEY.md section 8 f4.  The statement it is
-// checked against is the host mirror ciri-long_amd/align.py (itself pinned to outputs of the reference,
-// tests/golden/make_bsj_golden.py); where the reference's own choice depends on the hash order of a Python set (ties
-// in sort_ss) the rule is first-seen order, as in the mirror.
+// (get_ss_altered_length, sort_ss: four tiers, sorted by four keys) -- SURVEY.md section 8 f4.  The statements it is
+// checked against are oracle/splice_oracle.c and the host mirror ciri-long_amd/align.py (both pinned to outputs of the
+// reference, tests/golden/make_bsj_golden.py); where the reference's own choice depends on the hash order of a Python
+// set (ties in sort_ss) the rule is first-seen order, as in both.
 //
 // Annotated splice sites (align.py:474-568, the GTF/BED-derived SS_INDEX) are four sorted arrays of genome-wide
 // positions (strand x start/end) in HBM; a candidate finds the annotated shifts near its two ends by binary search, as

@@ -210,3 +210,42 @@ def oracle_edit_distance(x, y):
     L.clo_edit_distance.restype = C.c_int32
     L.clo_edit_distance.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
     return int(L.clo_edit_distance(bx, len(bx), by, len(by)))
+
+
+# ---- splice signals (oracle/splice_oracle.c) ----------------------------------------------------------------------
+_SPLICE_MOTIFS = [('GT', 'AG'), ('GC', 'AG'), ('AT', 'AC'), ('GT', 'AC'), ('AT', 'AG')]      # (donor, acceptor), align.py:32-45
+
+
+def _rc_upper(s):
+    t = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A'}
+    return ''.join(t.get(c, c) for c in reversed(s))
+
+
+def oracle_splice_signal(contig, start, end, clip_base, host, is_canonical=True, site_runs=None):
+    """The splice-signal step for one candidate on the characters of its contig.  host: iterable of '+'/'-' or None;
+    site_runs: (positions int64, counts int64[4]) of this contig's annotated sites (1-based, four ascending runs) or None.
+    Returns (ss_site | None, us_free, ds_free) like find_annotated_signal + find_denovo_signal, or 'edge' where the
+    neighbourhood leaves the contig."""
+    L = oracle()
+    L.clo_splice_signal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    raw = contig if isinstance(contig, bytes) else contig.encode('latin-1')
+    hm = (1 if host and '+' in host else 0) | (2 if host and '-' in host else 0)
+    out = np.zeros(8, dtype=np.int32)
+    pos, cnt = site_runs if site_runs is not None else (np.zeros(1, dtype=np.int64), np.zeros(4, dtype=np.int64))
+    pos = np.ascontiguousarray(pos, dtype=np.int64); cnt = np.ascontiguousarray(cnt, dtype=np.int64)
+    L.clo_splice_signal(raw, len(raw), start, end, clip_base, hm, 10, 3, 1 if is_canonical else 0, pos.ctypes.data, cnt.ctypes.data, out.ctypes.data)
+    status, us_free, ds_free, found, strand, i, j, m = (int(x) for x in out)
+    if status:
+        return 'edge'
+    site = None
+    text = raw.decode('latin-1')
+    if found == 1:
+        donor, acceptor = _SPLICE_MOTIFS[m]
+        site = ('{}-{}*|{}-{}'.format(acceptor, donor, i, j), '-' if strand else '+', i, j)
+    elif found == 2:
+        us_ss, ds_ss = text[start + i - 2:start + i], text[end + j:end + j + 2]
+        if strand:
+            us_ss, ds_ss = _rc_upper(ds_ss), _rc_upper(us_ss)
+        site = ('{}-{}|{}-{}'.format(us_ss, ds_ss, i, j), '-' if strand else '+', i, j)
+    return site, us_free, ds_free

@@ -147,6 +147,42 @@ def test_kernel_rows_match_python_statement(is_canonical, annotated):
 
 
 @pytest.mark.parametrize('annotated', [False, True])
+def test_kernel_rows_match_c_oracle(annotated):
+    """The kernel's rows against oracle/splice_oracle.c (pinned to the reference's outputs by tests/test_splice_oracle.py),
+    field by field, all five motif classes."""
+    import oracle_lib
+    from ciri_long_amd import hip
+    contigs, cands = _world(1234 + annotated, 3000)
+    ss_index = _annotation(contigs, cands, 17) if annotated else None
+    ctx = hip.Context(0)
+    dev = hip.Genome(ctx, contigs)
+    dev.set_splice_sites(ss_index)
+    rows = dev.splice_signals([(c[0], c[1], c[2], c[3], (1 if c[4] and '+' in c[4] else 0) | (2 if c[4] and '-' in c[4] else 0)) for c in cands],
+                              10, 3, False).tolist()
+    runs = {c: hip.flatten_splice_sites({c: ss_index[c]} if ss_index and c in ss_index else None, {c: 0}, {c: len(v)}) for c, v in contigs.items()}
+    motifs = oracle_lib._SPLICE_MOTIFS
+    n = 0
+    for cand, r in zip(cands, rows):
+        if r[0]:
+            continue
+        ctg, st, en, cb, hs = cand
+        want = oracle_lib.oracle_splice_signal(contigs[ctg], st, en, cb, hs, False, runs[ctg])
+        assert want != 'edge', cand
+        got = None
+        if r[3] == 1:
+            got = ('{}-{}*|{}-{}'.format(motifs[r[7]][1], motifs[r[7]][0], r[5], r[6]), '-' if r[4] else '+', r[5], r[6])
+        elif r[3] == 2:
+            us_ss, ds_ss = contigs[ctg][st + r[5] - 2:st + r[5]], contigs[ctg][en + r[6]:en + r[6] + 2]
+            if r[4]:
+                us_ss, ds_ss = oracle_lib._rc_upper(ds_ss), oracle_lib._rc_upper(us_ss)
+            got = ('{}-{}|{}-{}'.format(us_ss, ds_ss, r[5], r[6]), '-' if r[4] else '+', r[5], r[6])
+        assert (got, r[1], r[2]) == want, (cand, r, want)
+        n += 1
+    dev.close(); ctx.close()
+    assert n > 0.8 * len(cands)
+
+
+@pytest.mark.parametrize('annotated', [False, True])
 def test_find_signal_batch_equals_per_read_path(annotated):
     """align.find_signal_batch (GPU rows + the Python statement for what the kernel hands back) == the per-read calls."""
     from ciri_long_amd import align, env, hip

@@ -72,3 +72,38 @@ def test_oracle_equals_python_mirror(is_canonical, annotated):
         n_ok += 1
         n_found += got[0] is not None
     assert n_ok > 0.85 * len(cands) and n_found > 0.4 * n_ok and n_edge > 0
+
+
+def test_reference_answers_on_seeded_worlds():
+    """6 000 candidates answered by the REFERENCE's own find_annotated_signal / find_denovo_signal
+    (tests/golden/make_splice_golden.py): canonical-only and all five motif classes, with and without annotated sites.
+    The C oracle (inside the contig) and the Python mirror (everywhere) must give the same answers; where the reference's
+    pick was tied in its set order, presence and the free-sliding lengths are compared."""
+    import test_gpu_splice as tgs
+    from ciri_long_amd import align, env
+    with gzip.open(os.path.join(HERE, 'golden', 'splice_golden.json.gz'), 'rt') as f:
+        golden = json.load(f)
+    n_c = n_py = n_edge = 0
+    for cfg in golden:
+        contigs, cands = tgs._world(cfg['seed'], cfg['n'])
+        host = tgs._Genome(contigs)
+        ss_index = tgs._annotation(contigs, cands, cfg['seed'] + 1) if cfg['annotated'] else None
+        env.initializer(None, host.contig_len, host, None, None, ss_index)
+        runs = {c: _runs(ss_index, c, host.contig_len[c]) for c in contigs}
+        assert len(cands) == len(cfg['rows'])
+        for cand, (want_site, us_free, ds_free, tied) in zip(cands, cfg['rows']):
+            ctg, st, en, cb, hs = cand
+            mirror = tgs._host_answer(align, cand, cfg['canonical'])
+            assert [mirror[1], mirror[2]] == [us_free, ds_free] and (mirror[0] is None) == (want_site is None), cand
+            if not tied:
+                assert (list(mirror[0]) if mirror[0] else None) == want_site, (cand, mirror, want_site)
+                n_py += 1
+            got = oracle_lib.oracle_splice_signal(contigs[ctg], st, en, cb, hs, cfg['canonical'], runs[ctg])
+            if got == 'edge':
+                n_edge += 1
+                continue
+            assert [got[1], got[2]] == [us_free, ds_free] and (got[0] is None) == (want_site is None), cand
+            if not tied:
+                assert (list(got[0]) if got[0] else None) == want_site, (cand, got, want_site)
+                n_c += 1
+    assert n_c > 4500 and n_py > 5000 and 0 < n_edge < 900

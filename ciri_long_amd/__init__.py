@@ -1,4 +1,4 @@
-"""ciri-long_amd: MI355X (gfx950) implementation of CIRI-long's per-read hot path
+"""ciri_long_amd (repository directory also reachable as ciri-long_amd/): MI355X (gfx950) implementation of CIRI-long's per-read hot path
 (find_ccs consensus -> find_bsj clip re-alignment by Smith-Waterman), behind CIRI-long's own Python interfaces.
 
 Modules mirror the reference tree:

@@ -4,7 +4,7 @@
 // flanks: up to 2 x 100 string slices and comparisons in Python), align.py:571-695 (find_denovo_signal: str.find of
 // the donor/acceptor dinucleotides over two windows of <= 262 bases, all pairs of occurrences) and align.py:698-733
 // (get_ss_altered_length, sort_ss: four tiers, sorted by four keys) -- SURVEY.md section 8 f4.  The statements it is
-// checked against are oracle/splice_oracle.c and the host mirror ciri-long_amd/align.py (both pinned to outputs of the
+// checked against are oracle/splice_oracle.c and the host mirror ciri_long_amd/align.py (both pinned to outputs of the
 // reference, tests/golden/make_bsj_golden.py); where the reference's own choice depends on the hash order of a Python
 // set (ties in sort_ss) the rule is first-seen order, as in both.
 //

@@ -1,6 +1,6 @@
 /* splice_oracle.c -- CPU statement of the splice-signal step around a candidate back-splice junction.
  *
- * TEST INFRASTRUCTURE ONLY: the checker of K6 (ciri-long_amd/csrc/splice_scan.hip).  Nothing under ciri-long_amd/ may
+ * TEST INFRASTRUCTURE ONLY: the checker of K6 (ciri_long_amd/csrc/splice_scan.hip).  Nothing under ciri_long_amd/ may
  * load it.  It restates, on the raw characters of one contig:
  *     CIRI_long/align.py:477-493   how far the junction slides between identical flanks (us_free, ds_free)
  *     CIRI_long/align.py:495-568   find_annotated_signal: pairs of annotated sites near both ends

@@ -1,7 +1,7 @@
 /*
  * ssw_oracle.c -- CPU restatement of CIRI-long's vendored striped Smith-Waterman.
  *
- * TEST INFRASTRUCTURE ONLY.  Nothing under ciri-long_amd/ (the product) may link,
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ciri_long_amd/ (the product) may link,
  * import or execute this file.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py use it, and only as the checker.
  *

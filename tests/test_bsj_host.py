@@ -1,4 +1,4 @@
-"""Host side of the BSJ step (ciri-long_amd/find_bsj.py, align.py) against golden vectors produced by the reference's
+"""Host side of the BSJ step (ciri_long_amd/find_bsj.py, align.py) against golden vectors produced by the reference's
 own Python (tests/golden/make_bsj_golden.py) with the deterministic mapper/genome doubles of tests/fake_mapper.py.
 
 CPU tests substitute the oracle for the batched GPU call (test infrastructure only); the `gpu` test runs the real

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, 'ciri-long_amd', 'libclh.so')
+SO = os.path.join(ROOT, 'ciri_long_amd', 'libclh.so')
 
 
 def _declared(header):
@@ -87,8 +87,8 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
 
 
 def test_product_never_imports_the_oracle():
-    """The oracle is test infrastructure: nothing under ciri-long_amd/ may reference it."""
-    pkg = os.path.join(ROOT, 'ciri-long_amd')
+    """The oracle is test infrastructure: nothing under ciri_long_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'ciri_long_amd')
     for dp, _, fs in os.walk(pkg):
         for f in fs:
             if f.endswith(('.py', '.hip', '.h', '.cpp')):

@@ -1,4 +1,4 @@
-"""Collapse-stage call sites of the kernels (ciri-long_amd/collapse.py) against golden vectors
+"""Collapse-stage call sites of the kernels (ciri_long_amd/collapse.py) against golden vectors
 produced by the reference's own Python (tests/golden/make_collapse_golden.py; see its header for the two absent
 dependencies it had to supply).  CPU tests substitute the oracles for the batched GPU calls (test infrastructure only);
 the `gpu` tests run the real K1/K1b/K3/K4 path."""

@@ -1,4 +1,4 @@
-"""K6 (splice_scan.hip) against the Python statement of the same step (ciri-long_amd/align.py: find_annotated_signal ->
+"""K6 (splice_scan.hip) against the Python statement of the same step (ciri_long_amd/align.py: find_annotated_signal ->
 find_denovo_signal, themselves pinned to outputs of the reference by test_bsj_host.test_splice_signal_search)."""
 import json
 import os

@@ -1,7 +1,7 @@
 #!/bin/bash
 # builds libclh_dbg.so with the K3 phase clocks compiled in, then prints the breakdown
 set -e
-cd "$(dirname "$0")/../ciri-long_amd/csrc"
+cd "$(dirname "$0")/../ciri_long_amd/csrc"
 for f in clh_api ssw_wavefront ssw_traceback ccs_poa edit_distance genome splice_scan fastx_ccs; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DCLH_DEBUG_POA -DCLH_PROBE_BUILD -c $f.hip -o /tmp/$f.dbg.o &
 done
@@ -10,4 +10,4 @@ hipcc --offload-arch=gfx950 -shared -fPIC -o ../libclh_dbg.so /tmp/clh_api.dbg.o
 cd ../..
 [ -n "$BUILD_ONLY" ] && exit 0
 python tools/k3_phases.py "$@"
-rm -f ciri-long_amd/libclh_dbg.so
+rm -f ciri_long_amd/libclh_dbg.so

@@ -1,5 +1,5 @@
 """K6 rate: splice-signal search for N candidate junctions on a resident synthetic genome vs the per-read Python
-statement (ciri-long_amd/align.py, what the reference runs per read).  usage: python tools/splice_bench.py [N] [genome_mb]"""
+statement (ciri_long_amd/align.py, what the reference runs per read).  usage: python tools/splice_bench.py [N] [genome_mb]"""
 import os
 import sys
 import time

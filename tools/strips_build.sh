@@ -1,7 +1,7 @@
 #!/bin/bash
 # libclh_dbg.so with only the RV=1 and row-strip classes of K1 (fast to build); extra -D flags may be passed
 set -e
-cd "$(dirname "$0")/../ciri-long_amd/csrc"
+cd "$(dirname "$0")/../ciri_long_amd/csrc"
 for f in clh_api ssw_wavefront ssw_traceback ccs_poa edit_distance genome fastx_ccs; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DCLH_STRIPS_BUILD "$@" -c $f.hip -o /tmp/$f.dbg.o &
 done

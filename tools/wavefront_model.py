@@ -1,6 +1,6 @@
 """numpy model of the anti-diagonal wavefront pass the HIP kernel runs (design aid + executable spec).
 
-Not the product and not the oracle: it mirrors the DATAFLOW of ciri-long_amd/csrc/ssw_wavefront.hip
+Not the product and not the oracle: it mirrors the DATAFLOW of ciri_long_amd/csrc/ssw_wavefront.hip
 (128 virtual lanes = 64 lanes x {lo,hi} 16-bit halves, RV rows per virtual lane, one column per virtual
 lane per step, boundary values handed to the next virtual lane one step later) so that the design can be
 checked against oracle/ on the CPU before a kernel is written.  tests/test_wavefront_model.py runs it

@@ -29,28 +29,12 @@
  *    Fewer than 2 full copies -> no repeat.  A tail of >= 20 bases after the last cut is kept as a partial copy, unless
  *    the 64-cut cap ended the search (the rest of the read is then an unscanned stretch of copies and is left out).
  *    A copy longer than 2800 bases -> no consensus (limit of v1: 16-bit cells of the alignment kernel).
- * 3. consensus.  Partial-order alignment of the copies in read order ("clh-poa v1", below), heaviest path.
+ * 3. consensus.  Partial-order alignment of the copies in read order (poa_oracle.c), heaviest bundle, restricted to the
+ *    nodes crossed by at least (copies + 1) / 2 of the copies (the partial last copy counts as a copy).
  *
- * Specification "clh-poa v1" (scores from the reference's call sites: match 10, mismatch -4, gap -8; tests/test_poa.py:30)
- * --------------------------
- * Linear gap cost.  Fitting alignment: the sequence is aligned end to end, the graph's ends are free.
- * Rows = nodes in topological order (rank 1..N), row 0 = virtual start with H0[j] = j*gap.
- *   D[v][j] = max over in-edges (p->v) in insertion order, then row 0, of H[p][j-1] + s(v, j)      (strict > keeps first)
- *   V[v][j] = max over in-edges in insertion order of H[p][j] + gap
- *   H[v][0] = 0;  H[v][j] = D; if V > H take V; then if H[v][j-1] + gap > H take it
- * End cell: largest H[v][m], ties to the lowest rank.  Walking back, sequence bases left of the first aligned node
- * are insertions.
- * Adding the path: a base aligned to a node with the same base re-uses it; with another base it re-uses the member of
- * the node's aligned set holding that base, else a new node joins the set; inserted bases get new nodes.  Consecutive
- * used nodes get an edge (weight +1 if present; a node keeps at most 12 in-edges, more is an error -> no consensus).
- * Order keys: a new aligned node takes its partner's key; an inserted node takes key(last aligned node)+t (t-th since
- * then), leading insertions sit just below the first aligned node.  Re-ranking: candidates = nodes sorted by (key, id);
- * that order can violate an edge when a base re-used a member of an aligned set that ranks after the row it was
- * aligned to, so the final order is the depth-first post-order over in-edges (stored order) taken in candidate order
- * (identical to the candidate order whenever that is already topological); then key = rank << 20.
- * Consensus: in rank order, best[v] = in-edge with the largest weight (ties: larger score of its source, then first),
- * score[v] = weight + score[source]; the path ends at the node with the largest score (ties: larger rank) and is
- * followed back through best[] to a node without in-edges.
+ * Step 3 is spoa.poa(copies, 0, ., 10, -4, -8, -2, -24, -1) -- local alignment, two-piece gap cost, the call of the
+ * reference's tests/test_poa.py:30, whose assertion (:32) equates the length of that consensus with the length of
+ * find_consensus' -- as stated in poa_oracle.c ("clh-poa v2": a restatement of the published spoa algorithm).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -62,10 +46,6 @@
 #define CCS_MAX_CUTS 64
 #define CCS_MIN_TAIL 20
 #define POA_MAX_COPY 2800
-#define POA_MAXP 12
-#define POA_MATCH 10
-#define POA_MISMATCH (-4)
-#define POA_GAP (-8)
 
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
@@ -152,230 +132,10 @@ int clo_ccs_segments(const int8_t *seq, int32_t L, int32_t *cuts, int32_t *ncuts
     return p0;
 }
 
-/* ---------------------------------------------------------------------------------------------------------- */
-typedef struct {
-    int n, cap;
-    int8_t *base;
-    int8_t *np;
-    int32_t *pred;      /* [cap][POA_MAXP] */
-    int32_t *pw;        /* [cap][POA_MAXP] */
-    int32_t *aligned;   /* [cap][3], -1 = none */
-    int64_t *key;
-    int32_t *order;     /* rank-1 -> node */
-    int32_t *rank;      /* node -> rank (1..n) */
-} poa_graph;
+/* step 3 lives in poa_oracle.c */
+int clo_poa(int32_t nseq, const int8_t *seqs, const int32_t *off, const int32_t *params, int8_t *cons, int32_t cap,
+            int8_t *msa, int64_t msa_cap, int32_t *ncols, int32_t *scores);
 
-static void g_init(poa_graph *g, int cap)
-{
-    g->n = 0; g->cap = cap;
-    g->base = (int8_t *)malloc((size_t)cap);
-    g->np = (int8_t *)calloc((size_t)cap, 1);
-    g->pred = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap * POA_MAXP);
-    g->pw = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap * POA_MAXP);
-    g->aligned = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap * 3);
-    g->key = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
-    g->order = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
-    g->rank = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
-}
-static void g_free(poa_graph *g)
-{
-    free(g->base); free(g->np); free(g->pred); free(g->pw); free(g->aligned); free(g->key); free(g->order); free(g->rank);
-}
-static int g_new(poa_graph *g, int base, int64_t key)
-{
-    if (g->n >= g->cap) return -1;
-    int v = g->n++;
-    g->base[v] = (int8_t)base; g->np[v] = 0; g->key[v] = key;
-    g->aligned[v * 3] = g->aligned[v * 3 + 1] = g->aligned[v * 3 + 2] = -1;
-    return v;
-}
-static int g_edge(poa_graph *g, int u, int v)
-{
-    for (int e = 0; e < g->np[v]; ++e)
-        if (g->pred[v * POA_MAXP + e] == u) { g->pw[v * POA_MAXP + e] += 1; return 0; }
-    if (g->np[v] >= POA_MAXP) return -1;
-    g->pred[v * POA_MAXP + g->np[v]] = u;
-    g->pw[v * POA_MAXP + g->np[v]] = 1;
-    g->np[v] += 1;
-    return 0;
-}
-static poa_graph *g_sort_ctx;
-static int g_cmp(const void *a, const void *b)
-{
-    int x = *(const int32_t *)a, y = *(const int32_t *)b;
-    if (g_sort_ctx->key[x] != g_sort_ctx->key[y]) return g_sort_ctx->key[x] < g_sort_ctx->key[y] ? -1 : 1;
-    return x < y ? -1 : (x > y);
-}
-static void g_rerank(poa_graph *g)
-{
-    const int n = g->n;
-    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
-    int32_t *stk = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *sti = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
-    int8_t *seen = (int8_t *)calloc((size_t)n, 1);
-    for (int i = 0; i < n; ++i) cand[i] = i;
-    g_sort_ctx = g;
-    qsort(cand, (size_t)n, sizeof(int32_t), g_cmp);
-    int out = 0;
-    for (int c = 0; c < n; ++c) {
-        if (seen[cand[c]]) continue;
-        int sp = 0;
-        stk[0] = cand[c]; sti[0] = 0; seen[cand[c]] = 1;
-        while (sp >= 0) {
-            const int u = stk[sp];
-            if (sti[sp] < g->np[u]) {
-                const int pr = g->pred[u * POA_MAXP + sti[sp]];
-                sti[sp] += 1;
-                if (!seen[pr]) { seen[pr] = 1; ++sp; stk[sp] = pr; sti[sp] = 0; }
-            } else {
-                g->order[out++] = u;
-                --sp;
-            }
-        }
-    }
-    for (int r = 0; r < n; ++r) { g->rank[g->order[r]] = r + 1; g->key[g->order[r]] = (int64_t)(r + 1) << 20; }
-    free(cand); free(stk); free(sti); free(seen);
-}
-
-/* align seq (codes, length m) to the graph and add it.  returns 0, or -1 on capacity/in-degree overflow */
-static int poa_add(poa_graph *g, const int8_t *seq, int m)
-{
-    if (g->n == 0) {
-        for (int j = 0; j < m; ++j) {
-            int v = g_new(g, seq[j], (int64_t)(j + 1) << 20);
-            if (v < 0) return -1;
-            if (j > 0 && g_edge(g, v - 1, v) != 0) return -1;
-        }
-        g_rerank(g);
-        return 0;
-    }
-    const int N = g->n, Wd = m + 1;
-    int32_t *H = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N + 1) * Wd);
-    uint8_t *dir = (uint8_t *)malloc((size_t)(N + 1) * Wd);   /* 0 start, 1 diag, 2 vert, 3 horiz; high nibble = in-edge slot (15 = row 0) */
-    for (int j = 0; j <= m; ++j) { H[j] = j * POA_GAP; dir[j] = 3; }
-    for (int r = 1; r <= N; ++r) {
-        const int v = g->order[r - 1];
-        int32_t *Hr = H + (size_t)r * Wd;
-        uint8_t *dr = dir + (size_t)r * Wd;
-        Hr[0] = 0; dr[0] = 0;
-        for (int j = 1; j <= m; ++j) {
-            const int s = (g->base[v] == seq[j - 1] && seq[j - 1] < 4) ? POA_MATCH : POA_MISMATCH;
-            int best = INT32_MIN, bd = 0;
-            for (int e = 0; e < g->np[v]; ++e) {
-                const int pr = g->rank[g->pred[v * POA_MAXP + e]];
-                const int c = H[(size_t)pr * Wd + j - 1] + s;
-                if (c > best) { best = c; bd = 1 | (e << 4); }
-            }
-            { const int c = H[j - 1] + s; if (c > best) { best = c; bd = 1 | (15 << 4); } }
-            for (int e = 0; e < g->np[v]; ++e) {
-                const int pr = g->rank[g->pred[v * POA_MAXP + e]];
-                const int c = H[(size_t)pr * Wd + j] + POA_GAP;
-                if (c > best) { best = c; bd = 2 | (e << 4); }
-            }
-            { const int c = Hr[j - 1] + POA_GAP; if (c > best) { best = c; bd = 3; } }
-            Hr[j] = best; dr[j] = (uint8_t)bd;
-        }
-    }
-    int br = 1, bs = H[(size_t)1 * Wd + m];
-    for (int r = 2; r <= N; ++r) if (H[(size_t)r * Wd + m] > bs) { bs = H[(size_t)r * Wd + m]; br = r; }
-
-    /* walk back: pairs (node or -1, seq index) in reverse */
-    int32_t *pn = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N + m + 2));
-    int32_t *pj = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N + m + 2));
-    int np_ = 0, r = br, j = m;
-    while (j > 0) {
-        if (r == 0) { pn[np_] = -1; pj[np_++] = --j; continue; }
-        const uint8_t d = dir[(size_t)r * Wd + j];
-        const int v = g->order[r - 1];
-        if ((d & 3) == 1) { pn[np_] = v; pj[np_++] = j - 1; --j; const int e = d >> 4; r = e == 15 ? 0 : g->rank[g->pred[v * POA_MAXP + e]]; }
-        else if ((d & 3) == 2) { const int e = d >> 4; r = g->rank[g->pred[v * POA_MAXP + e]]; }
-        else if ((d & 3) == 3) { pn[np_] = -1; pj[np_++] = j - 1; --j; }
-        else break;   /* H[v][0]: start of the aligned part; remaining bases (none, j == 0) */
-    }
-    free(H); free(dir);
-
-    /* first aligned node ahead (for the keys of leading insertions) */
-    int lead = 0, first_anchor = -1;
-    for (int t = np_ - 1; t >= 0; --t) { if (pn[t] >= 0) { first_anchor = pn[t]; break; } ++lead; }
-    int64_t maxkey = 0;
-    for (int v = 0; v < N; ++v) if (g->key[v] > maxkey) maxkey = g->key[v];
-
-    int prev_used = -1, since = 0, rc = 0;
-    int64_t anchor_key = first_anchor >= 0 ? g->key[first_anchor] - (lead + 1) : maxkey;
-    for (int t = np_ - 1; t >= 0 && rc == 0; --t) {
-        const int b = seq[pj[t]];
-        int use;
-        if (pn[t] < 0) {
-            ++since;
-            use = g_new(g, b, anchor_key + since);
-        } else {
-            const int v = pn[t];
-            anchor_key = g->key[v]; since = 0;
-            use = -1;
-            if (g->base[v] == b) use = v;
-            else for (int a = 0; a < 3; ++a) { const int w = g->aligned[v * 3 + a]; if (w >= 0 && g->base[w] == b) { use = w; break; } }
-            if (use < 0) {
-                use = g_new(g, b, g->key[v]);
-                if (use >= 0) {
-                    /* join the aligned set of v: every member learns the new node and vice versa */
-                    int members[4], nm = 0;
-                    members[nm++] = v;
-                    for (int a = 0; a < 3; ++a) if (g->aligned[v * 3 + a] >= 0) members[nm++] = g->aligned[v * 3 + a];
-                    int slot = 0;
-                    for (int q = 0; q < nm; ++q) {
-                        const int w = members[q];
-                        for (int a = 0; a < 3; ++a) if (g->aligned[w * 3 + a] < 0) { g->aligned[w * 3 + a] = use; break; }
-                        if (slot < 3) g->aligned[use * 3 + slot++] = w;
-                    }
-                }
-            }
-        }
-        if (use < 0) { rc = -1; break; }
-        if (prev_used >= 0 && g_edge(g, prev_used, use) != 0) rc = -1;
-        prev_used = use;
-    }
-    free(pn); free(pj);
-    if (rc == 0) g_rerank(g);
-    return rc;
-}
-
-static int poa_consensus(poa_graph *g, int8_t *out, int cap)
-{
-    const int N = g->n;
-    int32_t *score = (int32_t *)calloc((size_t)N, sizeof(int32_t));
-    int32_t *bp = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
-    int top = -1, tops = -1;
-    for (int r = 1; r <= N; ++r) {
-        const int v = g->order[r - 1];
-        int bw = -1, bsrc = -1;
-        for (int e = 0; e < g->np[v]; ++e) {
-            const int u = g->pred[v * POA_MAXP + e], w = g->pw[v * POA_MAXP + e];
-            if (w > bw || (w == bw && score[u] > score[bsrc])) { bw = w; bsrc = u; }
-        }
-        bp[v] = bsrc;
-        score[v] = bsrc >= 0 ? bw + score[bsrc] : 0;
-        if (score[v] >= tops) { tops = score[v]; top = v; }     /* ties: larger rank */
-    }
-    int len = 0;
-    for (int v = top; v >= 0; v = bp[v]) ++len;
-    if (len > cap) { free(score); free(bp); return -1; }
-    int k = len;
-    for (int v = top; v >= 0; v = bp[v]) out[--k] = g->base[v];
-    free(score); free(bp);
-    return len;
-}
-
-/* consensus of nseq sequences (packed codes, offsets[nseq+1]).  returns length or -1 */
-int clo_poa_consensus(int32_t nseq, const int8_t *seqs, const int32_t *off, int8_t *out, int32_t cap)
-{
-    int total = off[nseq];
-    poa_graph g;
-    g_init(&g, total + 8);
-    int rc = 0;
-    for (int s = 0; s < nseq && rc == 0; ++s) rc = poa_add(&g, seqs + off[s], off[s + 1] - off[s]);
-    int len = rc == 0 ? poa_consensus(&g, out, cap) : -1;
-    g_free(&g);
-    return len;
-}
 
 /* find_consensus: segs[2*i], segs[2*i+1] = start, end of copy i.  returns consensus length, 0 = no repeat, -1 = error */
 int clo_find_consensus(const int8_t *seq, int32_t L, int32_t *segs, int32_t *nseg, int8_t *ccs, int32_t cap, int32_t *period)
@@ -400,7 +160,10 @@ int clo_find_consensus(const int8_t *seq, int32_t L, int32_t *segs, int32_t *nse
         memcpy(buf + off[i], seq + segs[2 * i], (size_t)(segs[2 * i + 1] - segs[2 * i]));
         off[i + 1] = off[i] + segs[2 * i + 1] - segs[2 * i];
     }
-    const int len = clo_poa_consensus(n, buf, off, ccs, cap);
+    /* local alignment, the scores of tests/test_poa.py:30; nodes crossed by fewer than half of the copies are left out of
+       the consensus (the unaligned overhang of a copy cut a few bases early or late would otherwise lead or trail it) */
+    const int32_t par[8] = {0, 10, -4, -8, -2, -24, -1, (n + 1) / 2};
+    const int len = clo_poa(n, buf, off, par, ccs, cap, NULL, 0, NULL, NULL);
     free(off); free(buf);
     if (len < 0) { *nseg = 0; return -1; }
     return len;

@@ -167,8 +167,9 @@ def _ccs_lib():
     if not getattr(lib, '_ccs_ready', False):
         lib.clo_find_consensus.restype = C.c_int
         lib.clo_find_consensus.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
-        lib.clo_poa_consensus.restype = C.c_int
-        lib.clo_poa_consensus.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.clo_poa.restype = C.c_int
+        lib.clo_poa.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                C.c_void_p, C.c_void_p]
         lib.clo_ccs_segments.restype = C.c_int
         lib.clo_ccs_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib._ccs_ready = True
@@ -192,14 +193,34 @@ def oracle_find_consensus(seq):
     return seg, decode(out[:n]), period.value
 
 
-def oracle_poa(seqs):
+POA_DEFAULT = (10, -4, -8, -2, -24, -1)       # the scores of every reference call site (collapse.py:267,504; tests/test_poa.py:30)
+
+
+def oracle_poa(seqs, algorithm=0, genmsa=False, m=10, n=-4, g=-8, e=-2, q=-24, c=-1, with_scores=False, min_coverage=0):
+    """oracle/poa_oracle.c: spoa.poa(seqs, algorithm, genmsa, m, n, g, e, q, c) -> consensus | (consensus, msa[, scores]).
+    None where an implementation limit was hit; ValueError on invalid parameters."""
     arrs = [np.ascontiguousarray(encode(s) if not isinstance(s, np.ndarray) else s, dtype=np.int8) for s in seqs]
     off = np.zeros(len(arrs) + 1, dtype=np.int32)
     np.cumsum([len(a) for a in arrs], out=off[1:])
-    data = np.concatenate(arrs)
+    data = np.concatenate(arrs) if arrs else np.zeros(1, dtype=np.int8)
     out = np.zeros(int(off[-1]) + 8, dtype=np.int8)
-    n = _ccs_lib().clo_poa_consensus(len(arrs), data.ctypes.data, off.ctypes.data, out.ctypes.data, len(out))
-    return None if n < 0 else decode(out[:n])
+    par = np.array([algorithm, m, n, g, e, q, c, min_coverage], dtype=np.int32)
+    ncols = C.c_int32(0)
+    msa_cap = (int(off[-1]) + 8) * max(len(arrs), 1)
+    msa = np.zeros(msa_cap, dtype=np.int8)
+    scores = np.zeros(len(arrs) + 1, dtype=np.int32)
+    k = _ccs_lib().clo_poa(len(arrs), data.ctypes.data, off.ctypes.data, par.ctypes.data, out.ctypes.data, len(out),
+                           msa.ctypes.data if genmsa else None, msa_cap, C.byref(ncols), scores.ctypes.data)
+    if k == -2:
+        raise ValueError('invalid poa parameters')
+    cons = None if k < 0 else decode(out[:k])
+    if not genmsa and not with_scores:
+        return cons
+    rows = []
+    if genmsa and k >= 0:
+        nc = ncols.value
+        rows = [''.join('-' if x == 45 else 'ACGTN'[x] for x in msa[r * nc:(r + 1) * nc]) for r in range(len(arrs))]
+    return (cons, rows, [int(x) for x in scores[:len(arrs)]]) if with_scores else (cons, rows)
 
 
 def oracle_edit_distance(x, y):

@@ -1,5 +1,6 @@
-"""CPU checks of the consensus specification (oracle/ccs_oracle.c).  There is no pyccs/spoa to compare with (PARITY
-UNPINNED): what can be checked is the contract CIRI-long consumes and that the method does what it is for."""
+"""CPU checks of the consensus specification (oracle/ccs_oracle.c + oracle/poa_oracle.c).  There is no pyccs/spoa to
+compare with (PARITY UNPINNED): what can be checked is the contract CIRI-long consumes, the reference's own structural
+test, and that the method does what it is for."""
 import re
 
 import numpy as np
@@ -21,8 +22,10 @@ def test_reference_test_poa_structure():
     for a, b in bounds[:5]:
         assert 130 <= b - a <= 150
     assert set(ccs) <= set('ACGT')
-    assert 140 <= len(ccs) <= 160
-    assert abs(len(oracle_lib.oracle_poa(SEGMENTS)) - 144) <= 2
+    # the reference's assertion (tests/test_poa.py:30-32): same length as poa(copies, 0, True, 10, -4, -8, -2, -24, -1)
+    cons, msa = oracle_lib.oracle_poa(SEGMENTS, 0, True, 10, -4, -8, -2, -24, -1)
+    assert len(ccs) == len(cons) == 144
+    assert len(msa) == len(SEGMENTS) and all(r.replace('-', '') == s for r, s in zip(msa, SEGMENTS))
 
 
 def test_recovers_templates_and_rejects_linear_reads():

@@ -1,0 +1,306 @@
+"""Dataflow model of K3 (csrc/ccs_poa.hip) in numpy -- not the product and not the oracle.
+
+oracle/poa_oracle.c states the aligner the way spoa computes it: five full int32 matrices and a back-track that compares
+matrix values.  The kernel cannot keep matrices; it computes a row at a time from its source rows and leaves ONE byte per
+cell (two more for rows with several in-edges) from which the same back-track is replayed.  This file is that row-wise
+formulation, cell for cell what the kernel does, so that the derivation can be checked on the CPU against the oracle
+(tests/test_poa_model.py) before and independently of any GPU run:
+
+* source rows are read as H and the two clamped differences dF = max(F + e - g - H, -1), dO = max(O + c - q - H, -1)
+  (a vertical gap state below H - 1 in that frame can never win, tie or be back-tracked into);
+* the horizontal states come from two prefix maxima over M0 = max(diagonal, F, O[, 0]) ("hat" values) and the identities
+  Q = Qhat, E[j] = max(Ehat[j], Qhat[j-1] + g);
+* per cell: bit 0 zero (local mode: stop), 1 diagonal, 2 vertical, 3 vertical move continues upwards (extend-up),
+  4 horizontal move continues to the left (extend-left), 5 hx: the E or Q chain of this column extends the previous
+  column's, 6 vstop: an upward run ends with the step out of this cell; rows with several in-edges add the in-edge slots
+  (diagonal, vertical, upward run) in a second plane.
+"""
+import numpy as np
+
+NEG = -(1 << 28)
+B_ZERO, B_DIAG, B_VERT, B_EXTUP, B_EXTLEFT, B_HX, B_VSTOP = 1, 2, 4, 8, 16, 32, 64
+
+
+class Params(object):
+    def __init__(self, algorithm=0, m=10, n=-4, g=-8, e=-2, q=-24, c=-1):
+        if g >= e:
+            raise NotImplementedError('linear gap cost (g >= e) is not built into the kernel')
+        if g <= q or e >= c:          # affine: one piece (spoa: AlignmentEngine::Create)
+            q, c = g, e
+        self.algorithm, self.m, self.n, self.g, self.e, self.q, self.c = algorithm, m, n, g, e, q, c
+
+
+def row0(P, L):
+    """H, dF, dO of row 0 (no node), columns 0..L"""
+    j = np.arange(L + 1)
+    if P.algorithm == 0:
+        h = np.zeros(L + 1, dtype=np.int64)
+    else:
+        h = np.maximum(P.g + (j - 1) * P.e, P.q + (j - 1) * P.c)
+        h[0] = 0
+    return h, np.full(L + 1, -1, dtype=np.int64), np.full(L + 1, -1, dtype=np.int64)
+
+
+def prefix_hat(m0, open_, ext):
+    """hat[j] = max over 0 <= k < j of m0[k] + open + (j-1-k) ext, j = 1..L (hat[0] = NEG)"""
+    L = len(m0) - 1
+    k = np.arange(L + 1)
+    run = np.maximum.accumulate(m0 - k * ext)              # inclusive prefix maximum in the gap-free frame
+    hat = np.full(L + 1, NEG, dtype=np.int64)
+    hat[1:] = run[:-1] + open_ - ext + k[1:] * ext
+    return hat
+
+
+def dp_row(P, code, seq, srcs, col0):
+    """One row.  srcs = list of (H, dF, dO) of the source rows in in-edge order (row 0 for a node without in-edges);
+    col0 = H[r][0].  Returns (H, dF, dO, byte plane, slot plane) for columns 0..L (column 0 of the planes unused)."""
+    L = len(seq)
+    s = np.where(seq == code, P.m, P.n).astype(np.int64)
+    multi = len(srcs) > 1
+    d = fe = fo = oe = None
+    for k, (h, df, do) in enumerate(srcs):
+        dk = h[:-1] + s                                     # H[p][j-1] + s(i, j), j = 1..L
+        fek, fok, oek = (h + df)[1:], h[1:], (h + do)[1:]   # Fs, H, Os of the source at column j
+        if k == 0:
+            d, fe, fo, oe = dk, fek, fok, oek
+            kd = np.zeros(L, dtype=np.int64); kfe = kd.copy(); kfo = kd.copy(); koe = kd.copy()
+        else:
+            kd = np.where(dk > d, k, kd); d = np.maximum(d, dk)
+            kfe = np.where(fek > fe, k, kfe); fe = np.maximum(fe, fek)
+            kfo = np.where(fok > fo, k, kfo); fo = np.maximum(fo, fok)
+            koe = np.where(oek > oe, k, koe); oe = np.maximum(oe, oek)
+    fnew, onew = P.g + np.maximum(fe, fo), P.q + np.maximum(oe, fo)
+    m0 = np.empty(L + 1, dtype=np.int64)
+    m0[0] = col0
+    m0[1:] = np.maximum(np.maximum(d, fnew), onew)
+    if P.algorithm == 0:
+        m0[1:] = np.maximum(m0[1:], 0)
+    ehat, qhat = prefix_hat(m0, P.g, P.e), prefix_hat(m0, P.q, P.c)
+    H = np.maximum(m0, np.maximum(ehat, qhat))
+    H[0] = col0
+    E = ehat.copy()
+    E[2:] = np.maximum(ehat[2:], qhat[1:-1] + P.g)
+    Q = qhat
+    h1, hl = H[1:], H[:-1]
+    bits = np.zeros(L, dtype=np.int64)
+    if P.algorithm == 0:
+        bits |= np.where(h1 == 0, B_ZERO, 0)
+    bits |= np.where(h1 == d, B_DIAG, 0)
+    vFE, vFO, vOE = h1 == fe + P.g, h1 == fo + P.g, h1 == oe + P.q
+    bits |= np.where(vFE | vFO | vOE, B_VERT, 0)
+    # which class the vertical move comes from: smallest (slot, class) in the order FE, FO, OE
+    big = 1 << 20
+    key = np.minimum(np.minimum(np.where(vFE, kfe * 4 + 0, big), np.where(vFO, kfo * 4 + 1, big)), np.where(vOE, koe * 4 + 2, big))
+    kv = np.where(key < big, key >> 2, 0)
+    bits |= np.where((key < big) & ((key & 3) != 1), B_EXTUP, 0)
+    ext_left = (h1 == E[:-1] + P.e) | ~(h1 == hl + P.g)
+    bits |= np.where(ext_left, B_EXTLEFT, 0)
+    hx = (E[:-1] + P.e == E[1:]) | (Q[:-1] + P.c == Q[1:])
+    bits |= np.where(hx, B_HX, 0)
+    # upward run out of this cell: smallest (slot, class) in the order F-open, F-extend, O-open, O-extend
+    keyx = np.minimum(np.minimum(np.where(fo >= fe, kfo * 4 + 0, big), np.where(fe >= fo, kfe * 4 + 1, big)),
+                      np.minimum(np.where(fo >= oe, kfo * 4 + 2, big), np.where(oe >= fo, koe * 4 + 3, big)))
+    kx = keyx >> 2
+    bits |= np.where((keyx & 1) == 0, B_VSTOP, 0)
+    slots = (kd | (kv << 4) | (kx << 8)) if multi else None
+    # what the following rows read from this one
+    fs_new, os_new = P.e + np.maximum(fe, fo), P.c + np.maximum(oe, fo)
+    dF = np.full(L + 1, -1, dtype=np.int64); dO = np.full(L + 1, -1, dtype=np.int64)
+    dF[1:] = np.maximum(fs_new - h1, -1)
+    dO[1:] = np.maximum(os_new - h1, -1)
+    assert dF.max() <= P.e - P.g and dO.max() <= P.c - P.q
+    return H, dF, dO, bits, slots
+
+
+class Graph(object):
+    MAXP, MAXA = 12, 4
+
+    def __init__(self):
+        self.code, self.pred, self.pw, self.aligned, self.cov, self.nout = [], [], [], [], [], []
+        self.order, self.rank = [], []            # order[r-1] = node; rank[node] = r
+
+    def new(self, code):
+        self.code.append(int(code)); self.pred.append([]); self.pw.append([]); self.aligned.append([]); self.cov.append(0)
+        self.nout.append(0); self.rank.append(0)
+        return len(self.code) - 1
+
+    def edge(self, u, v, w):
+        if u in self.pred[v]:
+            self.pw[v][self.pred[v].index(u)] += w
+        else:
+            if len(self.pred[v]) >= self.MAXP:
+                raise OverflowError('in-degree')
+            self.pred[v].append(u); self.pw[v].append(w); self.nout[u] += 1
+
+    def span(self, v):
+        rs = [self.rank[v]] + [self.rank[a] for a in self.aligned[v]]
+        return min(rs), max(rs)
+
+
+def align(P, G, seq):
+    """pn[j] = rank of the node base j is aligned to (0: none), end-cell score"""
+    N, L = len(G.order), len(seq)
+    rows = [row0(P, L)]
+    planes = [None]
+    sinks = []
+    # column 0 of the global mode: H[i][0] = max(F, O)[i][0] with F[i][0] = e + max over sources (a source row: g)
+    f0, o0 = [0], [0]
+    best, bi, bj = (0 if P.algorithm == 0 else NEG), 0, 0
+    for r in range(1, N + 1):
+        v = G.order[r - 1]
+        pr = [G.rank[u] for u in G.pred[v]] or [0]
+        if G.pred[v]:
+            f0.append(P.e + max(f0[p] for p in pr)); o0.append(P.c + max(o0[p] for p in pr))
+        else:
+            f0.append(P.g); o0.append(P.q)
+        col0 = max(f0[r], o0[r]) if P.algorithm == 1 else 0
+        H, dF, dO, bits, slots = dp_row(P, G.code[v], seq, [rows[p] for p in pr], col0)
+        rows.append((H, dF, dO)); planes.append((bits, slots, pr))
+        sink = G.nout[v] == 0
+        if P.algorithm == 0 or (sink and P.algorithm == 2):
+            jm = int(np.argmax(H[1:])) + 1
+            if H[jm] > best:
+                best, bi, bj = int(H[jm]), r, jm
+        elif sink and H[L] > best:
+            best, bi, bj = int(H[L]), r, L
+    pn = [0] * L
+    r, j = bi, bj
+    while r > 0 and j > 0:
+        bits, slots, pr = planes[r]
+        b = int(bits[j - 1])
+        sl = int(slots[j - 1]) if slots is not None else 0
+        if b & B_ZERO:
+            break
+        if b & B_DIAG:
+            pn[j - 1] = r
+            r, j = pr[sl & 15], j - 1
+        elif b & B_VERT:
+            r = pr[(sl >> 4) & 15]
+            if b & B_EXTUP:
+                while True:
+                    bits, slots, pr = planes[r]
+                    b2 = int(bits[j - 1])
+                    s2 = int(slots[j - 1]) if slots is not None else 0
+                    r = pr[(s2 >> 8) & 15]
+                    if (b2 & B_VSTOP) or r == 0:
+                        break
+        else:
+            j -= 1
+            if b & B_EXTLEFT:
+                while True:
+                    c = j
+                    j -= 1
+                    if not (int(bits[c - 1]) & B_HX):
+                        break
+    return pn, best
+
+
+def fuse(G, seq, pn):
+    N, L = len(G.order), len(seq)
+    bnd, nextb = [0] * L, N + 1
+    for j in range(L - 1, -1, -1):
+        if pn[j] > 0:
+            nextb = G.span(G.order[pn[j] - 1])[0]
+        bnd[j] = nextb
+    keys = [((r * 4 + 2) << 24, G.order[r - 1]) for r in range(1, N + 1)]
+    used = []
+    for j in range(L):
+        b = int(seq[j])
+        if pn[j] > 0:
+            v = G.order[pn[j] - 1]
+            use = v if G.code[v] == b else next((a for a in G.aligned[v] if G.code[a] == b), -1)
+            if use < 0:
+                hi = G.span(v)[1]
+                use = G.new(b)
+                if len(G.aligned[v]) >= G.MAXA:
+                    raise OverflowError('aligned set')
+                for a in G.aligned[v]:
+                    G.aligned[a].append(use); G.aligned[use].append(a)
+                G.aligned[v].append(use); G.aligned[use].append(v)
+                keys.append((((hi + 1) * 4 + 0) << 24, use))
+        else:
+            use = G.new(b)
+            keys.append((((bnd[j] * 4 + 1) << 24) + j, use))
+        used.append(use)
+        G.cov[use] += 1
+        if j > 0:
+            G.edge(used[j - 1], use, 2)
+    keys.sort()
+    G.order = [v for _, v in keys]
+    for r, v in enumerate(G.order):
+        G.rank[v] = r + 1
+    return used
+
+
+def consensus(G, min_cov=0):
+    N = len(G.order)
+    score, bp = [-1] * N, [-1] * N
+
+    def relax(v, barred):
+        for u, w in zip(G.pred[v], G.pw[v]):
+            if barred and score[u] == -1:
+                continue
+            if score[v] < w or (score[v] == w and score[bp[v]] <= score[u]):
+                score[v], bp[v] = w, u
+        if bp[v] >= 0:
+            score[v] += score[bp[v]]
+    top = -1
+    for v in G.order:
+        relax(v, False)
+        if top < 0 or score[top] < score[v]:
+            top = v
+    while G.nout[top]:
+        start = top
+        for h in range(N):
+            if start in G.pred[h]:
+                for u in G.pred[h]:
+                    if u != start:
+                        score[u] = -1
+        top = -1
+        for v in G.order[G.rank[start]:]:
+            score[v], bp[v] = -1, -1
+            relax(v, True)
+            if top < 0 or score[top] < score[v]:
+                top = v
+    path = []
+    v = top
+    while v >= 0:
+        path.append(v)
+        v = bp[v]
+    path.reverse()
+    return [G.code[v] for v in path if G.cov[v] >= min_cov]
+
+
+def poa(seqs, algorithm=0, genmsa=False, m=10, n=-4, g=-8, e=-2, q=-24, c=-1, min_coverage=0):
+    """seqs: int8 code arrays.  -> (consensus codes, msa rows (codes, 45 = '-'), end-cell scores)"""
+    P = Params(algorithm, m, n, g, e, q, c)
+    G = Graph()
+    paths, scores = [], []
+    for s in seqs:
+        s = np.asarray(s, dtype=np.int64)
+        if len(s) == 0:
+            paths.append([]); scores.append(0)
+            continue
+        if not G.order:
+            pn, sc = [0] * len(s), 0
+        else:
+            pn, sc = align(P, G, s)
+        scores.append(sc)
+        paths.append(fuse(G, s, pn))
+    cons = consensus(G, min_coverage)
+    rows = []
+    if genmsa:
+        col, nc, i = {}, 0, 0
+        while i < len(G.order):
+            v = G.order[i]
+            col[v] = nc
+            for a in G.aligned[v]:
+                col[a] = nc
+                i += 1
+            i += 1; nc += 1
+        for p in paths:
+            row = [45] * nc
+            for v in p:
+                row[col[v]] = G.code[v]
+            rows.append(row)
+    return cons, rows, scores

@@ -3,20 +3,21 @@
 //
 // What they replace: pyccs.find_consensus (called at CIRI_long/find_ccs.py:14) and the spoa engine inside it.  Those are
 // external packages that exist neither in the reference tree nor in this environment: PARITY UNPINNED.  Both kernels
-// implement, bit for bit, the specification written for this project in oracle/ccs_oracle.c ("clh-ccs v1" / "clh-poa v1");
-// read that header for every rule and tie-break.  One read per wavefront, one wavefront per workgroup.
+// implement, bit for bit, what oracle/ccs_oracle.c ("clh-ccs v1": period and copy boundaries, this project's own
+// specification) and oracle/poa_oracle.c ("clh-poa v2": a restatement of the published spoa algorithm -- two-piece gap
+// cost, local/global/overlap alignment, heaviest bundle) state; read those headers for every rule and tie-break.
+// One read per wavefront, one wavefront per workgroup.
 //
 // K2: 8-mer codes of the read sit in LDS.  Matches per offset are counted per PAIR of equal 8-mers (positions chained per
 //     hash bucket with LDS atomics, each pair visited once: O(L * copies) instead of O(L^2/4) comparisons); the smoothed
 //     maximum, the harmonic test and the per-copy boundary search (same chains, a histogram over the candidate offsets)
 //     are lane-parallel with shuffle reductions.
-// K3: persistent waves pull reads from an atomic counter; each owns a workspace slot in HBM (graph arrays, int16 DP
-//     matrix, direction bytes; slots are sized for the common case, the few reads that need more run in a second
-//     launch over a handful of large slots).  A DP row (one graph node) is computed by the 64 lanes over the sequence positions: the
-//     diagonal/vertical maxima over the node's in-edges are independent per position, the horizontal gap chain
-//     H[j] = max(A[j], H[j-1]+g) is a max-plus prefix scan (linear gap cost), done with DPP-free shuffles per 64-wide
-//     chunk and a carried running maximum.  The walk-back, the graph update and the heaviest-path pass are sequential by
-//     nature and run wave-uniformly (every lane the same control flow, lane 0 stores).
+// K3: persistent waves pull reads from an atomic counter; each owns a workspace slot in HBM (graph arrays, one byte per
+//     DP cell for the back-track, the few rows a far successor reads; slots are sized for the common case, the few reads
+//     that need more claim one of a handful of large slots).  A DP row (one graph node) is computed by the 64 lanes over
+//     the sequence positions: the diagonal and the two vertical gap states over the node's in-edges are independent per
+//     position, the two horizontal gap states are max-plus prefix scans (DPP).  The back-track and the heaviest-bundle
+//     pass are sequential by nature and run wave-uniformly on data staged in registers; the graph update is data-parallel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "clh_device.h"
@@ -29,11 +30,9 @@ static constexpr int CCS_MIN_SUPPORT = 12;
 static constexpr int CCS_SMOOTH = 3;
 static constexpr int CCS_MAX_CUTS = 64;
 static constexpr int CCS_MIN_TAIL = 20;
-static constexpr int POA_MAXP = 12;
-static constexpr int POA_MATCH = 10;
-static constexpr int POA_MISMATCH = -4;
-static constexpr int POA_GAP = -8;
-static constexpr int POA_MAX_COPY = 2800;            // longest copy: cells are int16 and hold H - jl*gap <= 10*2800 + 8*512
+static constexpr int POA_MAXP = 12;                  // in-edges a node can hold (implementation limit)
+static constexpr int POA_MAXA = 4;                   // other members of an aligned set (5 letter codes)
+static constexpr int POA_MAX_COPY = 2800;            // longest sequence: cells are int16 (match score <= 11)
 
 // Phase boundary inside one wave that exchanges data between lanes through HBM: complete the stores, then drop the
 // CU's L1 so that no line read before the stores can be served stale (buffer_inv sc1; a few microseconds, used a
@@ -56,19 +55,6 @@ __device__ __forceinline__ int wave_prefix_max(int v) {
                  "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
                  : "+v"(v));
-    return v;
-}
-
-// H value of a far source row, read from HBM without letting the compiler merge it with an LDS read (see poa_add)
-__device__ __forceinline__ int far_h(const short* ptr) {
-    int x;
-    asm volatile("global_load_sshort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(ptr) : "memory");
-    return x;
-}
-
-__device__ __forceinline__ int wmax_i(int v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
     return v;
 }
 
@@ -228,350 +214,485 @@ __global__ void __launch_bounds__(64) ccs_scan_long_kernel(const CcsParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K3
+// K3 -- partial-order alignment (spoa's recurrences and back-track, oracle/poa_oracle.c) and heaviest-bundle consensus
 // ------------------------------------------------------------------------------------------------------------
+// The row-at-a-time formulation computed here is stated and proven equal to the oracle's five-matrix statement on the
+// CPU in tools/poa_model.py (tests/test_poa_model.py).  Per cell the kernel leaves ONE byte from which spoa's
+// value-comparing back-track is replayed (rows with several in-edges leave 16 more bits: the in-edge slots).
+static constexpr int B_ZERO = 1, B_DIAG = 2, B_VERT = 4, B_EXTUP = 8, B_EXTLEFT = 16, B_HX = 32, B_VSTOP = 64;
+static constexpr int POA_NEG = -30000;               // "minus infinity" of a stored (int16) cell
+static constexpr int POA_MAX_ROWS = 65000;           // ranks travel in 16 bits
+
 struct PoaWs {            // views into one wave's workspace slot
-    int8_t* base; int8_t* np; int32_t* pred; int32_t* pw; int32_t* aligned; long long* key; int32_t* order; int32_t* rank;
-    int32_t* pn; int32_t* pj; int32_t* score; int32_t* bp; short* H; uint8_t* dir;
-    uint2* ri; uint32_t* tab; short* carry; int cpitch;
+    int8_t* base; int8_t* np; int32_t* pred; int32_t* pw; int32_t* aligned; int32_t* cov; int32_t* nout; int32_t* order; int32_t* rank;
+    int32_t* pn; int32_t* pj; long long* key; int32_t* bnd;                  // per base of the sequence being added
+    uint2* ri; uint32_t* rx; uint32_t* tab; int32_t* score; int32_t* bp; short* col0;     // rank space
+    short* carry; int cpitch;
+    uint8_t* dp; size_t dp_bytes;                                            // the rest of the slot: DP planes of the current sequence
+    uint8_t* dirA; uint16_t* dirB; short* keepH; uint8_t* keepD;             // set per sequence (poa_add)
 };
 
-// row pitch (elements) of the DP matrix and of the direction bytes for a copy of m bases: column j sits at element j+7,
-// so the 2/4/8 columns a lane owns start at an aligned element, and the pitch is a multiple of 16
+// row pitch (elements) of the DP planes for a sequence of m bases: column j sits at element j+7,
+// so the 2..8 columns a lane owns start at an aligned element, and the pitch is a multiple of 16
 __host__ __device__ inline int poa_pitch(int m) { return (m + 8 + 15) & ~15; }
 
-__device__ PoaWs carve(uint8_t* slot, int ncap, int mcap)
+__host__ __device__ inline size_t poa_fixed_bytes(int ncap, int mcap, int* cpitch_out)
+{
+    size_t o = 0;
+    auto add = [&](size_t bytes) { o = (o + bytes + 15) & ~(size_t)15; };
+    add(sizeof(int32_t) * (size_t)ncap * POA_MAXP); add(sizeof(int32_t) * (size_t)ncap * POA_MAXP);        // pred, pw
+    add(sizeof(int32_t) * (size_t)ncap * POA_MAXA);                                                        // aligned
+    add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap);   // cov nout order rank
+    add(sizeof(int32_t) * (size_t)(ncap + mcap + 2)); add(sizeof(int32_t) * (size_t)(ncap + mcap + 2));    // pn pj (pn doubles as the consensus path)
+    add(sizeof(long long) * (size_t)(mcap + 2)); add(sizeof(int32_t) * (size_t)(mcap + 2));                // key bnd
+    add(sizeof(uint2) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));   // ri rx tab
+    add(sizeof(int32_t) * (size_t)(ncap + 2)); add(sizeof(int32_t) * (size_t)(ncap + 2)); add(sizeof(short) * (size_t)(ncap + 2));        // score bp col0
+    const int cp = (ncap + 2 + 7) & ~7;
+    if (cpitch_out) *cpitch_out = cp;
+    add(sizeof(short) * 6 * (size_t)cp);                                                                    // carries: 2 x (H, E, Q)
+    add(ncap); add(ncap);                                                                                  // base np
+    return o;
+}
+// DP planes of one sequence against N rows: byte plane, slot plane of nm rows, kept rows (H int16 + vertical states int8)
+__host__ __device__ inline size_t poa_dp_bytes(int N, int m, int nm, int nk)
+{
+    const size_t gp = (size_t)poa_pitch(m);
+    return (((size_t)(N + 1) * gp + 15) & ~(size_t)15) + (size_t)nm * gp * 2 + (size_t)nk * gp * 2 + (size_t)nk * gp + 64;
+}
+__host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)       // worst case: every row has several in-edges and is kept
+{
+    return poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(ncap, mcap - 1, ncap, ncap) + 64;
+}
+
+__device__ PoaWs carve(uint8_t* slot, size_t slot_bytes, int ncap, int mcap)
 {
     PoaWs w;
     size_t o = 0;
     auto take = [&](size_t bytes) { uint8_t* q = slot + o; o = (o + bytes + 15) & ~(size_t)15; return q; };
-    w.key = (long long*)take(sizeof(long long) * ncap);
     w.pred = (int32_t*)take(sizeof(int32_t) * (size_t)ncap * POA_MAXP);
     w.pw = (int32_t*)take(sizeof(int32_t) * (size_t)ncap * POA_MAXP);
-    w.aligned = (int32_t*)take(sizeof(int32_t) * (size_t)ncap * 3);
+    w.aligned = (int32_t*)take(sizeof(int32_t) * (size_t)ncap * POA_MAXA);
+    w.cov = (int32_t*)take(sizeof(int32_t) * ncap);
+    w.nout = (int32_t*)take(sizeof(int32_t) * ncap);
     w.order = (int32_t*)take(sizeof(int32_t) * ncap);
     w.rank = (int32_t*)take(sizeof(int32_t) * ncap);
     w.pn = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
     w.pj = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
-    w.score = (int32_t*)take(sizeof(int32_t) * ncap);
-    w.bp = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + 2));
+    w.key = (long long*)take(sizeof(long long) * (size_t)(mcap + 2));
+    w.bnd = (int32_t*)take(sizeof(int32_t) * (size_t)(mcap + 2));
     w.ri = (uint2*)take(sizeof(uint2) * (size_t)(ncap + 2));
+    w.rx = (uint32_t*)take(sizeof(uint32_t) * (size_t)(ncap + 2));
     w.tab = (uint32_t*)take(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));
+    w.score = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + 2));
+    w.bp = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + 2));
+    w.col0 = (short*)take(sizeof(short) * (size_t)(ncap + 2));
     w.cpitch = (ncap + 2 + 7) & ~7;
-    w.carry = (short*)take(sizeof(short) * 2 * (size_t)w.cpitch);
+    w.carry = (short*)take(sizeof(short) * 6 * (size_t)w.cpitch);
     w.base = (int8_t*)take(ncap);
     w.np = (int8_t*)take(ncap);
-    w.H = (short*)take(sizeof(short) * (size_t)(ncap + 1) * poa_pitch(mcap - 1));
-    w.dir = (uint8_t*)take((size_t)(ncap + 1) * poa_pitch(mcap - 1));
+    w.dp = slot + o;
+    w.dp_bytes = slot_bytes > o ? slot_bytes - o : 0;
+    w.dirA = nullptr; w.dirB = nullptr; w.keepH = nullptr; w.keepD = nullptr;
     return w;
 }
 
-__host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)
-{
-    size_t o = 0;
-    auto add = [&](size_t bytes) { o = (o + bytes + 15) & ~(size_t)15; };
-    add(sizeof(long long) * ncap); add(sizeof(int32_t) * (size_t)ncap * POA_MAXP); add(sizeof(int32_t) * (size_t)ncap * POA_MAXP);
-    add(sizeof(int32_t) * (size_t)ncap * 3); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap);
-    add(sizeof(int32_t) * (size_t)(ncap + mcap + 2)); add(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
-    add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * (size_t)(ncap + 2)); add(sizeof(uint2) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));
-    add(sizeof(short) * 2 * (size_t)((ncap + 2 + 7) & ~7)); add(ncap); add(ncap);
-    add(sizeof(short) * (size_t)(ncap + 1) * poa_pitch(mcap - 1)); add((size_t)(ncap + 1) * poa_pitch(mcap - 1));
-    return o + 64;
-}
-
-extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];     // K3's dynamic LDS block (POA_LDS_BYTES, declared below)
-static constexpr int POA_RERANK_LDS_KEYS = 768;                        // new-node keys staged in LDS for the merge (6 KiB)
-
-// merge the nodes created by the last sequence ([n_old, n_new), keys ascending in creation order) into the rank order
-__device__ void poa_rerank(const PoaWs& w, int n_old, int n_new, int lane)
-{
-    const int added = n_new - n_old;
-    // old node at rank r (key r<<20): new rank = r + #{new nodes with key < its key}.  The binary search runs over the new
-    // keys in LDS (the H ring is idle here) instead of a chain of dependent HBM loads per probe.
-    long long* lkeys = (long long*)poa_lds;
-    const bool in_lds = added <= POA_RERANK_LDS_KEYS;
-    if (in_lds) {
-        for (int i = lane; i < added; i += 64) lkeys[i] = w.key[n_old + i];
-        __syncthreads();
-    }
-    for (int r = 1 + lane; r <= n_old; r += 64) {
-        const int v = w.order[r - 1];
-        const long long k = (long long)r << 20;
-        int lo = 0, hi = added;                      // lower_bound over new keys
-        if (in_lds) while (lo < hi) { const int mid = (lo + hi) >> 1; if (lkeys[mid] < k) lo = mid + 1; else hi = mid; }
-        else while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.key[n_old + mid] < k) lo = mid + 1; else hi = mid; }
-        w.rank[v] = r + lo;
-    }
-    // new node i: new rank = 1 + i + #{old nodes with key <= its key} = 1 + i + clamp(key >> 20, 0, n_old)
-    for (int i = lane; i < added; i += 64) {
-        long long q = w.key[n_old + i] >> 20;
-        if (q < 0) q = 0;
-        if (q > n_old) q = n_old;
-        w.rank[n_old + i] = 1 + i + (int)q;
-    }
-    phase_sync();
-    // candidate order (by key, id).  It can violate an edge when a base re-used a member of an aligned set that ranks
-    // after the row it was aligned to; the specification's final order is the depth-first post-order over in-edges
-    // taken in candidate order, which IS the candidate order whenever that is already topological (the common case,
-    // detected in parallel).
-    int bad = 0;
-    for (int v = lane; v < n_new; v += 64) {
-        const int r = w.rank[v];
-        w.bp[r - 1] = v;                                   // bp doubles as the candidate order here
-        const int np = w.np[v];
-        for (int e = 0; e < np; ++e) bad |= (w.rank[w.pred[v * POA_MAXP + e]] >= r);
-    }
-    phase_sync();
-    if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) {
-        for (int v = lane; v < n_new; v += 64) { const int r = w.rank[v]; w.order[r - 1] = v; w.key[v] = (long long)r << 20; }
-        phase_sync();
-        return;
-    }
-    for (int v = lane; v < n_new; v += 64) w.score[v] = 0;     // score doubles as the visited flags
-    phase_sync();
-    int outn = 0;
-    for (int c = 0; c < n_new; ++c) {                          // wave-uniform, every lane stores
-        const int root = w.bp[c];
-        if (w.score[root]) continue;
-        int sp = 0;
-        w.pn[0] = root; w.pj[0] = 0; w.score[root] = 1;
-        while (sp >= 0) {
-            const int u = w.pn[sp];
-            const int i = w.pj[sp];
-            if (i < w.np[u]) {
-                const int pr = w.pred[u * POA_MAXP + i];
-                w.pj[sp] = i + 1;
-                if (!w.score[pr]) { w.score[pr] = 1; ++sp; w.pn[sp] = pr; w.pj[sp] = 0; }
-            } else {
-                w.order[outn++] = u;
-                --sp;
-            }
-        }
-    }
-    phase_sync();
-    for (int r = 1 + lane; r <= n_new; r += 64) { const int v = w.order[r - 1]; w.rank[v] = r; w.key[v] = (long long)r << 20; }
-    phase_sync();
-}
+extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];     // K3's dynamic LDS block
+static constexpr int POA_LDS_BYTES = 9216;           // ring of recent rows (DP) / keys (re-rank) / score per rank (heaviest bundle)
+static constexpr int POA_RERANK_LDS_KEYS = POA_LDS_BYTES / 8;
+static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whose scores fit the LDS block
 
 #ifdef CLH_DEBUG_POA
-__device__ unsigned long long g_t[8];
 #define TSTAMP(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define TSTAMP(k) do {} while (0)
 #endif
-static constexpr int POA_LDS_BYTES = 6144;           // ring of recent H rows (DP) / score per rank (heaviest path)
-static constexpr int POA_RING_SHORTS = POA_LDS_BYTES / 2;
-static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whose scores fit the LDS block
-static_assert(POA_RERANK_LDS_KEYS * 8 <= POA_LDS_BYTES, "rerank keys must fit the K3 LDS block");
-#define lds_ring ((short*)poa_lds)
 
-// columns per lane, LDS row pitch and ring depth for a copy of m bases
-__device__ __forceinline__ int poa_cols(int m) { const int c = (m + 63) >> 6; return c < 2 ? 2 : (c > 8 ? 8 : c); }   // columns per lane
+// columns per lane, LDS row pitch and ring depth for a sequence of m bases
+__device__ __forceinline__ int poa_cols(int m) { const int c = (m + 63) >> 6; return c < 2 ? 2 : (c > 8 ? 8 : c); }
 __device__ __forceinline__ int poa_ring(int m) {
     const int W = 64 * poa_cols(m);
     const int lp = poa_pitch(m < W ? m : W);
-    int ring = 16;                                   // power of two, so slot = rank & (ring-1); lp <= 528, so ring >= 4
-    while (ring * lp > POA_RING_SHORTS) ring >>= 1;
+    int ring = 16;                                   // power of two, so slot = rank & (ring-1); a ring row is 3 bytes per element
+    while (ring * lp * 3 > POA_LDS_BYTES) ring >>= 1;
     return ring;
 }
 
-// direction byte: a code that DEcreases along the specification's evaluation order -- diagonal from in-edge e: 0x3F - e,
-// diagonal from row 0: 0x20, vertical from in-edge e: 0x1F - e, horizontal: 0 -- so that a candidate carried as
-// (value << 8) | code needs one signed max to take the larger value and, between equal values, keep the earlier candidate
-// (the strict '>' chain of the specification).  The layout (move group in bits 4-5, 15 - slot in bits 0-3) makes the
-// decode of the walk-back two shifts and a subtraction.
-static constexpr int POA_CODE_DIAG = 0x3F, POA_CODE_ROW0 = 0x20, POA_CODE_VERT = 0x1F;
+__device__ __forceinline__ int dpp_shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1; lane 0 keeps `fill`
 
-// C+1 H values (columns first-1 .. first+C-1) of a far source row from HBM; assembly for the reason given at far_h
+// exclusive prefix maximum over all cells to the left: in-lane running maximum, one cross-lane scan, the value entering
+// the pass on the left (`left`, lane 0's predecessor).  a[] in, pe[] out (pe[k] = max of everything left of cell k).
 template <int C>
-__device__ __forceinline__ void far_row(const short* ptr, int (&h)[C], int& hprev) {
-    asm volatile("global_load_sshort %0, %1, off" : "=v"(hprev) : "v"(ptr) : "memory");
+__device__ __forceinline__ void scan_left(const int (&a)[C], int left, int (&pe)[C])
+{
+    constexpr int NEGB = -(1 << 30);
+    int run[C];
+    run[0] = NEGB;
 #pragma unroll
-    for (int k = 0; k < C; ++k) asm volatile("global_load_sshort %0, %1, off" : "=v"(h[k]) : "v"(ptr + 1 + k) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k = 1; k < C; ++k) run[k] = run[k - 1] > a[k - 1] ? run[k - 1] : a[k - 1];
+    const int tot = run[C - 1] > a[C - 1] ? run[C - 1] : a[C - 1];
+    const int incl = wave_prefix_max(tot);
+    int excl = dpp_shr1(NEGB, incl);
+    excl = left > excl ? left : excl;
 #pragma unroll
-    for (int k = 0; k < C; ++k) asm volatile("" : "+v"(h[k]));
-    asm volatile("" : "+v"(hprev));
+    for (int k = 0; k < C; ++k) pe[k] = run[k] > excl ? run[k] : excl;
 }
 
-// DP rows of one copy against the graph.  Lane l owns C adjacent columns (C = 2..8: ceil(copy length / 64)), so a row of up to
-// W = 64*C columns is ONE step: one wide LDS read per source row, the candidates of the C cells in registers, an in-lane
-// max-plus scan, one cross-lane DPP scan, one wide LDS write, one wide direction-byte store.  Copies longer than W are
-// swept in passes of W columns (passes outer, rows inner); the value that leaves a row on the right is handed to the next
-// pass through a per-row carry array in HBM.  The graph rows (w.ri) and the carries are streamed 64 rows at a time into
-// one register per lane and read with v_readlane, so LDS holds nothing but the ring of the last RING rows.
-//
-// Cells are kept as X[r][j] = H[r][j] - jl*gap, jl = column within the pass (gap < 0): the horizontal move then costs
-// nothing (X[j] = max(A[j], X[j-1]): a plain prefix maximum), the diagonal move adds (match|mismatch) - gap, the vertical
-// move adds gap, the row-0 diagonal is one constant per pass -- no per-column term anywhere.  Carries between passes
-// are H values (X at local column 0 equals H).  A candidate is (X << 8) | (25 - ordinal); for the horizontal chain the
-// low byte of what a cell offers to its right neighbours is replaced by the horizontal code, the lowest of all, so the
-// plain signed max also implements "horizontal only if strictly larger" and the winner's low byte is the direction.
+// DP rows of one sequence against the graph.  Lane l owns C adjacent columns (C = 2..8: ceil(length / 64)), so a row of up
+// to W = 64*C columns is ONE step; longer sequences are swept in passes of W columns (passes outer, rows inner), the
+// cell that leaves a row on the right handed to the next pass through per-row carries (H, E, Q) in HBM.  Graph rows
+// (w.ri, w.rx) and carries are streamed 64 rows at a time into one register per lane and read with v_readlane; LDS holds
+// the ring of the last RING rows (H int16, vertical states one byte) for near sources that are not the row before -- that
+// one is forwarded from registers; far sources come from "kept" rows in HBM.
 template <int C>
-__device__ void dp_rows(const PoaWs& w, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out)
+__device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out, int& bc_out)
 {
-    constexpr int NEG = -(1 << 30);
+    constexpr int NEGB = -(1 << 30);
     constexpr int W = 64 * C;
-    constexpr int HCODE = 0;                                     // horizontal: clearing the low byte makes a horizontal offer
-    constexpr int DIAG_MATCH = (POA_MATCH - POA_GAP) * 256, DIAG_MIS = (POA_MISMATCH - POA_GAP) * 256;
     const int npass = (m + W - 1) / W;
-    const int gp = poa_pitch(m);                                 // row pitch of H and dir in HBM
-    const int lp = poa_pitch(m < W ? m : W);                     // row pitch of the LDS ring (one pass wide)
+    const int gp = poa_pitch(m);
+    const int lp = poa_pitch(m < W ? m : W);
     const int RING = poa_ring(m), rmask = RING - 1;
+    const bool sw = S.algorithm == 0, nw = S.algorithm == 1;
+    const int g = S.g, e = S.e, q = S.q, c = S.c, sm = S.m, sn = S.n;
+    short* ringH = (short*)poa_lds;
+    uint8_t* ringD = (uint8_t*)(ringH + RING * lp);
     const int lm = ((m - 1) % W) / C, km = (m - 1) % C;          // where column m lives in the last pass
-    int bs = NEG, br = 0x7fffffff;
+    int bs = sw ? 0 : NEGB, br = 0, bc = 0;
     for (int pass = 0; pass < npass; ++pass) {
         const int col0 = pass * W + C * lane;                    // cell k is column col0+k+1, element col0+k+8 of an HBM row
         const bool more = pass + 1 < npass, last = !more;
-        int sb[C];                                               // this lane's bases of the copy (100: none / not ACGT)
+        int sb[C];                                               // this lane's bases (100: beyond the sequence)
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const int j = col0 + k + 1;
-            const int c = j <= m ? (int)seq[j - 1] : 100;
-            sb[k] = (c >= 0 && c < 4) ? c : 100;
-        }
-        const int row0 = (pass * W) * (POA_GAP * 256) + POA_CODE_ROW0;   // row-0 diagonal: X = (j-1) gap + s - jl gap
-        const short* cprev = w.carry + (size_t)(pass & 1) * w.cpitch;
-        short* cnext = w.carry + (size_t)((pass + 1) & 1) * w.cpitch;
-        uint2 blk = 1 + lane <= N ? w.ri[1 + lane] : make_uint2(0, 0);
-        int cblk = pass > 0 && 1 + lane <= N ? (int)cprev[1 + lane] : 0;
-        int px[C], pcin = 0;                                     // the previous row of this pass, still in registers (see source())
+        for (int k = 0; k < C; ++k) { const int j = col0 + k + 1; sb[k] = j <= m ? (int)seq[j - 1] : 100; }
+        const int jl0 = C * lane + 1;                            // local column of cell 0; cell k: (jl0 + k) * e in the frame of the first piece
+        auto row0_h = [&](int j) -> int {                        // H[0][j]: row 0 (no node) as a source
+            const int l1 = g + (j - 1) * e, l2 = q + (j - 1) * c;
+            return (sw || j == 0) ? 0 : (l1 > l2 ? l1 : l2);
+        };
+        const short* cprev = w.carry + (size_t)(pass & 1) * 3 * w.cpitch;
+        short* cnext = w.carry + (size_t)((pass + 1) & 1) * 3 * w.cpitch;
+        // streams: graph row, plane indices, the three values entering the row on the left
+        uint2 blk = make_uint2(0, 0); uint32_t xblk = 0; int cH = 0, cE = POA_NEG, cQ = POA_NEG;
+        auto fetch = [&](int rr, uint2& b, uint32_t& x, int& h, int& ee, int& qq) {
+            b = make_uint2(0, 0); x = 0; h = 0; ee = POA_NEG; qq = POA_NEG;
+            if (rr <= N) {
+                b = w.ri[rr]; x = w.rx[rr];
+                if (pass > 0) { h = (int)cprev[rr]; ee = (int)cprev[w.cpitch + rr]; qq = (int)cprev[2 * w.cpitch + rr]; }
+                else if (nw) h = (int)w.col0[rr];
+            }
+        };
+        fetch(1 + lane, blk, xblk, cH, cE, cQ);
+        int px[C], pf[C], po[C], pcin = 0;                       // the previous row, still in registers
 #pragma unroll
-        for (int k = 0; k < C; ++k) px[k] = 0;
+        for (int k = 0; k < C; ++k) { px[k] = 0; pf[k] = 0; po[k] = 0; }
         for (int rb = 1; rb <= N; rb += 64) {
-            const int nr = rb + 64 + lane;
-            const uint2 nxt = nr <= N ? w.ri[nr] : make_uint2(0, 0);           // next 64 graph rows, consumed after this block
-            const int cnx = pass > 0 && nr <= N ? (int)cprev[nr] : 0;
+            uint2 nblk; uint32_t nxblk; int nH, nE, nQ;
+            fetch(rb + 64 + lane, nblk, nxblk, nH, nE, nQ);
             const int cnt = N - rb + 1 < 64 ? N - rb + 1 : 64;
-            int cob = 0;
+            int cobH = 0, cobE = 0, cobQ = 0;
             for (int i = 0; i < cnt; ++i) {
                 const int r = rb + i;
                 const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
-                const int cin = __builtin_amdgcn_readlane(cblk, i);             // H[r][pass*W] = X at local column 0; 0 in the first pass
-                const int vb = (int)(int8_t)(d0 & 0xff), np = (int)((d0 >> 8) & 0xf);
+                const uint32_t rxv = (uint32_t)__builtin_amdgcn_readlane((int)xblk, i);
+                const int cinH = __builtin_amdgcn_readlane(cH, i), cinE = __builtin_amdgcn_readlane(cE, i), cinQ = __builtin_amdgcn_readlane(cQ, i);
+                const int vb = (int)(d0 & 0xff), np = (int)((d0 >> 8) & 0xf);
+                const bool sink = (d0 & 0x1000u) != 0;
+                const bool tolds = (d0 & 0x4000u) != 0;          // read later from the LDS ring
                 const bool keep = (d0 & 0x8000u) != 0;           // read later from HBM by a far successor
-                const bool tolds = (d0 & 0x4000u) != 0;          // read later from the LDS ring (a near source that is not the next row)
                 const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
-                short* cur = lds_ring + (r & rmask) * lp;
-                int best[C], ss[C];
+                const int mi = (int)(rxv & 0xffff), ki = (int)(rxv >> 16);
+                int ss[C];
 #pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    ss[k] = sb[k] == vb ? DIAG_MATCH : DIAG_MIS;
-                    best[k] = ss[k] + row0;
-                }
-                auto source = [&](int e, int q) {
-                    int h[C], hprev;
-                    if (q == r - 1) {
-                        // the row just computed (the usual source: a chain) is forwarded from registers; going through the
-                        // LDS ring would put a write->read round trip on every row's critical path
+                for (int k = 0; k < C; ++k) ss[k] = sb[k] == vb ? sm : sn;
+                // one source row: H at the lane's columns and the one before, Fs = F + e - g, Os = O + c - q
+                auto source = [&](int qr, int (&h)[C], int& hprev, int (&fs)[C], int (&os)[C]) {
+                    if (qr == 0) {
 #pragma unroll
-                        for (int k = 0; k < C; ++k) h[k] = px[k];
-                        hprev = __builtin_amdgcn_update_dpp(0, px[C - 1], 0x138, 0xf, 0xf, true);     // wave_shr:1
+                        for (int k = 0; k < C; ++k) { h[k] = row0_h(col0 + k + 1); fs[k] = h[k] - 1; os[k] = h[k] - 1; }
+                        hprev = row0_h(col0);
+                    } else if (qr == r - 1) {
+#pragma unroll
+                        for (int k = 0; k < C; ++k) { h[k] = px[k]; fs[k] = pf[k]; os[k] = po[k]; }
+                        hprev = dpp_shr1(0, px[C - 1]);
                         hprev = lane == 0 ? pcin : hprev;
-                    } else if (r - q < RING) {
-                        const short* src = lds_ring + (q & rmask) * lp + C * lane + 8;
-                        hprev = src[-1];
-                        // element-wise 16-bit LDS reads: sign extension comes with the load, and LDS instructions do not
-                        // occupy the VALU (a 128-bit read would cost one unpack instruction per cell)
+                    } else if (r - qr < RING) {
+                        const short* sh = ringH + (qr & rmask) * lp + C * lane + 8;
+                        const uint8_t* sd = ringD + (qr & rmask) * lp + C * lane + 8;
+                        hprev = sh[-1];
 #pragma unroll
-                        for (int k = 0; k < C; ++k) h[k] = src[k];
+                        for (int k = 0; k < C; ++k) { h[k] = sh[k]; const int dd = sd[k]; fs[k] = h[k] + (dd & 7) - 1; os[k] = h[k] + (dd >> 3) - 1; }
                     } else {
-                        far_row<C>(w.H + (size_t)q * gp + col0 + 7, h, hprev);
-                        if (lane == 0 && pass > 0) hprev += W * POA_GAP;     // that element was stored in the previous pass's frame
-                    }
-                    const int cd = POA_CODE_DIAG - e, cv = POA_GAP * 256 + POA_CODE_VERT - e;
+                        const int kq = (int)(__builtin_amdgcn_readfirstlane((int)w.rx[qr]) >> 16) & 0xffff;
+                        const short* sh = w.keepH + (size_t)kq * gp + col0 + 8;
+                        const uint8_t* sd = w.keepD + (size_t)kq * gp + col0 + 8;
+                        int dd[C];
+                        asm volatile("global_load_sshort %0, %1, off" : "=v"(hprev) : "v"(sh - 1) : "memory");
 #pragma unroll
-                    for (int k = 0; k < C; ++k) {
-                        const int up = k == 0 ? hprev : h[k - 1];
-                        const int c1 = (up << 8) + ss[k] + cd;
-                        const int c2 = (h[k] << 8) + cv;
-                        best[k] = c1 > best[k] ? c1 : best[k];
-                        best[k] = c2 > best[k] ? c2 : best[k];
+                        for (int k = 0; k < C; ++k) asm volatile("global_load_sshort %0, %1, off" : "=v"(h[k]) : "v"(sh + k) : "memory");
+#pragma unroll
+                        for (int k = 0; k < C; ++k) asm volatile("global_load_ubyte %0, %1, off" : "=v"(dd[k]) : "v"(sd + k) : "memory");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < C; ++k) { asm volatile("" : "+v"(h[k]), "+v"(dd[k])); fs[k] = h[k] + (dd[k] & 7) - 1; os[k] = h[k] + (dd[k] >> 3) - 1; }
+                        asm volatile("" : "+v"(hprev));
                     }
                 };
-                if (np > 0) source(0, p0);
-                if (np > 1) source(1, p1);
-                if (np > 2) source(2, p2);
-                if (np > 3) {                                    // rare: in-edges beyond the third come from HBM
-                    const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
-                    for (int e = 3; e < np; ++e) source(e, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + e]]));
-                }
-                // horizontal chain = prefix maximum: what the cells to the left offer (their value, horizontal code)
-                int run[C];                                      // in-lane exclusive running maximum
-                run[0] = NEG;
+                int m0[C], fsn[C], osn[C], pb[C], slots[C];
+                if (np <= 1) {
+                    int h[C], hprev, fs[C], os[C];
+                    source(np == 0 ? 0 : p0, h, hprev, fs, os);
 #pragma unroll
-                for (int k = 1; k < C; ++k) {
-                    const int y = best[k - 1] & ~0xff;
-                    run[k] = run[k - 1] > y ? run[k - 1] : y;
+                    for (int k = 0; k < C; ++k) {
+                        const int d = (k == 0 ? hprev : h[k - 1]) + ss[k];
+                        const int fe = fs[k], fo = h[k], oe = os[k];
+                        const int mx = fe > fo ? fe : fo, mo = oe > fo ? oe : fo;
+                        const int fnew = g + mx, onew = q + mo;
+                        int mm = d > fnew ? d : fnew;
+                        mm = onew > mm ? onew : mm;
+                        if (sw) mm = mm > 0 ? mm : 0;
+                        m0[k] = mm; fsn[k] = e + mx; osn[k] = c + mo;
+                        const bool cFE = fe + g == mm, cFO = fo + g == mm, cOE = oe + q == mm;
+                        int b = 0;
+                        b |= d == mm ? B_DIAG : 0;
+                        b |= (cFE | cFO | cOE) ? B_VERT : 0;
+                        b |= (cFE | (!cFO & cOE)) ? B_EXTUP : 0;
+                        b |= fo >= fe ? B_VSTOP : 0;
+                        pb[k] = b; slots[k] = 0;
+                    }
+                } else {
+                    // several in-edges: every class keeps (value << 8) | (15 - slot): one signed max takes the larger value
+                    // and, between equal values, the earlier in-edge
+                    int D[C], FE[C], FO[C], OE[C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) { D[k] = NEGB; FE[k] = NEGB; FO[k] = NEGB; OE[k] = NEGB; }
+                    auto add_source = [&](int slot, int qr) {
+                        int h[C], hprev, fs[C], os[C];
+                        source(qr, h, hprev, fs, os);
+                        const int code = 15 - slot;
+#pragma unroll
+                        for (int k = 0; k < C; ++k) {
+                            const int dv = (((k == 0 ? hprev : h[k - 1]) + ss[k]) << 8) | code;
+                            const int fev = (fs[k] << 8) | code, fov = (h[k] << 8) | code, oev = (os[k] << 8) | code;
+                            D[k] = dv > D[k] ? dv : D[k]; FE[k] = fev > FE[k] ? fev : FE[k];
+                            FO[k] = fov > FO[k] ? fov : FO[k]; OE[k] = oev > OE[k] ? oev : OE[k];
+                        }
+                    };
+                    add_source(0, p0);
+                    add_source(1, p1);
+                    if (np > 2) add_source(2, p2);
+                    if (np > 3) {                                // rare: in-edges beyond the third come from HBM
+                        const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
+                        for (int s2 = 3; s2 < np; ++s2) add_source(s2, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + s2]]));
+                    }
+#pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const int d = D[k] >> 8, fe = FE[k] >> 8, fo = FO[k] >> 8, oe = OE[k] >> 8;
+                        const int kd = 15 - (D[k] & 15), kfe = 15 - (FE[k] & 15), kfo = 15 - (FO[k] & 15), koe = 15 - (OE[k] & 15);
+                        const int mx = fe > fo ? fe : fo, mo = oe > fo ? oe : fo;
+                        const int fnew = g + mx, onew = q + mo;
+                        int mm = d > fnew ? d : fnew;
+                        mm = onew > mm ? onew : mm;
+                        if (sw) mm = mm > 0 ? mm : 0;
+                        m0[k] = mm; fsn[k] = e + mx; osn[k] = c + mo;
+                        const int big = 1 << 20;
+                        const int k1 = fe + g == mm ? kfe * 4 + 0 : big, k2 = fo + g == mm ? kfo * 4 + 1 : big, k3 = oe + q == mm ? koe * 4 + 2 : big;
+                        int key = k1 < k2 ? k1 : k2;
+                        key = k3 < key ? k3 : key;
+                        const int x1 = fo >= fe ? kfo * 4 + 0 : big, x2 = fe >= fo ? kfe * 4 + 1 : big, x3 = fo >= oe ? kfo * 4 + 2 : big, x4 = oe >= fo ? koe * 4 + 3 : big;
+                        int keyx = x1 < x2 ? x1 : x2;
+                        keyx = x3 < keyx ? x3 : keyx;
+                        keyx = x4 < keyx ? x4 : keyx;
+                        int b = 0;
+                        b |= d == mm ? B_DIAG : 0;
+                        b |= key < big ? B_VERT : 0;
+                        b |= (key < big && (key & 3) != 1) ? B_EXTUP : 0;
+                        b |= (keyx & 1) == 0 ? B_VSTOP : 0;
+                        pb[k] = b;
+                        slots[k] = kd | ((key < big ? key >> 2 : 0) << 4) | ((keyx >> 2) << 8);
+                    }
                 }
-                const int ylast = best[C - 1] & ~0xff;
-                const int incl = wave_prefix_max(run[C - 1] > ylast ? run[C - 1] : ylast);
-                int excl = __builtin_amdgcn_update_dpp(NEG, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1
-                const int xc = cin << 8;
-                excl = xc > excl ? xc : excl;
-                int fin[C];
+                // horizontal states: two prefix maxima in the gap-free frames of the two pieces
+                int ehat[C], qhat[C];
+                {
+                    int a[C], pe[C];
+                    const int leftE = cinH > cinE + e - g ? cinH : cinE + e - g;       // = E[first column of the pass] - g
+#pragma unroll
+                    for (int k = 0; k < C; ++k) a[k] = m0[k] - (jl0 + k) * e;
+                    scan_left<C>(a, leftE, pe);
+#pragma unroll
+                    for (int k = 0; k < C; ++k) ehat[k] = pe[k] + (g - e) + (jl0 + k) * e;
+                    const int leftQ = cinH > cinQ + c - q ? cinH : cinQ + c - q;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) a[k] = m0[k] - (jl0 + k) * c;
+                    scan_left<C>(a, leftQ, pe);
+#pragma unroll
+                    for (int k = 0; k < C; ++k) qhat[k] = pe[k] + (q - c) + (jl0 + k) * c;
+                }
+                int H[C], E[C];
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
-                    const int a = run[k] > excl ? run[k] : excl;
-                    fin[k] = best[k] > a ? best[k] : a;
+                    int hh = m0[k] > ehat[k] ? m0[k] : ehat[k];
+                    H[k] = qhat[k] > hh ? qhat[k] : hh;
                 }
+                // the neighbour's value is fetched by every lane BEFORE the select: a DPP read executed under an exec mask that
+                // excludes lane 0 would find its source lane disabled
+                const int qsh = dpp_shr1(0, qhat[C - 1]);
+                const int qleft = lane == 0 ? cinQ : qsh;
 #pragma unroll
-                for (int k = 0; k < C; ++k) px[k] = fin[k] >> 8;
-                pcin = cin;
-                if (tolds && lane == 0) cur[7] = (short)cin;     // element of local column 0: the left neighbour of cell 0
+                for (int k = 0; k < C; ++k) {                    // E as spoa holds it: a gap may open on a cell reached by the other piece
+                    const int qp = (k == 0 ? qleft : qhat[k - 1]) + g;
+                    E[k] = ehat[k] > qp ? ehat[k] : qp;
+                }
+                const int hsh = dpp_shr1(0, H[C - 1]), esh = dpp_shr1(0, E[C - 1]);
+                const int hleft = lane == 0 ? cinH : hsh;
+                const int eleft = lane == 0 ? cinE : esh;
+                int out[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const int hl = k == 0 ? hleft : H[k - 1], ep = k == 0 ? eleft : E[k - 1], qp = k == 0 ? qleft : qhat[k - 1];
+                    int b = H[k] == m0[k] ? pb[k] & (B_DIAG | B_VERT | B_EXTUP) : 0;
+                    b |= pb[k] & B_VSTOP;
+                    b |= (sw && H[k] == 0) ? B_ZERO : 0;
+                    b |= ((H[k] == ep + e) | !(H[k] == hl + g)) ? B_EXTLEFT : 0;
+                    b |= ((ep + e == E[k]) | (qp + c == qhat[k])) ? B_HX : 0;
+                    out[k] = b;
+                }
+                // ---- what later rows and the back-track read --------------------------------------------------------------
+#pragma unroll
+                for (int k = 0; k < C; ++k) { px[k] = H[k]; pf[k] = fsn[k]; po[k] = osn[k]; }
+                pcin = cinH;
                 if (col0 + 1 <= m) {
-                    short* dst = cur + C * lane + 8;
-                    uint8_t* dd = w.dir + (size_t)r * gp + col0 + 8;
-                    if (tolds) {
+                    uint8_t* dd = w.dirA + (size_t)r * gp + col0 + 8;
+                    uint32_t w0 = 0, w1 = 0;
 #pragma unroll
-                        for (int k = 0; k < C; ++k) dst[k] = (short)px[k];             // ds_write_b16 takes the low half: no packing
-                    }
-                    // direction bytes: C contiguous bytes per lane, as the widest stores their count allows
-                    uint32_t d0 = 0, d1 = 0;
+                    for (int k = 0; k < C && k < 4; ++k) w0 |= ((uint32_t)out[k] & 0xffu) << (8 * k);
 #pragma unroll
-                    for (int k = 0; k < C && k < 4; ++k) d0 |= ((uint32_t)fin[k] & 0xffu) << (8 * k);
-#pragma unroll
-                    for (int k = 4; k < C; ++k) d1 |= ((uint32_t)fin[k] & 0xffu) << (8 * (k - 4));
-                    if constexpr (C == 8) *(uint2*)dd = make_uint2(d0, d1);
+                    for (int k = 4; k < C; ++k) w1 |= ((uint32_t)out[k] & 0xffu) << (8 * (k - 4));
+                    if constexpr (C == 8) *(uint2*)dd = make_uint2(w0, w1);
                     else if constexpr (C >= 4) {
-                        __builtin_memcpy(dd, &d0, 4);
-                        if constexpr (C == 5) dd[4] = (uint8_t)d1;
-                        if constexpr (C >= 6) { const uint16_t lo = (uint16_t)d1; __builtin_memcpy(dd + 4, &lo, 2); }
-                        if constexpr (C == 7) dd[6] = (uint8_t)(d1 >> 16);
+                        __builtin_memcpy(dd, &w0, 4);
+                        if constexpr (C == 5) dd[4] = (uint8_t)w1;
+                        if constexpr (C >= 6) { const uint16_t lo = (uint16_t)w1; __builtin_memcpy(dd + 4, &lo, 2); }
+                        if constexpr (C == 7) dd[6] = (uint8_t)(w1 >> 16);
                     } else {
-                        const uint16_t lo = (uint16_t)d0;
+                        const uint16_t lo = (uint16_t)w0;
                         __builtin_memcpy(dd, &lo, 2);
-                        if constexpr (C == 3) dd[2] = (uint8_t)(d0 >> 16);
+                        if constexpr (C == 3) dd[2] = (uint8_t)(w0 >> 16);
                     }
-                    if (keep) {
-                        short* hd = w.H + (size_t)r * gp + col0 + 8;
+                    if (np > 1) {
+                        uint16_t* db = w.dirB + (size_t)mi * gp + col0 + 8;
 #pragma unroll
-                        for (int k = 0; k < C; ++k) hd[k] = (short)px[k];
+                        for (int k = 0; k < C; ++k) db[k] = (uint16_t)slots[k];
+                    }
+                    if (tolds | keep) {
+                        int dv[C];
+#pragma unroll
+                        for (int k = 0; k < C; ++k) {
+                            int df = fsn[k] - H[k] + 1, dq = osn[k] - H[k] + 1;
+                            df = df > 0 ? df : 0; dq = dq > 0 ? dq : 0;
+                            dv[k] = df | (dq << 3);
+                        }
+                        if (tolds) {
+                            short* dh = ringH + (r & rmask) * lp + C * lane + 8;
+                            uint8_t* dl = ringD + (r & rmask) * lp + C * lane + 8;
+#pragma unroll
+                            for (int k = 0; k < C; ++k) { dh[k] = (short)H[k]; dl[k] = (uint8_t)dv[k]; }
+                        }
+                        if (keep) {
+                            short* hd = w.keepH + (size_t)ki * gp + col0 + 8;
+                            uint8_t* hb = w.keepD + (size_t)ki * gp + col0 + 8;
+#pragma unroll
+                            for (int k = 0; k < C; ++k) { hd[k] = (short)H[k]; hb[k] = (uint8_t)dv[k]; }
+                        }
                     }
                 }
-                if (keep && pass == 0 && lane == 0) w.H[(size_t)r * gp + 7] = 0;
-                if (last) {
-                    int hm = fin[0];
+                if (tolds && lane == 0) ringH[(r & rmask) * lp + 7] = (short)cinH;     // element of local column 0
+                if (keep && pass == 0 && lane == 0) w.keepH[(size_t)ki * gp + 7] = (short)cinH;
+                // ---- end cell: first strict maximum in (rank, column) order --------------------------------------------
+                if (sw | (!nw & sink)) {
+                    int rk = NEGB;
 #pragma unroll
-                    for (int k = 1; k < C; ++k) hm = km == k ? fin[k] : hm;
-                    hm >>= 8;                                    // same column for every row: X compares like H
-                    if (lane == lm && hm > bs) { bs = hm; br = r; }          // strict >: lowest rank on ties
-                } else {
-                    const int right = __builtin_amdgcn_readlane(fin[C - 1], 63) >> 8;
-                    cob = lane == i ? right + W * POA_GAP : cob;             // as an H value: X at local column W is H - W gap
+                    for (int k = 0; k < C; ++k) {
+                        const int kv = col0 + k + 1 <= m ? (H[k] << 4) | (15 - k) : NEGB;
+                        rk = kv > rk ? kv : rk;
+                    }
+                    const int v = rk >> 4;
+                    if (v > bs || (pass > 0 && v == bs && r < br)) { bs = v; br = r; bc = col0 + 1 + 15 - (rk & 15); }
+                } else if (nw & sink & last) {
+                    int hm = H[0];
+#pragma unroll
+                    for (int k = 1; k < C; ++k) hm = km == k ? H[k] : hm;
+                    if (lane == lm && hm > bs) { bs = hm; br = r; bc = m; }
+                }
+                if (more) {
+                    const int rH = __builtin_amdgcn_readlane(H[C - 1], 63), rE = __builtin_amdgcn_readlane(E[C - 1], 63), rQ = __builtin_amdgcn_readlane(qhat[C - 1], 63);
+                    cobH = lane == i ? rH : cobH; cobE = lane == i ? (rE < POA_NEG ? POA_NEG : rE) : cobE; cobQ = lane == i ? (rQ < POA_NEG ? POA_NEG : rQ) : cobQ;
                 }
                 asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
             }
-            if (more && lane < cnt) cnext[rb + lane] = (short)cob;
-            blk = nxt; cblk = cnx;
+            if (more && lane < cnt) { cnext[rb + lane] = (short)cobH; cnext[w.cpitch + rb + lane] = (short)cobE; cnext[2 * w.cpitch + rb + lane] = (short)cobQ; }
+            blk = nblk; xblk = nxblk; cH = nH; cE = nE; cQ = nQ;
         }
         if (more) phase_sync();
     }
-    bs_out = __shfl(bs, lm); br_out = __shfl(br, lm);
+    // best over the lanes: value descending, rank ascending, column ascending
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int s2 = __shfl_xor(bs, d), r2 = __shfl_xor(br, d), c2 = __shfl_xor(bc, d);
+        if (s2 > bs || (s2 == bs && (r2 < br || (r2 == br && c2 < bc)))) { bs = s2; br = r2; bc = c2; }
+    }
+    bs_out = bs; br_out = br; bc_out = bc;
 }
 
-// returns the new node count, or -1 on overflow
-__device__ int poa_add(const PoaWs& w, int N_, int ncap, int mcap, const int8_t* seq, int m_, int lane, unsigned long long* tacc)
+// merge the nodes created by the last sequence ([n_old, n_new), keys ascending in creation order) into the rank order.
+// key of a new node = ((s * 4 + class) << 24) + position, s = the old rank it goes in front of; an old node of rank r
+// compares as (r * 4 + 2) << 24.  returns 0, or -1 if the order would violate an edge (cannot happen: aligned sets stay
+// contiguous; checked because everything downstream relies on it)
+__device__ int poa_rerank(const PoaWs& w, int n_old, int n_new, int lane)
+{
+    const int added = n_new - n_old;
+    long long* lkeys = (long long*)poa_lds;
+    const bool in_lds = added <= POA_RERANK_LDS_KEYS;
+    if (in_lds) {
+        for (int i = lane; i < added; i += 64) lkeys[i] = w.key[i];
+        __syncthreads();
+    }
+    for (int r = 1 + lane; r <= n_old; r += 64) {
+        const int v = w.order[r - 1];
+        const long long k = ((long long)r * 4 + 2) << 24;
+        int lo = 0, hi = added;                      // lower_bound over new keys
+        if (in_lds) while (lo < hi) { const int mid = (lo + hi) >> 1; if (lkeys[mid] < k) lo = mid + 1; else hi = mid; }
+        else while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.key[mid] < k) lo = mid + 1; else hi = mid; }
+        w.rank[v] = r + lo;
+    }
+    for (int i = lane; i < added; i += 64) w.rank[n_old + i] = i + (int)(w.key[i] >> 26);      // i new nodes + (s - 1) old nodes in front, 1-based
+    phase_sync();
+    int bad = 0;
+    for (int v = lane; v < n_new; v += 64) {
+        const int r = w.rank[v];
+        w.order[r - 1] = v;
+        const int np = w.np[v];
+        for (int s2 = 0; s2 < np; ++s2) bad |= (w.rank[w.pred[v * POA_MAXP + s2]] >= r);
+    }
+    phase_sync();
+    return __builtin_amdgcn_ballot_w64(bad != 0) ? -1 : 0;
+}
+
+// ranks of the first and the last member of the aligned set of node v
+__device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& hi)
+{
+    lo = hi = w.rank[v];
+    for (int t = 0; t < POA_MAXA; ++t) {
+        const int x = w.aligned[v * POA_MAXA + t];
+        if (x < 0) break;
+        const int rr = w.rank[x];
+        lo = rr < lo ? rr : lo; hi = rr > hi ? rr : hi;
+    }
+}
+
+// returns the new node count; -1 graph limits, -2 workspace.  *score_out = end-cell score.
+// path_out (may be null): node of every base (for the MSA)
+__device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8_t* seq, int m_, int lane, int* score_out, int32_t* path_out, unsigned long long* tacc)
 {
     // wave-uniform by construction; say so, or every quantity derived from them lives in VGPRs behind exec-mask branches
     const int N = __builtin_amdgcn_readfirstlane(N_), m = __builtin_amdgcn_readfirstlane(m_);
@@ -579,241 +700,304 @@ __device__ int poa_add(const PoaWs& w, int N_, int ncap, int mcap, const int8_t*
 #ifdef CLH_DEBUG_POA
     tlast = __builtin_amdgcn_s_memtime();
 #endif
-    if (N == 0) {
-        if (m > ncap) return -1;
-        for (int j = lane; j < m; j += 64) {
-            w.base[j] = seq[j]; w.np[j] = j > 0 ? 1 : 0; w.key[j] = (long long)(j + 1) << 20;
-            w.aligned[j * 3] = w.aligned[j * 3 + 1] = w.aligned[j * 3 + 2] = -1;
-            if (j > 0) { w.pred[j * POA_MAXP] = j - 1; w.pw[j * POA_MAXP] = 1; }
-            w.order[j] = j; w.rank[j] = j + 1;
-        }
-        phase_sync();
-        return m;
-    }
-    int bs = -(1 << 28), br = 0x7fffffff;          // end cell: largest H[r][m], lowest rank on ties
-    // ---- DP rows --------------------------------------------------------------------------------------------
-    // Graph rows in rank space, built in parallel: base, in-degree, ranks of the first three sources (w.ri, 8 bytes a
-    // row; further in-edges are rare and fetched where needed).  Row 0 of the matrix is arithmetic (j*gap).
-    const int pitch = poa_pitch(m);
-    const int RING = poa_ring(m);
-    {
+    *score_out = 0;
+    if (m == 0) return N;
+    int bs = 0, br = 0, bc = 0;
+    if (N > 0) {
+        if (N > POA_MAX_ROWS || (S.algorithm == 1 && N > 25000)) return -1;
+        // ---- graph rows in rank space (w.ri: base, in-degree, sink, ranks of the first three sources) ---------------------
+        const int pitch = poa_pitch(m);
+        const int RING = poa_ring(m);
         uint32_t* ri32 = (uint32_t*)w.ri;
 #pragma unroll 4
         for (int r = 1 + lane; r <= N; r += 64) {
             const int v = w.order[r - 1];
             const int np = w.np[v];
             uint32_t pr[3] = {0, 0, 0};
-            for (int e = 0; e < 3; ++e) if (e < np) pr[e] = (uint32_t)w.rank[w.pred[v * POA_MAXP + e]];
-            w.ri[r] = make_uint2((uint32_t)(w.base[v] & 0xff) | ((uint32_t)np << 8) | (pr[0] << 16), pr[1] | (pr[2] << 16));
+            for (int s2 = 0; s2 < 3; ++s2) if (s2 < np) pr[s2] = (uint32_t)w.rank[w.pred[v * POA_MAXP + s2]];
+            w.ri[r] = make_uint2((uint32_t)(w.base[v] & 0xff) | ((uint32_t)np << 8) | (w.nout[v] == 0 ? 0x1000u : 0u) | (pr[0] << 16), pr[1] | (pr[2] << 16));
         }
         phase_sync();
-        // a row's H values go to HBM only if some later row reads them from there, i.e. it is a source of a row at
-        // least RING ranks further on (bits 14 and 15 of the in-degree byte field are free: in-degree <= 12)
+        // where will row r read source p from?  the row before it: registers; another recent row: the LDS ring (0x4000);
+        // an older one: its kept row in HBM (0x8000)
         for (int r = 1 + lane; r <= N; r += 64) {
             const uint2 d = w.ri[r];
             const int np = (int)((d.x >> 8) & 0xf);
             const int p0 = (int)(d.x >> 16), p1 = (int)(d.y & 0xffff), p2 = (int)(d.y >> 16);
-            // where will row r read source p from?  the row before it: registers; another recent row: the LDS ring (0x4000);
-            // an older one: its row in HBM (0x8000).  Rows nobody reads from memory store nothing but direction bytes.
-            auto mark = [&](int q) { if (r - q >= RING) atomicOr(&ri32[q * 2], 0x8000u); else if (r - q >= 2) atomicOr(&ri32[q * 2], 0x4000u); };
+            auto mark = [&](int q) { if (q == 0) return; if (r - q >= RING) atomicOr(&ri32[q * 2], 0x8000u); else if (r - q >= 2) atomicOr(&ri32[q * 2], 0x4000u); };
             if (np > 0) mark(p0);
             if (np > 1) mark(p1);
             if (np > 2) mark(p2);
-            if (np > 3) { const int v = w.order[r - 1]; for (int e = 3; e < np; ++e) mark(w.rank[w.pred[v * POA_MAXP + e]]); }
+            if (np > 3) { const int v = w.order[r - 1]; for (int s2 = 3; s2 < np; ++s2) mark(w.rank[w.pred[v * POA_MAXP + s2]]); }
         }
         phase_sync();
-        switch (poa_cols(m)) {            // columns per lane: the smallest that covers the copy in one pass (8 beyond 512)
-            case 2: dp_rows<2>(w, N, m, seq, lane, bs, br); break;
-            case 3: dp_rows<3>(w, N, m, seq, lane, bs, br); break;
-            case 4: dp_rows<4>(w, N, m, seq, lane, bs, br); break;
-            case 5: dp_rows<5>(w, N, m, seq, lane, bs, br); break;
-            case 6: dp_rows<6>(w, N, m, seq, lane, bs, br); break;
-            case 7: dp_rows<7>(w, N, m, seq, lane, bs, br); break;
-            default: dp_rows<8>(w, N, m, seq, lane, bs, br); break;
+        // plane indices: rows with several in-edges (slot plane) and kept rows, counted in rank order
+        int nm = 0, nk = 0;
+        for (int r0 = 1; r0 <= N; r0 += 64) {
+            const int r = r0 + lane;
+            const uint32_t d = r <= N ? ri32[r * 2] : 0u;
+            const bool multi = ((d >> 8) & 0xf) > 1, kp = (d & 0x8000u) != 0;
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(multi), bk = __builtin_amdgcn_ballot_w64(kp);
+            const unsigned long long below = ((unsigned long long)1 << lane) - 1;
+            if (r <= N) w.rx[r] = (uint32_t)(nm + __builtin_popcountll(bm & below)) | ((uint32_t)(nk + __builtin_popcountll(bk & below)) << 16);
+            nm += __builtin_popcountll(bm); nk += __builtin_popcountll(bk);
         }
+        if (nm > 65535 || nk > 65535) return -1;
+        if (poa_dp_bytes(N, m, nm, nk) > w.dp_bytes) return -2;
+        {
+            const size_t gp = (size_t)pitch;
+            size_t o = ((size_t)(N + 1) * gp + 15) & ~(size_t)15;
+            w.dirA = w.dp;
+            w.dirB = (uint16_t*)(w.dp + o); o += (size_t)nm * gp * 2;
+            w.keepH = (short*)(w.dp + o); o += (size_t)nk * gp * 2;
+            w.keepD = w.dp + o;
+        }
+        if (S.algorithm == 1) {
+            // global mode: H[i][0] = max(F, O)[i][0], F[i][0] = e + max over sources (a node without in-edges: g), O likewise.
+            // A chain over the ranks, wave-uniform (every lane computes and stores the same values); not a hot path.
+            for (int r = 1; r <= N; ++r) {
+                const int v = w.order[r - 1];
+                const int np = w.np[v];
+                int f = np ? -(1 << 28) : S.g - S.e, o = np ? -(1 << 28) : S.q - S.c;
+                for (int s2 = 0; s2 < np; ++s2) {
+                    const int pr = w.rank[w.pred[v * POA_MAXP + s2]];
+                    f = w.score[pr] > f ? w.score[pr] : f; o = w.bp[pr] > o ? w.bp[pr] : o;
+                }
+                f += S.e; o += S.c;
+                w.score[r] = f; w.bp[r] = o;
+                const int h = f > o ? f : o;
+                w.col0[r] = (short)(h < POA_NEG ? POA_NEG : h);
+                __syncthreads();
+            }
+        }
+        phase_sync();
+        switch (poa_cols(m)) {            // columns per lane: the smallest that covers the sequence in one pass (8 beyond 512)
+            case 2: dp_rows<2>(w, S, N, m, seq, lane, bs, br, bc); break;
+            case 3: dp_rows<3>(w, S, N, m, seq, lane, bs, br, bc); break;
+            case 4: dp_rows<4>(w, S, N, m, seq, lane, bs, br, bc); break;
+            case 5: dp_rows<5>(w, S, N, m, seq, lane, bs, br, bc); break;
+            case 6: dp_rows<6>(w, S, N, m, seq, lane, bs, br, bc); break;
+            case 7: dp_rows<7>(w, S, N, m, seq, lane, bs, br, bc); break;
+            default: dp_rows<8>(w, S, N, m, seq, lane, bs, br, bc); break;
+        }
+        phase_sync();
     }
-    phase_sync();
+    *score_out = bs;
     TSTAMP(0);
-    const int dpitch = pitch, dcol = 7;                // direction bytes: row pitch, element of column 0
-    // ---- walk back (sequential by nature, wave-uniform) -------------------------------------------------------
-    // One dependent HBM load per step would cost ~1 us each; instead the lanes hold a 32x32 patch of direction bytes
-    // (ranks r0..r0-31, columns j0..j0-31; 16 bytes per lane) and, on the fast path, the LDS graph rows of those ranks,
-    // so the chain runs on v_readlane until it leaves the patch (~28 steps).  pn[j] = rank matched to sequence position j (0: inserted base), staged in
-    // one register per lane and stored 64 positions at a time; ranks become node ids in parallel afterwards.
+    // ---- back-track (sequential by nature, wave-uniform) ----------------------------------------------------------
+    // The lanes hold a 32x32 patch of the byte plane (ranks r0..r0-31, columns j0..j0-31; 16 bytes per lane), of the slot
+    // plane for the rows that have one, and the graph rows of those ranks, so the chain runs on v_readlane until it leaves
+    // the patch.  pn[j] = rank aligned to base j (0: none), staged in one register per lane, stored 64 bases at a time.
     {
-        int r = __builtin_amdgcn_readfirstlane(br), j = m;
+        int r = __builtin_amdgcn_readfirstlane(br), j = br > 0 ? __builtin_amdgcn_readfirstlane(bc) : 0;
+        for (int t = j + lane; t < m; t += 64) w.pn[t] = 0;                     // bases behind the end cell
+        const int gp = poa_pitch(m);
         int r0 = -64, j0 = -64;
-        uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0, ri = 0;     // lane l: row r0-(l>>1), columns j0-16*(l&1)-15 .. j0-16*(l&1)
-        int buf = 0;
+        uint32_t pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, ri = 0;     // lane l: row r0-(l>>1), columns j0-16*(l&1)-15 .. j0-16*(l&1)
+        uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, pb4 = 0, pb5 = 0, pb6 = 0, pb7 = 0;
+        int buf = 0, mode = 0;                                   // mode 1: inside an upward run, 2: inside a leftward run
+        const bool sw = S.algorithm == 0;
+        int guard = 2 * (N + m) + 64;                           // every step lowers r or j: a longer walk means corrupt planes
         while (j > 0 && r > 0) {
+            if (--guard < 0) return -3;
             int a = r0 - r, b = j0 - j;
             if ((unsigned)a >= 32u || (unsigned)b >= 32u) {
                 r0 = r; j0 = j;
                 const int rr = r - (lane >> 1), jlo = j - 16 * (lane & 1) - 15;       // lowest column of this lane's 16
-                pw0 = pw1 = pw2 = pw3 = 0;
-                if (rr >= 1 && jlo + 15 >= 1) {
-                    // bytes at columns jlo..jlo+15 (row-internal; columns below 0 belong to the previous row or, for
-                    // row 1, to row 0 -- in bounds, never looked at)
-                    const uint8_t* src = w.dir + (size_t)rr * dpitch + dcol + jlo;
-                    uint32_t t[4];
-                    __builtin_memcpy(t, src, 16);
-                    pw0 = t[0]; pw1 = t[1]; pw2 = t[2]; pw3 = t[3];
+                pa0 = pa1 = pa2 = pa3 = 0; pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = 0; ri = 0;
+                if (rr >= 1) {
+                    const uint2 gr = w.ri[rr];
+                    ri = (lane & 1) ? gr.y : gr.x;
+                    if (jlo + 15 >= 1) {
+                        // bytes at columns jlo..jlo+15 (columns below 0 belong to the previous row: in bounds, never looked at)
+                        const uint8_t* src = w.dirA + (size_t)rr * gp + 7 + jlo;
+                        uint32_t t[4];
+                        __builtin_memcpy(t, src, 16);
+                        pa0 = t[0]; pa1 = t[1]; pa2 = t[2]; pa3 = t[3];
+                        if (((gr.x >> 8) & 0xf) > 1) {
+                            const uint16_t* sb2 = w.dirB + (size_t)(w.rx[rr] & 0xffff) * gp + 7 + jlo;
+                            uint32_t u[8];
+                            __builtin_memcpy(u, sb2, 32);
+                            pb0 = u[0]; pb1 = u[1]; pb2 = u[2]; pb3 = u[3]; pb4 = u[4]; pb5 = u[5]; pb6 = u[6]; pb7 = u[7];
+                        }
+                    }
                 }
-                ri = rr >= 1 ? ((const uint32_t*)w.ri)[rr * 2 + (lane & 1)] : 0u;
                 a = 0; b = 0;
             }
             // column j0-b sits in lane 2a+(b>>4) at byte 15-(b&15)
-            const int byte = 15 - (b & 15), src_lane = a * 2 + (b >> 4);
-            const uint32_t sel = (byte >> 2) == 0 ? pw0 : ((byte >> 2) == 1 ? pw1 : ((byte >> 2) == 2 ? pw2 : pw3));
-            const int d = (__builtin_amdgcn_readlane((int)sel, src_lane) >> ((byte & 3) * 8)) & 0xff;
-            // code -> move: group 3 diagonal from in-edge e, 2 diagonal from row 0, 1 vertical from in-edge e, 0 horizontal
-            const int grp = d >> 4, e = 15 - (d & 15);
-            const int kind = grp == 0 ? 3 : (grp == 1 ? 2 : 1);
-            int pre = 0;
-            if (grp & 1) {                                // an in-edge slot (groups 3 and 1): rank of that source
-                if (e == 0) pre = (int)((uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2) >> 16);
-                else if (e < 3) {
-                    const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2 + 1);
-                    pre = e == 1 ? (int)(q1 & 0xffff) : (int)(q1 >> 16);
-                } else {
-                    const int v = w.order[r - 1];
-                    pre = __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + e]]);
-                }
+            const int idx = 15 - (b & 15), src_lane = a * 2 + (b >> 4);
+            const uint32_t sela = (idx >> 2) == 0 ? pa0 : ((idx >> 2) == 1 ? pa1 : ((idx >> 2) == 2 ? pa2 : pa3));
+            const int d = (__builtin_amdgcn_readlane((int)sela, src_lane) >> ((idx & 3) * 8)) & 0xff;
+            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2), g1 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2 + 1);
+            const int np = (int)((g0 >> 8) & 0xf);
+            int sl = 0;
+            if (np > 1) {
+                const int w2 = idx >> 1;
+                const uint32_t selb = w2 == 0 ? pb0 : (w2 == 1 ? pb1 : (w2 == 2 ? pb2 : (w2 == 3 ? pb3 : (w2 == 4 ? pb4 : (w2 == 5 ? pb5 : (w2 == 6 ? pb6 : pb7))))));
+                sl = (__builtin_amdgcn_readlane((int)selb, src_lane) >> ((idx & 1) * 16)) & 0xffff;
             }
-            if (kind == 2) { r = pre; continue; }
-            --j;
-            buf = lane == (j & 63) ? (kind == 1 ? r : 0) : buf;
-            if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
-            if (kind == 1) r = pre;
+            auto pred_rank = [&](int s2) -> int {
+                if (np == 0) return 0;
+                if (s2 == 0) return (int)(g0 >> 16);
+                if (s2 == 1) return (int)(g1 & 0xffff);
+                if (s2 == 2) return (int)(g1 >> 16);
+                const int v = w.order[r - 1];
+                return __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + s2]]);
+            };
+            if (mode == 1) {                                     // upward run: one more node without a base
+                r = pred_rank((sl >> 8) & 15);
+                if (d & B_VSTOP) mode = 0;
+                continue;
+            }
+            if (mode == 2) {                                     // leftward run: one more base without a node
+                --j;
+                buf = lane == (j & 63) ? 0 : buf;
+                if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
+                if (!(d & B_HX)) mode = 0;
+                continue;
+            }
+            if (sw && (d & B_ZERO)) break;
+            if (d & B_DIAG) {
+                --j;
+                buf = lane == (j & 63) ? r : buf;
+                if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
+                r = pred_rank(sl & 15);
+            } else if (d & B_VERT) {
+                r = pred_rank((sl >> 4) & 15);
+                mode = (d & B_EXTUP) ? 1 : 0;
+            } else {
+                --j;
+                buf = lane == (j & 63) ? 0 : buf;
+                if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
+                mode = (d & B_EXTLEFT) ? 2 : 0;
+            }
         }
         int fill_to = j;
-        if (j & 63) { fill_to = j & ~63; const int q = fill_to + lane; if (q < m) w.pn[q] = buf; }
+        if (j & 63) { fill_to = j & ~63; const int q = fill_to + lane; if (q < m && q >= 0) w.pn[q] = q < j ? 0 : buf; }
         for (int q = lane; q < fill_to; q += 64) w.pn[q] = 0;
     }
     phase_sync();
     TSTAMP(1);
-    // ---- graph update, data-parallel over the sequence positions ---------------------------------------------------
-    // Position i touches only its own matched node's aligned set and the in-edge list of the node it ends up using, and
-    // the nodes of one path are distinct, so the sequential rule of the specification (oracle poa_add) is evaluated
-    // per lane; node ids of new nodes are a prefix count in position order, keys come from the last matched position.
+    // ---- fuse the path into the graph (Graph::AddAlignment), data-parallel over the bases -------------------------------
+    // Base i touches only its own aligned node's set and the in-edge list of the node it ends on, and the nodes of one
+    // path are distinct, so the sequential rule is evaluated per lane; ids of new nodes are a prefix count in base order.
     int n = N, fail = 0;
     {
-        // first matched position (keys of leading insertions count back from it)
-        int lead = m;
-        long long key_fa = 0;
-        for (int i0 = 0; i0 < m; i0 += 64) {
+        // old rank in front of which a run of unaligned bases goes: first rank of the aligned set of the next aligned base
+        int nextb = N + 1;
+        for (int i0 = ((m - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
             const int i = i0 + lane;
             const int rk = i < m ? w.pn[i] : 0;
+            int lo = 0, hi = 0;
+            if (rk > 0) group_span(w, w.order[rk - 1], lo, hi);
             const unsigned long long mb = __builtin_amdgcn_ballot_w64(rk > 0);
-            if (mb) {
-                const int t = __builtin_ctzll(mb);
-                lead = i0 + t;
-                const int rk0 = __builtin_amdgcn_readlane(rk, t);
-                key_fa = w.key[w.order[rk0 - 1]];
-                break;
-            }
+            const unsigned long long at_or_above = ~(((unsigned long long)1 << lane) - 1);
+            const unsigned long long up = mb & at_or_above;
+            const int src = up ? __builtin_ctzll(up) : 0;
+            const int lo_src = __shfl(lo, src);
+            if (i < m) w.bnd[i] = up ? lo_src : nextb;
+            if (mb) nextb = __shfl(lo, __builtin_ctzll(mb));
         }
-        int lmi = -1;                       // last matched position so far, and its node's key
-        long long lmk = 0;
         for (int i0 = 0; i0 < m; i0 += 64) {
             const int i = i0 + lane;
             const bool act = i < m;
             const int rk = act ? w.pn[i] : 0;
             const int v = rk > 0 ? w.order[rk - 1] : -1;
             const int b = act ? (int)seq[i] : 0;
-            long long kv = 0;
             int use = -1;
             if (v >= 0) {
-                kv = w.key[v];
                 if (w.base[v] == b) use = v;
-                else for (int q = 0; q < 3; ++q) { const int x = w.aligned[v * 3 + q]; if (x >= 0 && w.base[x] == b) { use = x; break; } }
+                else for (int t = 0; t < POA_MAXA; ++t) { const int x = w.aligned[v * POA_MAXA + t]; if (x < 0) break; if (w.base[x] == b) { use = x; break; } }
             }
             const bool isnew = act && use < 0;
             const unsigned long long nb = __builtin_amdgcn_ballot_w64(isnew);
-            const unsigned long long mb = __builtin_amdgcn_ballot_w64(v >= 0);
             const unsigned long long below = ((unsigned long long)1 << lane) - 1;
             if (isnew) use = n + __builtin_popcountll(nb & below);
             n += __builtin_popcountll(nb);
-            // anchor of an inserted base: the last matched position before it
-            const unsigned long long mlow = mb & below;
-            const int src = mlow ? 63 - __builtin_clzll(mlow) : 0;
-            const int klo = __shfl((int)(kv & 0xffffffff), src), khi = __shfl((int)(kv >> 32), src);
             if (isnew && use < ncap) {
                 long long key;
-                if (v >= 0) key = kv;
-                else if (mlow) key = (((long long)khi << 32) | (uint32_t)klo) + (i - (i0 + src));
-                else if (lmi >= 0) key = lmk + (i - lmi);
-                else if (lead < m) key = key_fa - lead + i;
-                else key = ((long long)N << 20) + i + 1;       // max key == N<<20 after a re-rank
-                w.base[use] = (int8_t)b; w.np[use] = 0; w.key[use] = key;
-                int al0 = -1, al1 = -1, al2 = -1;
-                if (v >= 0) {                                  // join the aligned set of v
-                    int members[4], nm = 0;
-                    members[nm++] = v;
-                    for (int q = 0; q < 3; ++q) if (w.aligned[v * 3 + q] >= 0) members[nm++] = w.aligned[v * 3 + q];
-                    for (int q = 0; q < nm; ++q) {
-                        const int x = members[q];
-                        for (int t = 0; t < 3; ++t) if (w.aligned[x * 3 + t] < 0) { w.aligned[x * 3 + t] = use; break; }
-                        if (q == 0) al0 = x; else if (q == 1) al1 = x; else if (q == 2) al2 = x;
+                int al[POA_MAXA];
+#pragma unroll
+                for (int t = 0; t < POA_MAXA; ++t) al[t] = -1;
+                if (v >= 0) {                                  // a new member of the aligned set of v: directly behind the set
+                    int lo, hi;
+                    group_span(w, v, lo, hi);
+                    key = ((long long)(hi + 1) * 4 + 0) << 24;
+                    int nm2 = 0;
+                    for (int t = 0; t < POA_MAXA; ++t) {
+                        const int x = w.aligned[v * POA_MAXA + t];
+                        if (x < 0) break;
+                        al[nm2++] = x;
+                        int u = 0;
+                        while (u < POA_MAXA && w.aligned[x * POA_MAXA + u] >= 0) ++u;
+                        if (u < POA_MAXA) w.aligned[x * POA_MAXA + u] = use; else fail = 1;
                     }
-                }
-                w.aligned[use * 3] = al0; w.aligned[use * 3 + 1] = al1; w.aligned[use * 3 + 2] = al2;
+                    if (nm2 < POA_MAXA) { al[nm2] = v; w.aligned[v * POA_MAXA + nm2] = use; } else fail = 1;
+                } else key = (((long long)w.bnd[i] * 4 + 1) << 24) + i;
+                w.base[use] = (int8_t)b; w.np[use] = 0; w.cov[use] = 0; w.nout[use] = 0; w.key[use - N] = key;
+#pragma unroll
+                for (int t = 0; t < POA_MAXA; ++t) w.aligned[use * POA_MAXA + t] = al[t];
             }
-            if (act) w.pj[i] = use;
-            if (mb) {
-                const int t = 63 - __builtin_clzll(mb);
-                lmi = i0 + t;
-                lmk = ((long long)__shfl((int)(kv >> 32), t) << 32) | (uint32_t)__shfl((int)(kv & 0xffffffff), t);
-            }
+            if (act) { w.pj[i] = use; if (path_out) path_out[i] = use; }
         }
         if (n > ncap) return -1;
         phase_sync();
-        for (int i = 1 + lane; i < m; i += 64) {
-            const int u = w.pj[i - 1], x = w.pj[i];
+        for (int i = lane; i < m; i += 64) {
+            const int x = w.pj[i];
+            w.cov[x] += 1;
+            if (i == 0) continue;
+            const int u = w.pj[i - 1];
             const int cnt = w.np[x];
             int found = -1;
-            for (int e = 0; e < cnt; ++e) if (w.pred[x * POA_MAXP + e] == u) { found = e; break; }
-            if (found >= 0) w.pw[x * POA_MAXP + found] += 1;
+            for (int s2 = 0; s2 < cnt; ++s2) if (w.pred[x * POA_MAXP + s2] == u) { found = s2; break; }
+            if (found >= 0) w.pw[x * POA_MAXP + found] += 2;
             else if (cnt >= POA_MAXP) fail = 1;
-            else { w.pred[x * POA_MAXP + cnt] = u; w.pw[x * POA_MAXP + cnt] = 1; w.np[x] = (int8_t)(cnt + 1); }
+            else { w.pred[x * POA_MAXP + cnt] = u; w.pw[x * POA_MAXP + cnt] = 2; w.np[x] = (int8_t)(cnt + 1); w.nout[u] += 1; }
         }
         if (__builtin_amdgcn_ballot_w64(fail != 0)) return -1;
     }
     phase_sync();
     TSTAMP(2);
-    poa_rerank(w, N, n, lane);
+    if (N == 0) {
+        for (int v = lane; v < n; v += 64) { w.order[v] = v; w.rank[v] = v + 1; }
+        phase_sync();
+    } else if (poa_rerank(w, N, n, lane) != 0) return -1;
     TSTAMP(3);
     return n;
 }
 
-// heaviest path.  The pass over the rows in rank order is a dependent chain (the score of a source decides ties between
-// equally heavy in-edges), so it runs wave-uniformly -- but on a rank-space image of the graph built in parallel (w.tab,
-// 3 words a row: in-degree, up to 3 source ranks and their weights) and streamed 64 rows at a time into registers, with
-// the scores in LDS and the previous row's score forwarded in a register, so the chain never waits for HBM.  Rows with
-// more than 3 in-edges or a weight above 255 fetch their lists from HBM (rare).  Back pointers leave through a lane
-// buffer; the final chase reads them back 64 ranks at a time.
-__device__ int poa_consensus(const PoaWs& w, int N_, int8_t* out, int cap, int lane)
+// Heaviest bundle (Graph::TraverseHeaviestBundle + BranchCompletion).  The pass over the rows in rank order is a dependent
+// chain, so it runs wave-uniformly -- on a rank-space image of the graph built in parallel (w.tab, 3 words a row:
+// in-degree, up to 3 source ranks and their weights) and streamed 64 rows at a time into registers, with the scores in LDS
+// (graphs above POA_LDS_SCORES rows: in HBM) and the previous row's score forwarded in a register.  Rows with more than 3
+// in-edges or a weight above 255 fetch their lists from HBM (rare).  Back pointers leave through a lane buffer; the final
+// chase reads them back 64 ranks at a time.  The consensus keeps the nodes crossed by at least min_cov sequences.
+__device__ int poa_consensus(const PoaWs& w, int N_, int min_cov, int8_t* out, int cap, int lane)
 {
     const int N = __builtin_amdgcn_readfirstlane(N_);
-    if (N <= POA_LDS_SCORES) {
-        int* score = (int*)poa_lds;
+    if (N == 0) return 0;
+    const bool in_lds = N <= POA_LDS_SCORES;
+    int* score = in_lds ? (int*)poa_lds : w.score;
 #pragma unroll 4
-        for (int r = 1 + lane; r <= N; r += 64) {
-            const int v = w.order[r - 1];
-            int np = w.np[v];
-            uint32_t pr[3] = {0, 0, 0}, wt[3] = {0, 0, 0};
-            bool wide = np > 3;
-            for (int e = 0; e < 3; ++e) if (e < np) { pr[e] = (uint32_t)w.rank[w.pred[v * POA_MAXP + e]]; wt[e] = (uint32_t)w.pw[v * POA_MAXP + e]; wide |= wt[e] > 255u; }
-            w.tab[r * 3 + 0] = (uint32_t)(wide ? 0x7f : np) | (pr[0] << 16);
-            w.tab[r * 3 + 1] = pr[1] | (pr[2] << 16);
-            w.tab[r * 3 + 2] = (wt[0] & 0xff) | ((wt[1] & 0xff) << 8) | ((wt[2] & 0xff) << 16);
-        }
-        if (lane == 0) score[0] = 0;
-        phase_sync();
-        int top = 0, tops = -1, prev = 0;                 // prev = score of rank r-1
+    for (int r = 1 + lane; r <= N; r += 64) {
+        const int v = w.order[r - 1];
+        int np = w.np[v];
+        uint32_t pr[3] = {0, 0, 0}, wt[3] = {0, 0, 0};
+        bool wide = np > 3;
+        for (int s2 = 0; s2 < 3; ++s2) if (s2 < np) { pr[s2] = (uint32_t)w.rank[w.pred[v * POA_MAXP + s2]]; wt[s2] = (uint32_t)w.pw[v * POA_MAXP + s2]; wide |= wt[s2] > 255u; }
+        w.tab[r * 3 + 0] = (uint32_t)(wide ? 0x7f : np) | (w.nout[v] == 0 ? 0x80u : 0u) | (pr[0] << 16);
+        w.tab[r * 3 + 1] = pr[1] | (pr[2] << 16);
+        w.tab[r * 3 + 2] = (wt[0] & 0xff) | ((wt[1] & 0xff) << 8) | ((wt[2] & 0xff) << 16);
+    }
+    if (lane == 0) score[0] = -1;
+    phase_sync();
+    // one pass over ranks (from, N]: barred = skip tails whose score is -1 (BranchCompletion).  returns the best rank
+    auto pass = [&](int from, bool barred) -> int {
+        int top = 0, tops = -(1 << 30), prev = from >= 1 ? __builtin_amdgcn_readfirstlane(score[from]) : -1;
+        const int base0 = from + 1;
         uint32_t b0 = 0, b1 = 0, b2 = 0;
-        if (1 + lane <= N) { b0 = w.tab[(1 + lane) * 3]; b1 = w.tab[(1 + lane) * 3 + 1]; b2 = w.tab[(1 + lane) * 3 + 2]; }
-        for (int rb = 1; rb <= N; rb += 64) {
+        if (base0 + lane <= N) { b0 = w.tab[(base0 + lane) * 3]; b1 = w.tab[(base0 + lane) * 3 + 1]; b2 = w.tab[(base0 + lane) * 3 + 2]; }
+        for (int rb = base0; rb <= N; rb += 64) {
             const int nr = rb + 64 + lane;
             uint32_t n0 = 0, n1 = 0, n2 = 0;
             if (nr <= N) { n0 = w.tab[nr * 3]; n1 = w.tab[nr * 3 + 1]; n2 = w.tab[nr * 3 + 2]; }
@@ -823,77 +1007,111 @@ __device__ int poa_consensus(const PoaWs& w, int N_, int8_t* out, int cap, int l
                 const int r = rb + i;
                 const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, i), t1 = (uint32_t)__builtin_amdgcn_readlane((int)b1, i), t2 = (uint32_t)__builtin_amdgcn_readlane((int)b2, i);
                 const int np = (int)(t0 & 0x7f);
-                int bw = -1, bsrc = 0, bscore = 0;
+                int sc = -1, bsrc = 0, bscore = 0;               // score so far, chosen tail (rank, 0 = none) and its score
+                auto relax = [&](int u, int wt) {
+                    const int su = u == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[u]);
+                    if (barred && su == -1) return;
+                    if (sc < wt || (sc == wt && bscore <= su)) { sc = wt; bsrc = u; bscore = su; }
+                };
                 if (np == 0x7f) {
                     const int v = w.order[r - 1];
                     const int cn = w.np[v];
-                    for (int e = 0; e < cn; ++e) {
-                        const int u = __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + e]]);
-                        const int wt = __builtin_amdgcn_readfirstlane(w.pw[v * POA_MAXP + e]);
-                        const int su = u == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[u]);
-                        if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = u; bscore = su; }
-                    }
+                    for (int s2 = 0; s2 < cn; ++s2)
+                        relax(__builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + s2]]), __builtin_amdgcn_readfirstlane(w.pw[v * POA_MAXP + s2]));
                 } else {
-                    const int p0 = (int)(t0 >> 16), p1 = (int)(t1 & 0xffff), p2 = (int)(t1 >> 16);
-                    if (np > 0) { const int su = p0 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p0]); bw = (int)(t2 & 0xff); bsrc = p0; bscore = su; }
-                    if (np > 1) { const int su = p1 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p1]); const int wt = (int)((t2 >> 8) & 0xff); if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = p1; bscore = su; } }
-                    if (np > 2) { const int su = p2 == r - 1 ? prev : __builtin_amdgcn_readfirstlane(score[p2]); const int wt = (int)((t2 >> 16) & 0xff); if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = p2; bscore = su; } }
+                    if (np > 0) relax((int)(t0 >> 16), (int)(t2 & 0xff));
+                    if (np > 1) relax((int)(t1 & 0xffff), (int)((t2 >> 8) & 0xff));
+                    if (np > 2) relax((int)(t1 >> 16), (int)((t2 >> 16) & 0xff));
                 }
-                const int sc = bsrc > 0 ? bw + bscore : 0;
+                if (bsrc > 0) sc += bscore;
                 score[r] = sc;
-                bpb = lane == i ? bsrc : bpb;                 // back pointer (rank, 0 = none)
+                bpb = lane == i ? bsrc : bpb;
                 prev = sc;
-                if (sc >= tops) { tops = sc; top = r; }       // ties: larger rank
-                asm volatile("" ::: "memory");
+                if (sc > tops) { tops = sc; top = r; }           // first strictly largest
+                if (in_lds) asm volatile("" ::: "memory"); else __syncthreads();
             }
             if (lane < cnt) w.bp[rb + lane] = bpb;
             b0 = n0; b1 = n1; b2 = n2;
         }
+        return top;
+    };
+    int top = pass(0, false);
+    for (int rounds = 0;; ++rounds) {
+        if (rounds > N) return -1;                               // every completion moves to a later rank
         phase_sync();
-        // chase the back pointers: lane l holds bp[c0 - l]; the path descends a few ranks per step
-        int len = 0, r = top, c0 = -1000, pb = 0, blk = 0;
-        while (r > 0) {
-            int off = c0 - r;
-            if ((unsigned)off >= 64u) { c0 = r; blk = r - lane >= 1 ? w.bp[r - lane] : 0; off = 0; }
-            pb = lane == (len & 63) ? r : pb;
-            ++len;
-            if ((len & 63) == 0) w.pn[len - 64 + lane] = pb;
-            r = __builtin_amdgcn_readlane(blk, off);
+        const uint32_t tt = w.tab[top * 3];
+        if (__builtin_amdgcn_readfirstlane((int)tt) & 0x80) break;                  // a sink: done
+        // BranchCompletion: the other tails of the successors of `top` are barred, later ranks recomputed
+        for (int r = top + 1 + lane; r <= N; r += 64) {
+            const int v = w.order[r - 1];
+            const int np = w.np[v];
+            bool succ = false;
+            for (int s2 = 0; s2 < np; ++s2) succ |= w.rank[w.pred[v * POA_MAXP + s2]] == top;
+            if (succ) for (int s2 = 0; s2 < np; ++s2) { const int u = w.rank[w.pred[v * POA_MAXP + s2]]; if (u != top) score[u] = -1; }
         }
-        if (len & 63) { const int q = (len & ~63) + lane; if (q < len) w.pn[q] = pb; }
-        if (len > cap) return -1;
         phase_sync();
-        for (int k = lane; k < len; k += 64) out[len - 1 - k] = w.base[w.order[w.pn[k] - 1]];
-        return len;
+        const int t2 = pass(top, true);
+        if (t2 <= 0) break;                                                          // cannot happen
+        top = t2;
     }
-    int top = -1, tops = -1;
-    for (int r = 1; r <= N; ++r) {       // wave-uniform sequential pass
-        const int v = w.order[r - 1];
-        const int np = w.np[v];
-        int bw = -1, bsrc = -1, bscore = 0;
-        for (int e = 0; e < np; ++e) {
-            const int u = w.pred[v * POA_MAXP + e], wt = w.pw[v * POA_MAXP + e];
-            const int su = w.score[u];
-            if (wt > bw || (wt == bw && su > bscore)) { bw = wt; bsrc = u; bscore = su; }
-        }
-        const int sc = bsrc >= 0 ? bw + bscore : 0;
-        w.bp[v] = bsrc; w.score[v] = sc;
-        __syncthreads();
-        if (sc >= tops) { tops = sc; top = v; }
+    // chase the back pointers: lane l holds bp[c0 - l]; the path descends a few ranks per step
+    int len = 0, r = top, c0 = -1000, pbuf = 0, blk = 0;
+    while (r > 0) {
+        if (len > N) return -1;                                  // a path visits a rank once
+        int off = c0 - r;
+        if ((unsigned)off >= 64u) { c0 = r; blk = r - lane >= 1 ? w.bp[r - lane] : 0; off = 0; }
+        pbuf = lane == (len & 63) ? r : pbuf;
+        ++len;
+        if ((len & 63) == 0) w.pn[len - 64 + lane] = pbuf;
+        r = __builtin_amdgcn_readlane(blk, off);
     }
-    int len = 0;
-    for (int v = top; v >= 0; v = w.bp[v]) ++len;
-    if (len > cap) return -1;
-    int k = len;
-    for (int v = top; v >= 0; v = w.bp[v]) { --k; if (lane == 0) out[k] = w.base[v]; }
-    return len;
+    if (len & 63) { const int q = (len & ~63) + lane; if (q < len) w.pn[q] = pbuf; }
+    phase_sync();
+    // output in path order (pn holds it reversed), nodes below min_cov left out
+    int olen = 0;
+    for (int k0 = 0; k0 < len; k0 += 64) {
+        const int k = k0 + lane;
+        int v = -1;
+        if (k < len) v = w.order[w.pn[len - 1 - k] - 1];
+        const bool kp = v >= 0 && w.cov[v] >= min_cov;
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(kp);
+        const int pos = olen + __builtin_popcountll(bm & (((unsigned long long)1 << lane) - 1));
+        if (kp && pos < cap) out[pos] = w.base[v];
+        olen += __builtin_popcountll(bm);
+    }
+    return olen > cap ? -1 : olen;
 }
 
-__global__ void __launch_bounds__(64, 5) poa_consensus_kernel(const CcsParams p)
+// MSA columns: one per aligned set in rank order.  col[node] via w.score (free by now); returns the number of columns
+__device__ int poa_msa_columns(const PoaWs& w, int N, int lane)
+{
+    int nc = 0;
+    for (int r0 = 1; r0 <= N; r0 += 64) {
+        const int r = r0 + lane;
+        bool lead = false;
+        int v = -1;
+        if (r <= N) { v = w.order[r - 1]; int lo, hi; group_span(w, v, lo, hi); lead = lo == r; }
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(lead);
+        if (lead) w.score[v] = nc + __builtin_popcountll(bm & (((unsigned long long)1 << lane) - 1));
+        nc += __builtin_popcountll(bm);
+    }
+    phase_sync();
+    for (int r = 1 + lane; r <= N; r += 64) {
+        const int v = w.order[r - 1];
+        int lo, hi;
+        group_span(w, v, lo, hi);
+        if (lo != r) w.bp[v] = w.score[w.order[lo - 1]]; else w.bp[v] = w.score[v];
+    }
+    phase_sync();
+    return nc;
+}
+
+__global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
 {
     const int lane = threadIdx.x & 63;
     uint8_t* slot = p.poa_ws + (size_t)blockIdx.x * p.slot_bytes;
-    for (;;) {
+    const PoaScores S = p.sc;
+    for (int turns = 0; turns <= p.n; ++turns) {             // a wave takes at most every read once
         int idx = 0;
         if (lane == 0) idx = atomicAdd(p.work_counter, 1);
         idx = __builtin_amdgcn_readfirstlane(idx);    // wave-uniform in the compiler's eyes too: scalar loads, scalar branches, SGPR pointers below
@@ -903,72 +1121,91 @@ __global__ void __launch_bounds__(64, 5) poa_consensus_kernel(const CcsParams p)
         const int L = (int)(p.read_off[rd + 1] - off);
         const int8_t* seq = p.reads + off;
         if (p.tier == 1 && __builtin_amdgcn_readfirstlane(p.results[rd].status) != 1) continue;   // second tier: only what did not fit a first-tier slot
-        const CcsScan sc = p.scan[rd];
         CcsResult res;
-        const int period = __builtin_amdgcn_readfirstlane(sc.period);
-        res.nseg = 0; res.ccs_len = 0; res.period = period; res.status = 0;
+        res.nseg = 0; res.ccs_len = 0; res.period = 0; res.status = 0;
+        // the sequences: copies found by K2, or the explicit sequences of a group (poa API)
+        const int32_t* cuts;
+        int ncuts, period;
+        bool tail;
+        if (p.xcuts) {
+            const int64_t c0 = p.xcut_off[rd];
+            cuts = p.xcuts + c0; ncuts = (int)(p.xcut_off[rd + 1] - c0); period = -1; tail = true;
+        } else {
+            const CcsScan* sc = p.scan + rd;
+            period = __builtin_amdgcn_readfirstlane(sc->period);
+            ncuts = __builtin_amdgcn_readfirstlane(sc->ncuts);
+            cuts = sc->cuts;
+            const int bl = ncuts > 0 ? __builtin_amdgcn_readfirstlane(cuts[ncuts - 1]) : 0;
+            tail = L - bl >= CCS_MIN_TAIL && ncuts < CCS_MAX_CUTS;     // a scan that stopped at its cap leaves the rest of the read out
+        }
+        res.period = period;
         if (period == 0) { if (lane == 0) p.results[rd] = res; continue; }
-        // copies
         int nseg = 0, b = 0, maxlen = 0, total = 0;
-        const int ncuts = __builtin_amdgcn_readfirstlane(sc.ncuts);
-        for (int i = 0; i < ncuts; ++i) {
-            const int cut = __builtin_amdgcn_readfirstlane(sc.cuts[i]);
-            if (lane == 0) { p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg] = b; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg + 1] = cut; }
+        for (int i = 0; i <= ncuts; ++i) {
+            if (i == ncuts && !tail) break;
+            const int cut = i < ncuts ? __builtin_amdgcn_readfirstlane(cuts[i]) : L;
+            if (!p.xcuts && lane == 0) { p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg] = b; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg + 1] = cut; }
             const int len = cut - b;
             maxlen = len > maxlen ? len : maxlen; total += len;
             b = cut; ++nseg;
-        }
-        // period < 0: explicit copies (poa API), keep any tail.  A scan that stopped at its cap leaves the rest of the read out.
-        if ((L - b >= CCS_MIN_TAIL && (period < 0 || ncuts < CCS_MAX_CUTS)) || (period < 0 && L > b)) {
-            if (lane == 0) { p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg] = b; p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * nseg + 1] = L; }
-            const int len = L - b;
-            maxlen = len > maxlen ? len : maxlen; total += len;
-            ++nseg;
         }
         const int ncap = total + 8, mcap = maxlen + 1;
         if (maxlen > POA_MAX_COPY) { res.status = 4; if (lane == 0) p.results[rd] = res; continue; }   // cells are int16
         // workspace: this wave's slot, or -- a read that needs more -- one of the large slots, claimed for the duration of
         // the read; none free (or none large enough): status 1, the second launch over the large slots takes the read
         uint8_t* ws = slot;
+        size_t ws_bytes = p.slot_bytes;
         int big = -1;
-        const size_t need = poa_slot_bytes(ncap, mcap);
-        if (need > p.slot_bytes) {
-            if (p.tier == 0 && p.n_big > 0 && need <= p.big_slot_bytes) {
-                if (lane == 0)
-                    for (int t = 0; t < 64 && big < 0; ++t) {
-                        const int cand = (int)((blockIdx.x * 7u + (unsigned)t * 131u + (unsigned)rd) % (unsigned)p.n_big);
-                        if (atomicCAS(&p.big_busy[cand], 0, 1) == 0) big = cand;
-                    }
-                big = __builtin_amdgcn_readfirstlane(big);
+        const size_t need_min = poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(maxlen + 8, maxlen, 0, 0) + 64;
+        bool use_big = need_min > p.slot_bytes;
+        int N = 0, len = -1, ncols = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (use_big) {
+                if (p.tier == 0 && p.n_big > 0 && need_min <= p.big_slot_bytes) {
+                    if (lane == 0)
+                        for (int t = 0; t < 64 && big < 0; ++t) {
+                            const int cand = (int)((blockIdx.x * 7u + (unsigned)t * 131u + (unsigned)rd) % (unsigned)p.n_big);
+                            if (atomicCAS(&p.big_busy[cand], 0, 1) == 0) big = cand;
+                        }
+                    big = __builtin_amdgcn_readfirstlane(big);
+                }
+                if (big < 0) { N = -2; break; }
+                ws = p.big_ws + (size_t)big * p.big_slot_bytes; ws_bytes = p.big_slot_bytes;
             }
-            if (big < 0) { res.status = 1; if (lane == 0) p.results[rd] = res; continue; }
-            ws = p.big_ws + (size_t)big * p.big_slot_bytes;
-        }
-        const PoaWs w = carve(ws, ncap, mcap);
-        phase_sync();
-        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int N = 0;
-        b = 0;
-        for (int s = 0; s < nseg && N >= 0; ++s) {
-            const int e = s < ncuts ? __builtin_amdgcn_readfirstlane(sc.cuts[s]) : L;
-            N = poa_add(w, N, ncap, mcap, seq + b, e - b, lane, tacc);
-            b = e;
-        }
-        int len = -1;
-        if (N < 0) res.status = 2;
-        else {
+            PoaWs w = carve(ws, ws_bytes, ncap, mcap);
+            phase_sync();
+            unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            N = 0; b = 0;
+            int si = 0;
+            for (int i = 0; i <= ncuts && N >= 0; ++i) {
+                if (i == ncuts && !tail) break;
+                const int cut = i < ncuts ? __builtin_amdgcn_readfirstlane(cuts[i]) : L;
+                int sc1 = 0;
+                N = poa_add(w, S, N, ncap, seq + b, cut - b, lane, &sc1, p.msa_col ? p.msa_col + off + b : nullptr, tacc);
+                if (p.aln_score && si < CCS_SEG_CAP && lane == 0) p.aln_score[(size_t)rd * CCS_SEG_CAP + si] = sc1;
+                b = cut; ++si;
+            }
+            if (N == -2 && !use_big && p.tier == 0) { use_big = true; continue; }     // the DP planes outgrew this slot: once more in a large one
+            if (N >= 0) {
+                const int mc = S.min_cov >= 0 ? S.min_cov : (nseg + 1) / 2;
+                len = poa_consensus(w, N, mc, p.ccs + off, L, lane);
+                if (len >= 0 && p.msa_col) {
+                    phase_sync();
+                    ncols = poa_msa_columns(w, N, lane);
+                    for (int t = lane; t < L; t += 64) p.msa_col[off + t] = w.bp[p.msa_col[off + t]];
+                }
 #ifdef CLH_DEBUG_POA
-            unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+                if (lane == 0) for (int k = 0; k < 5; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
 #endif
-            len = poa_consensus(w, N, p.ccs + off, L, lane);
-#ifdef CLH_DEBUG_POA
-            tacc[4] += __builtin_amdgcn_s_memtime() - tc0;
-            if (lane == 0) for (int k = 0; k < 5; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
-#endif
-            if (len < 0) res.status = 3;
-            else { res.nseg = nseg; res.ccs_len = len; }
+            }
+            break;
         }
-        if (lane == 0) p.results[rd] = res;
+        if (N == -2) res.status = 1;
+        else if (N == -3) res.status = 5;
+        else if (N < 0) res.status = 2;
+        else if (len < 0) res.status = 3;
+        else { res.nseg = nseg; res.ccs_len = len; }
+        if (lane == 0) { p.results[rd] = res; if (p.msa_ncols) p.msa_ncols[rd] = ncols; }
         __syncthreads();
         if (big >= 0) {                      // every store into the large slot has landed before another wave may claim it
             __threadfence();
@@ -998,5 +1235,6 @@ hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream)
 }
 
 size_t poa_slot_bytes_host(int ncap, int mcap) { return poa_slot_bytes(ncap, mcap); }
+size_t poa_slot_min_bytes_host(int ncap, int mcap) { return poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(mcap + 8, mcap - 1, 0, 0) + 64; }
 
 }  // namespace clh

@@ -55,16 +55,35 @@ struct clh_ctx {
         size_t cap = 256;
         while (cap < bytes) cap += cap < (64u << 20) ? cap : (64u << 20);
         void* p = nullptr;
-        if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+        if (hipMalloc(&p, cap) != hipSuccess) {
+            // out of memory with blocks parked in the cache: give them back and try once more
+            (void)hipGetLastError();
+            for (auto& kv : cache) (void)hipFree(kv.second);
+            cache.clear();
+            if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
         sizes.push_back({p, cap});
         return p;
     }
+    // parked blocks are bounded: consensus workspaces are tens of GB and their size differs from batch to batch, so the
+    // oldest large blocks go back to the driver once the parked total passes the cap
+    static constexpr size_t kCacheCap = (size_t)72 << 30;
     void release(void* p)
     {
         if (!p) return;
         std::lock_guard<std::mutex> g(mu);
         for (size_t i = 0; i < sizes.size(); ++i)
-            if (sizes[i].first == p) { cache.push_back({sizes[i].second, p}); sizes.erase(sizes.begin() + i); return; }
+            if (sizes[i].first == p) {
+                cache.push_back({sizes[i].second, p});
+                sizes.erase(sizes.begin() + i);
+                size_t parked = 0;
+                for (auto& kv : cache) parked += kv.first;
+                for (size_t k = 0; parked > kCacheCap && k < cache.size();) {
+                    if (cache[k].first >= ((size_t)256 << 20)) { parked -= cache[k].first; (void)hipFree(cache[k].second); cache.erase(cache.begin() + k); }
+                    else ++k;
+                }
+                return;
+            }
     }
     std::vector<std::pair<void*, size_t>> sizes;   // live allocations
 };
@@ -866,7 +885,7 @@ struct clh_ccs_plan {
     int64_t total = 0;
     size_t slot_bytes = 0, slot_bytes_big = 0;      // second tier: a few slots sized for the worst case of the batch
     void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr, *d_ws_big = nullptr,
-         *d_counter = nullptr, *d_order = nullptr, *d_reads = nullptr;
+         *d_counter = nullptr, *d_order = nullptr, *d_reads = nullptr, *d_score = nullptr;
     hipStream_t last_stream = nullptr;
     bool ran = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // K2 start, K2 stop = K3 start, K3 stop
@@ -877,11 +896,15 @@ extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
-    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_reads, pl->d_long, pl->d_k2ws, pl->d_busy};
+    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_reads, pl->d_long, pl->d_k2ws, pl->d_busy, pl->d_score};
     for (void* b : bufs) pl->ctx->release(b);
     for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
     delete pl;
 }
+
+// scores of the consensus step of find_consensus: local alignment with the numbers of the reference's call
+// (tests/test_poa.py:30), consensus over the nodes crossed by at least half of the copies (oracle/ccs_oracle.c)
+static clh::PoaScores ccs_scores() { clh::PoaScores s; s.algorithm = 0; s.m = 10; s.n = -4; s.g = -8; s.e = -2; s.q = -24; s.c = -1; s.min_cov = -1; return s; }
 
 static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off, int mcap_hint)
 {
@@ -902,19 +925,25 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->lcap = (std::min(lmax, clh::kK2LdsMax) + 63) & ~63;
     pl->lmax = lmax; pl->n_long = (int)long_idx.size();
     // Workspace.  The worst case of a read of L bases is a graph of L+8 nodes against copies of L/2 + L/16 bases (period
-    // <= L/2, tolerance period/8; copies above 2800 bases are refused by the kernel) -- ~L^2 bytes, while the common case
-    // (period of a few hundred bases) needs a small fraction of that.  So: 5120 first-tier slots (20 waves per CU x 256
-    // CUs) share a fixed budget, and the reads that do not fit one (status 1 after the first launch) run in a second
-    // launch over up to 1024 slots of worst-case size (64 GB at most: HBM is 288 GB).
-    const int mcap_worst = mcap_hint > 0 ? mcap_hint + 1 : std::min(lmax / 2 + lmax / 16 + 8, 2801);
+    // <= L/2, tolerance period/8; sequences above 2800 bases are refused by the kernel), every row kept and with several
+    // in-edges -- ~6 bytes per cell of that -- while the common case (period of a few hundred bases) needs a small
+    // fraction.  So the first-tier slots (16 waves per CU x 256 CUs) share a budget, a wave whose read outgrows its slot
+    // claims one of a few worst-case slots, and whatever found none free runs in a second launch over those.  Both budgets
+    // follow the free memory of the device (HBM is 288 GB on an MI355X; nothing here assumes it).
+    const int mcap_worst = mcap_hint > 0 ? std::min(mcap_hint + 1, 2801) : std::min(lmax / 2 + lmax / 16 + 8, 2801);
     const size_t need_worst = clh::poa_slot_bytes_host(lmax + 8, mcap_worst);
-    pl->nslots = (int)std::max<long long>(1, std::min<long long>(5120, std::max(n, 1)));
-    unsigned long long budget = 40ull << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { fail(CLH_E_HIP, "hipMemGetInfo failed"); delete pl; return nullptr; }
+    { std::lock_guard<std::mutex> g(ctx->mu); for (auto& kv : ctx->cache) free_b += kv.first; }      // parked blocks are ours to reuse
+    pl->nslots = (int)std::max<long long>(1, std::min<long long>(4096, std::max(n, 1)));
+    unsigned long long budget = std::min<unsigned long long>(40ull << 30, (unsigned long long)(free_b * 0.40));
     if (const char* e = getenv("CLH_POA_BUDGET_MB")) budget = std::max(1ull, strtoull(e, nullptr, 10)) << 20;     // tests: force the second tier
     pl->slot_bytes = std::min<size_t>(need_worst, (size_t)((budget / (unsigned long long)pl->nslots) & ~255ull));
+    pl->slot_bytes = std::max<size_t>(pl->slot_bytes, 4096);
     if (pl->slot_bytes < need_worst) {
+        const unsigned long long budget_big = std::min<unsigned long long>(64ull << 30, (unsigned long long)(free_b * 0.35));
         pl->slot_bytes_big = need_worst;
-        pl->nslots_big = (int)std::max<unsigned long long>(2, std::min<unsigned long long>(1024, (64ull << 30) / need_worst));
+        pl->nslots_big = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(1024, budget_big / need_worst));
         pl->nslots_big = std::min(pl->nslots_big, std::max(n, 1));
     }
     pl->d_off = ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));
@@ -951,6 +980,21 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     return pl;
 }
 
+// the K3 launches of a plan: first tier over every read, second tier over what found no slot large enough
+static int launch_poa_tiers(clh_ccs_plan* pl, clh::CcsParams& P, hipStream_t st)
+{
+    P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
+    P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap; P.tier = 0;
+    if (pl->nslots_big) { P.big_ws = (uint8_t*)pl->d_ws_big; P.big_slot_bytes = pl->slot_bytes_big; P.big_busy = (int*)pl->d_busy; P.n_big = pl->nslots_big; }
+    HIPCHK(clh::launch_poa(P, pl->nslots, st));
+    if (pl->nslots_big) {       // the reads the first tier left with status 1
+        clh::CcsParams Q = P;
+        Q.poa_ws = (uint8_t*)pl->d_ws_big; Q.slot_bytes = pl->slot_bytes_big; Q.work_counter = (int*)pl->d_counter + 1; Q.tier = 1;
+        HIPCHK(clh::launch_poa(Q, pl->nslots_big, st));
+    }
+    return 0;
+}
+
 extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
 {
     if (!pl || !d_reads) return fail(CLH_E_ARG, "clh_ccs_run: null argument");
@@ -961,22 +1005,20 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     memset(&P, 0, sizeof(P));
     P.reads = (const int8_t*)d_reads; P.read_off = (const int64_t*)pl->d_off; P.scan = (clh::CcsScan*)pl->d_scan;
     P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
-    P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
-    P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
+    P.n = pl->n; P.lcap = pl->lcap;
     P.long_idx = (const int32_t*)pl->d_long; P.k2_ws = (uint8_t*)pl->d_k2ws; P.k2_slot = clh::k2_long_slot_bytes(pl->lmax);
     P.n_long = pl->n_long; P.k2_lmax = pl->lmax; P.k2_lds_max = clh::kK2LdsMax;
+    P.sc = ccs_scores();
+    P.aln_score = (int32_t*)pl->d_score;
     if (!pl->ev[0]) for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMemsetAsync(pl->d_counter, 0, 8, st));
+    const bool trace = getenv("CLH_TRACE") != nullptr;
     HIPCHK(hipEventRecord(pl->ev[0], st));
     HIPCHK(clh::launch_ccs_scan(P, st));
+    if (trace) { fprintf(stderr, "[clh] K2 launched (n=%d lcap=%d)\n", pl->n, pl->lcap); HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[clh] K2 done\n"); }
     HIPCHK(hipEventRecord(pl->ev[1], st));
-    if (pl->nslots_big) { P.big_ws = (uint8_t*)pl->d_ws_big; P.big_slot_bytes = pl->slot_bytes_big; P.big_busy = (int*)pl->d_busy; P.n_big = pl->nslots_big; }
-    HIPCHK(clh::launch_poa(P, pl->nslots, st));
-    if (pl->nslots_big) {       // the reads the first tier left with status 1
-        clh::CcsParams Q = P;
-        Q.poa_ws = (uint8_t*)pl->d_ws_big; Q.slot_bytes = pl->slot_bytes_big; Q.work_counter = (int*)pl->d_counter + 1; Q.tier = 1;
-        HIPCHK(clh::launch_poa(Q, pl->nslots_big, st));
-    }
+    if (int rc = launch_poa_tiers(pl, P, st)) return rc;
+    if (trace) { fprintf(stderr, "[clh] K3 launched (slots %d x %zu, big %d x %zu)\n", pl->nslots, pl->slot_bytes, pl->nslots_big, pl->slot_bytes_big); HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[clh] K3 done\n"); }
     HIPCHK(hipEventRecord(pl->ev[2], st));
     pl->last_stream = st; pl->ran = true;
     return 0;
@@ -1007,6 +1049,17 @@ extern "C" int clh_ccs_fetch(clh_ccs_plan* pl, clh_ccs_t* out, int32_t* segs, in
     return 0;
 }
 
+// device pointers of the last run's outputs, for callers that keep post-processing on the GPU: rows (clh_ccs_t[n]),
+// segs (int32[n][2*65]) and the packed consensus codes (offsets = the read offsets of the plan)
+extern "C" int clh_ccs_results_dev(const clh_ccs_plan* pl, const void** rows, const void** segs, const void** ccs)
+{
+    if (!pl) return fail(CLH_E_ARG, "clh_ccs_results_dev: null plan");
+    if (rows) *rows = pl->d_res;
+    if (segs) *segs = pl->d_segs;
+    if (ccs) *ccs = pl->d_ccs;
+    return 0;
+}
+
 extern "C" int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, clh_ccs_t* out, int32_t* segs, int8_t* ccs)
 {
     if (!ctx || !reads || !read_off || !out) return fail(CLH_E_ARG, "clh_ccs_batch: null argument");
@@ -1023,57 +1076,87 @@ extern "C" int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const
     return rc;
 }
 
+// spoa's AlignmentEngine::Create rules + what the kernel's 16-bit cells can hold
+static int poa_check_opts(const clh_poa_opts* o, clh::PoaScores* s)
+{
+    clh_poa_opts d;
+    d.algorithm = 0; d.m = 10; d.n = -4; d.g = -8; d.e = -2; d.q = -24; d.c = -1; d.min_coverage = 0;
+    if (o) d = *o;
+    if (d.algorithm < 0 || d.algorithm > 2) return fail(CLH_E_ARG, "poa: algorithm must be 0 (local), 1 (global) or 2 (overlap)");
+    if (d.g > 0 || d.q > 0) return fail(CLH_E_ARG, "poa: gap opening penalty must be non-positive");
+    if (d.e > 0 || d.c > 0) return fail(CLH_E_ARG, "poa: gap extension penalty must be non-positive");
+    if (d.g >= d.e) return fail(CLH_E_UNSUPPORTED, "poa: linear gap cost (g >= e) is not built into the kernel");
+    if (d.g <= d.q || d.e >= d.c) { d.q = d.g; d.c = d.e; }          // affine: one piece
+    if (d.m < 1 || d.m > 11 || d.n > d.m || d.n < -100) return fail(CLH_E_UNSUPPORTED, "poa: match score must be 1..11, mismatch -100..match (16-bit cells)");
+    if (d.e - d.g > 6 || d.c - d.q > 30) return fail(CLH_E_UNSUPPORTED, "poa: e - g <= 6 and c - q <= 30 required (vertical gap states are kept as small differences)");
+    if (std::max(d.g + 2799 * d.e, d.q + 2799 * d.c) < -30000) return fail(CLH_E_UNSUPPORTED, "poa: gap extension too costly for 16-bit cells");
+    if (d.min_coverage < 0) return fail(CLH_E_ARG, "poa: min_coverage must be >= 0");
+    s->algorithm = d.algorithm; s->m = d.m; s->n = d.n; s->g = d.g; s->e = d.e; s->q = d.q; s->c = d.c; s->min_cov = d.min_coverage;
+    return 0;
+}
+
 // consensus of explicit groups of sequences (the spoa.poa call shape): group k = sequences [group_off[k], group_off[k+1])
 extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64_t* seq_off, const int64_t* group_off,
-                             int32_t* out_len, int8_t* out_ccs)
+                             const clh_poa_opts* opts, int32_t* out_len, int8_t* out_ccs, int32_t* msa_col, int32_t* msa_ncols, int32_t* aln_score)
 {
     if (!ctx || ngroups < 0 || !seqs || !seq_off || !group_off || !out_len || !out_ccs) return fail(CLH_E_ARG, "clh_poa_batch: null argument");
-    std::vector<int64_t> roff((size_t)ngroups + 1);
-    std::vector<clh::CcsScan> scan((size_t)std::max(ngroups, 1));
+    clh::PoaScores sc;
+    if (int rc = poa_check_opts(opts, &sc)) return rc;
+    std::vector<int64_t> roff((size_t)ngroups + 1), xoff((size_t)ngroups + 1);
+    std::vector<int32_t> xcuts;
     for (int k = 0; k < ngroups; ++k) {
         const int64_t s0 = group_off[k], s1 = group_off[k + 1];
-        if (s1 - s0 < 1 || s1 - s0 > 65) return fail(CLH_E_UNSUPPORTED, "a consensus group must hold 1..65 sequences");
+        if (s1 - s0 < 1) return fail(CLH_E_ARG, "a consensus group must hold at least one sequence");
+        if (seq_off[s1] - seq_off[s0] > (1 << 24)) return fail(CLH_E_UNSUPPORTED, "a consensus group above 16 M bases");
         roff[k] = seq_off[s0];
-        clh::CcsScan& sc = scan[k];
-        memset(&sc, 0, sizeof(sc));
-        sc.period = -1; sc.ncuts = (int32_t)(s1 - s0 - 1);
-        for (int64_t i = s0 + 1; i < s1; ++i) sc.cuts[i - s0 - 1] = (int32_t)(seq_off[i] - seq_off[s0]);
+        xoff[k] = (int64_t)xcuts.size();
+        for (int64_t i = s0 + 1; i < s1; ++i) xcuts.push_back((int32_t)(seq_off[i] - seq_off[s0]));
     }
+    xoff[ngroups] = (int64_t)xcuts.size();
     roff[ngroups] = ngroups ? seq_off[group_off[ngroups]] : 0;
     // groups must tile the packed array contiguously
     for (int k = 0; k + 1 < ngroups; ++k) if (seq_off[group_off[k + 1]] != roff[k + 1]) return fail(CLH_E_ARG, "groups must be contiguous");
+    if (ngroups == 0) return 0;
     int mcap = 1;
     for (int64_t i = 0; i < group_off[ngroups]; ++i) mcap = std::max<int>(mcap, (int)(seq_off[i + 1] - seq_off[i]));
     clh_ccs_plan* pl = ccs_plan_create(ctx, ngroups, roff.data(), mcap);
     if (!pl) return CLH_E_ARG;
     int rc = 0;
-    const size_t total = (size_t)(roff[ngroups] - roff[0]);
-    pl->d_reads = ctx->alloc(total + (size_t)roff[0] + 64);
-    if (!pl->d_reads) rc = fail(CLH_E_HIP, "out of device memory");
-    if (!rc && hipMemcpyAsync(pl->d_reads, seqs, (size_t)roff[ngroups], hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D failed");
-    if (!rc && ngroups && hipMemcpyAsync(pl->d_scan, scan.data(), sizeof(clh::CcsScan) * (size_t)ngroups, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "H2D failed");
-    if (!rc && ngroups) {
+    const size_t total = (size_t)roff[ngroups];
+    pl->d_reads = ctx->alloc(total + 64);
+    void* d_xcuts = ctx->alloc(sizeof(int32_t) * (xcuts.size() + 1));
+    void* d_xoff = ctx->alloc(sizeof(int64_t) * (size_t)(ngroups + 1));
+    void* d_col = msa_col ? ctx->alloc(sizeof(int32_t) * (total + 1)) : nullptr;
+    void* d_ncols = msa_col ? ctx->alloc(sizeof(int32_t) * (size_t)ngroups) : nullptr;
+    if (aln_score) pl->d_score = ctx->alloc(sizeof(int32_t) * clh::CCS_SEG_CAP * (size_t)ngroups);
+    hipStream_t st = ctx->stream;
+    if (!pl->d_reads || !d_xcuts || !d_xoff || (msa_col && (!d_col || !d_ncols)) || (aln_score && !pl->d_score)) rc = fail(CLH_E_HIP, "out of device memory");
+    if (!rc && hipMemcpyAsync(pl->d_reads, seqs, total, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(CLH_E_HIP, "H2D failed");
+    if (!rc && !xcuts.empty() && hipMemcpyAsync(d_xcuts, xcuts.data(), sizeof(int32_t) * xcuts.size(), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(CLH_E_HIP, "H2D failed");
+    if (!rc && hipMemcpyAsync(d_xoff, xoff.data(), sizeof(int64_t) * (size_t)(ngroups + 1), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(CLH_E_HIP, "H2D failed");
+    if (!rc && aln_score && hipMemsetAsync(pl->d_score, 0, sizeof(int32_t) * clh::CCS_SEG_CAP * (size_t)ngroups, st) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
+    if (!rc) {
         clh::CcsParams P;
         memset(&P, 0, sizeof(P));
         P.reads = (const int8_t*)pl->d_reads; P.read_off = (const int64_t*)pl->d_off; P.scan = (clh::CcsScan*)pl->d_scan;
         P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
-        P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
-        P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap;
-        if (hipMemsetAsync(pl->d_counter, 0, 8, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
-        if (pl->nslots_big) { P.big_ws = (uint8_t*)pl->d_ws_big; P.big_slot_bytes = pl->slot_bytes_big; P.big_busy = (int*)pl->d_busy; P.n_big = pl->nslots_big; }
-        if (!rc && clh::launch_poa(P, pl->nslots, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "launch failed");
-        if (!rc && pl->nslots_big) {
-            clh::CcsParams Q = P;
-            Q.poa_ws = (uint8_t*)pl->d_ws_big; Q.slot_bytes = pl->slot_bytes_big; Q.work_counter = (int*)pl->d_counter + 1; Q.tier = 1;
-            if (clh::launch_poa(Q, pl->nslots_big, ctx->stream) != hipSuccess) rc = fail(CLH_E_HIP, "launch failed");
-        }
-        pl->ran = true; pl->last_stream = ctx->stream;
+        P.sc = sc; P.xcuts = (const int32_t*)d_xcuts; P.xcut_off = (const int64_t*)d_xoff;
+        P.msa_col = (int32_t*)d_col; P.msa_ncols = (int32_t*)d_ncols; P.aln_score = (int32_t*)pl->d_score;
+        if (hipMemsetAsync(pl->d_counter, 0, 8, st) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
+        if (!rc) rc = launch_poa_tiers(pl, P, st);
+        pl->ran = true; pl->last_stream = st;
     }
-    if (!rc && ngroups) {
+    if (!rc) {
         std::vector<clh_ccs_t> res((size_t)ngroups);
         rc = clh_ccs_fetch(pl, res.data(), nullptr, out_ccs);
-        for (int k = 0; k < ngroups && !rc; ++k) out_len[k] = res[k].nseg > 0 && res[k].status == 0 ? res[k].ccs_len : -1;
-    }
+        for (int k = 0; k < ngroups && !rc; ++k) out_len[k] = res[k].nseg > 0 && res[k].status == 0 ? res[k].ccs_len : -(1 + res[k].status);
+        if (!rc && msa_col && (hipMemcpy(msa_col, d_col, sizeof(int32_t) * total, hipMemcpyDeviceToHost) != hipSuccess ||
+                               (msa_ncols && hipMemcpy(msa_ncols, d_ncols, sizeof(int32_t) * (size_t)ngroups, hipMemcpyDeviceToHost) != hipSuccess)))
+            rc = fail(CLH_E_HIP, "D2H failed");
+        if (!rc && aln_score && hipMemcpy(aln_score, pl->d_score, sizeof(int32_t) * clh::CCS_SEG_CAP * (size_t)ngroups, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(CLH_E_HIP, "D2H failed");
+    } else (void)hipStreamSynchronize(st);
+    ctx->release(d_xcuts); ctx->release(d_xoff); ctx->release(d_col); ctx->release(d_ncols);
     clh_ccs_plan_destroy(pl);
     return rc;
 }

@@ -72,7 +72,15 @@ struct CcsResult {        // K3 output per read
     int32_t nseg;         // 0 = no consensus
     int32_t ccs_len;
     int32_t period;
-    int32_t status;       // 0 ok, 1 workspace slot too small, 2 graph overflow, 3 consensus overflow
+    int32_t status;       // 0 ok, 1 workspace slot too small, 2 graph limits (in-degree, aligned set, 65535 rows), 3 consensus overflow, 4 sequence above 2800 bases
+};
+
+// scores and mode of the partial-order aligner (spoa.poa(seqs, algorithm, genmsa, m, n, g, e, q, c)); affine is passed as
+// q = g, c = e; the linear sub-type (g >= e) is refused by the host side
+struct PoaScores {
+    int32_t algorithm;    // 0 local, 1 global, 2 overlap
+    int32_t m, n, g, e, q, c;
+    int32_t min_cov;      // consensus keeps nodes crossed by >= min_cov sequences; -1: (sequences + 1) / 2 (find_consensus)
 };
 
 struct CcsParams {
@@ -97,11 +105,20 @@ struct CcsParams {
     int* big_busy;
     int32_t n_big;
     int32_t tier;              // K3: 0 = every read (too large for the slot: status 1); 1 = only the reads left with status 1
+    PoaScores sc;
+    // explicit sequences (the spoa.poa call shape): "read" rd is the concatenation of the sequences of group rd, whose
+    // inner boundaries (relative to the group's first base) are xcuts[xcut_off[rd] .. xcut_off[rd+1]); nullptr: copies from `scan`
+    const int32_t* xcuts;
+    const int64_t* xcut_off;
+    int32_t* msa_col;          // optional, packed like reads: MSA column of every base; msa_ncols[rd] = number of columns
+    int32_t* msa_ncols;
+    int32_t* aln_score;        // optional, [n][CCS_SEG_CAP]: end-cell score of the alignment of each of the first 65 sequences (tests)
 };
 
 hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream);
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream);
 size_t poa_slot_bytes_host(int ncap, int mcap);
+size_t poa_slot_min_bytes_host(int ncap, int mcap);
 static constexpr int kK2LdsMax = 16000;
 inline size_t k2_long_slot_bytes(int lmax) { return ((size_t)8 * ((size_t)lmax / 2 + 2) + (size_t)6 * (size_t)lmax + 255) & ~(size_t)255; }
 

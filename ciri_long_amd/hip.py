@@ -104,7 +104,9 @@ def lib():
         L.clh_edit_plan_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_edit_distance_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_edit_distance_batch.restype = C.c_int
-        L.clh_poa_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_poa_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_ccs_results_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -215,25 +217,48 @@ class Context(object):
             raise ClhError('clh_ccs_batch failed (%d): %s' % (rc, last_error()))
         return out, segs, ccs
 
-    def poa_batch(self, seqs, seq_off, group_off):
-        """Consensus per group of sequences -> list of str (None where no consensus)."""
+    def poa_batch(self, seqs, seq_off, group_off, algorithm=0, scores=(10, -4, -8, -2, -24, -1), min_coverage=0, genmsa=False,
+                  with_scores=False):
+        """spoa.poa per group of sequences: -> list of consensus str, or list of (consensus, msa rows[, end-cell scores of
+        the first 65 sequences]) with genmsa / with_scores.  Raises ClhError when a group has no consensus (a sequence above
+        2800 bases, a node with more than 12 in-edges) or the scores are outside what the kernel honours."""
         seqs = np.ascontiguousarray(seqs, dtype=np.int8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
         group_off = np.ascontiguousarray(group_off, dtype=np.int64)
         ng = len(group_off) - 1
         lens = np.zeros(ng, dtype=np.int32)
         out = np.zeros(max(1, len(seqs)), dtype=np.int8)
-        rc = lib().clh_poa_batch(self._h, ng, seqs.ctypes.data, seq_off.ctypes.data, group_off.ctypes.data, lens.ctypes.data, out.ctypes.data)
+        opts = np.array([algorithm] + [int(x) for x in scores] + [min_coverage], dtype=np.int32)
+        col = np.zeros(max(1, len(seqs)), dtype=np.int32) if genmsa else None
+        ncols = np.zeros(max(1, ng), dtype=np.int32) if genmsa else None
+        asc = np.zeros((max(1, ng), CCS_SEG_CAP), dtype=np.int32) if with_scores else None
+        rc = lib().clh_poa_batch(self._h, ng, seqs.ctypes.data, seq_off.ctypes.data, group_off.ctypes.data, opts.ctypes.data,
+                                 lens.ctypes.data, out.ctypes.data, col.ctypes.data if genmsa else None,
+                                 ncols.ctypes.data if genmsa else None, asc.ctypes.data if with_scores else None)
         if rc != 0:
             raise ClhError('clh_poa_batch failed (%d): %s' % (rc, last_error()))
         bases = np.frombuffer(b'ACGTN', dtype=np.uint8)
         res = []
         for k in range(ng):
             if lens[k] < 0:
-                res.append(None)
-            else:
-                o = int(seq_off[group_off[k]])
-                res.append(bases[np.minimum(out[o:o + lens[k]], 4)].tobytes().decode())
+                raise ClhError('poa: no consensus for group %d (status %d: 1 workspace, 2 graph limits -- more than 12 in-edges or '
+                               '65000 nodes, 3 output, 4 sequence above 2800 bases)' % (k, -1 - int(lens[k])))
+            o = int(seq_off[group_off[k]])
+            cons = bases[np.minimum(out[o:o + int(lens[k])], 4)].tobytes().decode()
+            if not genmsa and not with_scores:
+                res.append(cons)
+                continue
+            rows = []
+            if genmsa:
+                for i in range(int(group_off[k]), int(group_off[k + 1])):
+                    row = np.full(int(ncols[k]), ord('-'), dtype=np.uint8)
+                    a, b = int(seq_off[i]), int(seq_off[i + 1])
+                    row[col[a:b]] = bases[np.minimum(seqs[a:b], 4)]
+                    rows.append(row.tobytes().decode())
+            item = (cons, rows)
+            if with_scores:
+                item = item + ([int(x) for x in asc[k, :min(CCS_SEG_CAP, int(group_off[k + 1] - group_off[k]))]],)
+            res.append(item)
         return res
 
     def edit_distance_batch(self, xs, ys):

@@ -3,25 +3,26 @@
     poa(seqs, algorithm, genmsa, m, n, g, e, q, c) -> (consensus, msa)
 
 PARITY UNPINNED (pyspoa is not part of the reference tree and not installable here).  The engine is the partial-order
-aligner of csrc/ccs_poa.hip ("clh-poa v1", oracle/ccs_oracle.c): fitting alignment with a LINEAR gap cost, scores
-match 10 / mismatch -4 / gap -8.  The arguments are accepted for signature compatibility; ``m, n, g`` must be the values
-every reference call site passes (10, -4, -8) -- other scores are not built into the kernel yet and raise
-``NotImplementedError`` -- and ``algorithm`` (local/global/overlap), ``e, q, c`` (affine / two-piece gaps) have no
-effect.  ``genmsa`` is honoured only as far as the return shape goes: the MSA list is empty.
+aligner of csrc/ccs_poa.hip, a restatement of the published spoa algorithm (oracle/poa_oracle.c): ``algorithm`` 0 local /
+1 global / 2 overlap; a gap of k bases costs max(g + (k-1) e, q + (k-1) c), with spoa's rule for falling back to the
+one-piece (affine) model; heaviest-bundle consensus; ``genmsa`` returns one row per sequence.  Nothing is accepted and
+ignored: what the kernel does not honour raises -- the linear model (g >= e), scores outside its 16-bit cells (match 1..11,
+e - g <= 6, c - q <= 30), a sequence above 2800 bases, a graph node with more than 12 in-edges (``hip.ClhError``).
 """
 import numpy as np
 
 from . import hip
 
-_BASES = np.frombuffer(b'ACGTN', dtype=np.uint8)
 
-
-def poa(seqs, algorithm=0, genmsa=True, m=10, n=-4, g=-8, e=-2, q=-24, c=-1):
-    if (m, n, g) != (10, -4, -8):
-        raise NotImplementedError('clh-poa v1 has the scores of the reference call sites built in: m=10, n=-4, g=-8')
+def poa(seqs, algorithm=0, genmsa=True, m=5, n=-4, g=-8, e=-6, q=-10, c=-4, min_coverage=None):
+    """Defaults are pyspoa's; every CIRI-long call site passes all nine arguments."""
+    seqs = [s for s in seqs]
     if not seqs:
         return '', []
+    if any(len(s) == 0 for s in seqs):
+        raise ValueError('poa: empty sequence')
     ctx = hip.default_context()
     data, off = hip.pack(seqs)
-    out = ctx.poa_batch(data, off, np.array([0, len(seqs)], dtype=np.int64))
-    return out[0], []
+    out = ctx.poa_batch(data, off, np.array([0, len(seqs)], dtype=np.int64), algorithm=int(algorithm), scores=(m, n, g, e, q, c),
+                        min_coverage=int(min_coverage or 0), genmsa=bool(genmsa))
+    return out[0] if genmsa else (out[0], [])

@@ -107,29 +107,45 @@ int clh_ssw_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* r
                   clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used);
 
 /* ---- cyclic consensus: the batch form of pyccs.find_consensus (CIRI_long/find_ccs.py:14) -----------------------
- * pyccs/spoa are external and absent from the reference tree: this implements the specification stated in
- * oracle/ccs_oracle.c (PARITY UNPINNED).  Per read: tandem-repeat period by 8-mer self-matches, copy boundaries,
- * partial-order consensus of the copies.  segs holds [start,end) pairs, 65 per read; ccs is packed like reads. */
+ * pyccs/spoa are external and absent from the reference tree (PARITY UNPINNED).  Per read: tandem-repeat period by
+ * 8-mer self-matches and copy boundaries (this project's specification, oracle/ccs_oracle.c), then the consensus of
+ * the copies by partial-order alignment as spoa computes it (oracle/poa_oracle.c: local alignment, scores
+ * 10/-4/-8/-2/-24/-1 -- the call of the reference's tests/test_poa.py:30).  segs holds [start,end) pairs, 65 per read;
+ * ccs is packed like reads. */
 #define CLH_CCS_SEG_CAP 65
 typedef struct {
     int32_t nseg;      /* 0: no tandem repeat / no consensus (find_consensus would return (None, None)) */
     int32_t ccs_len;
     int32_t period;
-    int32_t status;    /* 0 ok; >0 treated as no consensus: 1 workspace, 2 graph capacity/in-degree, 3 output, 4 copy longer than 2800 bases */
+    int32_t status;    /* 0 ok; >0 treated as no consensus: 1 workspace, 2 graph limits (12 in-edges, 65000 rows), 3 output, 4 sequence longer than 2800 bases */
 } clh_ccs_t;
 typedef struct clh_ccs_plan clh_ccs_plan;
 clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off);
 void clh_ccs_plan_destroy(clh_ccs_plan* plan);
 int clh_ccs_run(clh_ccs_plan* plan, const void* d_reads, void* stream);
 int clh_ccs_fetch(clh_ccs_plan* plan, clh_ccs_t* out, int32_t* segs, int8_t* ccs);
+/* Device pointers of the last run's outputs (rows: clh_ccs_t[n]; segs: int32[n][2*65]; ccs: packed codes at the read
+ * offsets), for callers that keep the next step on the GPU.  Any of the three may be NULL. */
+int clh_ccs_results_dev(const clh_ccs_plan* plan, const void** rows, const void** segs, const void** ccs);
 /* HIP-event durations (ms) of the last run: ms[0] = repeat scan (K2), ms[1] = partial-order consensus (K3). */
 int clh_ccs_plan_timing(clh_ccs_plan* plan, float* ms);
 int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, clh_ccs_t* out, int32_t* segs, int8_t* ccs);
-/* The spoa.poa call shape (collapse.py:267,504; tests/test_poa.py:30): consensus of explicit groups of sequences.
- * Group k = sequences [group_off[k], group_off[k+1]) of the packed array (1..65 per group, groups contiguous).
- * out_ccs is packed by the offset of each group's first sequence; out_len[k] = -1 when no consensus could be built. */
+
+/* The spoa.poa call shape -- poa(seqs, algorithm, genmsa, m, n, g, e, q, c), collapse.py:267,504 (algorithm 2),
+ * tests/test_poa.py:30 (algorithm 0, genmsa) -- for a batch of groups of sequences.  Group k = sequences
+ * [group_off[k], group_off[k+1]) of the packed array (any number >= 1, groups contiguous, each sequence <= 2800 bases).
+ * opts NULL = {0, 10, -4, -8, -2, -24, -1, 0}.  algorithm: 0 local, 1 global, 2 overlap; a gap of k bases costs
+ * max(g + (k-1) e, q + (k-1) c); g <= q or e >= c selects the one-piece (affine) model as spoa does; the linear model
+ * (g >= e) and scores outside the kernel's 16-bit cells (m 1..11, e - g <= 6, c - q <= 30) fail with CLH_E_UNSUPPORTED --
+ * nothing is silently ignored.  min_coverage > 0 leaves nodes crossed by fewer sequences out of the consensus.
+ * out_ccs is packed by the offset of each group's first sequence; out_len[k] < 0 when no consensus could be built
+ * (-(1 + status), status as in clh_ccs_t).  msa_col (may be NULL; one int32 per base, packed like seqs) receives the MSA
+ * column of every base, msa_ncols[k] the number of columns of group k: row i of the MSA is '-' everywhere except
+ * row[msa_col[b]] = base b for the bases b of sequence i.  aln_score (may be NULL; int32[ngroups][65]) receives the
+ * end-cell score of the alignment of each of the first 65 sequences of a group. */
+typedef struct { int32_t algorithm, m, n, g, e, q, c, min_coverage; } clh_poa_opts;
 int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64_t* seq_off, const int64_t* group_off,
-                  int32_t* out_len, int8_t* out_ccs);
+                  const clh_poa_opts* opts, int32_t* out_len, int8_t* out_ccs, int32_t* msa_col, int32_t* msa_ncols, int32_t* aln_score);
 
 /* ---- Stage 1 from file to file -------------------------------------------------------------
  * The read loop of find_ccs_reads (CIRI_long/find_ccs.py:29-96) in native code: FASTA/FASTQ, plain or gzip, one header and

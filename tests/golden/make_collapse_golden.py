@@ -8,7 +8,7 @@ dependencies cannot run here and are supplied for the duration of this script --
   * `distance` (utils.py:153-159) needs python-Levenshtein/edlib: the name `distance` in the reference's collapse module
     is bound to the exact dynamic programme of oracle/edit_oracle.c (the integer is uniquely defined);
   * `spoa.poa` (imported inside cluster_sequence): a module object named `spoa` whose poa() is this project's own
-    consensus specification (oracle/ccs_oracle.c).  Consensus strings in the fixture are therefore NOT reference
+    restatement of the published spoa algorithm (oracle/poa_oracle.c), called with the arguments the reference passes.  Consensus strings in the fixture are therefore NOT reference
     outputs (parity with spoa is unpinned); what the fixture pins around them is the reference's control flow
     (distance matrix, linkage order, 0.3 threshold, cluster membership, rounds of 50).
 
@@ -51,7 +51,7 @@ def noisy_rotations(rng, circ_seq, n, sub=0.03, ins=0.03, dele=0.03):
 def main():
     align, env, find_bsj = mb.load_reference()
     spoa_mod = types.ModuleType('spoa')
-    spoa_mod.poa = lambda seqs, *a: (oracle_lib.oracle_poa(list(seqs)), [])
+    spoa_mod.poa = lambda seqs, algorithm, genmsa, m, n, g, e, q, c: (oracle_lib.oracle_poa(list(seqs), algorithm, False, m, n, g, e, q, c), [])
     sys.modules['spoa'] = spoa_mod
     from CIRI_long import collapse, utils
     collapse.distance = lambda x, y: oracle_lib.oracle_edit_distance(x, y)

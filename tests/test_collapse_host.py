@@ -55,7 +55,7 @@ def cpu_kernels(monkeypatch):
     monkeypatch.setattr(ssw_wrap.Aligner, 'align_batch', align_batch)
     monkeypatch.setattr(collapse, 'distance_batch', distance_batch)
     monkeypatch.setattr(utils, 'distance_batch', distance_batch)
-    monkeypatch.setattr(spoa, 'poa', lambda seqs, *a: (oracle_lib.oracle_poa(list(seqs)), []))
+    monkeypatch.setattr(spoa, 'poa', lambda seqs, algorithm, genmsa, m, n, g, e, q, c: (oracle_lib.oracle_poa(list(seqs), algorithm, False, m, n, g, e, q, c), []))
 
 
 def _check_all(golden):

@@ -1,5 +1,6 @@
-"""K2/K3 (repeat scan + partial-order consensus) through the C ABI against the CPU statement of the same specification
-(oracle/ccs_oracle.c).  PARITY UNPINNED with respect to pyccs/spoa (absent); bit-exact with respect to the oracle."""
+"""K2/K3 (repeat scan + partial-order consensus) through the C ABI against the CPU statements (oracle/ccs_oracle.c for
+the copy boundaries, oracle/poa_oracle.c for the spoa algorithm).  PARITY UNPINNED with respect to pyccs/spoa (absent);
+bit-exact with respect to the oracle."""
 import numpy as np
 import pytest
 
@@ -121,14 +122,94 @@ def test_reads_longer_than_the_lds_scan_limit():
 
 
 def test_spoa_call_shape():
-    from ciri_long_amd import spoa
+    from ciri_long_amd import hip, spoa
     cons, msa = spoa.poa(SEGMENTS, 0, True, 10, -4, -8, -2, -24, -1)     # tests/test_poa.py:30
-    assert cons == oracle_lib.oracle_poa(SEGMENTS) and msa == []
-    cons2, _ = spoa.poa(SEGMENTS, 2, False, 10, -4, -8, -2, -24, -1)     # collapse.py:267,504
-    assert cons2 == cons
-    assert spoa.poa(['ACGTACGTAA'], 0, True, 10, -4, -8, -2, -24, -1)[0] == 'ACGTACGTAA'
-    with pytest.raises(NotImplementedError):
-        spoa.poa(SEGMENTS, 1, True, -1, -1, -1, -1, -1)                   # find_bsj.py:496 (dead code in the reference)
+    want = oracle_lib.oracle_poa(SEGMENTS, 0, True, 10, -4, -8, -2, -24, -1)
+    assert (cons, msa) == tuple(want) and len(cons) == 144
+    assert len(msa) == len(SEGMENTS) and [r.replace('-', '') for r in msa] == SEGMENTS
+    cons2, msa2 = spoa.poa(SEGMENTS, 2, False, 10, -4, -8, -2, -24, -1)  # collapse.py:267,504
+    assert msa2 == [] and cons2 == oracle_lib.oracle_poa(SEGMENTS, 2, False, 10, -4, -8, -2, -24, -1)
+    # the three modes are three code paths: same input, different alignments
+    rows = [oracle_lib.oracle_poa(SEGMENTS, a, True, 10, -4, -8, -2, -24, -1)[1][5] for a in (0, 1, 2)]
+    got = [spoa.poa(SEGMENTS, a, True, 10, -4, -8, -2, -24, -1)[1][5] for a in (0, 1, 2)]
+    assert got == rows and rows[0] != rows[1]
+    assert spoa.poa(['ACGTACGTAA'], 0, True, 10, -4, -8, -2, -24, -1) == ('ACGTACGTAA', ['ACGTACGTAA'])
+    # nothing is accepted and ignored: the linear model, scores outside the 16-bit cells, invalid modes raise
+    for bad in ((1, True, -1, -1, -1, -1, -1, -1),                       # find_bsj.py:496 (dead code in the reference): m < 1
+                (0, True, 5, -4, -8, -8, -8, -8),                         # linear
+                (3, True, 10, -4, -8, -2, -24, -1), (0, True, 10, -4, 8, -2, -24, -1), (0, True, 12, -4, -8, -2, -24, -1),
+                (0, True, 10, -4, -8, -1, -40, -1)):
+        with pytest.raises(hip.ClhError):
+            spoa.poa(SEGMENTS, *bad)
+
+
+def _family(rng, t_len, n, rate, alphabet='ACGT'):
+    import random
+    t = ''.join(rng.choice(alphabet) for _ in range(t_len))
+    seqs = []
+    for _ in range(n):
+        out = []
+        for ch in t:
+            x = rng.random()
+            if x < rate * 0.35:
+                out.append(rng.choice('ACGT'))
+            elif x < rate * 0.65:
+                out.append(ch); out.append(rng.choice('ACGT'))
+            elif x >= rate:
+                out.append(ch)
+        s = ''.join(out) or 'A'
+        if rng.random() < 0.3:
+            s = s[rng.randrange(0, max(1, len(s) // 2)):] or 'C'
+        if rng.random() < 0.2:
+            s = s[len(s) // 3:] + s[:len(s) // 3]
+        seqs.append(s)
+    return seqs
+
+
+PARS = [(10, -4, -8, -2, -24, -1), (5, -4, -8, -6, -10, -4), (5, -4, -8, -6, -8, -6), (3, -5, -4, -3, -9, -1), (2, -1, -2, -1, -3, -1)]
+
+
+@pytest.mark.parametrize('algorithm', [0, 1, 2])
+def test_poa_modes_scores_msa_equal_the_oracle(algorithm):
+    """Random families through clh_poa_batch: consensus, every MSA row and every end-cell score equal the five-matrix
+    statement, for the reference's scores, pyspoa's defaults (convex), an affine set and two more; sequences of 10..1400
+    bases (2..8 columns per lane, several column passes), 2..40 sequences, with and without min_coverage."""
+    import random
+    from ciri_long_amd import hip
+    rng = random.Random(500 + algorithm)
+    ctx = hip.default_context()
+    shapes = [(12, 5), (40, 9), (90, 6), (150, 12), (300, 7), (520, 5), (700, 4), (1400, 3), (60, 40)]
+    for it in range(45):
+        t_len, n = shapes[it % len(shapes)]
+        seqs = _family(rng, t_len, n, rng.choice([0, 0.05, 0.15, 0.3]), rng.choice(['ACGT', 'ACGT', 'AC', 'ACGTN']))
+        par = PARS[it % len(PARS)] if it >= 5 else PARS[0]
+        mc = rng.choice([0, 0, (len(seqs) + 1) // 2])
+        want = oracle_lib.oracle_poa(seqs, algorithm, True, *par, with_scores=True, min_coverage=mc)
+        data, off = hip.pack(seqs)
+        got = ctx.poa_batch(data, off, np.array([0, len(seqs)], dtype=np.int64), algorithm=algorithm, scores=par, min_coverage=mc,
+                            genmsa=True, with_scores=True)[0]
+        assert got[2] == want[2][:65], (it, 'scores')
+        assert got[0] == want[0], (it, 'consensus')
+        assert got[1] == want[1], (it, 'msa')
+
+
+def test_poa_batch_of_groups_large_clusters_and_limits():
+    """Several groups in one call (the batch form of collapse.py:504), a cluster of 150 sequences (the reference's
+    correct_cluster takes up to 200 reads), and the stated limits: a sequence above 2800 bases raises."""
+    import random
+    from ciri_long_amd import hip, spoa
+    rng = random.Random(9)
+    ctx = hip.default_context()
+    groups = [_family(rng, rng.choice([30, 80, 200]), rng.randint(1, 12), 0.15) for _ in range(40)]
+    groups.append(_family(rng, 120, 150, 0.12))
+    flat = [s for g in groups for s in g]
+    data, off = hip.pack(flat)
+    goff = np.cumsum([0] + [len(g) for g in groups]).astype(np.int64)
+    got = ctx.poa_batch(data, off, goff, algorithm=2, scores=PARS[0])
+    for k, g in enumerate(groups):
+        assert got[k] == oracle_lib.oracle_poa(g, 2, False, *PARS[0]), k
+    with pytest.raises(hip.ClhError):
+        spoa.poa(['ACGT' * 701, 'ACGT' * 700], 2, False, 10, -4, -8, -2, -24, -1)
 
 
 def test_find_ccs_reads_files_and_resume(tmp_path):

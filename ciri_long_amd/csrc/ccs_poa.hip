@@ -308,7 +308,13 @@ static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whos
 #endif
 
 // columns per lane, LDS row pitch and ring depth for a sequence of m bases
-__device__ __forceinline__ int poa_cols(int m) { const int c = (m + 63) >> 6; return c < 2 ? 2 : (c > 8 ? 8 : c); }
+#ifndef POA_MAXC
+#define POA_MAXC 4          // columns per lane: more of them spill registers (measured: 8 -> 50.8 ms, 4 -> 31.3 ms per 100 k reads)
+#endif
+#ifndef POA_WAVES
+#define POA_WAVES 4
+#endif
+__device__ __forceinline__ int poa_cols(int m) { const int c = (m + 63) >> 6; return c < 2 ? 2 : (c > POA_MAXC ? POA_MAXC : c); }
 __device__ __forceinline__ int poa_ring(int m) {
     const int W = 64 * poa_cols(m);
     const int lp = poa_pitch(m < W ? m : W);
@@ -774,11 +780,15 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
         switch (poa_cols(m)) {            // columns per lane: the smallest that covers the sequence in one pass (8 beyond 512)
             case 2: dp_rows<2>(w, S, N, m, seq, lane, bs, br, bc); break;
             case 3: dp_rows<3>(w, S, N, m, seq, lane, bs, br, bc); break;
+#if POA_MAXC > 4
             case 4: dp_rows<4>(w, S, N, m, seq, lane, bs, br, bc); break;
             case 5: dp_rows<5>(w, S, N, m, seq, lane, bs, br, bc); break;
             case 6: dp_rows<6>(w, S, N, m, seq, lane, bs, br, bc); break;
             case 7: dp_rows<7>(w, S, N, m, seq, lane, bs, br, bc); break;
             default: dp_rows<8>(w, S, N, m, seq, lane, bs, br, bc); break;
+#else
+            default: dp_rows<4>(w, S, N, m, seq, lane, bs, br, bc); break;
+#endif
         }
         phase_sync();
     }
@@ -1106,7 +1116,7 @@ __device__ int poa_msa_columns(const PoaWs& w, int N, int lane)
     return nc;
 }
 
-__global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
+__global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsParams p)
 {
     const int lane = threadIdx.x & 63;
     uint8_t* slot = p.poa_ws + (size_t)blockIdx.x * p.slot_bytes;
@@ -1188,7 +1198,13 @@ __global__ void __launch_bounds__(64, 4) poa_consensus_kernel(const CcsParams p)
             if (N == -2 && !use_big && p.tier == 0) { use_big = true; continue; }     // the DP planes outgrew this slot: once more in a large one
             if (N >= 0) {
                 const int mc = S.min_cov >= 0 ? S.min_cov : (nseg + 1) / 2;
+#ifdef CLH_DEBUG_POA
+                const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
                 len = poa_consensus(w, N, mc, p.ccs + off, L, lane);
+#ifdef CLH_DEBUG_POA
+                tacc[4] += __builtin_amdgcn_s_memtime() - tc0;
+#endif
                 if (len >= 0 && p.msa_col) {
                     phase_sync();
                     ncols = poa_msa_columns(w, N, lane);

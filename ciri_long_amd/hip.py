@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'libclh.so')
+SO_PATH = os.environ.get('CLH_LIB') or os.path.join(_HERE, 'libclh.so')     # CLH_LIB: another build of the same ABI (kernel experiments)
 
 
 class HipUnavailable(RuntimeError):

@@ -1,19 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the GPU part of CIRI-long's per-read hot path on MI355X.
 
-Workloads (BASELINE.json `configs`):
-  c3 (default)  "100k NanoSim reads ~1 kb, full CCS+POA+SSW+BSJ pipeline, 1 MI355X": per GPU 100 000 synthetic
-                NanoSim-shaped reads (half rolling-circle, half linear negatives).  A step = cyclic consensus of every read
-                (K2 repeat scan + K3 partial-order consensus) followed by the Smith-Waterman re-alignment of the clipped
-                part of every consensus against the read's 2 kb window (K1, call-path options: no second best, no CIGAR,
-                find_bsj.py:204-224).  The mapper between the two stages (minimap2/bwa) is external CPU code and is not
-                part of the step; the clip batch is built once from a warm-up run and is resident in HBM like the reads.
-  c2            "10k reads ~1 kb, SSW-only kernel vs 2 kb window": the complete s_align of the reference (second best,
-                begin/end, CIGAR) for 10 000 read-vs-window pairs per GPU.
+Headline workload (BASELINE.json `configs[2]`, the configuration the metric is quoted on and which fits one GPU):
+  c3 (default)  "100k NanoSim reads ~1 kb, full CCS+POA+SSW+BSJ pipeline, 1 MI355X".  Per GPU 100 000 synthetic
+                NanoSim-shaped reads (half rolling-circle, half linear negatives); the 2 kb windows of all reads form a
+                genome that is resident in HBM (the product's device route, align.DeviceGenome).  A timed step is the
+                device part of `call` for the batch, start to finish:
+                  1. cyclic consensus of every read: K2 repeat scan + K3 partial-order consensus (find_ccs.py:14);
+                  2. the clipped part of every consensus (its last 30 %, >= 20 bases) is gathered ON THE DEVICE from the K3
+                     output of this very step (the external mapper that picks the clip in CIRI-long is CPU code and not
+                     part of the step);
+                  3. K5 `count_n` of the candidate windows (find_bsj.py:199-201);
+                  4. K1 Smith-Waterman of each clip against its window, read in place from the resident genome, call-path
+                     options (find_bsj.py:204-224: no second best, no CIGAR);
+                  5. the result rows come back to the host (D2H inside the timed region) and become candidate junctions;
+                  6. K6 splice-signal search around every candidate junction (find_bsj.py:286-301), rows back on the host.
+                `value` = reads / wall time of that step over all ranks.
+  c2            configs[1]: the complete s_align of the reference (second best, begin/end, CIGAR) for 10 000 ~1 kb reads vs
+                their 2 kb windows.
+  c4            the per-GPU share of configs[3]: 125 000 reads of 500-4000 bases through the c3 step.
 
-One process per GPU, reads sharded by rank, no data-path collective (weak scaling).  Inputs are packed int8 codes in
-HBM before the timed region.  Prints ONE JSON line on rank 0 with `roofline` (dominant launch vs the HBM roofline, plus
-the integer-VALU view that actually bounds these DP kernels) and `cpu_baseline` (host cores of this box).
+At N = 1 the default run also reports, under `extra`, one line each for c2, c4, the production shape of the clip
+re-alignment (20-300 nt clips vs +-200 kb windows of a resident genome), the C5-shaped collapse kernels (K4 edit
+distances, K1+K1b junction alignments) and the file-to-file stage 1 (`clh_ccs_file`), each with its own roofline object.
+
+One process per GPU, reads sharded by rank, no data-path collective (weak scaling); with N > 1 the seven counters of
+`call` (main.py:81-100) are all-reduced on RCCL after the timed loop, as the reference merges them.  Inputs are packed
+int8 codes in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -30,6 +43,12 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 NCHECK = 24                                 # reads of the batch spot-checked against the oracle (by the CPU leg)
 PK_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0       # SIMDs x Hz / 4 cycles: packed-16 ops are half rate (tools/ubench/valu_rate.hip)
+WINDOW = 2000
+B_ASCII = np.frombuffer(b'ACGTN', dtype=np.uint8)
+
+
+def clip_len(n):
+    return max(20, int(0.3 * n))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -61,7 +80,7 @@ def _cpu_worker(arg):
                 row = None
                 if seg is not None:
                     c = oracle_lib.encode(ccs)
-                    w = oracle_lib.oracle_align(wins[i], np.ascontiguousarray(c[-max(20, int(0.3 * len(c))):]), 1, 1, 1, 1)
+                    w = oracle_lib.oracle_align(wins[i], np.ascontiguousarray(c[-clip_len(len(c)):]), 1, 1, 1, 1)
                     row = [w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']]
                 expect.append((seg, row))
             else:
@@ -74,10 +93,13 @@ def _cpu_worker(arg):
         if have_ref:
             prof = ref.ssw_init(q.ctypes.data, len(q), mat.ctypes.data, 5, 2)
             p = ref.ssw_align(prof, r.ctypes.data, len(r), 1, 1, 1, 0, 0, oracle_lib.mask_len(len(q)))
-            ref.align_destroy(p)
+            out = (p.contents.ref_begin1, p.contents.ref_end1, p.contents.read_begin1, p.contents.read_end1) if p else None
+            if p:
+                ref.align_destroy(p)
             ref.init_destroy(prof)
-        else:
-            oracle_lib.oracle_align(r, q, 1, 1, 1, 1)
+            return out
+        w = oracle_lib.oracle_align(r, q, 1, 1, 1, 1)
+        return (w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end'])
 
     while time.time() < deadline:
         q, r = reads[k % nsample], wins[k % nsample]
@@ -85,7 +107,12 @@ def _cpu_worker(arg):
             seg, ccs, _ = oracle_lib.oracle_find_consensus(q)
             if seg is not None:
                 c = oracle_lib.encode(ccs)
-                ssw(np.ascontiguousarray(c[-max(20, int(0.3 * len(c))):]), r)
+                cl = np.ascontiguousarray(c[-clip_len(len(c)):])
+                if int((r == 4).sum()) < 0.3 * len(r):                 # find_bsj.py:199-201
+                    a = ssw(cl, r)
+                    if a is not None:                                   # find_bsj.py:286-301 on the window as the contig
+                        cb = min(20, max(0, len(cl) - (a[3] - a[2] + 1)))
+                        oracle_lib.oracle_splice_signal(B_ASCII[np.minimum(r, 4)].tobytes(), a[0], a[1] + 1, cb, None, True)
         else:
             ssw(q, r)
         done += 1
@@ -105,13 +132,367 @@ def cpu_baseline(seconds, workload, nsample=2048):
     el = max(r[1] for r in res)
     if workload != 'c2':
         kind = 'port'
-        what = ('consensus by the CPU statement of this project\'s own specification (oracle/ccs_oracle.c; pyccs/spoa are '
-                'not available) + clip re-alignment by ' + ('the reference\'s libssw.so' if res[0][2] == 'reference' else 'the scalar port'))
+        what = ('consensus by the CPU statement (oracle/ccs_oracle.c + oracle/poa_oracle.c; pyccs/spoa are not available), N count, '
+                'clip re-alignment by ' + ('the reference\'s libssw.so' if res[0][2] == 'reference' else 'the scalar port') +
+                ', splice-signal search by oracle/splice_oracle.c')
     else:
         kind = res[0][2]
         what = 'ssw_init+ssw_align flag=1 per alignment, inputs pre-encoded'
     return {'value': total / el, 'unit': 'reads/s', 'cores': ncores, 'kind': kind, '_expect': res[0][3],
             'sample': '%d reads (first %d of the batch, repeated; %s) in %.1f s on %d processes' % (total, nsample, what, el, ncores)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class _DevArray(object):
+    """a raw device pointer as a torch tensor (torch is plumbing here: streams, device buffers)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
+
+
+def roofline_of(launches, traffic_file=True):
+    dom = max(launches, key=lambda x: x['ms'])
+    ach = dom['alg_bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    if traffic_file and os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(dom['kernel'])
+        except Exception:
+            traffic = None
+    return {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+            'traffic': traffic, 'launch_ms': dom['ms'], 'alg_bytes_per_launch': dom['alg_bytes'],
+            'note': 'integer DP kernels: hundreds of cell updates per compulsory byte; the VALU issue rate binds, not HBM (DESIGN.md section 3)'}
+
+
+def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False):
+    """per read-length class HIP-event durations of K1 (and K1b), with their algorithmic bytes and cell counts"""
+    ssw_plan.set_profiling(True)
+    acc, accb = None, [0.0, 0.0]
+    for _ in range(PROF):
+        run()
+        tm, tb = ssw_plan.timing()
+        acc = tm if acc is None else [x + y for x, y in zip(acc, tm)]
+        accb = [accb[0] + tb[0], accb[1] + tb[1]]
+    srow, _c = ssw_plan.fetch()
+    ssw_plan.set_profiling(False)
+    qlen = np.diff(qoff)
+    b_alg = qlen + wlen + 40 + 4 * srow['cigar_len'].astype(np.int64)
+    classes = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32]
+    rows16 = ((qlen + 15) // 16) * 16
+    cls = np.array([next((c for c in classes if 128 * c >= r), 32) for r in rows16]) if len(qlen) else np.zeros(0, dtype=int)
+    out, cells_total, k1ms = [], 0, 0.0
+    for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
+        sel = cls == rv
+        span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
+        cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
+        cells_total += cells; k1ms += k1 / PROF
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv, 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+    if c2:
+        out.append({'kernel': 'ssw_traceback_kernel[small window]', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
+        out.append({'kernel': 'ssw_traceback_kernel[large window, outliers]', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0})
+    valu = {'bound': 'valu', 'kernel': 'ssw_align_kernel (all classes)', 'unit': 'GCUPS',
+            'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
+            'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,
+            'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / 6 packed ops per cell pair (gapO == gapE path)'}
+    valu['frac'] = valu['achieved'] / valu['peak'] if valu['achieved'] else None
+    return out, valu
+
+
+class FullStep(object):
+    """the c3 / c4 step (module docstring): everything the timed region needs, built once"""
+
+    def __init__(self, torch, hip, synth, ctx, wl, nreads, rank, expect):
+        self.torch, self.nreads = torch, nreads
+        reads, wins = make_batch(synth, wl, nreads, rank)
+        rd, self.ro = hip.pack(reads)
+        self.d_reads = torch.from_numpy(rd.view(np.uint8)).cuda()
+        # every kernel of the step is ordered on ONE explicit stream (a NULL handle would select libclh's private stream,
+        # unordered with torch's)
+        self.tstream = torch.cuda.Stream()
+        self.stream = self.tstream.cuda_stream
+        # the windows of all reads as one resident genome (K5): window k = [k * WINDOW, (k + 1) * WINDOW)
+        assert all(len(w) == WINDOW for w in wins)
+        text = B_ASCII[np.minimum(np.concatenate(wins), 4)].tobytes().decode()
+        self.genome = hip.Genome(ctx, [('windows', text)])
+        self.glen = len(text)
+        del text
+        self.ccs_plan = ctx.ccs_plan(self.ro)
+        self.ccs_plan.run(self.d_reads.data_ptr(), self.stream)
+        crow, csegs, ccs = self.ccs_plan.fetch()
+        assert int((crow['status'] != 0).sum()) == 0, 'consensus kernel reported capacity errors'
+        self.crow = crow
+        self.has = has = np.nonzero(crow['nseg'] > 0)[0]
+        # clip k = the last 30 % (>= 20 bases) of consensus k; K3 is deterministic, so the lengths found now hold for every
+        # step and the gather below reads the bytes K3 has written in THAT step
+        clen = np.array([clip_len(int(x)) for x in crow['ccs_len'][has]], dtype=np.int64)
+        src0 = self.ro[has] + crow['ccs_len'][has].astype(np.int64) - clen
+        self.co = np.zeros(len(has) + 1, dtype=np.int64)
+        np.cumsum(clen, out=self.co[1:])
+        idx = np.repeat(src0 - self.co[:-1], clen) + np.arange(int(self.co[-1]), dtype=np.int64)
+        self.d_idx = torch.from_numpy(idx).cuda()
+        torch.cuda.synchronize()
+        _rows, _segs, p_ccs = self.ccs_plan.results_dev()
+        self.d_ccs = torch.as_tensor(_DevArray(p_ccs, int(self.ro[-1])), device='cuda')
+        self.win_off = has.astype(np.int64) * WINDOW
+        self.win_len = np.full(len(has), WINDOW, dtype=np.int64)
+        self.ssw_plan = self.genome.plan_windows(self.co, self.win_off, self.win_len.astype(np.int32), np.zeros(len(has), dtype=np.uint8),
+                                                 hip.score_matrix(1, 1), 1, 1, flag=1, score_size=2, want_score2=False, want_cigar=False)
+        self.clen = clen
+        self.zeros32 = np.zeros(len(has), dtype=np.int32)
+        self.ctg_off = np.zeros(len(has), dtype=np.int64)
+        self.ctg_len = np.full(len(has), self.glen, dtype=np.int64)
+        self.t_k5 = self.t_k6 = self.t_fetch = 0.0
+        self.last = None
+        if expect is not None:   # parity spot check outside the timed region, against the answers the CPU leg left
+            self.step()
+            srow = self.last['rows']
+            pos = {int(k): j for j, k in enumerate(has)}
+            for k in range(min(len(expect), nreads)):
+                want_seg, want_row = expect[k]
+                n = int(crow['nseg'][k])
+                got_seg = ';'.join('%d-%d' % (csegs[k, i, 0], csegs[k, i, 1]) for i in range(n)) if n > 0 else None
+                assert got_seg == want_seg, (k, got_seg, want_seg)
+                if want_row is not None:
+                    r = srow[pos[k]]
+                    assert [int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])] == want_row, k
+
+    def step(self):
+        torch = self.torch
+        self.ccs_plan.run(self.d_reads.data_ptr(), self.stream)                       # 1. K2 + K3
+        with torch.cuda.stream(self.tstream):
+            d_clips = self.d_ccs[self.d_idx]                                          # 2. clips out of this step's K3 output
+        t0 = time.perf_counter()
+        ncount = self.genome.count_n_spans(self.win_off, self.win_len)                # 3. K5
+        keep = ncount < 0.3 * self.win_len
+        t1 = time.perf_counter()
+        self.ssw_plan.run(d_clips.data_ptr(), self.genome.codes_ptr, self.stream)     # 4. K1, windows read in place
+        rows, _ = self.ssw_plan.fetch()                                               # 5. rows to the host
+        t2 = time.perf_counter()
+        start = self.win_off + rows['ref_begin1'].astype(np.int64)
+        end = self.win_off + rows['ref_end1'].astype(np.int64) + 1
+        cb = np.clip(self.clen - (rows['read_end1'].astype(np.int64) - rows['read_begin1'] + 1), 0, 20).astype(np.int32)
+        sig = self.genome.splice_signals({'ctg_off': self.ctg_off, 'ctg_len': self.ctg_len, 'start': start, 'end': end,
+                                          'clip_base': cb, 'host_mask': self.zeros32}, 10, 3, True)     # 6. K6
+        t3 = time.perf_counter()
+        self.t_k5 += t1 - t0; self.t_fetch += t2 - t1; self.t_k6 += t3 - t2
+        self.last = {'rows': rows, 'sig': sig, 'keep': keep, 'clips': d_clips}
+
+    def counters(self):
+        """the seven counters of `call` (main.py:50-51, 96-100) as this step fills them"""
+        sig = self.last['sig']
+        return np.array([self.nreads, len(self.has), 0, len(self.has), int((self.last['rows']['score1'] > 0).sum()),
+                         int((sig[:, 3] > 0).sum()), 0], dtype=np.int64)
+
+    def launches(self, nsteps, PROF=3):
+        k2 = k3 = 0.0
+        for _ in range(PROF):
+            self.ccs_plan.run(self.d_reads.data_ptr(), self.stream)
+            a, b = self.ccs_plan.timing()
+            k2 += a / PROF; k3 += b / PROF
+        L = np.diff(self.ro)
+        has, crow = self.has, self.crow
+        b_k3 = int(L[has].sum() + crow['ccs_len'][has].sum() + 16 * crow['nseg'][has].sum() + 16 * self.nreads)
+        out = [{'kernel': 'ccs_scan_kernel', 'reads': self.nreads, 'ms': k2, 'alg_bytes': int(L.sum() + 272 * self.nreads)},
+               {'kernel': 'poa_consensus_kernel', 'reads': int(len(has)), 'ms': k3, 'alg_bytes': b_k3}]
+        d_clips = self.last['clips']
+        k1, valu = k1_launches(self.ssw_plan, lambda: self.ssw_plan.run(d_clips.data_ptr(), self.genome.codes_ptr, self.stream),
+                               self.co, self.win_len)
+        out += k1
+        n = max(nsteps, 1)
+        out.append({'kernel': 'genome_count_n_kernel', 'windows': int(len(has)), 'ms': self.t_k5 / n * 1e3, 'alg_bytes': int(24 * len(has)),
+                    'note': 'wall time of the C-ABI call: upload of the spans, kernel, download of the counts'})
+        out.append({'kernel': 'splice_scan_kernel', 'candidates': int(len(has)), 'ms': self.t_k6 / n * 1e3, 'alg_bytes': int(72 * len(has)),
+                    'note': 'wall time of the C-ABI call: upload of the candidates, kernel, download of the rows'})
+        out.append({'kernel': '(K1 wait + D2H of the result rows)', 'rows': int(len(has)), 'ms': self.t_fetch / n * 1e3, 'alg_bytes': int(40 * len(has)),
+                    'note': 'host wall time from the K1 launch to the rows on the host; overlaps the K1 kernels listed above'})
+        return out, valu
+
+
+def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmup, expect):
+    fs = FullStep(torch, hip, synth, ctx, wl, nreads, rank, expect)
+    for _ in range(warmup):
+        fs.step()
+    fs.t_k5 = fs.t_k6 = fs.t_fetch = 0.0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fs.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    counters = fs.counters()
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        # the one exchange of `call`: the seven counters, summed over the ranks (main.py:81-100) -- on RCCL
+        c = torch.from_numpy(counters).cuda()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        counters = c.cpu().numpy()
+        assert int(counters[0]) == world * nreads, 'junction-count all-reduce: total does not add up'
+    launches, valu = fs.launches(steps)
+    sig = fs.last['sig']
+    res = {'value': world * nreads * steps / el, 'ms_per_step': el / steps * 1e3, 'launches': launches, 'valu_roofline': valu,
+           'roofline': roofline_of(launches), 'reads_with_consensus': int(len(fs.has)),
+           'counters': dict(zip(['total', 'consensus', 'raw_unmapped', 'ccs_mapped', 'bsj', 'signal', 'partial'], [int(x) for x in counters])),
+           'splice_handed_back': int((sig[:, 0] != 0).sum())}
+    fs.genome.close()
+    return res
+
+
+def run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, steps, warmup, expect):
+    reads, wins = make_batch(synth, 'c2', nreads, rank)
+    rd, ro = hip.pack(reads)
+    fd, fo = hip.pack(wins)
+    d_reads = torch.from_numpy(rd.view(np.uint8)).cuda()
+    d_wins = torch.from_numpy(fd.view(np.uint8)).cuda()
+    tstream = torch.cuda.Stream()
+    stream = tstream.cuda_stream
+    torch.cuda.synchronize()
+    ssw_plan = ctx.plan(ro, fo, hip.score_matrix(1, 1), 1, 1, flag=1, score_size=2, want_score2=True, want_cigar=True)
+    ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
+    srow, scig = ssw_plan.fetch()
+    assert int((srow['status'] & ~9).sum()) == 0, 'alignments with error status'
+    if expect is not None:
+        for k in range(min(len(expect), nreads)):
+            want_row, want_cigar = expect[k]
+            r = srow[k]
+            assert [int(r['score1']), int(r['score2']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']),
+                    int(r['read_end1']), int(r['ref_end2'])] == want_row, k
+            assert [int(x) for x in scig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want_cigar, k
+
+    def step():
+        ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
+        return ssw_plan.fetch()                     # rows and CIGARs on the host inside the timed region
+
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    launches, valu = k1_launches(ssw_plan, lambda: ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream), ro, np.diff(fo), c2=True)
+    return {'value': world * nreads * steps / el, 'ms_per_step': el / steps * 1e3, 'launches': launches, 'valu_roofline': valu,
+            'roofline': roofline_of(launches)}
+
+
+# ---- the further lines of `extra` (N = 1 only) -------------------------------------------------------------------------
+def extra_production_shape(torch, hip, synth, ctx, n=4000):
+    """20-300 nt clips against hit +- 200 kb windows of a resident 20 Mb genome (find_bsj.py:191-216), K5 + K1"""
+    rng = np.random.Generator(np.random.PCG64(synth.SEEDS['C3'] + 1))
+    G = 20_000_000
+    codes = rng.integers(0, 4, G).astype(np.int8)
+    genome = hip.Genome(ctx, [('chr1', B_ASCII[codes].tobytes().decode())])
+    woff = np.zeros(n, dtype=np.int64); wlen = np.zeros(n, dtype=np.int64); clips = []
+    for k in range(n):
+        c = int(rng.integers(300000, G - 300000))
+        s, e = c - 200000, c + 200000 + int(rng.integers(100, 1500))
+        L = int(rng.integers(20, 301))
+        p = int(rng.integers(s, e - L))
+        clips.append(synth.mutate(codes[p:p + L], rng))
+        woff[k], wlen[k] = s, e - s
+    minus = rng.integers(0, 2, n).astype(np.uint8)
+    cd, co = hip.pack(clips)
+    d_clips = torch.from_numpy(cd.view(np.uint8)).cuda()
+    tstream = torch.cuda.Stream()
+    stream = tstream.cuda_stream
+    torch.cuda.synchronize()
+    plan = genome.plan_windows(co, woff, wlen.astype(np.int32), minus, hip.score_matrix(1, 1), 1, 1, flag=1, score_size=2, want_score2=False, want_cigar=False)
+
+    def step():
+        genome.count_n_spans(woff, wlen)
+        plan.run(d_clips.data_ptr(), genome.codes_ptr, stream)
+        return plan.fetch()
+    step()
+    K = 3
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    el = (time.perf_counter() - t0) / K
+    launches, valu = k1_launches(plan, lambda: plan.run(d_clips.data_ptr(), genome.codes_ptr, stream), co, wlen)
+    genome.close()
+    return {'workload': 'production shape: %d clips of 20-300 nt vs hit +- 200 kb windows of a resident 20 Mb genome, both strands (K5 count_n + K1, rows to the host)' % n,
+            'value': n / el, 'unit': 'clips/s', 'ms_per_step': el * 1e3, 'launches': launches, 'valu_roofline': valu, 'roofline': roofline_of(launches, False)}
+
+
+def extra_collapse(torch, hip, synth, ctx, ncl=200):
+    """C5-shaped collapse kernels (collapse.py:373-387, 466-473): pairwise edit distances of 50 homopolymer-compressed reads
+    per cluster (K4) and the per-read alignment of the doubled read against the cluster's 50-nt junction, 10/4/8/2, CIGAR"""
+    from ciri_long_amd import utils
+    rng = np.random.Generator(np.random.PCG64(synth.SEEDS['C5']))
+    B = 'ACGT'
+    xs, ys, reads, juncs = [], [], [], []
+    for _c in range(ncl):
+        tm = synth.template(rng)
+        circ = ''.join(B[b] for b in tm)
+        cl = [''.join(B[b] for b in synth.mutate(np.roll(tm, int(rng.integers(0, len(tm)))), rng)) for _ in range(50)]
+        hpc = [utils.compress_seq(r) for r in cl]
+        for i in range(50):
+            reads.append(cl[i]); juncs.append(circ[-25:] + circ[:25])
+            for j in range(i + 1, 50):
+                xs.append(hpc[i]); ys.append(hpc[j])
+    tstream = torch.cuda.Stream()
+    st = tstream.cuda_stream
+    ep = ctx.edit_plan(xs, ys)
+    qd, qo = hip.pack([r + r for r in reads]); fd, fo = hip.pack(juncs)
+    d_q = torch.from_numpy(qd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
+    sp = ctx.plan(qo, fo, hip.score_matrix(10, 4), 8, 2, flag=1, score_size=2, want_score2=False, want_cigar=True)
+    torch.cuda.synchronize()
+
+    def step():
+        ep.run(st)
+        sp.run(d_q.data_ptr(), d_f.data_ptr(), st)
+        return ep.fetch(), sp.fetch()
+    step()
+    K = 3
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    el = (time.perf_counter() - t0) / K
+    ep.run(st); torch.cuda.synchronize()
+    k4ms = ep.timing()
+    launches, valu = k1_launches(sp, lambda: sp.run(d_q.data_ptr(), d_f.data_ptr(), st), qo, np.diff(fo), c2=True)
+    launches.insert(0, {'kernel': 'edit_distance_kernel', 'pairs': len(xs), 'ms': k4ms, 'alg_bytes': int(sum(len(x) + len(y) + 4 for x, y in zip(xs, ys)))})
+    return {'workload': 'C5-shaped collapse kernels: %d clusters x 50 reads: %d edit distances (K4) + %d junction alignments 10/4/8/2 with CIGAR (K1+K1b), results to the host' % (ncl, len(xs), len(reads)),
+            'value': len(reads) / el, 'unit': 'reads/s', 'ms_per_step': el * 1e3, 'launches': launches, 'valu_roofline': valu, 'roofline': roofline_of(launches, False)}
+
+
+def extra_stage1(hip, synth, ctx, n=100000):
+    """file-to-file stage 1 (find_ccs.find_ccs_reads, find_ccs.py:21-103) by clh_ccs_file on a synthetic FASTQ"""
+    import shutil
+    import tempfile
+    reads, _ = synth.c2_batch(n, seed=synth.SEEDS['C3'])
+    d = tempfile.mkdtemp(dir='/tmp')
+    try:
+        fq = os.path.join(d, 'in.fastq')
+        with open(fq, 'wb') as f:
+            for k, r in enumerate(reads):
+                s = B_ASCII[r].tobytes()
+                f.write(b'@read%07d\n' % k + s + b'\n+\n' + b'I' * len(s) + b'\n')
+        size = os.path.getsize(fq)
+        ctx.ccs_file(fq, 1, os.path.join(d, 'w.ccs.fa'), os.path.join(d, 'w.raw.fa'))
+        t0 = time.perf_counter()
+        tot, ro, _ = ctx.ccs_file(fq, 1, os.path.join(d, 'n.ccs.fa'), os.path.join(d, 'n.raw.fa'))
+        el = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return {'workload': 'stage 1 file to files: %d-read FASTQ (%d MB) -> tmp/*.ccs.fa + *.raw.fa (parse, encode, K2+K3, write)' % (tot, size >> 20),
+            'e2e_stage1_reads_per_s': tot / el, 'value': tot / el, 'unit': 'reads/s', 'fastq_MB_per_s': size / el / 1e6, 'reads_with_consensus': int(ro),
+            'roofline': {'bound': 'host', 'note': 'bound by the FASTQ parser thread, not by a kernel (DESIGN.md section 8)'}}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -121,12 +502,13 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', choices=('c3', 'c2', 'c4'), default='c3')
-    ap.add_argument('--reads', type=int, default=0, help='reads per GPU (default: 100000 for c3, 10000 for c2)')
+    ap.add_argument('--reads', type=int, default=0, help='reads per GPU (default: 100000 for c3, 10000 for c2, 125000 for c4)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the extra lines (c2, c4, production shape, collapse, stage 1)')
     args = ap.parse_args()
     wl = args.workload
-    full = wl != 'c2'            # c3 / c4: consensus + clip re-alignment; c2: Smith-Waterman only
+    full = wl != 'c2'            # c3 / c4: the whole device part of `call`; c2: Smith-Waterman only
     nreads = args.reads or {'c3': 100000, 'c2': 10000, 'c4': 125000}[wl]
 
     rank = int(os.environ.get('RANK', '0'))
@@ -152,157 +534,51 @@ def main():
 
     from ciri_long_amd import hip, synth
     expect = cpu.pop('_expect') if cpu else None     # None: no CPU leg in this run (multi-GPU, --no-cpu, profiler): no spot check
-    reads, wins = make_batch(synth, wl, nreads, rank)
-    rd, ro = hip.pack(reads)
-    d_reads = torch.from_numpy(rd.view(np.uint8)).cuda()
     ctx = hip.Context(local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
-    mat = hip.score_matrix(1, 1)
-    launches = []
-
     if full:
-        ccs_plan = ctx.ccs_plan(ro)
-        ccs_plan.run(d_reads.data_ptr(), stream)
-        crow, csegs, ccs = ccs_plan.fetch()
-        assert int((crow['status'] != 0).sum()) == 0, 'consensus kernel reported capacity errors'
-        has = np.nonzero(crow['nseg'] > 0)[0]
-        # the clipped part the BSJ step would re-align: here the last 30 % (>= 20 bases) of each consensus
-        clips, cwins = [], []
-        for k in has:
-            c = ccs[ro[k]:ro[k] + int(crow['ccs_len'][k])]
-            clips.append(np.ascontiguousarray(c[-max(20, int(0.3 * len(c))):]))
-            cwins.append(wins[k])
-        cd, co = hip.pack(clips)
-        fd, fo = hip.pack(cwins)
-        d_clips = torch.from_numpy(cd.view(np.uint8)).cuda()
-        d_wins = torch.from_numpy(fd.view(np.uint8)).cuda()
-        ssw_plan = ctx.plan(co, fo, mat, 1, 1, flag=1, score_size=2, want_score2=False, want_cigar=False)
-        if expect is not None:   # parity spot check outside the timed region, against the answers the CPU leg left
-            ssw_plan.run(d_clips.data_ptr(), d_wins.data_ptr(), stream)
-            srow, _ = ssw_plan.fetch()
-            pos = {int(k): j for j, k in enumerate(has)}
-            for k in range(min(len(expect), nreads)):
-                want_seg, want_row = expect[k]
-                n = int(crow['nseg'][k])
-                got_seg = ';'.join('%d-%d' % (csegs[k, i, 0], csegs[k, i, 1]) for i in range(n)) if n > 0 else None
-                assert got_seg == want_seg, (k, got_seg, want_seg)
-                if want_row is not None:
-                    r = srow[pos[k]]
-                    assert [int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])] == want_row, k
-
-        def step():
-            ccs_plan.run(d_reads.data_ptr(), stream)
-            ssw_plan.run(d_clips.data_ptr(), d_wins.data_ptr(), stream)
+        res = run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, args.steps, args.warmup, expect)
     else:
-        fd, fo = hip.pack(wins)
-        d_wins = torch.from_numpy(fd.view(np.uint8)).cuda()
-        ssw_plan = ctx.plan(ro, fo, mat, 1, 1, flag=1, score_size=2, want_score2=True, want_cigar=True)
-        ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
-        srow, scig = ssw_plan.fetch()
-        assert int((srow['status'] & ~9).sum()) == 0, 'alignments with error status'
-        if expect is not None:
-            for k in range(min(len(expect), nreads)):
-                want_row, want_cigar = expect[k]
-                r = srow[k]
-                assert [int(r['score1']), int(r['score2']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']),
-                        int(r['read_end1']), int(r['ref_end2'])] == want_row, k
-                assert [int(x) for x in scig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want_cigar, k
+        res = run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, args.steps, args.warmup, expect)
 
-        def step():
-            ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
-    # ---- per-launch durations (HIP events on the stream the kernels run on), outside the timed region ----
-    PROF = 3
-    if full:
-        k2 = k3 = 0.0
-        for _ in range(PROF):
-            ccs_plan.run(d_reads.data_ptr(), stream)
-            a, b = ccs_plan.timing()
-            k2 += a / PROF; k3 += b / PROF
-        L = np.diff(ro)
-        b_k3 = int(L[has].sum() + crow['ccs_len'][has].sum() + 16 * crow['nseg'][has].sum() + 16 * nreads)
-        launches.append({'kernel': 'ccs_scan_kernel', 'reads': nreads, 'ms': k2, 'alg_bytes': int(L.sum() + 272 * nreads)})
-        launches.append({'kernel': 'poa_consensus_kernel', 'reads': int(len(has)), 'ms': k3, 'alg_bytes': b_k3})
-    ssw_plan.set_profiling(True)
-    acc, accb = None, [0.0, 0.0]
-    for _ in range(PROF):
-        if full:
-            ssw_plan.run(d_clips.data_ptr(), d_wins.data_ptr(), stream)
-        else:
-            ssw_plan.run(d_reads.data_ptr(), d_wins.data_ptr(), stream)
-        tm, tb = ssw_plan.timing()
-        acc = tm if acc is None else [x + y for x, y in zip(acc, tm)]
-        accb = [accb[0] + tb[0], accb[1] + tb[1]]
-    srow, _c = ssw_plan.fetch()
-    qoff, woff = (co, fo) if full else (ro, fo)
-    qlen, wlen = np.diff(qoff), np.diff(woff)
-    b_alg = qlen + wlen + 40 + 4 * srow['cigar_len'].astype(np.int64)
-    classes = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32]
-    rows16 = ((qlen + 15) // 16) * 16
-    cls = np.array([next(c for c in classes if 128 * c >= r) for r in rows16]) if len(qlen) else np.zeros(0, dtype=int)
-    cells_total, k1ms = 0, 0.0
-    for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
-        sel = cls == rv
-        span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
-        cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
-        cells_total += cells; k1ms += k1 / PROF
-        launches.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv, 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
-    if wl == 'c2':
-        launches.append({'kernel': 'ssw_traceback_kernel[small window]', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
-        launches.append({'kernel': 'ssw_traceback_kernel[large window, outliers]', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0})
-    dom = max(launches, key=lambda x: x['ms'])
-    ach = dom['alg_bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
-    traffic = None
-    tf = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get(dom['kernel'])
-        except Exception:
-            traffic = None
-    roofline = {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': traffic, 'launch_ms': dom['ms'], 'alg_bytes_per_launch': dom['alg_bytes'],
-                'note': 'integer DP kernels: hundreds of cell updates per compulsory byte; the VALU issue rate binds, not HBM (DESIGN.md section 3)'}
-    valu = {'bound': 'valu', 'kernel': 'ssw_align_kernel (all classes)', 'unit': 'GCUPS',
-            'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
-            'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,
-            'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / 6 packed ops per cell pair (gapO == gapE path)'}
-    valu['frac'] = valu['achieved'] / valu['peak'] if valu['achieved'] else None
-
+    step_text = ('through the device part of the call path, start to finish in every timed step: cyclic consensus (K2+K3) of every '
+                 'read; the clipped part of each consensus gathered on the device from that step\'s K3 output; N count of the candidate '
+                 'windows (K5); Smith-Waterman (K1) of each clip against its 2 kb window read in place from the resident genome; result '
+                 'rows to the host; splice-signal search (K6) around every candidate junction, rows to the host.  The external mapper '
+                 'of CIRI-long (minimap2/bwa, CPU) is not part of the step')
     out = {
         'metric': 'reads/s through CCS+SSW+BSJ (1/2/4/8 MI355X); % HBM roofline',
-        'value': world * nreads * args.steps / el, 'unit': 'reads/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
+        'value': res['value'], 'unit': 'reads/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic',
         'config': {
-            'workload': (('C4 (per-GPU share of 1 M reads, lengths 500-4000): ' if wl == 'c4' else 'C3: ') + '%d NanoSim-shaped reads per GPU (~1 kb for C3) through the GPU stages of the call path: cyclic consensus '
-                         '(K2+K3) of every read, then Smith-Waterman re-alignment (K1) of each consensus\' clipped part against '
-                         'its 2 kb window; the external mapper between them is not part of the step' % nreads) if full else
+            'workload': (('C4 (per-GPU share of 1 M reads, lengths 500-4000): ' if wl == 'c4' else 'C3: ') +
+                         '%d NanoSim-shaped reads per GPU (~1 kb for C3) %s' % (nreads, step_text)) if full else
                         ('C2: %d NanoSim-shaped ~1 kb reads per GPU, SSW step only, complete s_align (second best, begin/end, '
-                         'CIGAR) vs own 2 kb window' % nreads),
-            'reads_per_gpu': nreads, 'window': 2000, 'scoring': '1/1/1/1', 'parallelism': 'reads sharded x%d, no data-path collective' % world,
-            'consensus_parity': 'unpinned (pyccs/spoa absent; own specification, oracle/ccs_oracle.c)' if full else None},
-        'roofline': roofline, 'valu_roofline': valu, 'launches': launches,
+                         'CIGAR) vs own 2 kb window, rows and CIGARs to the host in every step' % nreads),
+            'reads_per_gpu': nreads, 'window': WINDOW, 'scoring': '1/1/1/1',
+            'parallelism': 'reads sharded x%d, no data-path collective%s' % (world, '; int64[7] counter all-reduce on RCCL after the timed loop' if world > 1 else ''),
+            'consensus_parity': 'unpinned (pyccs/spoa absent from the reference tree; clh-poa v2 restates the published spoa algorithm, oracle/poa_oracle.c)' if full else None},
+        'roofline': res['roofline'], 'valu_roofline': res['valu_roofline'], 'launches': res['launches'],
     }
-    if full:
-        out['config']['reads_with_consensus'] = int(len(has))
+    if 'reads_with_consensus' in res:
+        out['config']['reads_with_consensus'] = res['reads_with_consensus']
+        out['counters'] = res['counters']
+        out['splice_handed_back'] = res['splice_handed_back']
     out['cpu_baseline'] = cpu      # rank 0 at N=1 only; None under a profiler or with --no-cpu
+    if world == 1 and not args.no_extra and not profiled and wl == 'c3':
+        extra = {}
+        try:
+            s = run_c2(torch, dist, hip, synth, ctx, 10000, 0, 1, 3, 1, None)
+            extra['c2'] = dict(s, unit='reads/s', workload='C2: 10000 ~1 kb reads vs own 2 kb window, complete s_align incl. CIGAR, rows to the host')
+            s = run_full(torch, dist, hip, synth, ctx, 'c4', 125000, 0, 1, 2, 1, None)
+            extra['c4'] = dict(s, unit='reads/s', workload='C4 per-GPU share: 125000 reads of 500-4000 bases through the C3 step')
+            extra['production_shape'] = extra_production_shape(torch, hip, synth, ctx)
+            extra['collapse_c5'] = extra_collapse(torch, hip, synth, ctx)
+            extra['stage1_files'] = extra_stage1(hip, synth, ctx)
+            out['e2e_stage1_reads_per_s'] = extra['stage1_files']['e2e_stage1_reads_per_s']
+        except Exception as ex:                      # an extra line must not cost the headline
+            extra['error'] = repr(ex)
+        out['extra'] = extra
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -1150,6 +1150,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
         }
         res.period = period;
         if (period == 0) { if (lane == 0) p.results[rd] = res; continue; }
+        if (p.tier == 1 && lane == 0 && p.stats) atomicAdd(p.stats + 1, 1);
         int nseg = 0, b = 0, maxlen = 0, total = 0;
         for (int i = 0; i <= ncuts; ++i) {
             if (i == ncuts && !tail) break;
@@ -1181,6 +1182,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
                 }
                 if (big < 0) { N = -2; break; }
                 ws = p.big_ws + (size_t)big * p.big_slot_bytes; ws_bytes = p.big_slot_bytes;
+                if (lane == 0 && p.stats) atomicAdd(p.stats, 1);
             }
             PoaWs w = carve(ws, ws_bytes, ncap, mcap);
             phase_sync();

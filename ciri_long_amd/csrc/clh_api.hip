@@ -364,6 +364,7 @@ extern "C" int clh_genome_count_n(clh_genome* g, int32_t n, const int64_t* off, 
                 hipMemcpyAsync(out, d_out, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess))
         rc = fail(CLH_E_HIP, "N count failed");
+    if (rc) (void)hipStreamSynchronize(ctx->stream);      // nothing queued may still touch the buffers when they go back to the cache
     ctx->release(d_off); ctx->release(d_len); ctx->release(d_out);
     return rc;
 }
@@ -430,6 +431,7 @@ extern "C" int clh_splice_signal_batch(clh_genome* g, int32_t n, const int64_t* 
                 hipMemcpyAsync(out, d_o, ob, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess))
         rc = fail(CLH_E_HIP, "splice-signal scan failed");
+    if (rc) (void)hipStreamSynchronize(ctx->stream);      // see clh_genome_count_n
     ctx->release(d_t); ctx->release(d_o);
     return rc;
 }
@@ -945,6 +947,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
         pl->slot_bytes_big = need_worst;
         pl->nslots_big = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(1024, budget_big / need_worst));
         pl->nslots_big = std::min(pl->nslots_big, std::max(n, 1));
+        if (const char* e = getenv("CLH_POA_BIG_SLOTS")) pl->nslots_big = std::max(1, std::min(pl->nslots_big, atoi(e)));       // tests: make the large slots scarce
     }
     pl->d_off = ctx->alloc(sizeof(int64_t) * (size_t)(n + 1));
     pl->d_scan = ctx->alloc(sizeof(clh::CcsScan) * (size_t)std::max(n, 1));
@@ -983,7 +986,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
 // the K3 launches of a plan: first tier over every read, second tier over what found no slot large enough
 static int launch_poa_tiers(clh_ccs_plan* pl, clh::CcsParams& P, hipStream_t st)
 {
-    P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.work_order = (const int32_t*)pl->d_order;
+    P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.stats = (int*)pl->d_counter + 2; P.work_order = (const int32_t*)pl->d_order;
     P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap; P.tier = 0;
     if (pl->nslots_big) { P.big_ws = (uint8_t*)pl->d_ws_big; P.big_slot_bytes = pl->slot_bytes_big; P.big_busy = (int*)pl->d_busy; P.n_big = pl->nslots_big; }
     HIPCHK(clh::launch_poa(P, pl->nslots, st));
@@ -1046,6 +1049,22 @@ extern "C" int clh_ccs_fetch(clh_ccs_plan* pl, clh_ccs_t* out, int32_t* segs, in
     HIPCHK(hipMemcpy(out, pl->d_res, sizeof(clh::CcsResult) * (size_t)pl->n, hipMemcpyDeviceToHost));
     if (segs) HIPCHK(hipMemcpy(segs, pl->d_segs, sizeof(int32_t) * 2 * clh::CCS_SEG_CAP * (size_t)pl->n, hipMemcpyDeviceToHost));
     if (ccs && pl->total > 0) HIPCHK(hipMemcpy(ccs, pl->d_ccs, (size_t)pl->total, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// how the workspace tiers of the plan were used by the last run: out = {first-tier slots, bytes per slot, large slots,
+// bytes per large slot, reads that ran in a large slot claimed by a first-tier wave, reads run by the second launch}
+extern "C" int clh_ccs_plan_info(clh_ccs_plan* pl, int64_t* out)
+{
+    if (!pl || !out) return fail(CLH_E_ARG, "clh_ccs_plan_info: null argument");
+    out[0] = pl->nslots; out[1] = (int64_t)pl->slot_bytes; out[2] = pl->nslots_big; out[3] = (int64_t)pl->slot_bytes_big; out[4] = out[5] = 0;
+    if (pl->ran && pl->n > 0) {
+        HIPCHK(hipSetDevice(pl->ctx->device));
+        HIPCHK(hipStreamSynchronize(pl->last_stream));
+        int st[2] = {0, 0};
+        HIPCHK(hipMemcpy(st, (int*)pl->d_counter + 2, sizeof(st), hipMemcpyDeviceToHost));
+        out[4] = st[0]; out[5] = st[1];
+    }
     return 0;
 }
 
@@ -1142,7 +1161,7 @@ extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, 
         P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
         P.sc = sc; P.xcuts = (const int32_t*)d_xcuts; P.xcut_off = (const int64_t*)d_xoff;
         P.msa_col = (int32_t*)d_col; P.msa_ncols = (int32_t*)d_ncols; P.aln_score = (int32_t*)pl->d_score;
-        if (hipMemsetAsync(pl->d_counter, 0, 8, st) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
+        if (hipMemsetAsync(pl->d_counter, 0, 16, st) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
         if (!rc) rc = launch_poa_tiers(pl, P, st);
         pl->ran = true; pl->last_stream = st;
     }

@@ -92,6 +92,7 @@ struct CcsParams {
     int8_t* ccs;               // packed like reads (a consensus is never longer than its read)
     uint8_t* poa_ws;           // nslots * slot_bytes
     int* work_counter;
+    int* stats;                // [0] reads that ran in a claimed large slot, [1] reads run by the second launch
     const int32_t* work_order; // reads, longest first (or nullptr)
     unsigned long long slot_bytes;
     int32_t n;

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <zlib.h>
+#include <limits.h>
 
 #include <condition_variable>
 #include <mutex>
@@ -63,10 +64,32 @@ const int kMaxRead = 1 << 24;          // sanity bound of clh_ccs_plan_create
 
 }  // namespace
 
+extern "C" int clh_fastx_count(const char* in_path, int is_fastq, int64_t* n_records)
+{
+    if (!in_path || !n_records) return CLH_E_ARG;
+    gzFile in = gzopen(in_path, "rb");
+    if (!in) return CLH_E_ARG;
+    gzbuffer(in, 1 << 20);
+    LineReader lr(in);
+    std::string line;
+    int64_t lines = 0;
+    while (lr.next(line)) ++lines;
+    gzclose(in);
+    const int per = is_fastq ? 4 : 2;
+    *n_records = (lines + per - 1) / per;        // a trailing header without its sequence line is still a record (find_ccs.py:51-64)
+    return 0;
+}
+
 extern "C" int clh_ccs_file(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
                             int32_t batch_reads, clh_ccs_file_stats* stats)
 {
-    if (!ctx || !in_path || !ccs_fa_path || !raw_fa_path || !stats) return CLH_E_ARG;
+    return clh_ccs_file_range(ctx, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads, 0, -1, stats);
+}
+
+extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
+                                  int32_t batch_reads, int64_t first_record, int64_t max_records, clh_ccs_file_stats* stats)
+{
+    if (!ctx || !in_path || !ccs_fa_path || !raw_fa_path || !stats || first_record < 0) return CLH_E_ARG;
     if (batch_reads <= 0) batch_reads = 65536;
     memset(stats, 0, sizeof(*stats));
     gzFile in = gzopen(in_path, "rb");
@@ -93,12 +116,25 @@ extern "C" int clh_ccs_file(clh_ctx* ctx, const char* in_path, int is_fastq, con
         std::string header, seq, skip;
         int s = 0;
         bool done = false;
+        // this rank's shard starts at record `first_record`: the records in front are read past, not parsed
+        for (int64_t k = 0; k < first_record && !done; ++k)
+            for (int l = 0; l < (is_fastq ? 4 : 2); ++l) if (!lr.next(skip)) { done = true; break; }
+        int64_t left = max_records < 0 ? INT64_MAX : max_records;
+        if (left == 0) done = true;
+        if (done) {       // nothing to do: hand the consumer an empty last batch
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[s] == 0; }); }
+            slot[s].clear(); slot[s].last = true;
+            { std::lock_guard<std::mutex> lk(mu); filled[s] = 1; }
+            cv.notify_all();
+        }
         while (!done) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[s] == 0; }); }
             Batch& b = slot[s];
             b.clear();
             while ((int)b.hdr_off.size() < batch_reads && b.codes.size() < (size_t)256 << 20) {
+                if (left == 0) { done = true; break; }
                 if (!lr.next(header)) { done = true; break; }
+                --left;
                 const bool have_seq = lr.next(seq);
                 if (is_fastq) { lr.next(skip); lr.next(skip); }
                 rstrip(header); rstrip(seq);

@@ -187,39 +187,72 @@ def _assemble(read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_s
             '{}|{}-{}'.format(junc, clip_base, len(circ)), segments, seq)
 
 
+THREADS = 1               # mapper calls of a chunk run on this many threads (set by the stage drivers from `threads`)
+_POOL = None
+
+
+def _mapper_pool():
+    """The reference spreads its per-read loop over Pool(threads) (find_bsj.py:340-345).  Here the process owns a GPU and
+    must not fork, and the mappers release the GIL inside map(): a thread pool carries the mapper phase of a chunk while the
+    batched GPU phases stay on the calling thread."""
+    global _POOL
+    if THREADS <= 1:
+        return None
+    if _POOL is None or _POOL._max_workers != THREADS:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(THREADS)
+    return _POOL
+
+
+def _map_read(item, raw_filters, min_circ_fraction):
+    """Phase 1 for one read: everything that needs the mapper (find_bsj.py:243-273).
+    -> (counter keys touched, short read or None, pending tuple or None)"""
+    read_id, segments, ccs, raw = item
+    keys, short = [], None
+    seg_st, seg_en = _segment_span(segments)
+    if raw_filters:
+        # filter 1: reads that map linearly over (almost) their whole length are not circular (find_bsj.py:243-247)
+        raw_hit = get_primary_alignment(env.ALIGNER.map(raw))
+        if raw_hit and raw_hit.mlen > max(len(raw) * 0.8, len(raw) - 200):
+            return keys, short, None
+        if raw_hit and raw_hit.mlen > 1.5 * len(ccs):
+            return keys, short, None
+        keys.append('raw_unmapped')
+        # filter 2: the raw hit must touch the repeat region (find_bsj.py:254-257)
+        if raw_hit and (raw_hit.q_en < seg_st or raw_hit.q_st > seg_en):
+            return keys, short, None
+    ccs_hit = get_primary_alignment(env.ALIGNER.map(ccs * 2))
+    if raw_filters and ccs_hit is None and len(ccs) < 150:
+        short = (read_id, segments, ccs, raw)
+    if ccs_hit is None or seg_en - seg_st < ccs_hit.q_en - ccs_hit.q_st:
+        return keys, short, None
+    keys.append('ccs_mapped')
+    circ, junc = find_bsj(ccs)
+    circ_hit = get_primary_alignment(env.ALIGNER.map(circ))
+    if circ_hit is None or (min_circ_fraction and circ_hit.mlen < min_circ_fraction * len(circ)):
+        return keys, short, None
+    return keys, short, (read_id, segments, ccs, circ, junc, circ_hit, _clip_prepare(circ, circ_hit))
+
+
 def _scan_chunk(chunk, raw_filters, min_circ_fraction):
     reads_cnt = defaultdict(int)
     short_reads = []
     pending = []          # (read fields..., prepared clip result or job) in input order
     jobs = []
-    for read_id, segments, ccs, raw in chunk:
-        seg_st, seg_en = _segment_span(segments)
-        if raw_filters:
-            # filter 1: reads that map linearly over (almost) their whole length are not circular (find_bsj.py:243-247)
-            raw_hit = get_primary_alignment(env.ALIGNER.map(raw))
-            if raw_hit and raw_hit.mlen > max(len(raw) * 0.8, len(raw) - 200):
-                continue
-            if raw_hit and raw_hit.mlen > 1.5 * len(ccs):
-                continue
-            reads_cnt['raw_unmapped'] += 1
-            # filter 2: the raw hit must touch the repeat region (find_bsj.py:254-257)
-            if raw_hit and (raw_hit.q_en < seg_st or raw_hit.q_st > seg_en):
-                continue
-        ccs_hit = get_primary_alignment(env.ALIGNER.map(ccs * 2))
-        if raw_filters and ccs_hit is None and len(ccs) < 150:
-            short_reads.append((read_id, segments, ccs, raw))
-        if ccs_hit is None or seg_en - seg_st < ccs_hit.q_en - ccs_hit.q_st:
-            continue
-        reads_cnt['ccs_mapped'] += 1
-
-        circ, junc = find_bsj(ccs)
-        circ_hit = get_primary_alignment(env.ALIGNER.map(circ))
-        if circ_hit is None or (min_circ_fraction and circ_hit.mlen < min_circ_fraction * len(circ)):
-            continue
-        prep = _clip_prepare(circ, circ_hit)
-        if isinstance(prep, _ClipJob):
-            jobs.append(prep)
-        pending.append((read_id, segments, ccs, circ, junc, circ_hit, prep))
+    pool = _mapper_pool()
+    if pool is None:
+        mapped = [_map_read(item, raw_filters, min_circ_fraction) for item in chunk]
+    else:
+        mapped = list(pool.map(lambda item: _map_read(item, raw_filters, min_circ_fraction), chunk))     # input order kept
+    for keys, short, pend in mapped:
+        for k in keys:
+            reads_cnt[k] += 1
+        if short is not None:
+            short_reads.append(short)
+        if pend is not None:
+            if isinstance(pend[6], _ClipJob):
+                jobs.append(pend[6])
+            pending.append(pend)
 
     results = iter(_run_clip_jobs(jobs))
     ready = []
@@ -274,17 +307,25 @@ def _resident(genome):
 def scan_ccs_reads(ccs_seq, ref_fasta, ss_index, gtf_index, intron_index, is_canonical, out_dir, prefix, threads,
                    aligner=None, genome=None, contig_len=None):
     """Stage driver (find_bsj.py:328-372).  The reference forks a process pool per stage; here the calling process
-    (one per GPU) walks the chunks itself.  ``aligner``/``genome``/``contig_len`` may be injected (tests, or an already
+    (one per GPU) walks the chunks itself, with the mapper calls of a chunk on `threads` threads.  ``aligner``/``genome``/``contig_len`` may be injected (tests, or an already
     built index); by default a mappy splice-preset aligner is built from ``ref_fasta`` exactly as the reference does."""
+    global THREADS
     if aligner is None:
         import mappy as mp
         aligner = mp.Aligner(ref_fasta, n_threads=threads, preset='splice')
     if genome is None:
-        genome = aligner
-    if contig_len is None:
+        # the reference hands the mappy index itself to the workers as GENOME (find_bsj.py:340-341).  Here the FASTA is read
+        # once: it gives the contig lengths AND becomes the genome resident in HBM, so that clip windows are coordinates
+        # (K5/K1) and the splice-signal search runs on the device (K6)
         from .align import Fasta
-        contig_len = Fasta(ref_fasta).contig_len
+        genome = Fasta(ref_fasta)
+    if contig_len is None:
+        contig_len = genome.contig_len if hasattr(genome, 'contig_len') else None
+        if contig_len is None:
+            from .align import Fasta
+            contig_len = Fasta(ref_fasta).contig_len
     env.initializer(aligner, contig_len, _resident(genome), gtf_index, intron_index, ss_index)
+    THREADS = max(1, int(threads or 1))
 
     reads_count = defaultdict(int)
     short_reads = []
@@ -308,7 +349,9 @@ def recover_ccs_reads(short_reads, ref_fasta, ss_index, gtf_index, intron_index,
     if aligner is None:
         from bwapy import BwaAligner
         aligner = Aligner(BwaAligner(ref_fasta, options='-x ont2d -T 19'))
+    global THREADS
     env.initializer(aligner, genome.contig_len, _resident(genome), gtf_index, intron_index, ss_index)
+    THREADS = max(1, int(threads or 1))
 
     reads_count = defaultdict(int)
     with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'a') as out:

@@ -79,6 +79,9 @@ def lib():
         L.clh_ccs_plan_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_ccs_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p]
         L.clh_ccs_file.restype = C.c_int
+        L.clh_ccs_file_range.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
+        L.clh_ccs_file_range.restype = C.c_int
+        L.clh_fastx_count.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
         L.clh_genome_create.restype = C.c_void_p
         L.clh_genome_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.clh_genome_destroy.restype = None
@@ -107,11 +110,20 @@ def lib():
         L.clh_poa_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_results_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_ccs_plan_info.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
+
+
+def fastx_count(in_path, is_fastq):
+    """records of a FASTA/FASTQ(.gz) file as find_ccs_reads' loop counts them (host only, no GPU)"""
+    n = C.c_int64(0)
+    if lib().clh_fastx_count(os.fsencode(in_path), int(bool(is_fastq)), C.byref(n)) != 0:
+        raise ClhError('clh_fastx_count failed for %s' % in_path)
+    return int(n.value)
 
 
 def last_error():
@@ -282,11 +294,12 @@ class Context(object):
     def edit_plan(self, xs, ys):
         return EditPlan(self, xs, ys)
 
-    def ccs_file(self, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads=0):
-        """Stage 1 from file to file in native code -> (total_reads, reads_with_consensus, reads_too_long)"""
+    def ccs_file(self, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads=0, first_record=0, max_records=-1):
+        """Stage 1 from file to file in native code -> (total_reads, reads_with_consensus, reads_too_long); with
+        first_record / max_records for one rank's contiguous shard of the records"""
         st = (C.c_int64 * 3)()
-        rc = lib().clh_ccs_file(self._h, os.fsencode(in_path), int(bool(is_fastq)), os.fsencode(ccs_fa_path), os.fsencode(raw_fa_path),
-                                int(batch_reads), C.byref(st))
+        rc = lib().clh_ccs_file_range(self._h, os.fsencode(in_path), int(bool(is_fastq)), os.fsencode(ccs_fa_path), os.fsencode(raw_fa_path),
+                                      int(batch_reads), int(first_record), int(max_records), C.byref(st))
         if rc != 0:
             raise ClhError('clh_ccs_file failed (%d): %s' % (rc, last_error()))
         return int(st[0]), int(st[1]), int(st[2])
@@ -415,9 +428,15 @@ class Genome(object):
 
     def count_n(self, windows):
         """upper-case 'N' per window [(contig, start, end)] -- Counter(window)['N'] of find_bsj.py:199"""
-        n = len(windows)
-        off, ln = self._spans(windows)
+        return self.count_n_spans(*self._spans(windows))
+
+    def count_n_spans(self, off, ln):
+        """count_n for windows given as genome-wide (offset, length) int64 arrays"""
+        off = np.ascontiguousarray(off, dtype=np.int64); ln = np.ascontiguousarray(ln, dtype=np.int64)
+        n = len(off)
         out = np.zeros(n, dtype=np.int64)
+        if n == 0:
+            return out
         rc = lib().clh_genome_count_n(self._h, n, off.ctypes.data, ln.ctypes.data, out.ctypes.data)
         if rc != 0:
             raise ClhError('clh_genome_count_n failed (%d): %s' % (rc, last_error()))
@@ -456,6 +475,14 @@ class Genome(object):
             raise ClhError('clh_splice_signal_batch failed (%d): %s' % (rc, last_error()))
         return out
 
+    def plan_windows(self, read_off, win_off, win_len, minus, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,
+                     want_cigar=True, mask_len=None):
+        """A Plan whose references are windows (genome-wide offset, length, minus-strand flag) of this genome:
+        plan.run(d_reads_ptr, genome.codes_ptr, stream)."""
+        return Plan(self.ctx, read_off, None, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, mask_len,
+                    windows=(np.ascontiguousarray(win_off, dtype=np.int64), np.ascontiguousarray(win_len, dtype=np.int32),
+                             np.ascontiguousarray(minus, dtype=np.uint8)))
+
     def ssw_windows(self, reads, read_off, windows, minus, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,
                     want_cigar=True, mask_len=None):
         """ssw_batch with reference k = windows[k] = (contig, start, end), reverse-complemented where minus[k]."""
@@ -482,21 +509,29 @@ class Genome(object):
 class Plan(object):
     """A batch shape resident on the GPU: run() it on device pointers any number of times."""
 
-    def __init__(self, ctx, read_off, ref_off, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, mask_len):
+    def __init__(self, ctx, read_off, ref_off, mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, mask_len,
+                 windows=None):
         L = lib()
         self.ctx = ctx
         self.read_off = np.ascontiguousarray(read_off, dtype=np.int64)
-        self.ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
         self.n = len(self.read_off) - 1
         self.want_cigar = bool(want_cigar)
         o, self._mat = ctx._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar)
         ml = np.ascontiguousarray(mask_len, dtype=np.int32) if mask_len is not None else None
-        self._h = L.clh_ssw_plan(ctx._h, self.n, self.read_off.ctypes.data, self.ref_off.ctypes.data,
-                                 ml.ctypes.data if ml is not None else None, C.byref(o))
+        if windows is not None:
+            self._win = windows
+            self._h = L.clh_ssw_plan_windows(ctx._h, self.n, self.read_off.ctypes.data, windows[0].ctypes.data, windows[1].ctypes.data,
+                                             windows[2].ctypes.data, ml.ctypes.data if ml is not None else None, C.byref(o))
+        else:
+            self.ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
+            self._h = L.clh_ssw_plan(ctx._h, self.n, self.read_off.ctypes.data, self.ref_off.ctypes.data,
+                                     ml.ctypes.data if ml is not None else None, C.byref(o))
         if not self._h:
             raise ClhError('clh_ssw_plan failed: %s' % last_error())
 
     def run(self, d_reads_ptr, d_refs_ptr, stream=0):
+        """stream: a hipStream_t handle (e.g. torch.cuda.Stream().cuda_stream).  0 selects libclh's own private stream, which
+        is NOT ordered with torch's default stream: pass the stream your inputs are produced on."""
         rc = lib().clh_ssw_run(self._h, C.c_void_p(d_reads_ptr), C.c_void_p(d_refs_ptr), C.c_void_p(stream))
         if rc != 0:
             raise ClhError('clh_ssw_run failed (%d): %s' % (rc, last_error()))
@@ -556,6 +591,7 @@ class CcsPlan(object):
             raise ClhError('clh_ccs_plan_create failed: %s' % last_error())
 
     def run(self, d_reads_ptr, stream=0):
+        """stream: see Plan.run"""
         rc = lib().clh_ccs_run(self._h, C.c_void_p(d_reads_ptr), C.c_void_p(stream))
         if rc != 0:
             raise ClhError('clh_ccs_run failed (%d): %s' % (rc, last_error()))
@@ -566,6 +602,20 @@ class CcsPlan(object):
         if lib().clh_ccs_plan_timing(self._h, ms.ctypes.data) != 0:
             raise ClhError('clh_ccs_plan_timing: %s' % last_error())
         return float(ms[0]), float(ms[1])
+
+    def info(self):
+        """dict(slots, slot_bytes, big_slots, big_slot_bytes, ran_in_claimed_big_slot, ran_in_second_launch) of the last run"""
+        out = np.zeros(6, dtype=np.int64)
+        if lib().clh_ccs_plan_info(self._h, out.ctypes.data) != 0:
+            raise ClhError('clh_ccs_plan_info: %s' % last_error())
+        return dict(zip(('slots', 'slot_bytes', 'big_slots', 'big_slot_bytes', 'ran_in_claimed_big_slot', 'ran_in_second_launch'), (int(x) for x in out)))
+
+    def results_dev(self):
+        """device pointers (rows, segs, ccs) of the last run's outputs; ccs is packed at the read offsets"""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if lib().clh_ccs_results_dev(self._h, C.byref(a), C.byref(b), C.byref(c)) != 0:
+            raise ClhError('clh_ccs_results_dev: %s' % last_error())
+        return a.value, b.value, c.value
 
     def fetch(self):
         out = np.zeros(self.n, dtype=CCS_DTYPE)

@@ -84,7 +84,11 @@ clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_off, const i
 void clh_plan_destroy(clh_plan* plan);
 
 /* Launch the batch on packed code arrays that already live in HBM (device pointers).  Asynchronous on `stream`
- * (a hipStream_t, NULL = the context's own stream).  Results stay in HBM until clh_ssw_fetch. */
+ * (a hipStream_t).  NULL selects the context's own, private, non-blocking stream -- NOT the legacy default stream: work
+ * a caller has queued on the default stream (or on any other stream) is then unordered with these kernels.  A caller
+ * who produces inputs or consumes clh_ssw_results_dev() on a stream of its own passes THAT stream; hipStreamLegacy /
+ * hipStreamPerThread are passed through like any other handle.  Results stay in HBM until clh_ssw_fetch, which waits
+ * for the stream of the last run.  The same holds for every `stream` argument of this header. */
 int clh_ssw_run(clh_plan* plan, const void* d_reads, const void* d_refs, void* stream);
 
 /* Wait for the last run and copy results out.  cigar_buf may be NULL.  *cigar_used receives the u32 count. */
@@ -127,6 +131,9 @@ int clh_ccs_fetch(clh_ccs_plan* plan, clh_ccs_t* out, int32_t* segs, int8_t* ccs
 /* Device pointers of the last run's outputs (rows: clh_ccs_t[n]; segs: int32[n][2*65]; ccs: packed codes at the read
  * offsets), for callers that keep the next step on the GPU.  Any of the three may be NULL. */
 int clh_ccs_results_dev(const clh_ccs_plan* plan, const void** rows, const void** segs, const void** ccs);
+/* Workspace tiers of the plan and how the last run used them: out[6] = {first-tier slots, bytes per slot, large slots,
+ * bytes per large slot, reads that ran in a large slot claimed on the fly, reads run by the second launch}. */
+int clh_ccs_plan_info(clh_ccs_plan* plan, int64_t* out);
 /* HIP-event durations (ms) of the last run: ms[0] = repeat scan (K2), ms[1] = partial-order consensus (K3). */
 int clh_ccs_plan_timing(clh_ccs_plan* plan, float* ms);
 int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, clh_ccs_t* out, int32_t* segs, int8_t* ccs);
@@ -155,6 +162,13 @@ int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64
 typedef struct { int64_t total_reads, ro_reads, too_long; } clh_ccs_file_stats;
 int clh_ccs_file(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
                  int32_t batch_reads, clh_ccs_file_stats* stats);
+/* The same for the records [first_record, first_record + max_records) of the file (max_records < 0: to the end) -- one
+ * rank's contiguous shard of the reads (the reference hands chunks of the record stream to its pool, find_ccs.py:66-75);
+ * concatenating the outputs of consecutive shards gives the files of the unsharded call, byte for byte. */
+int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
+                       int32_t batch_reads, int64_t first_record, int64_t max_records, clh_ccs_file_stats* stats);
+/* number of records of a FASTA/FASTQ(.gz) file as that loop counts them (host only) */
+int clh_fastx_count(const char* in_path, int is_fastq, int64_t* n_records);
 
 /* ---- Resident genome ---------------------------------------------------------------------
  * The reference builds, per clipped read, a window string of hit +- 200 kb, counts its 'N', reverse-complements it for

@@ -75,3 +75,95 @@ def test_two_ranks_equal_one(tmp_path):
     assert got[1][2] is None                                # records only on rank 0 ...
     assert [tuple(r) for r in got[0][2]] == [tuple(r) for r in ret]   # ... in input order
     assert got[0][1] + got[1][1] == len(short)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole of `call` sharded over two ranks: files byte-identical to the one-rank run
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_stage1(path, is_fastq, ccs_path, raw_path, first, count):
+    """stand-in for hip.Context.ccs_file on a box without a GPU: the same files from the CPU statement of the consensus"""
+    import oracle_lib
+    from ciri_long_amd import find_ccs
+    total = ro = 0
+    with open(ccs_path, 'w') as out, open(raw_path, 'w') as trimmed:
+        for k, (header, seq) in enumerate(find_ccs.iter_reads(path)):
+            if k < first or k >= first + count:
+                continue
+            total += 1
+            seg, ccs, _ = oracle_lib.oracle_find_consensus(seq)
+            if seg is None:
+                continue
+            ro += 1
+            out.write('>{}\t{}\t{}\n{}\n'.format(header, seg, len(ccs), ccs))
+            trimmed.write('>{}\n{}\n'.format(header, seq))
+    return total, ro, 0
+
+
+def _setup_call_world():
+    import fake_mapper as fm
+    import oracle_lib
+    from ciri_long_amd import env, find_bsj, ssw_wrap
+
+    class R(object):
+        def __init__(s, d):
+            s.score, s.ref_begin, s.ref_end, s.query_begin, s.query_end = d['score'], d['ref_begin'], d['ref_end'], d['query_begin'], d['query_end']
+    ssw_wrap.align_pairs = lambda refs, qs, match=2, mismatch=2, gap_open=3, gap_extend=1, **kw: \
+        [R(oracle_lib.oracle_align(r, q, match, mismatch, gap_open, gap_extend)) for r, q in zip(refs, qs)]
+    w = fm.build_world()
+    env.initializer(fm.FakeMapper(w['genome']), w['genome'].contig_len, w['genome'], w['gtf_index'], None, w['ss_index'])
+    find_bsj.THREADS = 3          # the mapper phase of a chunk on a thread pool: same records, same order
+    return w
+
+
+def _call_worker(rank, world, port, out_dir, in_file, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ciri_long_amd import dist as cdist
+    _setup_call_world()
+    counts, short = cdist.call_sharded(in_file, out_dir, 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1)
+    q.put((rank, dict(counts), len(short)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_call_sharded_files_equal_the_single_rank_run(tmp_path):
+    sys.path.insert(0, ROOT)
+    import fake_mapper as fm
+    from ciri_long_amd import dist as cdist, find_bsj
+    w = fm.build_world()
+    reads = fm.build_reads(w, 14)
+    in_file = str(tmp_path / 'reads.fa')
+    with open(in_file, 'w') as f:
+        for rid, _seg, _ccs, raw in reads:
+            f.write('>%s some description\n%s\n' % (rid, raw))
+    one, two = tmp_path / 'one', tmp_path / 'two'
+    for d in (one, two):
+        (d / 'tmp').mkdir(parents=True)
+    # single process (no process group): the answer
+    _setup_call_world()
+    try:
+        counts1, short1 = cdist.call_sharded(in_file, str(one), 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1)
+    finally:
+        find_bsj.THREADS = 1
+    assert counts1['total'] == 14 and counts1['consensus'] >= 8 and counts1.get('bsj', 0) >= 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_call_worker, args=(r, 2, port, str(two), in_file, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, counts, nshort = q.get(timeout=280)
+        got[rank] = (counts, nshort)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] == dict(counts1)          # the all-reduced counters, on every rank
+    assert got[0][1] + got[1][1] == len(short1)
+    for name in ('tmp/p.ccs.fa', 'tmp/p.raw.fa', 'p.cand_circ.fa'):
+        assert (two / name).read_bytes() == (one / name).read_bytes(), name
+    assert (one / 'p.cand_circ.fa').stat().st_size > 0
+    assert sorted(os.listdir(two / 'tmp')) == ['p.ccs.fa', 'p.raw.fa']       # the per-rank parts are gone

@@ -80,3 +80,85 @@ def test_c3_full_size_batch_invariance_and_sample():
         assert got == seg, i
         if seg is not None:
             assert int(rows_a['ccs_len'][i]) == len(ccs) and int(sums_a[i]) == zlib.crc32(oracle_lib.encode(ccs).tobytes())
+
+
+def test_c4_mixed_lengths_batch_invariance_both_workspace_tiers_and_sample(monkeypatch):
+    """BASELINE config 4 (reads of 500-4000 bases, per-GPU share): 20 000 reads through K2/K3 and the clip of every
+    consensus through K1.  With the first-tier budget squeezed the long-period reads must take the large slots -- claimed
+    on the fly by first-tier waves AND in the second launch -- and come back identical; results do not depend on the order
+    or the split of the batch; 120 seeded reads equal the oracle (copy boundaries, consensus, clip alignment)."""
+    import torch
+    torch.cuda.init()                 # device buffers and streams of this test are torch's (plumbing)
+    from ciri_long_amd import hip, synth
+    n = 20000
+    reads, wins = synth.c4_batch(n, seed=synth.SEEDS['C4'])
+    assert min(len(r) for r in reads) < 700 and max(len(r) for r in reads) > 3500
+    ctx = hip.default_context()
+    rd, ro = hip.pack(reads)
+
+    def consensus(idx, budget_mb=None):
+        if budget_mb:
+            monkeypatch.setenv('CLH_POA_BUDGET_MB', str(budget_mb)); monkeypatch.setenv('CLH_POA_BIG_SLOTS', '3')
+        else:
+            monkeypatch.delenv('CLH_POA_BUDGET_MB', raising=False); monkeypatch.delenv('CLH_POA_BIG_SLOTS', raising=False)
+        data, off = hip.pack([reads[i] for i in idx])
+        d = torch.from_numpy(data.view(np.uint8)).cuda()
+        plan = ctx.ccs_plan(off)
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        plan.run(d.data_ptr(), st.cuda_stream)
+        rows, segs, ccs = plan.fetch()
+        info = plan.info()
+        plan.close()
+        sums = np.array([zlib.crc32(ccs[off[k]:off[k] + int(rows['ccs_len'][k])].tobytes()) for k in range(len(idx))], dtype=np.int64)
+        return rows, segs, sums, ccs, off, info
+
+    order = np.arange(n)
+    rows_a, segs_a, sums_a, ccs_a, off_a, info_a = consensus(order)
+    assert int((rows_a['status'] != 0).sum()) == 0
+    assert 0.3 * n < int((rows_a['nseg'] > 0).sum()) < 0.55 * n
+    # squeezed first tier (about 1.5 MB per slot): both routes into the large slots are taken, results identical
+    rows_s, segs_s, sums_s, _c, _o, info_s = consensus(order, budget_mb=6000)
+    assert info_s['slot_bytes'] < info_a['slot_bytes'] and info_s['big_slots'] > 0
+    assert info_s['ran_in_claimed_big_slot'] > 0 and info_s['ran_in_second_launch'] > 0, info_s
+    for f in ('nseg', 'ccs_len', 'period', 'status'):
+        assert np.array_equal(rows_a[f], rows_s[f]), f
+    assert np.array_equal(sums_a, sums_s)
+    rows_b, segs_b, sums_b, _c, _o, _i = consensus(order[::-1])
+    for f in ('nseg', 'ccs_len', 'period'):
+        assert np.array_equal(rows_a[f], rows_b[f][::-1]), f
+    assert np.array_equal(sums_a, sums_b[::-1])
+    sub = order[3::7]
+    rows_c, _s, sums_c, _c, _o, _i = consensus(sub)
+    assert np.array_equal(rows_a['ccs_len'][sub], rows_c['ccs_len']) and np.array_equal(sums_a[sub], sums_c)
+    # the clip of every consensus against its window (K1, call-path options), batch vs reversed batch
+    has = np.nonzero(rows_a['nseg'] > 0)[0]
+    clips = [np.ascontiguousarray(ccs_a[off_a[k] + int(rows_a['ccs_len'][k]) - max(20, int(0.3 * int(rows_a['ccs_len'][k]))):off_a[k] + int(rows_a['ccs_len'][k])]) for k in has]
+    mat = hip.score_matrix(1, 1)
+
+    def ssw(idx):
+        cd, co = hip.pack([clips[i] for i in idx]); fd, fo = hip.pack([wins[has[i]] for i in idx])
+        rows, _ = ctx.ssw_batch(cd, co, fd, fo, mat, 1, 1, want_score2=False, want_cigar=False)
+        return rows
+    fields = ('score1', 'ref_begin1', 'ref_end1', 'read_begin1', 'read_end1')
+    o2 = np.arange(len(has))
+    srow = ssw(o2)
+    assert _digest(srow, fields) == _digest(ssw(o2[::-1])[::-1], fields)
+    rng = np.random.default_rng(4)
+    picked = rng.choice(n, 120, replace=False)
+    pos = {int(k): j for j, k in enumerate(has)}
+    n_cons = 0
+    for i in picked:
+        seg, ccs, _ = oracle_lib.oracle_find_consensus(reads[i])
+        nseg = int(rows_a['nseg'][i])
+        got = ';'.join('%d-%d' % (segs_a[i, k, 0], segs_a[i, k, 1]) for k in range(nseg)) if nseg > 0 else None
+        assert got == seg, i
+        if seg is None:
+            continue
+        n_cons += 1
+        assert int(rows_a['ccs_len'][i]) == len(ccs) and int(sums_a[i]) == zlib.crc32(oracle_lib.encode(ccs).tobytes())
+        c = oracle_lib.encode(ccs)
+        w = oracle_lib.oracle_align(wins[i], np.ascontiguousarray(c[-max(20, int(0.3 * len(c))):]), 1, 1, 1, 1)
+        r = srow[pos[int(i)]]
+        assert [int(r[f]) for f in fields] == [w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']], i
+    assert n_cons >= 35

@@ -299,6 +299,7 @@ struct clh_genome {
     clh_ctx* ctx = nullptr;
     int64_t len = 0;
     void *d_codes = nullptr, *d_pre = nullptr;
+    void* d_ascii = nullptr;                    // the characters themselves (K6 compares flanks as the reference's strings do)
     void* d_sites = nullptr;                    // annotated splice sites (K6): four sorted runs of int64 in one buffer
     int64_t n_sites[4] = {0, 0, 0, 0};
 };
@@ -307,7 +308,7 @@ extern "C" void clh_genome_destroy(clh_genome* g)
 {
     if (!g) return;
     (void)hipSetDevice(g->ctx->device);
-    g->ctx->release(g->d_codes); g->ctx->release(g->d_pre); g->ctx->release(g->d_sites);
+    g->ctx->release(g->d_codes); g->ctx->release(g->d_pre); g->ctx->release(g->d_sites); g->ctx->release(g->d_ascii);
     delete g;
 }
 
@@ -320,7 +321,8 @@ extern "C" clh_genome* clh_genome_create(clh_ctx* ctx, const char* ascii, int64_
     const size_t nblk = (size_t)(len / clh::kGenomeBlock) + 2;
     g->d_codes = ctx->alloc((size_t)len + 64);
     g->d_pre = ctx->alloc(sizeof(unsigned int) * nblk);
-    void* d_ascii = ctx->alloc((size_t)len + 64);
+    g->d_ascii = ctx->alloc((size_t)len + 64);
+    void* d_ascii = g->d_ascii;
     bool ok = g->d_codes && g->d_pre && d_ascii;
     if (!ok) fail(CLH_E_HIP, "out of device memory for the genome");
     std::vector<unsigned int> pre(nblk, 0);
@@ -339,7 +341,6 @@ extern "C" clh_genome* clh_genome_create(clh_ctx* ctx, const char* ascii, int64_
              hipStreamSynchronize(ctx->stream) == hipSuccess;
         if (!ok) fail(CLH_E_HIP, "genome prefix upload failed");
     }
-    ctx->release(d_ascii);
     if (!ok) { clh_genome_destroy(g); return nullptr; }
     return g;
 }
@@ -426,7 +427,7 @@ extern "C" int clh_splice_signal_batch(clh_genome* g, int32_t n, const int64_t* 
     int rc = 0;
     if (!d_t || !d_o) rc = fail(CLH_E_HIP, "out of device memory");
     if (!rc && (hipMemcpyAsync(d_t, tasks.data(), tb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                clh::launch_splice_scan((const uint8_t*)g->d_codes, (const clh::SpliceTask*)d_t, n, search_extra, shift_threshold, is_canonical ? 1 : 0,
+                clh::launch_splice_scan((const uint8_t*)g->d_codes, (const uint8_t*)g->d_ascii, (const clh::SpliceTask*)d_t, n, search_extra, shift_threshold, is_canonical ? 1 : 0,
                                         sites, (int32_t*)d_o, ctx->stream) != hipSuccess ||
                 hipMemcpyAsync(out, d_o, ob, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess))

@@ -144,7 +144,7 @@ struct SpliceSites {
     const int64_t* pos[4];
     int64_t n[4];
 };
-hipError_t launch_splice_scan(const uint8_t* codes, const SpliceTask* tasks, int n, int search_extra, int shift_threshold, int canonical,
+hipError_t launch_splice_scan(const uint8_t* codes, const uint8_t* ascii, const SpliceTask* tasks, int n, int search_extra, int shift_threshold, int canonical,
                               const SpliceSites& sites, int32_t* out, hipStream_t stream);
 hipError_t launch_genome_count_n(const uint8_t* codes, const unsigned int* pre_n, const long long* off, const long long* len, long long* out, int n, hipStream_t stream);
 static constexpr int kGenomeBlock = 256;     // bases per entry of the N prefix table

@@ -17,9 +17,10 @@
 // already in HBM (K5), so there is nothing to stage -- consecutive lanes are consecutive candidates and the reads go
 // through L2.  The candidates are independent; the launch is bound by the latency of those reads, not by bandwidth.
 //
-// Out of the device path (status 1, the caller runs the Python statement for that candidate): neighbourhoods that
-// leave the contig (the reference's slices then wrap around, align.py:583-589), and flanks in which two bytes compare
-// equal as codes although the characters may differ (anything that is not A/C/G/T/a/c/g/t/N).
+// Next to a contig end the reference does not consult the annotation (align.py:495-496) and searches the motifs in what
+// Python's slices return there -- a negative start wraps around, an end beyond the contig is clipped (align.py:575-583);
+// the kernel applies the same slice rule.  The flanks are compared on the genome's raw characters (kept resident beside
+// the codes), as the reference's string comparison does.  Status 1 is left for invalid coordinates only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "clh_device.h"
@@ -65,7 +66,7 @@ __device__ __forceinline__ unsigned long long site_key(int i, int j, int w, int 
 
 // ANNO: annotated sites are loaded (the search without them keeps its smaller register file)
 template <bool ANNO>
-__global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restrict__ codes, const SpliceTask* __restrict__ tasks, int n,
+__global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ ascii, const SpliceTask* __restrict__ tasks, int n,
                                                           int search_extra, int shift_threshold, int canonical, SpliceSites sites,
                                                           int32_t* __restrict__ out)
 {
@@ -73,42 +74,55 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
     if (tid >= n) return;
     const SpliceTask t = tasks[tid];
     const uint8_t* g = codes + t.ctg_off;
+    const uint8_t* ch = ascii + t.ctg_off;               // the characters, for the string comparisons of align.py:477-493
     const long long L = t.ctg_len, S = t.start, E = t.end;
     const int cb = t.clip_base;
     int32_t* o = out + 8 * (size_t)tid;
-    int status = (S < 0 || S >= E || E > L) ? 1 : 0;
+    const int status = (S < 0 || S >= E || E > L) ? 1 : 0;
     int us_free = 0, ds_free = 0;
     if (!status) {
         // align.py:477-493: prefixes of length i after start and after end are equal (i < 100), suffixes before them alike
         for (int i = 1; i < 100; ++i) {
             if (E + i > L) break;
-            const uint32_t a = g[S + i - 1], b = g[E + i - 1];
-            if (a != b) break;
-            if ((a & 7u) == 4u && !(a & 16u)) status = 1;
+            if (ch[S + i - 1] != ch[E + i - 1]) break;
             ds_free = i;
         }
         for (int j = 1; j < 100; ++j) {
             if (S - j < 0) break;
-            const uint32_t a = g[S - j], b = g[E - j];
-            if (a != b) break;
-            if ((a & 7u) == 4u && !(a & 16u)) status = 1;
+            if (ch[S - j] != ch[E - j]) break;
             us_free = j;
         }
     }
     const int sl = cb + search_extra;
     const int us_len = sl + us_free, ds_len = sl + ds_free;
-    if (!status && (S - us_len - 2 < 0 || E + ds_len + 2 > L)) status = 1;
+    // align.py:495-496: next to a contig end the annotation is not consulted
+    const bool edge = S - us_len - 2 < 0 || E + ds_len + 2 > L;
+    // the two windows of find_denovo_signal as Python slices them (align.py:575-578): first index, length
+    long long ua, nu, da, nd;
+    {
+        auto pyslice = [&](long long a, long long b, long long& lo, long long& nn) {
+            if (a < 0) { a += L; if (a < 0) a = 0; } else if (a > L) a = L;
+            if (b < 0) { b += L; if (b < 0) b = 0; } else if (b > L) b = L;
+            lo = a; nn = b > a ? b - a : 0;
+        };
+        pyslice(S - us_len - 2, S + ds_len, ua, nu);
+        pyslice(E - us_len, E + ds_len + 2, da, nd);
+    }
+    const bool short_seq = nu < ds_len - us_len + 2 || nd < ds_len - us_len + 2;       // align.py:580-583: no search at all
+    // shift i <-> index i + us_len of the upstream slice (str.find from index 1: indices 1 .. n-2); downstream alike
+    const long long pu = ua + us_len, pd = da + us_len;   // genome position of shift 0 in each slice (S - 2 and E away from the ends)
     o[1] = us_free; o[2] = ds_free;
     int found = 0, b_strand = 0, b_i = 0, b_j = 0, b_motif = 0;
     constexpr bool anno = ANNO;
-    if (!status && anno && 2 * sl > 64) status = 1;
-    o[0] = status;
-    if (!status) {
+    const bool use_anno = anno && !edge;
+    const int status2 = (!status && use_anno && 2 * sl > 64) ? 1 : status;
+    o[0] = status2;
+    if (!status2) {
         const int T = cb + shift_threshold;
         unsigned long long best = ~0ull;
         // annotated shifts in [-sl, sl): exon starts are looked up one base further (align.py:507-546); [strand][kind]
         unsigned long long mu[2][2] = {{0, 0}, {0, 0}}, md[2][2] = {{0, 0}, {0, 0}};
-        if constexpr (ANNO) {
+        if constexpr (ANNO) if (use_anno) {
             const long long gs = t.ctg_off + S - sl, ge = t.ctg_off + E - sl;
             for (int strand = 0; strand < 2; ++strand) {
                 mu[strand][0] = site_mask(sites.pos[2 * strand], sites.n[2 * strand], gs + 1, 2 * sl);
@@ -141,10 +155,11 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
                             }
                     }
         }
-        const int lo = 1 - us_len, hi = ds_len;           // shifts whose dinucleotide lies inside the two windows
-        const int lo0 = imin(lo, -sl);                    // annotated shifts start at -search_length
+        const int lo = 1 - us_len;                        // shifts whose dinucleotide lies inside the two slices
+        const int hi_u = (int)nu - 2 - us_len, hi_d = (int)nd - 2 - us_len;      // ds_len away from the contig ends
+        const int lo0 = use_anno ? imin(lo, -sl) : lo;    // annotated shifts start at -search_length
         const int host = t.host_mask & 3;
-        for (int round = 0; round < 2 && !found; ++round) {
+        for (int round = 0; round < 2 && !found && !short_seq; ++round) {
             // host-gene strands first, the other strand(s) only if that finds nothing (align.py:640-695)
             // without a host gene both strands are searched at once
             const int mask = round == 0 ? (host ? host : 3) : (3 & ~host);
@@ -159,14 +174,15 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
                     if (strand == 0) { u0 = kAcceptor[m][0]; u1 = kAcceptor[m][1]; d0 = kDonor[m][0]; d1 = kDonor[m][1]; }
                     else { u0 = 3u - kDonor[m][1]; u1 = 3u - kDonor[m][0]; d0 = 3u - kAcceptor[m][1]; d1 = 3u - kAcceptor[m][0]; }
                     const int w = kWeight[m];
-                    for (int i = lo0; i <= hi; ++i) {
+                    const int hi_i = use_anno ? imax(hi_u, sl - 1) : hi_u, hi_j = use_anno ? imax(hi_d, sl - 1) : hi_d;
+                    for (int i = lo0; i <= hi_i; ++i) {
                         // a site: an occurrence of the motif, or an annotated shift of this strand (align.py:612-621)
-                        const bool ai = i >= -sl && i < sl && ((au >> (i + sl)) & 1);
-                        if (!ai && (i < lo || g[S + i - 2] != u0 || g[S + i - 1] != u1)) continue;
-                        const int jlo = imax(lo0, i - T), jhi = imin(hi, i + T);
+                        const bool ai = use_anno && i >= -sl && i < sl && ((au >> (i + sl)) & 1);
+                        if (!ai && (i < lo || i > hi_u || g[pu + i] != u0 || g[pu + i + 1] != u1)) continue;
+                        const int jlo = imax(lo0, i - T), jhi = imin(hi_j, i + T);
                         for (int j = jlo; j <= jhi; ++j) {
-                            const bool aj = j >= -sl && j < sl && ((ad >> (j + sl)) & 1);
-                            if (!aj && (j < lo || g[E + j] != d0 || g[E + j + 1] != d1)) continue;
+                            const bool aj = use_anno && j >= -sl && j < sl && ((ad >> (j + sl)) & 1);
+                            if (!aj && (j < lo || j > hi_d || g[pd + j] != d0 || g[pd + j + 1] != d1)) continue;
                             const unsigned long long key = site_key(i, j, w, cb, us_free, ds_free);
                             if (key < best) { best = key; found = 1; b_strand = strand; b_i = i; b_j = j; b_motif = m; }
                         }
@@ -178,14 +194,14 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
     o[3] = found; o[4] = b_strand; o[5] = b_i; o[6] = b_j; o[7] = b_motif;
 }
 
-hipError_t launch_splice_scan(const uint8_t* codes, const SpliceTask* tasks, int n, int search_extra, int shift_threshold, int canonical,
+hipError_t launch_splice_scan(const uint8_t* codes, const uint8_t* ascii, const SpliceTask* tasks, int n, int search_extra, int shift_threshold, int canonical,
                               const SpliceSites& sites, int32_t* out, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     if (sites.n[0] + sites.n[1] + sites.n[2] + sites.n[3] > 0)
-        hipLaunchKernelGGL(splice_scan_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, codes, tasks, n, search_extra, shift_threshold, canonical, sites, out);
+        hipLaunchKernelGGL(splice_scan_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, codes, ascii, tasks, n, search_extra, shift_threshold, canonical, sites, out);
     else
-        hipLaunchKernelGGL(splice_scan_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, codes, tasks, n, search_extra, shift_threshold, canonical, sites, out);
+        hipLaunchKernelGGL(splice_scan_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, codes, ascii, tasks, n, search_extra, shift_threshold, canonical, sites, out);
     return hipGetLastError();
 }
 

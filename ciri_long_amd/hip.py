@@ -353,7 +353,9 @@ class EditPlan(object):
 
     def close(self):
         if self._h:
-            lib().clh_edit_plan_destroy(self._h); self._h = None
+            if getattr(self.ctx, '_h', None):
+                lib().clh_edit_plan_destroy(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -409,7 +411,9 @@ class Genome(object):
 
     def close(self):
         if self._h:
-            lib().clh_genome_destroy(self._h); self._h = None
+            if getattr(self.ctx, '_h', None):        # a context closed first has already given everything back
+                lib().clh_genome_destroy(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -569,7 +573,8 @@ class Plan(object):
 
     def close(self):
         if getattr(self, '_h', None):
-            lib().clh_plan_destroy(self._h)
+            if getattr(self.ctx, '_h', None):
+                lib().clh_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -628,7 +633,8 @@ class CcsPlan(object):
 
     def close(self):
         if getattr(self, '_h', None):
-            lib().clh_ccs_plan_destroy(self._h)
+            if getattr(self.ctx, '_h', None):
+                lib().clh_ccs_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -97,10 +97,18 @@ static int sort_ss(const list_t* l, int us, int ds, int cb)
     return -1;
 }
 
+/* Python's s[a:b] on a string of length L: first index and length */
+static void pyslice(int64_t L, int64_t a, int64_t b, int64_t* lo, int64_t* n)
+{
+    if (a < 0) { a += L; if (a < 0) a = 0; } else if (a > L) a = L;
+    if (b < 0) { b += L; if (b < 0) b = 0; } else if (b > L) b = L;
+    *lo = a; *n = b > a ? b - a : 0;
+}
+
 /* g: the contig's characters, L its length; [start, end) the candidate; host_mask bit 0 '+', bit 1 '-';
  * site_pos / site_cnt: annotated sites of THIS contig as four ascending runs of 1-based positions
  * ('+' starts, '+' ends, '-' starts, '-' ends), all counts zero = no annotation for the contig.
- * out[8] = status (0 done, 1 = the neighbourhood leaves the contig: the reference's slices wrap around there),
+ * out[8] = status (0 done, 1 = invalid coordinates),
  * us_free, ds_free, found (0 none, 1 de novo, 2 annotated pair), strand (0 '+', 1 '-'), us_shift, ds_shift, motif. */
 int clo_splice_signal(const char* g, int64_t L, int64_t start, int64_t end, int32_t clip_base, int32_t host_mask,
                       int32_t search_extra, int32_t shift_threshold, int32_t is_canonical,
@@ -122,11 +130,13 @@ int clo_splice_signal(const char* g, int64_t L, int64_t start, int64_t end, int3
         us_free = j;
     }
     out[1] = us_free; out[2] = ds_free;
-    if (start - sl - us_free - 2 < 0 || end + sl + ds_free + 2 > L) { out[0] = 1; return 0; }      /* align.py:496-498 */
+    /* align.py:495-496: next to a contig end find_annotated_signal returns without looking at the annotation; the
+       de-novo search then runs on whatever Python's slices give there (negative start wraps, end is clipped) */
+    const int edge = start - sl - us_free - 2 < 0 || end + sl + ds_free + 2 > L;
 
     const int64_t* run[4]; int64_t cnt[4] = {0, 0, 0, 0};
     { int64_t at = 0; for (int k = 0; k < 4; ++k) { run[k] = site_pos ? site_pos + at : NULL; cnt[k] = site_cnt ? site_cnt[k] : 0; at += cnt[k]; } }
-    const int have_anno = cnt[0] + cnt[1] + cnt[2] + cnt[3] > 0;
+    const int have_anno = !edge && cnt[0] + cnt[1] + cnt[2] + cnt[3] > 0;
     int* us_anno[2]; int* ds_anno[2]; int n_us[2] = {0, 0}, n_ds[2] = {0, 0};
     for (int s = 0; s < 2; ++s) { us_anno[s] = (int*)malloc(sizeof(int) * (size_t)(4 * sl + 4)); ds_anno[s] = (int*)malloc(sizeof(int) * (size_t)(4 * sl + 4)); }
     list_t found = {NULL, 0, 0};
@@ -155,14 +165,17 @@ int clo_splice_signal(const char* g, int64_t L, int64_t start, int64_t end, int3
     /* ---- de-novo search (align.py:571-695) ---- */
     if (!rc_found) {
         const int us_len = sl + us_free, ds_len = sl + ds_free;
-        const char* us_seq = g + start - us_len - 2;                    /* [start - us_len - 2, start + ds_len) */
-        const char* ds_seq = g + end - us_len;                          /* [end - us_len, end + ds_len + 2)     */
-        const int wlen = us_len + ds_len + 2;
+        int64_t ua, nu, da, nd;
+        pyslice(L, start - us_len - 2, start + ds_len, &ua, &nu);       /* genome[start - us_len - 2 : start + ds_len] */
+        pyslice(L, end - us_len, end + ds_len + 2, &da, &nd);           /* genome[end - us_len : end + ds_len + 2]     */
+        const char* us_seq = g + ua;
+        const char* ds_seq = g + da;
+        const int short_seq = nu < ds_len - us_len + 2 || nd < ds_len - us_len + 2;      /* align.py:580-583: no search */
         const int OFF = us_len + sl + 2;                                /* shift -> index of the flag arrays */
         const int nflag = OFF + ds_len + sl + 4;
         char* fu = (char*)malloc((size_t)nflag); char* fd = (char*)malloc((size_t)nflag);
         const int host = host_mask & 3;
-        for (int round = 0; round < 2 && !found.n; ++round) {
+        for (int round = 0; round < 2 && !found.n && !short_seq; ++round) {
             int strands;
             if (round == 0) strands = host ? host : 3;                 /* no host gene: both strands at once */
             else { if (!host) break; strands = 3 & ~host; }
@@ -174,10 +187,8 @@ int clo_splice_signal(const char* g, int64_t L, int64_t start, int64_t end, int3
                     else { revcomp2(ACCEPTOR[m], ds_motif); revcomp2(DONOR[m], us_motif); }
                     memset(fu, 0, (size_t)nflag); memset(fd, 0, (size_t)nflag);
                     /* str.find from index 1 (align.py:604-611): occurrences at p >= 1, site = p - us_len */
-                    for (int p = 1; p + 2 <= wlen; ++p) {
-                        if (!memcmp(us_seq + p, us_motif, 2)) fu[p - us_len + OFF] = 1;
-                        if (!memcmp(ds_seq + p, ds_motif, 2)) fd[p - us_len + OFF] = 1;
-                    }
+                    for (int p = 1; p + 2 <= nu; ++p) if (!memcmp(us_seq + p, us_motif, 2)) fu[p - us_len + OFF] = 1;
+                    for (int p = 1; p + 2 <= nd; ++p) if (!memcmp(ds_seq + p, ds_motif, 2)) fd[p - us_len + OFF] = 1;
                     /* annotated shifts of this strand join the occurrences (align.py:612-621); sorted(set(...)) */
                     for (int a = 0; a < n_us[s]; ++a) fu[us_anno[s][a] + OFF] = 1;
                     for (int b = 0; b < n_ds[s]; ++b) fd[ds_anno[s][b] + OFF] = 1;

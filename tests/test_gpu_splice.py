@@ -112,18 +112,15 @@ def test_kernel_rows_match_python_statement(is_canonical, annotated):
     rows = dev.splice_signals([(c[0], c[1], c[2], c[3], (1 if c[4] and '+' in c[4] else 0) | (2 if c[4] and '-' in c[4] else 0)) for c in cands],
                               10, 3, is_canonical).tolist()
     motifs = list(align.SPLICE_SIGNAL)
-    n_dev = n_found = n_slide = n_minus = n_anno = 0
+    n_dev = n_found = n_slide = n_minus = n_anno = n_edge = 0
     for cand, r in zip(cands, rows):
         status, us_free, ds_free, found, strand, i, j, m = r
         want = _host_answer(align, cand, is_canonical)
-        if status:
-            # handed back: contig end or an ambiguous character in the flanks -- never silently wrong
-            ctg, st, en, cb, _ = cand
-            L = host.contig_len[ctg]
-            edge = st - (cb + 10) - want[1] - 2 < 0 or en + (cb + 10) + want[2] + 2 > L
-            flank = contigs[ctg][max(0, st - 100):st + 100] + contigs[ctg][max(0, en - 100):en + 100]
-            assert edge or any(ch not in 'ACGTacgtN' for ch in flank), cand
-            continue
+        # nothing is handed back: contig ends (Python's slice rules) and flanks with IUPAC / soft-masked characters
+        # (compared as characters) are the kernel's business too
+        assert status == 0, cand
+        ctg, st, en, cb, _ = cand
+        n_edge += st - (cb + 10) - want[1] - 2 < 0 or en + (cb + 10) + want[2] + 2 > host.contig_len[ctg]
         n_dev += 1
         got = None
         if found == 1:
@@ -141,7 +138,7 @@ def test_kernel_rows_match_python_statement(is_canonical, annotated):
         assert (got, us_free, ds_free) == want, (cand, r, want)
         n_slide += (us_free + ds_free) > 0
     # the cases are really exercised
-    assert n_dev > 0.8 * len(cands) and n_found > 0.4 * n_dev and n_slide > 0.3 * n_dev and n_minus > 0.1 * n_found
+    assert n_dev == len(cands) and n_edge > 0.01 * n_dev and n_found > 0.4 * n_dev and n_slide > 0.3 * n_dev and n_minus > 0.1 * n_found
     assert (n_anno > 0.1 * n_dev) if annotated else n_anno == 0
     dev.close(); ctx.close()
 
@@ -163,8 +160,7 @@ def test_kernel_rows_match_c_oracle(annotated):
     motifs = oracle_lib._SPLICE_MOTIFS
     n = 0
     for cand, r in zip(cands, rows):
-        if r[0]:
-            continue
+        assert r[0] == 0, cand
         ctg, st, en, cb, hs = cand
         want = oracle_lib.oracle_splice_signal(contigs[ctg], st, en, cb, hs, False, runs[ctg])
         assert want != 'edge', cand
@@ -179,7 +175,7 @@ def test_kernel_rows_match_c_oracle(annotated):
         assert (got, r[1], r[2]) == want, (cand, r, want)
         n += 1
     dev.close(); ctx.close()
-    assert n > 0.8 * len(cands)
+    assert n == len(cands)
 
 
 @pytest.mark.parametrize('annotated', [False, True])
@@ -219,5 +215,5 @@ def test_reference_goldens():
         n_anno += s['annotated'][0] is not None
         n_denovo += s['annotated'][0] is None and s['denovo'] is not None
     env.GENOME.device.close()
-    assert int((rows[:, 0] == 0).sum()) > 0.8 * len(cases)       # answered by the kernel, not handed back
+    assert int((rows[:, 0] == 0).sum()) == len(cases)            # every case answered by the kernel, none handed back
     assert n_anno >= 20 and n_denovo >= 20

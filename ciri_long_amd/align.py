@@ -426,8 +426,9 @@ def find_signal_batch(cands, is_canonical=True):
     cands = [(contig, start, end, clip_base, host_strand)] -> [(ss_site | None, us_free, ds_free)], each entry what
     find_annotated_signal followed (when it finds nothing) by find_denovo_signal(..., clip_base + 10, 3, is_canonical)
     gives.  When env.GENOME is resident on the GPU the candidates are scanned there (K6, splice_scan.hip; env.SS_INDEX
-    is uploaded once as sorted position runs); the candidates the kernel hands back (contig ends, characters other than
-    ACGTN) go through the functions above."""
+    is uploaded once as sorted position runs) -- contig ends and IUPAC / soft-masked flanks included; only candidates
+    the kernel cannot express (a host gene on a strand other than '+'/'-', a contig that is not resident, invalid
+    coordinates) go through the functions above."""
     out = [None] * len(cands)
     dev = getattr(env.GENOME, 'device', None)
     if not hasattr(dev, 'splice_signals'):

@@ -20,6 +20,7 @@ CLIP_MIN = 20            # find_bsj.py:191
 CLIP_MAX_FRACTION = 0.6  # find_bsj.py:193
 WINDOW_FLANK = 200000    # find_bsj.py:196-197
 WINDOW_MAX_N = 0.3       # find_bsj.py:200
+HOST_WINDOW_BYTES = 256 << 20   # host-window route: window bytes packed per GPU call
 
 
 def find_bsj(ccs):
@@ -126,7 +127,15 @@ def _run_clip_jobs(jobs):
                 res[k] = r
         return res
     from .ssw_wrap import align_pairs
-    res = align_pairs([j.window for j in jobs], [j.clip_seq for j in jobs], match=1, mismatch=1, gap_open=1, gap_extend=1)
+    # host-window route (no resident genome): a window is a string of up to 400 kb, so the jobs go to the GPU in groups
+    # of bounded size instead of one call holding every window of the chunk at once
+    res, group, size = [], [], 0
+    for j in jobs + [None]:
+        if j is None or (group and size + len(j.window) > HOST_WINDOW_BYTES):
+            res += align_pairs([x.window for x in group], [x.clip_seq for x in group], match=1, mismatch=1, gap_open=1, gap_extend=1)
+            group, size = [], 0
+        if j is not None:
+            group.append(j); size += len(j.window)
     for r in res:
         if r is None:   # the reference dereferences None here (find_bsj.py:206); make the failure explicit
             raise RuntimeError('Smith-Waterman of clipped bases returned no result')

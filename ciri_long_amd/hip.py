@@ -193,15 +193,16 @@ class Context(object):
         return o, mat
 
     def ssw_batch(self, reads, read_off, refs, ref_off, mat, gap_open, gap_extend, flag=1, score_size=2,
-                  want_score2=True, want_cigar=True, mask_len=None):
-        """Host arrays in, (rows: structured array, cigars: uint32 array) out."""
+                  want_score2=True, want_cigar=True, mask_len=None, filters=0, filterd=0):
+        """Host arrays in, (rows: structured array, cigars: uint32 array) out.  flag / filters / filterd as ssw_align
+        takes them (ssw.h:95-111: bit 1 score filter, bit 2 distance filter, bit 3 = bit 0 for the begin positions)."""
         L = lib()
         reads = np.ascontiguousarray(reads, dtype=np.int8)
         refs = np.ascontiguousarray(refs, dtype=np.int8)
         read_off = np.ascontiguousarray(read_off, dtype=np.int64)
         ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
         n = len(read_off) - 1
-        o, _keep = self._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar)
+        o, _keep = self._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, filters, filterd)
         out = np.zeros(n, dtype=ALIGN_DTYPE)
         cap = int(2 * (read_off[-1] if n else 0) + 2 * n + 8) if want_cigar else 1
         cig = np.zeros(cap, dtype=np.uint32)

@@ -86,7 +86,7 @@ def cigar_to_string(cig, qb, qe, qlen):
 
 
 def oracle_align(ref, query, match=1, mismatch=1, gap_open=1, gap_extend=1, flag=1, score_size=2, mat=None,
-                 maskl=None):
+                 maskl=None, filters=0, filterd=0):
     """Returns dict(score, score2, ref_begin, ref_end, query_begin, query_end, ref_end2, cigar(list), cigar_string)
     or None where the reference returns NULL."""
     r = encode(ref) if not isinstance(ref, np.ndarray) else ref
@@ -98,7 +98,7 @@ def oracle_align(ref, query, match=1, mismatch=1, gap_open=1, gap_extend=1, flag
     res = CloAlign()
     ml = mask_len(len(q)) if maskl is None else maskl
     rc = oracle().clo_ssw_align(q.ctypes.data, len(q), m.ctypes.data, n, score_size, r.ctypes.data, len(r),
-                                gap_open, gap_extend, flag, 0, 0, ml, C.byref(res))
+                                gap_open, gap_extend, flag, filters, filterd, ml, C.byref(res))
     if rc != 0:
         return None
     cig = [res.cigar[i] for i in range(res.cigarLen)]
@@ -135,7 +135,8 @@ def ref_lib():
     return _ref
 
 
-def ref_align(ref, query, match=1, mismatch=1, gap_open=1, gap_extend=1, flag=1, score_size=2, mat=None, maskl=None):
+def ref_align(ref, query, match=1, mismatch=1, gap_open=1, gap_extend=1, flag=1, score_size=2, mat=None, maskl=None,
+              filters=0, filterd=0):
     r = encode(ref) if not isinstance(ref, np.ndarray) else ref
     q = encode(query) if not isinstance(query, np.ndarray) else query
     r = np.ascontiguousarray(r, dtype=np.int8)
@@ -145,7 +146,7 @@ def ref_align(ref, query, match=1, mismatch=1, gap_open=1, gap_extend=1, flag=1,
     lib = ref_lib()
     prof = lib.ssw_init(q.ctypes.data, len(q), m.ctypes.data, n, score_size)
     ml = mask_len(len(q)) if maskl is None else maskl
-    p = lib.ssw_align(prof, r.ctypes.data, len(r), gap_open, gap_extend, flag, 0, 0, ml)
+    p = lib.ssw_align(prof, r.ctypes.data, len(r), gap_open, gap_extend, flag, filters, filterd, ml)
     if not p:
         lib.init_destroy(prof)
         return None

@@ -134,6 +134,28 @@ def test_options_score_size_flag_and_skips(ctx):
             (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end'])
 
 
+@pytest.mark.parametrize('flag', [2, 4, 8, 6, 10, 12, 14, 3, 5])
+def test_flag_bits_with_filters(ctx, flag):
+    """ssw_align's flag bits 1 (score filter: begin/CIGAR only if score >= filters) and 2 (distance filter: only if both
+    spans <= filterd) and bit 3 (begin positions), with thresholds that split the batch (ssw.c:834, 850): every field
+    and every CIGAR (or its absence) equals the scalar statement of ssw.c."""
+    rng = np.random.default_rng(500 + flag)
+    refs = [_rnd(rng, int(rng.integers(200, 700))) for _ in range(60)]
+    qs = [_mut(r[50:50 + int(rng.choice([30, 60, 120, 250]))], rng, float(rng.choice([0.0, 0.1, 0.25]))) for r in refs]
+    filters, filterd = 55, 100
+    rows, cig = _run(ctx, refs, qs, (1, 1, 1, 1), flag=flag, filters=filters, filterd=filterd)
+    n_with = n_without = n_begin = 0
+    for ref, q, r in zip(refs, qs, rows):
+        want = oracle_align(ref, q, 1, 1, 1, 1, flag=flag, filters=filters, filterd=filterd)
+        assert _row_tuple(r) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
+                                 want['query_end'], want['ref_end2']), (flag, len(q), _row_tuple(r), want)
+        assert [int(x) for x in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (flag, len(q))
+        n_with += len(want['cigar']) > 0
+        n_without += len(want['cigar']) == 0
+        n_begin += want['ref_begin'] >= 0
+    assert n_begin > 0 and (not (flag & 6) or (n_with > 0 and n_without > 0))       # the thresholds really split the batch
+
+
 def test_reference_test_ssw_orientation_430kb_query(ctx, testfa):
     """tests/test_ssw.py:5-15 of the reference: Aligner(seq1 (437 nt)) . align(seq2 (430 314 nt)) -- the QUERY is the long
     sequence, so its rows do not fit one launch class and run as 106 row strips of 4096."""

@@ -80,3 +80,19 @@ def test_flag_variants(flag):
         ref = _rnd(rng, 400)
         q = _mutate(ref[50:250], rng)
         assert oracle_align(ref, q, 2, 2, 3, 1, flag=flag) == ref_align(ref, q, 2, 2, 3, 1, flag=flag)
+
+
+@pytest.mark.parametrize('flag', [2, 4, 6, 8, 10, 12, 14, 3, 5])
+def test_flag_bits_with_filters(flag):
+    """flag bits 1/2 with thresholds that split the inputs (ssw.c:834, 850): the scalar statement equals the reference's
+    own library on every field and CIGAR (the GPU test of the same name holds the kernels to the statement)."""
+    rng = np.random.default_rng(600 + flag)
+    n_with = n_without = 0
+    for _ in range(60):
+        ref = _rnd(rng, int(rng.integers(200, 700)))
+        q = _mutate(ref[50:50 + int(rng.choice([30, 60, 120, 250]))], rng)
+        a = oracle_align(ref, q, 1, 1, 1, 1, flag=flag, filters=55, filterd=100)
+        b = ref_align(ref, q, 1, 1, 1, 1, flag=flag, filters=55, filterd=100)
+        assert a == b
+        n_with += bool(a['cigar']); n_without += not a['cigar']
+    assert not (flag & 6) or (n_with > 0 and n_without > 0)

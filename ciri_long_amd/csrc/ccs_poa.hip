@@ -219,7 +219,13 @@ __global__ void __launch_bounds__(64) ccs_scan_long_kernel(const CcsParams p)
 // The row-at-a-time formulation computed here is stated and proven equal to the oracle's five-matrix statement on the
 // CPU in tools/poa_model.py (tests/test_poa_model.py).  Per cell the kernel leaves ONE byte from which spoa's
 // value-comparing back-track is replayed (rows with several in-edges leave 16 more bits: the in-edge slots).
-static constexpr int B_ZERO = 1, B_DIAG = 2, B_VERT = 4, B_EXTUP = 8, B_EXTLEFT = 16, B_HX = 32, B_VSTOP = 64;
+// One byte per cell.  Bits 0-5: the move spoa's back-track takes out of the cell, as 62 - (its place in spoa's checking
+// order): 63 the cell is zero (local mode: stop); 62-s diagonal through in-edge s; 50 - 3s - {0, 1, 2} vertical through
+// in-edge s by F+e (the run goes on upwards), H+g, O+c (goes on); 14 / 13 / 12 horizontal by E+e (goes on to the left),
+// H+g, Q+c (goes on).  Bit 6 (hx): the E or Q chain of this column extends the previous column's.  Bit 7 (vstop): an
+// upward run ends with the step out of this cell.  Rows with several in-edges keep, in a second plane, the in-edge an
+// upward run leaves the cell through.
+static constexpr int CODE_ZERO = 63, CODE_DIAG = 62, CODE_VERT = 50, CODE_HORZ = 14, B_HX = 64, B_VSTOP = 128;
 static constexpr int POA_NEG = -30000;               // "minus infinity" of a stored (int16) cell
 static constexpr int POA_MAX_ROWS = 65000;           // ranks travel in 16 bits
 
@@ -229,7 +235,7 @@ struct PoaWs {            // views into one wave's workspace slot
     uint2* ri; uint32_t* rx; uint32_t* tab; int32_t* score; int32_t* bp; short* col0;     // rank space
     short* carry; int cpitch;
     uint8_t* dp; size_t dp_bytes;                                            // the rest of the slot: DP planes of the current sequence
-    uint8_t* dirA; uint16_t* dirB; short* keepH; uint8_t* keepD;             // set per sequence (poa_add)
+    uint8_t* dirA; uint8_t* dirB; short* keepH; uint8_t* keepD;             // set per sequence (poa_add)
 };
 
 // row pitch (elements) of the DP planes for a sequence of m bases: column j sits at element j+7,
@@ -253,11 +259,11 @@ __host__ __device__ inline size_t poa_fixed_bytes(int ncap, int mcap, int* cpitc
     add(ncap); add(ncap);                                                                                  // base np
     return o;
 }
-// DP planes of one sequence against N rows: byte plane, slot plane of nm rows, kept rows (H int16 + vertical states int8)
+// DP planes of one sequence against N rows: byte plane, slot plane (one byte) of nm rows, kept rows (H int16 + vertical states int8)
 __host__ __device__ inline size_t poa_dp_bytes(int N, int m, int nm, int nk)
 {
     const size_t gp = (size_t)poa_pitch(m);
-    return (((size_t)(N + 1) * gp + 15) & ~(size_t)15) + (size_t)nm * gp * 2 + (size_t)nk * gp * 2 + (size_t)nk * gp + 64;
+    return (((size_t)(N + 1) * gp + 15) & ~(size_t)15) + (((size_t)nm * gp + 15) & ~(size_t)15) + (size_t)nk * gp * 2 + (size_t)nk * gp + 64;
 }
 __host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)       // worst case: every row has several in-edges and is kept
 {
@@ -443,44 +449,50 @@ __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const i
                         asm volatile("" : "+v"(hprev));
                     }
                 };
-                int m0[C], fsn[C], osn[C], pb[C], slots[C];
+                // Every candidate of a cell travels as (value << 6) | code, code = 62 - (its place in spoa's checking order): one
+                // signed max takes the larger value and, between equal values, the move spoa's back-track would find first;
+                // the winner's low six bits ARE the cell's back-track code (csrc comment at CODE_*).
+                int PM[C], fsn[C], osn[C], xb[C];                // packed best of the non-horizontal moves; vertical states; bit 7 (vstop) and, rows with several in-edges, the slot of the upward run
                 if (np <= 1) {
                     int h[C], hprev, fs[C], os[C];
                     source(np == 0 ? 0 : p0, h, hprev, fs, os);
+                    const int kFE = (g << 6) + CODE_VERT, kFO = (g << 6) + CODE_VERT - 1, kOE = (q << 6) + CODE_VERT - 2;
 #pragma unroll
                     for (int k = 0; k < C; ++k) {
-                        const int d = (k == 0 ? hprev : h[k - 1]) + ss[k];
                         const int fe = fs[k], fo = h[k], oe = os[k];
+                        const int p1 = ((k == 0 ? hprev : h[k - 1]) << 6) + ((ss[k] << 6) + CODE_DIAG);
+                        const int p2 = (fe << 6) + kFE, p3 = (fo << 6) + kFO, p4 = (oe << 6) + kOE;
+                        int pm = p1 > p2 ? p1 : p2;
+                        pm = p3 > pm ? p3 : pm;
+                        pm = p4 > pm ? p4 : pm;
+                        if (sw) pm = pm > CODE_ZERO ? pm : CODE_ZERO;
+                        PM[k] = pm;
                         const int mx = fe > fo ? fe : fo, mo = oe > fo ? oe : fo;
-                        const int fnew = g + mx, onew = q + mo;
-                        int mm = d > fnew ? d : fnew;
-                        mm = onew > mm ? onew : mm;
-                        if (sw) mm = mm > 0 ? mm : 0;
-                        m0[k] = mm; fsn[k] = e + mx; osn[k] = c + mo;
-                        const bool cFE = fe + g == mm, cFO = fo + g == mm, cOE = oe + q == mm;
-                        int b = 0;
-                        b |= d == mm ? B_DIAG : 0;
-                        b |= (cFE | cFO | cOE) ? B_VERT : 0;
-                        b |= (cFE | (!cFO & cOE)) ? B_EXTUP : 0;
-                        b |= fo >= fe ? B_VSTOP : 0;
-                        pb[k] = b; slots[k] = 0;
+                        fsn[k] = e + mx; osn[k] = c + mo;
+                        xb[k] = fo >= fe ? 128 : 0;
                     }
                 } else {
-                    // several in-edges: every class keeps (value << 8) | (15 - slot): one signed max takes the larger value
-                    // and, between equal values, the earlier in-edge
-                    int D[C], FE[C], FO[C], OE[C];
+                    int MX[C], MO[C], XF[C], XO[C];
 #pragma unroll
-                    for (int k = 0; k < C; ++k) { D[k] = NEGB; FE[k] = NEGB; FO[k] = NEGB; OE[k] = NEGB; }
+                    for (int k = 0; k < C; ++k) { PM[k] = sw ? CODE_ZERO : NEGB; MX[k] = NEGB; MO[k] = NEGB; XF[k] = NEGB; XO[k] = NEGB; }
                     auto add_source = [&](int slot, int qr) {
                         int h[C], hprev, fs[C], os[C];
                         source(qr, h, hprev, fs, os);
-                        const int code = 15 - slot;
+                        const int kFE = (g << 6) + CODE_VERT - 3 * slot, kFO = kFE - 1, kOE = (q << 6) + CODE_VERT - 3 * slot - 2;
+                        const int xo = 2 * (POA_MAXP - slot) + 1, xe = xo - 1;       // upward run: open before extend, earlier in-edge first
 #pragma unroll
                         for (int k = 0; k < C; ++k) {
-                            const int dv = (((k == 0 ? hprev : h[k - 1]) + ss[k]) << 8) | code;
-                            const int fev = (fs[k] << 8) | code, fov = (h[k] << 8) | code, oev = (os[k] << 8) | code;
-                            D[k] = dv > D[k] ? dv : D[k]; FE[k] = fev > FE[k] ? fev : FE[k];
-                            FO[k] = fov > FO[k] ? fov : FO[k]; OE[k] = oev > OE[k] ? oev : OE[k];
+                            const int fe = fs[k], fo = h[k], oe = os[k];
+                            const int p1 = ((k == 0 ? hprev : h[k - 1]) << 6) + ((ss[k] << 6) + CODE_DIAG - slot);
+                            const int p2 = (fe << 6) + kFE, p3 = (fo << 6) + kFO, p4 = (oe << 6) + kOE;
+                            int pm = PM[k] > p1 ? PM[k] : p1;
+                            pm = p2 > pm ? p2 : pm; pm = p3 > pm ? p3 : pm; pm = p4 > pm ? p4 : pm;
+                            PM[k] = pm;
+                            int t = fe > fo ? fe : fo; MX[k] = t > MX[k] ? t : MX[k];
+                            t = oe > fo ? oe : fo; MO[k] = t > MO[k] ? t : MO[k];
+                            const int q1 = (fo << 6) + xo, q2 = (fe << 6) + xe, q3 = (oe << 6) + xe;
+                            t = q1 > q2 ? q1 : q2; XF[k] = t > XF[k] ? t : XF[k];
+                            t = q1 > q3 ? q1 : q3; XO[k] = t > XO[k] ? t : XO[k];
                         }
                     };
                     add_source(0, p0);
@@ -492,58 +504,44 @@ __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const i
                     }
 #pragma unroll
                     for (int k = 0; k < C; ++k) {
-                        const int d = D[k] >> 8, fe = FE[k] >> 8, fo = FO[k] >> 8, oe = OE[k] >> 8;
-                        const int kd = 15 - (D[k] & 15), kfe = 15 - (FE[k] & 15), kfo = 15 - (FO[k] & 15), koe = 15 - (OE[k] & 15);
-                        const int mx = fe > fo ? fe : fo, mo = oe > fo ? oe : fo;
-                        const int fnew = g + mx, onew = q + mo;
-                        int mm = d > fnew ? d : fnew;
-                        mm = onew > mm ? onew : mm;
-                        if (sw) mm = mm > 0 ? mm : 0;
-                        m0[k] = mm; fsn[k] = e + mx; osn[k] = c + mo;
-                        const int big = 1 << 20;
-                        const int k1 = fe + g == mm ? kfe * 4 + 0 : big, k2 = fo + g == mm ? kfo * 4 + 1 : big, k3 = oe + q == mm ? koe * 4 + 2 : big;
-                        int key = k1 < k2 ? k1 : k2;
-                        key = k3 < key ? k3 : key;
-                        const int x1 = fo >= fe ? kfo * 4 + 0 : big, x2 = fe >= fo ? kfe * 4 + 1 : big, x3 = fo >= oe ? kfo * 4 + 2 : big, x4 = oe >= fo ? koe * 4 + 3 : big;
-                        int keyx = x1 < x2 ? x1 : x2;
-                        keyx = x3 < keyx ? x3 : keyx;
-                        keyx = x4 < keyx ? x4 : keyx;
-                        int b = 0;
-                        b |= d == mm ? B_DIAG : 0;
-                        b |= key < big ? B_VERT : 0;
-                        b |= (key < big && (key & 3) != 1) ? B_EXTUP : 0;
-                        b |= (keyx & 1) == 0 ? B_VSTOP : 0;
-                        pb[k] = b;
-                        slots[k] = kd | ((key < big ? key >> 2 : 0) << 4) | ((keyx >> 2) << 8);
+                        fsn[k] = e + MX[k]; osn[k] = c + MO[k];
+                        // the in-edge an upward run leaves this cell through: the first with F == H+g (last step), F == F+e, O == H+q
+                        // (last step), O == O+c, in that order
+                        const int cf = XF[k] & 63, co = XO[k] & 63;
+                        const int sF = POA_MAXP - (cf >> 1), sO = POA_MAXP - (co >> 1);
+                        const bool useF = sF <= sO;
+                        const int slot = useF ? sF : sO, open = useF ? (cf & 1) : (co & 1);
+                        xb[k] = (open ? 128 : 0) | (slot << 8);
                     }
                 }
                 // horizontal states: two prefix maxima in the gap-free frames of the two pieces
-                int ehat[C], qhat[C];
+                int ehat[C], qhat[C], H[C];
                 {
                     int a[C], pe[C];
                     const int leftE = cinH > cinE + e - g ? cinH : cinE + e - g;       // = E[first column of the pass] - g
 #pragma unroll
-                    for (int k = 0; k < C; ++k) a[k] = m0[k] - (jl0 + k) * e;
+                    for (int k = 0; k < C; ++k) a[k] = (PM[k] >> 6) - (jl0 + k) * e;
                     scan_left<C>(a, leftE, pe);
 #pragma unroll
                     for (int k = 0; k < C; ++k) ehat[k] = pe[k] + (g - e) + (jl0 + k) * e;
                     const int leftQ = cinH > cinQ + c - q ? cinH : cinQ + c - q;
 #pragma unroll
-                    for (int k = 0; k < C; ++k) a[k] = m0[k] - (jl0 + k) * c;
+                    for (int k = 0; k < C; ++k) a[k] = (PM[k] >> 6) - (jl0 + k) * c;
                     scan_left<C>(a, leftQ, pe);
 #pragma unroll
                     for (int k = 0; k < C; ++k) qhat[k] = pe[k] + (q - c) + (jl0 + k) * c;
                 }
-                int H[C], E[C];
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
-                    int hh = m0[k] > ehat[k] ? m0[k] : ehat[k];
+                    const int m0 = PM[k] >> 6;
+                    int hh = m0 > ehat[k] ? m0 : ehat[k];
                     H[k] = qhat[k] > hh ? qhat[k] : hh;
                 }
                 // the neighbour's value is fetched by every lane BEFORE the select: a DPP read executed under an exec mask that
                 // excludes lane 0 would find its source lane disabled
                 const int qsh = dpp_shr1(0, qhat[C - 1]);
                 const int qleft = lane == 0 ? cinQ : qsh;
+                int E[C];
 #pragma unroll
                 for (int k = 0; k < C; ++k) {                    // E as spoa holds it: a gap may open on a cell reached by the other piece
                     const int qp = (k == 0 ? qleft : qhat[k - 1]) + g;
@@ -553,15 +551,18 @@ __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const i
                 const int hleft = lane == 0 ? cinH : hsh;
                 const int eleft = lane == 0 ? cinE : esh;
                 int out[C];
+                {
+                    const int kE = (e << 6) + CODE_HORZ, kG = (g << 6) + CODE_HORZ - 1, kC = (c << 6) + CODE_HORZ - 2, kQ = (q << 6) + CODE_HORZ - 3;
 #pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const int hl = k == 0 ? hleft : H[k - 1], ep = k == 0 ? eleft : E[k - 1], qp = k == 0 ? qleft : qhat[k - 1];
-                    int b = H[k] == m0[k] ? pb[k] & (B_DIAG | B_VERT | B_EXTUP) : 0;
-                    b |= pb[k] & B_VSTOP;
-                    b |= (sw && H[k] == 0) ? B_ZERO : 0;
-                    b |= ((H[k] == ep + e) | !(H[k] == hl + g)) ? B_EXTLEFT : 0;
-                    b |= ((ep + e == E[k]) | (qp + c == qhat[k])) ? B_HX : 0;
-                    out[k] = b;
+                    for (int k = 0; k < C; ++k) {
+                        const int hl = k == 0 ? hleft : H[k - 1], ep = k == 0 ? eleft : E[k - 1], qp = k == 0 ? qleft : qhat[k - 1];
+                        const int p5 = (ep << 6) + kE, p6 = (hl << 6) + kG, p7 = (qp << 6) + kC, p8 = (hl << 6) + kQ;
+                        int ph = p5 > p6 ? p5 : p6;
+                        ph = p7 > ph ? p7 : ph;
+                        const int pf = PM[k] > ph ? PM[k] : ph;
+                        // hx: E or Q of this column extends the previous column's (E[j-1]+e >= H[j-1]+g, Q[j-1]+c >= H[j-1]+q)
+                        out[k] = (pf & 63) | ((p5 >= p6) | (p7 >= p8) ? 64 : 0) | (xb[k] & 128);
+                    }
                 }
                 // ---- what later rows and the back-track read --------------------------------------------------------------
 #pragma unroll
@@ -586,9 +587,9 @@ __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const i
                         if constexpr (C == 3) dd[2] = (uint8_t)(w0 >> 16);
                     }
                     if (np > 1) {
-                        uint16_t* db = w.dirB + (size_t)mi * gp + col0 + 8;
+                        uint8_t* db = w.dirB + (size_t)mi * gp + col0 + 8;
 #pragma unroll
-                        for (int k = 0; k < C; ++k) db[k] = (uint16_t)slots[k];
+                        for (int k = 0; k < C; ++k) db[k] = (uint8_t)(xb[k] >> 8);
                     }
                     if (tolds | keep) {
                         int dv[C];
@@ -754,7 +755,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
             const size_t gp = (size_t)pitch;
             size_t o = ((size_t)(N + 1) * gp + 15) & ~(size_t)15;
             w.dirA = w.dp;
-            w.dirB = (uint16_t*)(w.dp + o); o += (size_t)nm * gp * 2;
+            w.dirB = w.dp + o; o += (((size_t)nm * gp + 15) & ~(size_t)15);
             w.keepH = (short*)(w.dp + o); o += (size_t)nk * gp * 2;
             w.keepD = w.dp + o;
         }
@@ -804,7 +805,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
         const int gp = poa_pitch(m);
         int r0 = -64, j0 = -64;
         uint32_t pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, ri = 0;     // lane l: row r0-(l>>1), columns j0-16*(l&1)-15 .. j0-16*(l&1)
-        uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, pb4 = 0, pb5 = 0, pb6 = 0, pb7 = 0;
+        uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;
         int buf = 0, mode = 0;                                   // mode 1: inside an upward run, 2: inside a leftward run
         const bool sw = S.algorithm == 0;
         int guard = 2 * (N + m) + 64;                           // every step lowers r or j: a longer walk means corrupt planes
@@ -814,7 +815,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
             if ((unsigned)a >= 32u || (unsigned)b >= 32u) {
                 r0 = r; j0 = j;
                 const int rr = r - (lane >> 1), jlo = j - 16 * (lane & 1) - 15;       // lowest column of this lane's 16
-                pa0 = pa1 = pa2 = pa3 = 0; pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = 0; ri = 0;
+                pa0 = pa1 = pa2 = pa3 = 0; pb0 = pb1 = pb2 = pb3 = 0; ri = 0;
                 if (rr >= 1) {
                     const uint2 gr = w.ri[rr];
                     ri = (lane & 1) ? gr.y : gr.x;
@@ -825,10 +826,9 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
                         __builtin_memcpy(t, src, 16);
                         pa0 = t[0]; pa1 = t[1]; pa2 = t[2]; pa3 = t[3];
                         if (((gr.x >> 8) & 0xf) > 1) {
-                            const uint16_t* sb2 = w.dirB + (size_t)(w.rx[rr] & 0xffff) * gp + 7 + jlo;
-                            uint32_t u[8];
-                            __builtin_memcpy(u, sb2, 32);
-                            pb0 = u[0]; pb1 = u[1]; pb2 = u[2]; pb3 = u[3]; pb4 = u[4]; pb5 = u[5]; pb6 = u[6]; pb7 = u[7];
+                            const uint8_t* sb2 = w.dirB + (size_t)(w.rx[rr] & 0xffff) * gp + 7 + jlo;
+                            __builtin_memcpy(t, sb2, 16);
+                            pb0 = t[0]; pb1 = t[1]; pb2 = t[2]; pb3 = t[3];
                         }
                     }
                 }
@@ -840,12 +840,6 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
             const int d = (__builtin_amdgcn_readlane((int)sela, src_lane) >> ((idx & 3) * 8)) & 0xff;
             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2), g1 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2 + 1);
             const int np = (int)((g0 >> 8) & 0xf);
-            int sl = 0;
-            if (np > 1) {
-                const int w2 = idx >> 1;
-                const uint32_t selb = w2 == 0 ? pb0 : (w2 == 1 ? pb1 : (w2 == 2 ? pb2 : (w2 == 3 ? pb3 : (w2 == 4 ? pb4 : (w2 == 5 ? pb5 : (w2 == 6 ? pb6 : pb7))))));
-                sl = (__builtin_amdgcn_readlane((int)selb, src_lane) >> ((idx & 1) * 16)) & 0xffff;
-            }
             auto pred_rank = [&](int s2) -> int {
                 if (np == 0) return 0;
                 if (s2 == 0) return (int)(g0 >> 16);
@@ -855,7 +849,12 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
                 return __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + s2]]);
             };
             if (mode == 1) {                                     // upward run: one more node without a base
-                r = pred_rank((sl >> 8) & 15);
+                int sl = 0;
+                if (np > 1) {
+                    const uint32_t selb = (idx >> 2) == 0 ? pb0 : ((idx >> 2) == 1 ? pb1 : ((idx >> 2) == 2 ? pb2 : pb3));
+                    sl = (__builtin_amdgcn_readlane((int)selb, src_lane) >> ((idx & 3) * 8)) & 0xff;
+                }
+                r = pred_rank(sl);
                 if (d & B_VSTOP) mode = 0;
                 continue;
             }
@@ -866,20 +865,23 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
                 if (!(d & B_HX)) mode = 0;
                 continue;
             }
-            if (sw && (d & B_ZERO)) break;
-            if (d & B_DIAG) {
+            const int code = d & 63;
+            if (code == CODE_ZERO) break;                        // local mode only: nothing else carries this code
+            if (code > CODE_VERT) {                              // diagonal through in-edge CODE_DIAG - code
                 --j;
                 buf = lane == (j & 63) ? r : buf;
                 if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
-                r = pred_rank(sl & 15);
-            } else if (d & B_VERT) {
-                r = pred_rank((sl >> 4) & 15);
-                mode = (d & B_EXTUP) ? 1 : 0;
-            } else {
+                r = pred_rank(CODE_DIAG - code);
+            } else if (code > CODE_HORZ) {                       // vertical: in-edge v / 3, by F+e, H+g, O+c (v % 3)
+                const int v = CODE_VERT - code;
+                const int slot = v / 3;
+                r = pred_rank(slot);
+                mode = (v - 3 * slot) != 1 ? 1 : 0;
+            } else {                                             // horizontal by E+e, H+g, Q+c
                 --j;
                 buf = lane == (j & 63) ? 0 : buf;
                 if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
-                mode = (d & B_EXTLEFT) ? 2 : 0;
+                mode = code != CODE_HORZ - 1 ? 2 : 0;
             }
         }
         int fill_to = j;

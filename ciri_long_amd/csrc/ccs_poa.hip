@@ -561,7 +561,7 @@ __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const i
                         ph = p7 > ph ? p7 : ph;
                         const int pf = PM[k] > ph ? PM[k] : ph;
                         // hx: E or Q of this column extends the previous column's (E[j-1]+e >= H[j-1]+g, Q[j-1]+c >= H[j-1]+q)
-                        out[k] = (pf & 63) | ((p5 >= p6) | (p7 >= p8) ? 64 : 0) | (xb[k] & 128);
+                        out[k] = (pf & 63) | (((p5 >= p6) | (p7 >= p8)) ? 64 : 0) | (xb[k] & 128);
                     }
                 }
                 // ---- what later rows and the back-track read --------------------------------------------------------------

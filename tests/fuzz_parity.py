@@ -1,5 +1,5 @@
 """Randomised parity hunt, larger than the test-suite: many seeds, shapes and scoring schemes against the CPU oracles.
-   python tools/fuzz_parity.py [minutes]      (prints the first mismatch and exits non-zero)"""
+   python tests/fuzz_parity.py [minutes]      (prints the first mismatch and exits non-zero)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

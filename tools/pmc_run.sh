@@ -10,11 +10,11 @@ i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $grp -d /tmp/pmc_$i -o run -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu "$@" > /tmp/pmc_$i.log 2>&1
+  rocprofv3 --pmc $grp -d /tmp/pmc_$i -o run -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extra "$@" > /tmp/pmc_$i.log 2>&1
 done
 python3 $GRAFT_REPO_ROOT/tools/rocpd_summary.py counters $(find /tmp/pmc_* -name "*.db" | sort) > $out/${tag}_pmc_summary.csv
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o run -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu "$@" > $out/${tag}_bench_profiled.json 2> /tmp/kt.err
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o run -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extra "$@" > $out/${tag}_bench_profiled.json 2> /tmp/kt.err
 python3 $GRAFT_REPO_ROOT/tools/rocpd_summary.py kernels $(find /tmp/kt -name "*.db" | head -1) > $out/${tag}_kernel_stats.csv
 tail -1 $out/${tag}_bench_profiled.json | cut -c1-300
 grep "poa_consensus\|ssw_align" $out/${tag}_pmc_summary.csv

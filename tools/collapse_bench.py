@@ -52,17 +52,6 @@ out = {'clusters': ncl, 'reads': len(reads), 'pairs': len(xs),
        'k4_ms': round(t_k4 * 1e3, 2), 'k4_pairs_per_s': round(len(xs) / t_k4), 'k4_gcups': round(cells / t_k4 / 1e9, 1),
        'junction_ssw_ms': round(t_ssw * 1e3, 2), 'junction_ssw_aln_per_s': round(len(reads) / t_ssw),
        'reads_per_s_both': round(len(reads) / (t_k4 + t_ssw))}
-try:
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
-    import oracle_lib
-    k = 1500
-    t0 = time.perf_counter()
-    want = [oracle_lib.oracle_edit_distance(x, y) for x, y in zip(xs[:k], ys[:k])]
-    dc = time.perf_counter() - t0
-    assert list(d[:k]) == want
-    out['cpu_statement_pairs_per_s_1core'] = round(k / dc)
-except ImportError:
-    pass
 refs = [''.join(B[b] for b in rng.integers(0, 4, 20)) for _ in range(2500 * min(ncl, 40))]
 qs = [''.join(B[b] for b in rng.integers(0, 4, 50))] * len(refs)
 ssw_wrap.align_pairs(refs[:100], qs[:100], 10, 4, 8, 2)

@@ -321,9 +321,9 @@ static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whos
 #define POA_WAVES 4
 #endif
 __device__ __forceinline__ int poa_cols(int m) { const int c = (m + 63) >> 6; return c < 2 ? 2 : (c > POA_MAXC ? POA_MAXC : c); }
+__device__ __forceinline__ int poa_ring_pitch(int m) { const int W = 64 * poa_cols(m); return poa_pitch(m < W ? m : W); }   // LDS row pitch: the widest pass
 __device__ __forceinline__ int poa_ring(int m) {
-    const int W = 64 * poa_cols(m);
-    const int lp = poa_pitch(m < W ? m : W);
+    const int lp = poa_ring_pitch(m);
     int ring = 16;                                   // power of two, so slot = rank & (ring-1); a ring row is 3 bytes per element
     while (ring * lp * 3 > POA_LDS_BYTES) ring >>= 1;
     return ring;
@@ -355,24 +355,26 @@ __device__ __forceinline__ void scan_left(const int (&a)[C], int left, int (&pe)
 // (w.ri, w.rx) and carries are streamed 64 rows at a time into one register per lane and read with v_readlane; LDS holds
 // the ring of the last RING rows (H int16, vertical states one byte) for near sources that are not the row before -- that
 // one is forwarded from registers; far sources come from "kept" rows in HBM.
+// One pass: the columns colbase+1 .. colbase+64*C (the last pass of a sequence may be narrower and then takes fewer
+// columns per lane: a row step costs a fixed part plus a part per column).  `pass` numbers the passes of the sequence
+// (carry buffers alternate), bs/br/bc carry the end cell across the passes.
 template <int C>
-__device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out, int& bc_out)
+__device__ void dp_pass(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int pass, const int colbase,
+                        const bool more, const int RING, int& bs, int& br, int& bc)
 {
     constexpr int NEGB = -(1 << 30);
     constexpr int W = 64 * C;
-    const int npass = (m + W - 1) / W;
     const int gp = poa_pitch(m);
-    const int lp = poa_pitch(m < W ? m : W);
-    const int RING = poa_ring(m), rmask = RING - 1;
+    const int lp = poa_ring_pitch(m);
+    const int rmask = RING - 1;
     const bool sw = S.algorithm == 0, nw = S.algorithm == 1;
     const int g = S.g, e = S.e, q = S.q, c = S.c, sm = S.m, sn = S.n;
     short* ringH = (short*)poa_lds;
     uint8_t* ringD = (uint8_t*)(ringH + RING * lp);
-    const int lm = ((m - 1) % W) / C, km = (m - 1) % C;          // where column m lives in the last pass
-    int bs = sw ? 0 : NEGB, br = 0, bc = 0;
-    for (int pass = 0; pass < npass; ++pass) {
-        const int col0 = pass * W + C * lane;                    // cell k is column col0+k+1, element col0+k+8 of an HBM row
-        const bool more = pass + 1 < npass, last = !more;
+    const int lm = (m - 1 - colbase) / C, km = (m - 1 - colbase) % C;      // where column m lives (last pass)
+    {
+        const int col0 = colbase + C * lane;                     // cell k is column col0+k+1, element col0+k+8 of an HBM row
+        const bool last = !more;
         int sb[C];                                               // this lane's bases (100: beyond the sequence)
 #pragma unroll
         for (int k = 0; k < C; ++k) { const int j = col0 + k + 1; sb[k] = j <= m ? (int)seq[j - 1] : 100; }
@@ -642,6 +644,34 @@ __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const i
         }
         if (more) phase_sync();
     }
+}
+
+// DP rows of one sequence: passes of 256 columns (4 per lane); the last pass takes 2..4 columns per lane by its width
+__device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out, int& bc_out)
+{
+    constexpr int NEGB = -(1 << 30);
+    constexpr int WMAX = 64 * POA_MAXC;
+    const int RING = poa_ring(m);
+    int bs = S.algorithm == 0 ? 0 : NEGB, br = 0, bc = 0;
+    int pass = 0;
+    for (int colbase = 0; colbase < m; colbase += WMAX, ++pass) {
+        const int rem = m - colbase;
+        const bool more = rem > WMAX;
+        const int cw = more ? POA_MAXC : poa_cols(rem);
+        switch (cw) {
+            case 2: dp_pass<2>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
+            case 3: dp_pass<3>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
+#if POA_MAXC > 4
+            case 4: dp_pass<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
+            case 5: dp_pass<5>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
+            case 6: dp_pass<6>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
+            case 7: dp_pass<7>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
+            default: dp_pass<8>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
+#else
+            default: dp_pass<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
+#endif
+        }
+    }
     // best over the lanes: value descending, rank ascending, column ascending
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -778,19 +808,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
             }
         }
         phase_sync();
-        switch (poa_cols(m)) {            // columns per lane: the smallest that covers the sequence in one pass (8 beyond 512)
-            case 2: dp_rows<2>(w, S, N, m, seq, lane, bs, br, bc); break;
-            case 3: dp_rows<3>(w, S, N, m, seq, lane, bs, br, bc); break;
-#if POA_MAXC > 4
-            case 4: dp_rows<4>(w, S, N, m, seq, lane, bs, br, bc); break;
-            case 5: dp_rows<5>(w, S, N, m, seq, lane, bs, br, bc); break;
-            case 6: dp_rows<6>(w, S, N, m, seq, lane, bs, br, bc); break;
-            case 7: dp_rows<7>(w, S, N, m, seq, lane, bs, br, bc); break;
-            default: dp_rows<8>(w, S, N, m, seq, lane, bs, br, bc); break;
-#else
-            default: dp_rows<4>(w, S, N, m, seq, lane, bs, br, bc); break;
-#endif
-        }
+        dp_rows(w, S, N, m, seq, lane, bs, br, bc);
         phase_sync();
     }
     *score_out = bs;

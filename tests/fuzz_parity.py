@@ -13,7 +13,7 @@ ctx = hip.default_context()
 B = 'ACGT'
 seed = int(time.time()) & 0xffff
 print('seed base', seed, flush=True)
-n_ssw = n_ccs = n_ed = n_null = n_ss = 0
+n_ssw = n_ccs = n_ed = n_null = n_ss = n_poa = 0
 it = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed + it)
@@ -71,6 +71,20 @@ while time.time() < t_end:
             np.save('gpurun_out/fuzz_fail_read.npy', r)
             print('CCS MISMATCH seed', seed + it - 1, 'k', k, len(r), str(got[k][0])[:80], str(w[0])[:80]); sys.exit(1)
     n_ccs += len(reads)
+    # ---- spoa.poa call shape: modes, score sets, MSA, end-cell scores ----
+    import random
+    from test_gpu_ccs import PARS, _family
+    prng = random.Random(seed + it)
+    for _ in range(25):
+        fam = _family(prng, prng.choice([15, 40, 90, 150, 300, 520, 900, 1500]), prng.randint(2, 14), prng.choice([0, 0.05, 0.15, 0.3]),
+                      prng.choice(['ACGT', 'ACGT', 'AC', 'ACGTN']))
+        alg = prng.choice([0, 1, 2]); par = prng.choice(PARS); mc = prng.choice([0, 0, (len(fam) + 1) // 2])
+        w = oracle_lib.oracle_poa(fam, alg, True, *par, with_scores=True, min_coverage=mc)
+        data, off = hip.pack(fam)
+        g = ctx.poa_batch(data, off, np.array([0, len(fam)], dtype=np.int64), algorithm=alg, scores=par, min_coverage=mc, genmsa=True, with_scores=True)[0]
+        if (g[0], g[1], g[2]) != (w[0], w[1], w[2][:65]):
+            print('POA MISMATCH seed', seed + it - 1, alg, par, mc, [len(x) for x in fam]); print(fam); sys.exit(1)
+        n_poa += 1
     # ---- edit distance ----
     xs, ys = [], []
     for _ in range(300):
@@ -99,5 +113,5 @@ while time.time() < t_end:
         if got[k] != want[k]:
             print('SPLICE MISMATCH seed', seed + it, 'k', k, cands[k][1:4], got[k], want[k]); sys.exit(1)
     n_ss += len(cands)
-    print('round', it, 'ok: ssw', n_ssw, 'ccs', n_ccs, 'edit', n_ed, 'splice', n_ss, flush=True)
-print('fuzz ok:', n_ssw, 'alignments (%d where the reference returns NULL: TRACE_ERR),' % n_null, n_ccs, 'consensus calls,', n_ed, 'edit distances,', n_ss, 'splice-signal searches')
+    print('round', it, 'ok: ssw', n_ssw, 'ccs', n_ccs, 'poa', n_poa, 'edit', n_ed, 'splice', n_ss, flush=True)
+print('fuzz ok:', n_ssw, 'alignments (%d where the reference returns NULL: TRACE_ERR),' % n_null, n_ccs, 'consensus calls,', n_poa, 'poa families,', n_ed, 'edit distances,', n_ss, 'splice-signal searches')

@@ -10,15 +10,18 @@ formulation, cell for cell what the kernel does, so that the derivation can be c
   (a vertical gap state below H - 1 in that frame can never win, tie or be back-tracked into);
 * the horizontal states come from two prefix maxima over M0 = max(diagonal, F, O[, 0]) ("hat" values) and the identities
   Q = Qhat, E[j] = max(Ehat[j], Qhat[j-1] + g);
-* per cell: bit 0 zero (local mode: stop), 1 diagonal, 2 vertical, 3 vertical move continues upwards (extend-up),
-  4 horizontal move continues to the left (extend-left), 5 hx: the E or Q chain of this column extends the previous
-  column's, 6 vstop: an upward run ends with the step out of this cell; rows with several in-edges add the in-edge slots
-  (diagonal, vertical, upward run) in a second plane.
+* per cell ONE byte, as the kernel leaves it: bits 0-5 the move spoa's back-track takes out of the cell, as 62 - (its place
+  in spoa's checking order): 63 zero (local mode: stop); 62-s diagonal through in-edge s; 50 - 3s - {0,1,2} vertical
+  through in-edge s by F+e (the run goes on upwards), H+g, O+c (goes on); 14/13/12 horizontal by E+e (goes on to the
+  left), H+g, Q+c (goes on); bit 6 hx: the E or Q chain of this column extends the previous column's; bit 7 vstop: an
+  upward run ends with the step out of this cell; rows with several in-edges add the in-edge an upward run leaves
+  through.  `dp_row` computes the code twice -- as the maximum of (value << 6 | code) over all candidates (the kernel's
+  way) and from equality tests in priority order -- and asserts that both agree.
 """
 import numpy as np
 
 NEG = -(1 << 28)
-B_ZERO, B_DIAG, B_VERT, B_EXTUP, B_EXTLEFT, B_HX, B_VSTOP = 1, 2, 4, 8, 16, 32, 64
+CODE_ZERO, CODE_DIAG, CODE_VERT, CODE_HORZ, B_HX, B_VSTOP = 63, 62, 50, 14, 64, 128
 
 
 class Params(object):
@@ -82,27 +85,39 @@ def dp_row(P, code, seq, srcs, col0):
     E[2:] = np.maximum(ehat[2:], qhat[1:-1] + P.g)
     Q = qhat
     h1, hl = H[1:], H[:-1]
-    bits = np.zeros(L, dtype=np.int64)
-    if P.algorithm == 0:
-        bits |= np.where(h1 == 0, B_ZERO, 0)
-    bits |= np.where(h1 == d, B_DIAG, 0)
-    vFE, vFO, vOE = h1 == fe + P.g, h1 == fo + P.g, h1 == oe + P.q
-    bits |= np.where(vFE | vFO | vOE, B_VERT, 0)
-    # which class the vertical move comes from: smallest (slot, class) in the order FE, FO, OE
     big = 1 << 20
-    key = np.minimum(np.minimum(np.where(vFE, kfe * 4 + 0, big), np.where(vFO, kfo * 4 + 1, big)), np.where(vOE, koe * 4 + 2, big))
-    kv = np.where(key < big, key >> 2, 0)
-    bits |= np.where((key < big) & ((key & 3) != 1), B_EXTUP, 0)
-    ext_left = (h1 == E[:-1] + P.e) | ~(h1 == hl + P.g)
-    bits |= np.where(ext_left, B_EXTLEFT, 0)
-    hx = (E[:-1] + P.e == E[1:]) | (Q[:-1] + P.c == Q[1:])
-    bits |= np.where(hx, B_HX, 0)
+    # (a) the kernel's way: every candidate as (value << 6) | code, one maximum
+    def pk(v, code):
+        return (np.asarray(v, dtype=np.int64) << 6) + code
+    pm = np.full(L, NEG << 6, dtype=np.int64)
+    for k, (h, df, do) in enumerate(srcs):
+        pm = np.maximum(pm, pk(h[:-1] + s, CODE_DIAG - k))
+        pm = np.maximum(pm, pk((h + df)[1:] + P.g, CODE_VERT - 3 * k))
+        pm = np.maximum(pm, pk(h[1:] + P.g, CODE_VERT - 3 * k - 1))
+        pm = np.maximum(pm, pk((h + do)[1:] + P.q, CODE_VERT - 3 * k - 2))
+    if P.algorithm == 0:
+        pm = np.maximum(pm, CODE_ZERO)
+    p5, p6, p7, p8 = pk(E[:-1] + P.e, CODE_HORZ), pk(hl + P.g, CODE_HORZ - 1), pk(Q[:-1] + P.c, CODE_HORZ - 2), pk(hl + P.q, CODE_HORZ - 3)
+    pf = np.maximum(pm, np.maximum(np.maximum(p5, p6), p7))
+    assert np.array_equal(pf >> 6, h1)
+    code = pf & 63
+    hx = (p5 >= p6) | (p7 >= p8)
+    # (b) equality tests in spoa's order (what a formulation without room for a code beside the value computes)
+    vFE, vFO, vOE = h1 == fe + P.g, h1 == fo + P.g, h1 == oe + P.q
+    key = np.minimum(np.minimum(np.where(vFE, kfe * 3 + 0, big), np.where(vFO, kfo * 3 + 1, big)), np.where(vOE, koe * 3 + 2, big))
+    code_b = np.where(h1 == E[:-1] + P.e, CODE_HORZ, np.where(h1 == hl + P.g, CODE_HORZ - 1, CODE_HORZ - 2))
+    code_b = np.where(key < big, CODE_VERT - key, code_b)
+    code_b = np.where(h1 == d, CODE_DIAG - kd, code_b)
+    if P.algorithm == 0:
+        code_b = np.where(h1 == 0, CODE_ZERO, code_b)
+    assert np.array_equal(code, code_b)
+    assert np.array_equal(hx, (E[:-1] + P.e == E[1:]) | (Q[:-1] + P.c == Q[1:]))
+    bits = code | np.where(hx, B_HX, 0)
     # upward run out of this cell: smallest (slot, class) in the order F-open, F-extend, O-open, O-extend
     keyx = np.minimum(np.minimum(np.where(fo >= fe, kfo * 4 + 0, big), np.where(fe >= fo, kfe * 4 + 1, big)),
                       np.minimum(np.where(fo >= oe, kfo * 4 + 2, big), np.where(oe >= fo, koe * 4 + 3, big)))
-    kx = keyx >> 2
     bits |= np.where((keyx & 1) == 0, B_VSTOP, 0)
-    slots = (kd | (kv << 4) | (kx << 8)) if multi else None
+    slots = (keyx >> 2) if multi else None
     # what the following rows read from this one
     fs_new, os_new = P.e + np.maximum(fe, fo), P.c + np.maximum(oe, fo)
     dF = np.full(L + 1, -1, dtype=np.int64); dO = np.full(L + 1, -1, dtype=np.int64)
@@ -168,25 +183,25 @@ def align(P, G, seq):
     while r > 0 and j > 0:
         bits, slots, pr = planes[r]
         b = int(bits[j - 1])
-        sl = int(slots[j - 1]) if slots is not None else 0
-        if b & B_ZERO:
+        code = b & 63
+        if code == CODE_ZERO:
             break
-        if b & B_DIAG:
+        if code > CODE_VERT:
             pn[j - 1] = r
-            r, j = pr[sl & 15], j - 1
-        elif b & B_VERT:
-            r = pr[(sl >> 4) & 15]
-            if b & B_EXTUP:
+            r, j = pr[CODE_DIAG - code], j - 1
+        elif code > CODE_HORZ:
+            v = CODE_VERT - code
+            r = pr[v // 3]
+            if v % 3 != 1:
                 while True:
                     bits, slots, pr = planes[r]
                     b2 = int(bits[j - 1])
-                    s2 = int(slots[j - 1]) if slots is not None else 0
-                    r = pr[(s2 >> 8) & 15]
+                    r = pr[int(slots[j - 1]) if slots is not None else 0]
                     if (b2 & B_VSTOP) or r == 0:
                         break
         else:
             j -= 1
-            if b & B_EXTLEFT:
+            if code != CODE_HORZ - 1:
                 while True:
                     c = j
                     j -= 1

@@ -308,20 +308,26 @@ static constexpr int POA_RERANK_LDS_KEYS = POA_LDS_BYTES / 8;
 static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whose scores fit the LDS block
 
 #ifdef CLH_DEBUG_POA
+#define DBGARG , unsigned long long* tacc
+#define DBGPASS , tacc
+#define DBGCNT(k, v) do { tacc[k] += (unsigned long long)(v) << 4; } while (0)
 #define TSTAMP(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
 #else
+#define DBGARG
+#define DBGPASS
+#define DBGCNT(k, v) do {} while (0)
 #define TSTAMP(k) do {} while (0)
 #endif
 
 // columns per lane, LDS row pitch and ring depth for a sequence of m bases
-#ifndef POA_MAXC
-#define POA_MAXC 4          // columns per lane: more of them spill registers (measured: 8 -> 50.8 ms, 4 -> 31.3 ms per 100 k reads)
+#ifndef POA_MAXCP
+#define POA_MAXCP 3         // packed registers (column pairs) per lane: up to 6 columns per lane, 384 per pass (measured: 2 -> 27.0, 3 -> 25.8, 4 -> 29.5 ms per 100k reads)
 #endif
 #ifndef POA_WAVES
 #define POA_WAVES 4
 #endif
-__device__ __forceinline__ int poa_cols(int m) { const int c = (m + 63) >> 6; return c < 2 ? 2 : (c > POA_MAXC ? POA_MAXC : c); }
-__device__ __forceinline__ int poa_ring_pitch(int m) { const int W = 64 * poa_cols(m); return poa_pitch(m < W ? m : W); }   // LDS row pitch: the widest pass
+__device__ __forceinline__ int poa_cols(int m) { const int c = (m + 127) >> 7; return c < 1 ? 1 : (c > POA_MAXCP ? POA_MAXCP : c); }   // column pairs per lane
+__device__ __forceinline__ int poa_ring_pitch(int m) { const int W = 128 * poa_cols(m); return poa_pitch(m < W ? m : W); }   // LDS row pitch: the widest pass
 __device__ __forceinline__ int poa_ring(int m) {
     const int lp = poa_ring_pitch(m);
     int ring = 16;                                   // power of two, so slot = rank & (ring-1); a ring row is 3 bytes per element
@@ -331,352 +337,417 @@ __device__ __forceinline__ int poa_ring(int m) {
 
 __device__ __forceinline__ int dpp_shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1; lane 0 keeps `fill`
 
-// exclusive prefix maximum over all cells to the left: in-lane running maximum, one cross-lane scan, the value entering
-// the pass on the left (`left`, lane 0's predecessor).  a[] in, pe[] out (pe[k] = max of everything left of cell k).
-template <int C>
-__device__ __forceinline__ void scan_left(const int (&a)[C], int left, int (&pe)[C])
-{
-    constexpr int NEGB = -(1 << 30);
-    int run[C];
-    run[0] = NEGB;
-#pragma unroll
-    for (int k = 1; k < C; ++k) run[k] = run[k - 1] > a[k - 1] ? run[k - 1] : a[k - 1];
-    const int tot = run[C - 1] > a[C - 1] ? run[C - 1] : a[C - 1];
-    const int incl = wave_prefix_max(tot);
-    int excl = dpp_shr1(NEGB, incl);
-    excl = left > excl ? left : excl;
-#pragma unroll
-    for (int k = 0; k < C; ++k) pe[k] = run[k] > excl ? run[k] : excl;
-}
-
 // DP rows of one sequence against the graph.  Lane l owns C adjacent columns (C = 2..8: ceil(length / 64)), so a row of up
 // to W = 64*C columns is ONE step; longer sequences are swept in passes of W columns (passes outer, rows inner), the
 // cell that leaves a row on the right handed to the next pass through per-row carries (H, E, Q) in HBM.  Graph rows
 // (w.ri, w.rx) and carries are streamed 64 rows at a time into one register per lane and read with v_readlane; LDS holds
 // the ring of the last RING rows (H int16, vertical states one byte) for near sources that are not the row before -- that
 // one is forwarded from registers; far sources come from "kept" rows in HBM.
-// One pass: the columns colbase+1 .. colbase+64*C (the last pass of a sequence may be narrower and then takes fewer
-// columns per lane: a row step costs a fixed part plus a part per column).  `pass` numbers the passes of the sequence
-// (carry buffers alternate), bs/br/bc carry the end cell across the passes.
-template <int C>
-__device__ void dp_pass(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int pass, const int colbase,
-                        const bool more, const int RING, int& bs, int& br, int& bc)
+// ---- packed 16-bit form of the pass ---------------------------------------------------------------------------------
+// Two cells per lane-operation: a register holds the cells of two columns in its 16-bit halves (v_pk_* arithmetic;
+// every value of the DP fits int16).  Lane l owns C = 2 CP adjacent columns as two "virtual lanes": the low halves of its
+// CP registers are columns C l .. C l + CP - 1, the high halves the next CP columns -- so the left neighbour of a cell is the
+// same half of the previous register, and only register 0 needs the hand-down (low half <- previous lane's high half of
+// the last register, high half <- own low half of the last register: one DPP move + one v_alignbit).  There is no room for
+// a code beside a 16-bit value, so the cell's back-track code comes from strictly-greater updates in spoa's checking
+// order: (best, code) <- (x, cx) where best < x, i.e. mask = sign(best - x), best = max(best, x), code = bfi(mask, cx,
+// code) -- four packed operations per candidate and pair of cells, the same for any number of in-edges.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_minu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pk_sra15(uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) >> (short)15); }     // 0xFFFF where the half is negative
+__device__ __forceinline__ uint32_t pk_subu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)); }
+__device__ __forceinline__ uint32_t pk_shr(uint32_t a, int n) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) >> (unsigned short)n); }
+__device__ __forceinline__ uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return (uint32_t)(lo & 0xffff) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }                   // v_bfi_b32
+// hand a packed value to the next virtual lane: new low half = previous lane's high half (lane 0: lane0_lo), new high half = own low half
+__device__ __forceinline__ uint32_t hand_down(uint32_t v, int lane0_lo) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp((int)((uint32_t)lane0_lo << 16), (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __builtin_amdgcn_alignbit(v, x, 16);
+}
+// (best, code) <- (x, cx) in the halves where best < x
+__device__ __forceinline__ void upd(uint32_t& best, uint32_t& code, uint32_t x, uint32_t cx) {
+    const uint32_t m = pk_sra15(pk_subs(best, x));
+    best = pk_max(best, x);
+    code = bfi(m, cx, code);
+}
+
+// exclusive prefix maximum over all columns to the left, packed layout: a[] in, pe[] out; `left` = the value entering the pass
+template <int CP>
+__device__ __forceinline__ void scan_left_pk(const uint32_t (&a)[CP], int left, uint32_t (&pe)[CP])
 {
     constexpr int NEGB = -(1 << 30);
-    constexpr int W = 64 * C;
+    uint32_t run[CP];
+    run[0] = 0x80008000u;
+#pragma unroll
+    for (int t = 1; t < CP; ++t) run[t] = pk_max(run[t - 1], a[t - 1]);
+    const uint32_t tot = pk_max(run[CP - 1], a[CP - 1]);
+    const int lo_t = (int)(short)(tot & 0xffffu), hi_t = (int)tot >> 16;
+    const int m2 = lo_t > hi_t ? lo_t : hi_t;
+    const int inc = wave_prefix_max(m2);
+    int exc = dpp_shr1(NEGB, inc);
+    exc = left > exc ? left : exc;                              // a 16-bit value from here on
+    const int exhi = exc > lo_t ? exc : lo_t;
+    const uint32_t ex2 = pack16(exc, exhi);
+#pragma unroll
+    for (int t = 0; t < CP; ++t) pe[t] = pk_max(run[t], ex2);
+}
+
+template <int CP>
+__device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int pass, const int colbase,
+                           const bool more, const int RING, int& bs_io, int& br_io, int& bc_io DBGARG)
+{
+    constexpr int C = 2 * CP;
     const int gp = poa_pitch(m);
     const int lp = poa_ring_pitch(m);
     const int rmask = RING - 1;
     const bool sw = S.algorithm == 0, nw = S.algorithm == 1;
-    const int g = S.g, e = S.e, q = S.q, c = S.c, sm = S.m, sn = S.n;
+    const int g = S.g, e = S.e, q = S.q, c = S.c;
+    const uint32_t g2 = dup16(g), e2 = dup16(e), q2 = dup16(q), c2 = dup16(c), sm2 = dup16(S.m), dsn2 = dup16(S.n - S.m);
+    const uint32_t NEG2 = dup16(POA_NEG), ONE2 = 0x00010001u;
     short* ringH = (short*)poa_lds;
     uint8_t* ringD = (uint8_t*)(ringH + RING * lp);
-    const int lm = (m - 1 - colbase) / C, km = (m - 1 - colbase) % C;      // where column m lives (last pass)
-    {
-        const int col0 = colbase + C * lane;                     // cell k is column col0+k+1, element col0+k+8 of an HBM row
-        const bool last = !more;
-        int sb[C];                                               // this lane's bases (100: beyond the sequence)
+    const bool last = !more;
+    const int lc0 = C * lane, col0 = colbase + lc0;              // register t: low half = column col0+t+1, high half = column col0+CP+t+1
+    const int mc = m - 1 - colbase;                              // last pass: where column m lives
+    const int lm = mc / C, tm = (mc % C) % CP, hm = (mc % C) / CP;
+    uint32_t sbP[CP], jeP[CP], jcP[CP];
 #pragma unroll
-        for (int k = 0; k < C; ++k) { const int j = col0 + k + 1; sb[k] = j <= m ? (int)seq[j - 1] : 100; }
-        const int jl0 = C * lane + 1;                            // local column of cell 0; cell k: (jl0 + k) * e in the frame of the first piece
-        auto row0_h = [&](int j) -> int {                        // H[0][j]: row 0 (no node) as a source
-            const int l1 = g + (j - 1) * e, l2 = q + (j - 1) * c;
-            return (sw || j == 0) ? 0 : (l1 > l2 ? l1 : l2);
-        };
-        const short* cprev = w.carry + (size_t)(pass & 1) * 3 * w.cpitch;
-        short* cnext = w.carry + (size_t)((pass + 1) & 1) * 3 * w.cpitch;
-        // streams: graph row, plane indices, the three values entering the row on the left
-        uint2 blk = make_uint2(0, 0); uint32_t xblk = 0; int cH = 0, cE = POA_NEG, cQ = POA_NEG;
-        auto fetch = [&](int rr, uint2& b, uint32_t& x, int& h, int& ee, int& qq) {
-            b = make_uint2(0, 0); x = 0; h = 0; ee = POA_NEG; qq = POA_NEG;
-            if (rr <= N) {
-                b = w.ri[rr]; x = w.rx[rr];
-                if (pass > 0) { h = (int)cprev[rr]; ee = (int)cprev[w.cpitch + rr]; qq = (int)cprev[2 * w.cpitch + rr]; }
-                else if (nw) h = (int)w.col0[rr];
+    // a column beyond the sequence has base code 100 (bit 6): pk_sra15(sbP << 9) is 0xFFFF in those halves -- recomputed
+    // where needed, a register per pair held across the row loop costs more (measured)
+    for (int t = 0; t < CP; ++t) {
+        const int jlo = col0 + t + 1, jhi = jlo + CP;
+        sbP[t] = pack16(jlo <= m ? (int)seq[jlo - 1] : 100, jhi <= m ? (int)seq[jhi - 1] : 100);
+        jeP[t] = pack16((lc0 + t + 1) * e, (lc0 + CP + t + 1) * e);
+        jcP[t] = pack16((lc0 + t + 1) * c, (lc0 + CP + t + 1) * c);
+    }
+    auto row0_h = [&](int j) -> int {                            // H[0][j]: row 0 (no node) as a source
+        const int l1 = g + (j - 1) * e, l2 = q + (j - 1) * c;
+        return (sw || j == 0) ? 0 : (l1 > l2 ? l1 : l2);
+    };
+    const short* cprev = w.carry + (size_t)(pass & 1) * 3 * w.cpitch;
+    short* cnext = w.carry + (size_t)((pass + 1) & 1) * 3 * w.cpitch;
+    uint2 blk = make_uint2(0, 0); uint32_t xblk = 0; int cH = 0, cE = POA_NEG, cQ = POA_NEG;
+    auto fetch = [&](int rr, uint2& b, uint32_t& x, int& h, int& ee, int& qq) {
+        b = make_uint2(0, 0); x = 0; h = 0; ee = POA_NEG; qq = POA_NEG;
+        if (rr <= N) {
+            b = w.ri[rr]; x = w.rx[rr];
+            if (pass > 0) { h = (int)cprev[rr]; ee = (int)cprev[w.cpitch + rr]; qq = (int)cprev[2 * w.cpitch + rr]; }
+            else if (nw) h = (int)w.col0[rr];
+        }
+    };
+    fetch(1 + lane, blk, xblk, cH, cE, cQ);
+    uint32_t px[CP], pf[CP], po[CP];                             // the previous row, still in registers (packed)
+    int pcin = 0;
+#pragma unroll
+    for (int t = 0; t < CP; ++t) { px[t] = 0; pf[t] = 0; po[t] = 0; }
+    // end cell within this pass, per virtual lane: value, rank (16 bits) and column offset within the half
+    uint32_t bsP = sw ? 0u : 0x80008000u, brP = 0, bcP = 0;
+    int nbest = -(1 << 30), nrow = 0;                            // global mode: cells (sink row, column m), wave-uniform
+    uint32_t lowP = 0x7fff7fffu;                                 // global / overlap: the lowest H of the pass (local cells are >= 0)
+    for (int rb = 1; rb <= N; rb += 64) {
+        uint2 nblk; uint32_t nxblk; int nH, nE, nQ;
+        fetch(rb + 64 + lane, nblk, nxblk, nH, nE, nQ);
+        const int cnt = N - rb + 1 < 64 ? N - rb + 1 : 64;
+        int cobH = 0, cobE = 0, cobQ = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int r = rb + i;
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
+            const uint32_t rxv = (uint32_t)__builtin_amdgcn_readlane((int)xblk, i);
+            const int cinH = __builtin_amdgcn_readlane(cH, i), cinE = __builtin_amdgcn_readlane(cE, i), cinQ = __builtin_amdgcn_readlane(cQ, i);
+            const int vb = (int)(d0 & 0xff), np = (int)((d0 >> 8) & 0xf);
+            const bool sink = (d0 & 0x1000u) != 0, tolds = (d0 & 0x4000u) != 0, keep = (d0 & 0x8000u) != 0;
+            const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
+            const int mi = (int)(rxv & 0xffff), ki = (int)(rxv >> 16);
+            uint32_t ss[CP];
+            {
+                const uint32_t vb2 = dup16(vb);
+#pragma unroll
+                for (int t = 0; t < CP; ++t) {
+                    const uint32_t nz = pk_minu(sbP[t] ^ vb2, ONE2);                 // 0 where the base equals the node's
+                    ss[t] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, nz) * __builtin_bit_cast(u16x2, dsn2) + __builtin_bit_cast(u16x2, sm2));
+                }
             }
-        };
-        fetch(1 + lane, blk, xblk, cH, cE, cQ);
-        int px[C], pf[C], po[C], pcin = 0;                       // the previous row, still in registers
+            // one source row, packed: H at the lane's columns, the same shifted by one column (register 0), Fs, Os
+            auto source = [&](int qr, uint32_t (&h)[CP], uint32_t& hsh0, uint32_t (&fs)[CP], uint32_t (&os)[CP]) {
+                if (qr == 0) {
 #pragma unroll
-        for (int k = 0; k < C; ++k) { px[k] = 0; pf[k] = 0; po[k] = 0; }
-        for (int rb = 1; rb <= N; rb += 64) {
-            uint2 nblk; uint32_t nxblk; int nH, nE, nQ;
-            fetch(rb + 64 + lane, nblk, nxblk, nH, nE, nQ);
-            const int cnt = N - rb + 1 < 64 ? N - rb + 1 : 64;
-            int cobH = 0, cobE = 0, cobQ = 0;
-            for (int i = 0; i < cnt; ++i) {
-                const int r = rb + i;
-                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
-                const uint32_t rxv = (uint32_t)__builtin_amdgcn_readlane((int)xblk, i);
-                const int cinH = __builtin_amdgcn_readlane(cH, i), cinE = __builtin_amdgcn_readlane(cE, i), cinQ = __builtin_amdgcn_readlane(cQ, i);
-                const int vb = (int)(d0 & 0xff), np = (int)((d0 >> 8) & 0xf);
-                const bool sink = (d0 & 0x1000u) != 0;
-                const bool tolds = (d0 & 0x4000u) != 0;          // read later from the LDS ring
-                const bool keep = (d0 & 0x8000u) != 0;           // read later from HBM by a far successor
-                const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
-                const int mi = (int)(rxv & 0xffff), ki = (int)(rxv >> 16);
-                int ss[C];
+                    for (int t = 0; t < CP; ++t) {
+                        h[t] = pack16(row0_h(col0 + t + 1), row0_h(col0 + CP + t + 1));
+                        fs[t] = pk_adds(h[t], 0xffffffffu); os[t] = fs[t];
+                    }
+                    hsh0 = pack16(row0_h(col0), row0_h(col0 + CP));
+                } else if (qr == r - 1) {
+                    DBGCNT(13, 1);
 #pragma unroll
-                for (int k = 0; k < C; ++k) ss[k] = sb[k] == vb ? sm : sn;
-                // one source row: H at the lane's columns and the one before, Fs = F + e - g, Os = O + c - q
-                auto source = [&](int qr, int (&h)[C], int& hprev, int (&fs)[C], int (&os)[C]) {
-                    if (qr == 0) {
+                    for (int t = 0; t < CP; ++t) { h[t] = px[t]; fs[t] = pf[t]; os[t] = po[t]; }
+                    hsh0 = hand_down(px[CP - 1], pcin);
+                } else {
+                    uint32_t dd[CP];
+                    int a0, a1;                                  // the two elements in front of the two halves
+                    if (r - qr < RING) {
+                        DBGCNT(11, 1);
+                        const short* sh = ringH + (qr & rmask) * lp + lc0 + 8;
+                        const uint8_t* sd = ringD + (qr & rmask) * lp + lc0 + 8;
+                        a0 = sh[-1]; a1 = sh[CP - 1];
 #pragma unroll
-                        for (int k = 0; k < C; ++k) { h[k] = row0_h(col0 + k + 1); fs[k] = h[k] - 1; os[k] = h[k] - 1; }
-                        hprev = row0_h(col0);
-                    } else if (qr == r - 1) {
-#pragma unroll
-                        for (int k = 0; k < C; ++k) { h[k] = px[k]; fs[k] = pf[k]; os[k] = po[k]; }
-                        hprev = dpp_shr1(0, px[C - 1]);
-                        hprev = lane == 0 ? pcin : hprev;
-                    } else if (r - qr < RING) {
-                        const short* sh = ringH + (qr & rmask) * lp + C * lane + 8;
-                        const uint8_t* sd = ringD + (qr & rmask) * lp + C * lane + 8;
-                        hprev = sh[-1];
-#pragma unroll
-                        for (int k = 0; k < C; ++k) { h[k] = sh[k]; const int dd = sd[k]; fs[k] = h[k] + (dd & 7) - 1; os[k] = h[k] + (dd >> 3) - 1; }
+                        for (int t = 0; t < CP; ++t) { h[t] = pack16(sh[t], sh[CP + t]); dd[t] = (uint32_t)sd[t] | ((uint32_t)sd[CP + t] << 16); }
                     } else {
+                        DBGCNT(12, 1);
                         const int kq = (int)(__builtin_amdgcn_readfirstlane((int)w.rx[qr]) >> 16) & 0xffff;
                         const short* sh = w.keepH + (size_t)kq * gp + col0 + 8;
                         const uint8_t* sd = w.keepD + (size_t)kq * gp + col0 + 8;
-                        int dd[C];
-                        asm volatile("global_load_sshort %0, %1, off" : "=v"(hprev) : "v"(sh - 1) : "memory");
+                        int hv[C], dv[C];
+                        asm volatile("global_load_sshort %0, %1, off" : "=v"(a0) : "v"(sh - 1) : "memory");
 #pragma unroll
-                        for (int k = 0; k < C; ++k) asm volatile("global_load_sshort %0, %1, off" : "=v"(h[k]) : "v"(sh + k) : "memory");
+                        for (int k = 0; k < C; ++k) asm volatile("global_load_sshort %0, %1, off" : "=v"(hv[k]) : "v"(sh + k) : "memory");
 #pragma unroll
-                        for (int k = 0; k < C; ++k) asm volatile("global_load_ubyte %0, %1, off" : "=v"(dd[k]) : "v"(sd + k) : "memory");
+                        for (int k = 0; k < C; ++k) asm volatile("global_load_ubyte %0, %1, off" : "=v"(dv[k]) : "v"(sd + k) : "memory");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                        for (int k = 0; k < C; ++k) { asm volatile("" : "+v"(h[k]), "+v"(dd[k])); fs[k] = h[k] + (dd[k] & 7) - 1; os[k] = h[k] + (dd[k] >> 3) - 1; }
-                        asm volatile("" : "+v"(hprev));
+                        for (int k = 0; k < C; ++k) asm volatile("" : "+v"(hv[k]), "+v"(dv[k]));
+                        asm volatile("" : "+v"(a0));
+                        a1 = hv[CP - 1];
+#pragma unroll
+                        for (int t = 0; t < CP; ++t) { h[t] = pack16(hv[t], hv[CP + t]); dd[t] = (uint32_t)dv[t] | ((uint32_t)dv[CP + t] << 16); }
+                    }
+                    hsh0 = pack16(a0, a1);
+#pragma unroll
+                    for (int t = 0; t < CP; ++t) {
+                        fs[t] = pk_adds(h[t], pk_subu(dd[t] & 0x00070007u, ONE2));
+                        os[t] = pk_adds(h[t], pk_subu(pk_shr(dd[t], 3) & 0x001f001fu, ONE2));
+                    }
+                }
+            };
+            DBGCNT(8, np > 1); DBGCNT(9, tolds); DBGCNT(10, keep);
+            uint32_t best[CP], code[CP], fsn[CP], osn[CP], xb[CP];   // xb: bit 7 of each half = vstop; multi rows: bits 8.. = slot of the upward run
+            if (np <= 1) {
+                uint32_t h[CP], hsh0, fs[CP], os[CP];
+                source(np == 0 ? 0 : p0, h, hsh0, fs, os);
+#pragma unroll
+                for (int t = 0; t < CP; ++t) {
+                    uint32_t b = sw ? 0u : NEG2, cd = dup16(CODE_ZERO);
+                    upd(b, cd, pk_adds(t == 0 ? hsh0 : h[t - 1], ss[t]), dup16(CODE_DIAG));
+                    upd(b, cd, pk_adds(fs[t], g2), dup16(CODE_VERT));
+                    upd(b, cd, pk_adds(h[t], g2), dup16(CODE_VERT - 1));
+                    upd(b, cd, pk_adds(os[t], q2), dup16(CODE_VERT - 2));
+                    best[t] = b; code[t] = cd;
+                    fsn[t] = pk_adds(pk_max(fs[t], h[t]), e2);
+                    osn[t] = pk_adds(pk_max(os[t], h[t]), c2);
+                    xb[t] = ~pk_sra15(pk_subs(h[t], fs[t])) & 0x00800080u;          // vstop: H_p >= Fs_p
+                }
+            } else {
+                uint32_t bD[CP], cD[CP], bV[CP], cV[CP], MX[CP], MO[CP], XF[CP], cF[CP], XO[CP], cO[CP];
+#pragma unroll
+                for (int t = 0; t < CP; ++t) { bD[t] = NEG2; cD[t] = 0; bV[t] = NEG2; cV[t] = 0; MX[t] = NEG2; MO[t] = NEG2; XF[t] = 0x80008000u; cF[t] = 0; XO[t] = 0x80008000u; cO[t] = 0; }
+                auto add_source = [&](int slot, int qr) {
+                    uint32_t h[CP], hsh0, fs[CP], os[CP];
+                    source(qr, h, hsh0, fs, os);
+                    const uint32_t xo = dup16(2 * (POA_MAXP - slot) + 1), xe = dup16(2 * (POA_MAXP - slot));
+#pragma unroll
+                    for (int t = 0; t < CP; ++t) {
+                        upd(bD[t], cD[t], pk_adds(t == 0 ? hsh0 : h[t - 1], ss[t]), dup16(CODE_DIAG - slot));
+                        upd(bV[t], cV[t], pk_adds(fs[t], g2), dup16(CODE_VERT - 3 * slot));
+                        upd(bV[t], cV[t], pk_adds(h[t], g2), dup16(CODE_VERT - 3 * slot - 1));
+                        upd(bV[t], cV[t], pk_adds(os[t], q2), dup16(CODE_VERT - 3 * slot - 2));
+                        MX[t] = pk_max(MX[t], pk_max(fs[t], h[t]));
+                        MO[t] = pk_max(MO[t], pk_max(os[t], h[t]));
+                        upd(XF[t], cF[t], h[t], xo); upd(XF[t], cF[t], fs[t], xe);     // upward run: open before extend, earlier in-edge first
+                        upd(XO[t], cO[t], h[t], xo); upd(XO[t], cO[t], os[t], xe);
                     }
                 };
-                // Every candidate of a cell travels as (value << 6) | code, code = 62 - (its place in spoa's checking order): one
-                // signed max takes the larger value and, between equal values, the move spoa's back-track would find first;
-                // the winner's low six bits ARE the cell's back-track code (csrc comment at CODE_*).
-                int PM[C], fsn[C], osn[C], xb[C];                // packed best of the non-horizontal moves; vertical states; bit 7 (vstop) and, rows with several in-edges, the slot of the upward run
-                if (np <= 1) {
-                    int h[C], hprev, fs[C], os[C];
-                    source(np == 0 ? 0 : p0, h, hprev, fs, os);
-                    const int kFE = (g << 6) + CODE_VERT, kFO = (g << 6) + CODE_VERT - 1, kOE = (q << 6) + CODE_VERT - 2;
-#pragma unroll
-                    for (int k = 0; k < C; ++k) {
-                        const int fe = fs[k], fo = h[k], oe = os[k];
-                        const int p1 = ((k == 0 ? hprev : h[k - 1]) << 6) + ((ss[k] << 6) + CODE_DIAG);
-                        const int p2 = (fe << 6) + kFE, p3 = (fo << 6) + kFO, p4 = (oe << 6) + kOE;
-                        int pm = p1 > p2 ? p1 : p2;
-                        pm = p3 > pm ? p3 : pm;
-                        pm = p4 > pm ? p4 : pm;
-                        if (sw) pm = pm > CODE_ZERO ? pm : CODE_ZERO;
-                        PM[k] = pm;
-                        const int mx = fe > fo ? fe : fo, mo = oe > fo ? oe : fo;
-                        fsn[k] = e + mx; osn[k] = c + mo;
-                        xb[k] = fo >= fe ? 128 : 0;
-                    }
-                } else {
-                    int MX[C], MO[C], XF[C], XO[C];
-#pragma unroll
-                    for (int k = 0; k < C; ++k) { PM[k] = sw ? CODE_ZERO : NEGB; MX[k] = NEGB; MO[k] = NEGB; XF[k] = NEGB; XO[k] = NEGB; }
-                    auto add_source = [&](int slot, int qr) {
-                        int h[C], hprev, fs[C], os[C];
-                        source(qr, h, hprev, fs, os);
-                        const int kFE = (g << 6) + CODE_VERT - 3 * slot, kFO = kFE - 1, kOE = (q << 6) + CODE_VERT - 3 * slot - 2;
-                        const int xo = 2 * (POA_MAXP - slot) + 1, xe = xo - 1;       // upward run: open before extend, earlier in-edge first
-#pragma unroll
-                        for (int k = 0; k < C; ++k) {
-                            const int fe = fs[k], fo = h[k], oe = os[k];
-                            const int p1 = ((k == 0 ? hprev : h[k - 1]) << 6) + ((ss[k] << 6) + CODE_DIAG - slot);
-                            const int p2 = (fe << 6) + kFE, p3 = (fo << 6) + kFO, p4 = (oe << 6) + kOE;
-                            int pm = PM[k] > p1 ? PM[k] : p1;
-                            pm = p2 > pm ? p2 : pm; pm = p3 > pm ? p3 : pm; pm = p4 > pm ? p4 : pm;
-                            PM[k] = pm;
-                            int t = fe > fo ? fe : fo; MX[k] = t > MX[k] ? t : MX[k];
-                            t = oe > fo ? oe : fo; MO[k] = t > MO[k] ? t : MO[k];
-                            const int q1 = (fo << 6) + xo, q2 = (fe << 6) + xe, q3 = (oe << 6) + xe;
-                            t = q1 > q2 ? q1 : q2; XF[k] = t > XF[k] ? t : XF[k];
-                            t = q1 > q3 ? q1 : q3; XO[k] = t > XO[k] ? t : XO[k];
-                        }
-                    };
-                    add_source(0, p0);
-                    add_source(1, p1);
-                    if (np > 2) add_source(2, p2);
-                    if (np > 3) {                                // rare: in-edges beyond the third come from HBM
-                        const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
-                        for (int s2 = 3; s2 < np; ++s2) add_source(s2, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + s2]]));
-                    }
-#pragma unroll
-                    for (int k = 0; k < C; ++k) {
-                        fsn[k] = e + MX[k]; osn[k] = c + MO[k];
-                        // the in-edge an upward run leaves this cell through: the first with F == H+g (last step), F == F+e, O == H+q
-                        // (last step), O == O+c, in that order
-                        const int cf = XF[k] & 63, co = XO[k] & 63;
-                        const int sF = POA_MAXP - (cf >> 1), sO = POA_MAXP - (co >> 1);
-                        const bool useF = sF <= sO;
-                        const int slot = useF ? sF : sO, open = useF ? (cf & 1) : (co & 1);
-                        xb[k] = (open ? 128 : 0) | (slot << 8);
-                    }
-                }
-                // horizontal states: two prefix maxima in the gap-free frames of the two pieces
-                int ehat[C], qhat[C], H[C];
-                {
-                    int a[C], pe[C];
-                    const int leftE = cinH > cinE + e - g ? cinH : cinE + e - g;       // = E[first column of the pass] - g
-#pragma unroll
-                    for (int k = 0; k < C; ++k) a[k] = (PM[k] >> 6) - (jl0 + k) * e;
-                    scan_left<C>(a, leftE, pe);
-#pragma unroll
-                    for (int k = 0; k < C; ++k) ehat[k] = pe[k] + (g - e) + (jl0 + k) * e;
-                    const int leftQ = cinH > cinQ + c - q ? cinH : cinQ + c - q;
-#pragma unroll
-                    for (int k = 0; k < C; ++k) a[k] = (PM[k] >> 6) - (jl0 + k) * c;
-                    scan_left<C>(a, leftQ, pe);
-#pragma unroll
-                    for (int k = 0; k < C; ++k) qhat[k] = pe[k] + (q - c) + (jl0 + k) * c;
+                add_source(0, p0);
+                add_source(1, p1);
+                if (np > 2) add_source(2, p2);
+                if (np > 3) {                                    // rare: in-edges beyond the third come from HBM
+                    const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
+                    for (int s2 = 3; s2 < np; ++s2) add_source(s2, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + s2]]));
                 }
 #pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const int m0 = PM[k] >> 6;
-                    int hh = m0 > ehat[k] ? m0 : ehat[k];
-                    H[k] = qhat[k] > hh ? qhat[k] : hh;
+                for (int t = 0; t < CP; ++t) {
+                    uint32_t b = sw ? 0u : NEG2, cd = dup16(CODE_ZERO);
+                    upd(b, cd, bD[t], cD[t]);                    // all diagonals before all verticals
+                    upd(b, cd, bV[t], cV[t]);
+                    best[t] = b; code[t] = cd;
+                    fsn[t] = pk_adds(MX[t], e2); osn[t] = pk_adds(MO[t], c2);
+                    // in-edge an upward run leaves through: the earlier of the two levels' first hits, F before O in one in-edge
+                    const uint32_t kF = pk_shr(cF[t], 1), kO = pk_shr(cO[t], 1);               // POA_MAXP - slot
+                    const uint32_t useO = pk_sra15(pk_subs(kF, kO));                             // 0xFFFF where F's in-edge comes later
+                    const uint32_t sel = bfi(useO, cO[t], cF[t]);
+                    const uint32_t slot2 = pk_subu(dup16(POA_MAXP), pk_shr(sel, 1));
+                    xb[t] = ((sel & ONE2) << 7) | (slot2 << 8);
                 }
-                // the neighbour's value is fetched by every lane BEFORE the select: a DPP read executed under an exec mask that
-                // excludes lane 0 would find its source lane disabled
-                const int qsh = dpp_shr1(0, qhat[C - 1]);
-                const int qleft = lane == 0 ? cinQ : qsh;
-                int E[C];
-#pragma unroll
-                for (int k = 0; k < C; ++k) {                    // E as spoa holds it: a gap may open on a cell reached by the other piece
-                    const int qp = (k == 0 ? qleft : qhat[k - 1]) + g;
-                    E[k] = ehat[k] > qp ? ehat[k] : qp;
-                }
-                const int hsh = dpp_shr1(0, H[C - 1]), esh = dpp_shr1(0, E[C - 1]);
-                const int hleft = lane == 0 ? cinH : hsh;
-                const int eleft = lane == 0 ? cinE : esh;
-                int out[C];
-                {
-                    const int kE = (e << 6) + CODE_HORZ, kG = (g << 6) + CODE_HORZ - 1, kC = (c << 6) + CODE_HORZ - 2, kQ = (q << 6) + CODE_HORZ - 3;
-#pragma unroll
-                    for (int k = 0; k < C; ++k) {
-                        const int hl = k == 0 ? hleft : H[k - 1], ep = k == 0 ? eleft : E[k - 1], qp = k == 0 ? qleft : qhat[k - 1];
-                        const int p5 = (ep << 6) + kE, p6 = (hl << 6) + kG, p7 = (qp << 6) + kC, p8 = (hl << 6) + kQ;
-                        int ph = p5 > p6 ? p5 : p6;
-                        ph = p7 > ph ? p7 : ph;
-                        const int pf = PM[k] > ph ? PM[k] : ph;
-                        // hx: E or Q of this column extends the previous column's (E[j-1]+e >= H[j-1]+g, Q[j-1]+c >= H[j-1]+q)
-                        out[k] = (pf & 63) | (((p5 >= p6) | (p7 >= p8)) ? 64 : 0) | (xb[k] & 128);
-                    }
-                }
-                // ---- what later rows and the back-track read --------------------------------------------------------------
-#pragma unroll
-                for (int k = 0; k < C; ++k) { px[k] = H[k]; pf[k] = fsn[k]; po[k] = osn[k]; }
-                pcin = cinH;
-                if (col0 + 1 <= m) {
-                    uint8_t* dd = w.dirA + (size_t)r * gp + col0 + 8;
-                    uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-                    for (int k = 0; k < C && k < 4; ++k) w0 |= ((uint32_t)out[k] & 0xffu) << (8 * k);
-#pragma unroll
-                    for (int k = 4; k < C; ++k) w1 |= ((uint32_t)out[k] & 0xffu) << (8 * (k - 4));
-                    if constexpr (C == 8) *(uint2*)dd = make_uint2(w0, w1);
-                    else if constexpr (C >= 4) {
-                        __builtin_memcpy(dd, &w0, 4);
-                        if constexpr (C == 5) dd[4] = (uint8_t)w1;
-                        if constexpr (C >= 6) { const uint16_t lo = (uint16_t)w1; __builtin_memcpy(dd + 4, &lo, 2); }
-                        if constexpr (C == 7) dd[6] = (uint8_t)(w1 >> 16);
-                    } else {
-                        const uint16_t lo = (uint16_t)w0;
-                        __builtin_memcpy(dd, &lo, 2);
-                        if constexpr (C == 3) dd[2] = (uint8_t)(w0 >> 16);
-                    }
-                    if (np > 1) {
-                        uint8_t* db = w.dirB + (size_t)mi * gp + col0 + 8;
-#pragma unroll
-                        for (int k = 0; k < C; ++k) db[k] = (uint8_t)(xb[k] >> 8);
-                    }
-                    if (tolds | keep) {
-                        int dv[C];
-#pragma unroll
-                        for (int k = 0; k < C; ++k) {
-                            int df = fsn[k] - H[k] + 1, dq = osn[k] - H[k] + 1;
-                            df = df > 0 ? df : 0; dq = dq > 0 ? dq : 0;
-                            dv[k] = df | (dq << 3);
-                        }
-                        if (tolds) {
-                            short* dh = ringH + (r & rmask) * lp + C * lane + 8;
-                            uint8_t* dl = ringD + (r & rmask) * lp + C * lane + 8;
-#pragma unroll
-                            for (int k = 0; k < C; ++k) { dh[k] = (short)H[k]; dl[k] = (uint8_t)dv[k]; }
-                        }
-                        if (keep) {
-                            short* hd = w.keepH + (size_t)ki * gp + col0 + 8;
-                            uint8_t* hb = w.keepD + (size_t)ki * gp + col0 + 8;
-#pragma unroll
-                            for (int k = 0; k < C; ++k) { hd[k] = (short)H[k]; hb[k] = (uint8_t)dv[k]; }
-                        }
-                    }
-                }
-                if (tolds && lane == 0) ringH[(r & rmask) * lp + 7] = (short)cinH;     // element of local column 0
-                if (keep && pass == 0 && lane == 0) w.keepH[(size_t)ki * gp + 7] = (short)cinH;
-                // ---- end cell: first strict maximum in (rank, column) order --------------------------------------------
-                if (sw | (!nw & sink)) {
-                    int rk = NEGB;
-#pragma unroll
-                    for (int k = 0; k < C; ++k) {
-                        const int kv = col0 + k + 1 <= m ? (H[k] << 4) | (15 - k) : NEGB;
-                        rk = kv > rk ? kv : rk;
-                    }
-                    const int v = rk >> 4;
-                    if (v > bs || (pass > 0 && v == bs && r < br)) { bs = v; br = r; bc = col0 + 1 + 15 - (rk & 15); }
-                } else if (nw & sink & last) {
-                    int hm = H[0];
-#pragma unroll
-                    for (int k = 1; k < C; ++k) hm = km == k ? H[k] : hm;
-                    if (lane == lm && hm > bs) { bs = hm; br = r; bc = m; }
-                }
-                if (more) {
-                    const int rH = __builtin_amdgcn_readlane(H[C - 1], 63), rE = __builtin_amdgcn_readlane(E[C - 1], 63), rQ = __builtin_amdgcn_readlane(qhat[C - 1], 63);
-                    cobH = lane == i ? rH : cobH; cobE = lane == i ? (rE < POA_NEG ? POA_NEG : rE) : cobE; cobQ = lane == i ? (rQ < POA_NEG ? POA_NEG : rQ) : cobQ;
-                }
-                asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
             }
-            if (more && lane < cnt) { cnext[rb + lane] = (short)cobH; cnext[w.cpitch + rb + lane] = (short)cobE; cnext[2 * w.cpitch + rb + lane] = (short)cobQ; }
-            blk = nblk; xblk = nxblk; cH = nH; cE = nE; cQ = nQ;
+            // horizontal states: two prefix maxima in the gap-free frames of the two pieces
+            uint32_t ehat[CP], qhat[CP];
+            {
+                uint32_t a[CP], pe[CP];
+                const int leftE = cinH > cinE + e - g ? cinH : cinE + e - g;       // = E[first column of the pass] - g
+#pragma unroll
+                for (int t = 0; t < CP; ++t) a[t] = pk_subs(best[t], jeP[t]);
+                scan_left_pk<CP>(a, leftE, pe);
+                const uint32_t ge2 = dup16(g - e);
+#pragma unroll
+                for (int t = 0; t < CP; ++t) ehat[t] = pk_adds(pk_adds(pe[t], jeP[t]), ge2);
+                const int leftQ = cinH > cinQ + c - q ? cinH : cinQ + c - q;
+#pragma unroll
+                for (int t = 0; t < CP; ++t) a[t] = pk_subs(best[t], jcP[t]);
+                scan_left_pk<CP>(a, leftQ, pe);
+                const uint32_t qc2 = dup16(q - c);
+#pragma unroll
+                for (int t = 0; t < CP; ++t) qhat[t] = pk_adds(pk_adds(pe[t], jcP[t]), qc2);
+            }
+            uint32_t Hf[CP], E[CP];
+#pragma unroll
+            for (int t = 0; t < CP; ++t) Hf[t] = pk_max(pk_max(best[t], ehat[t]), qhat[t]);
+            const uint32_t q0 = hand_down(qhat[CP - 1], cinQ);
+#pragma unroll
+            for (int t = 0; t < CP; ++t) E[t] = pk_max(ehat[t], pk_adds(t == 0 ? q0 : qhat[t - 1], g2));     // E as spoa holds it
+            const uint32_t h0 = hand_down(Hf[CP - 1], cinH), e0 = hand_down(E[CP - 1], cinE);
+            uint32_t out[CP];
+#pragma unroll
+            for (int t = 0; t < CP; ++t) {
+                const uint32_t hl = t == 0 ? h0 : Hf[t - 1], ep = t == 0 ? e0 : E[t - 1], qp = t == 0 ? q0 : qhat[t - 1];
+                const uint32_t c5 = pk_adds(ep, e2), c6 = pk_adds(hl, g2), c7 = pk_adds(qp, c2), c8 = pk_adds(hl, q2);
+                uint32_t b = best[t], cd = code[t];
+                upd(b, cd, c5, dup16(CODE_HORZ)); upd(b, cd, c6, dup16(CODE_HORZ - 1)); upd(b, cd, c7, dup16(CODE_HORZ - 2));
+                // hx: E or Q of this column extends the previous column's (E[j-1]+e >= H[j-1]+g, Q[j-1]+c >= H[j-1]+q)
+                const uint32_t both_lt = pk_sra15(pk_subs(c5, c6)) & pk_sra15(pk_subs(c7, c8));
+                out[t] = cd | (~both_lt & 0x00400040u) | (xb[t] & 0x00800080u);
+            }
+            // ---- what later rows and the back-track read ------------------------------------------------------------------
+#pragma unroll
+            for (int t = 0; t < CP; ++t) { px[t] = Hf[t]; pf[t] = fsn[t]; po[t] = osn[t]; }
+            pcin = cinH;
+            if (col0 + 1 <= m) {
+                uint8_t* dd = w.dirA + (size_t)r * gp + col0 + 8;
+                uint32_t w0 = 0, w1 = 0;                         // C bytes: the low halves' columns, then the high halves' (v_perm_b32 picks bytes 0 and 2)
+                if constexpr (CP == 1) w0 = __builtin_amdgcn_perm(0u, out[0], 0x0c0c0200u);
+                else if constexpr (CP == 2) w0 = __builtin_amdgcn_perm(out[1], out[0], 0x06020400u);
+                else if constexpr (CP == 3) { w0 = __builtin_amdgcn_perm(out[1], out[0], 0x0c0c0400u) | __builtin_amdgcn_perm(out[2], out[0], 0x02040c0cu);
+                                              w1 = __builtin_amdgcn_perm(out[2], out[1], 0x0c0c0602u); }
+                else { w0 = __builtin_amdgcn_perm(out[1], out[0], 0x0c0c0400u) | __builtin_amdgcn_perm(out[3], out[2], 0x04000c0cu);
+                       w1 = __builtin_amdgcn_perm(out[1], out[0], 0x0c0c0602u) | __builtin_amdgcn_perm(out[3], out[2], 0x06020c0cu); }
+                if constexpr (C == 8) *(uint2*)dd = make_uint2(w0, w1);
+                else if constexpr (C == 6) { __builtin_memcpy(dd, &w0, 4); const uint16_t x2 = (uint16_t)w1; __builtin_memcpy(dd + 4, &x2, 2); }
+                else if constexpr (C == 4) __builtin_memcpy(dd, &w0, 4);
+                else { const uint16_t x2 = (uint16_t)w0; __builtin_memcpy(dd, &x2, 2); }
+                if (np > 1) {
+                    uint8_t* db = w.dirB + (size_t)mi * gp + col0 + 8;
+#pragma unroll
+                    for (int t = 0; t < CP; ++t) { db[t] = (uint8_t)(xb[t] >> 8); db[CP + t] = (uint8_t)(xb[t] >> 24); }
+                }
+                if (tolds | keep) {
+                    uint32_t dv[CP];
+#pragma unroll
+                    for (int t = 0; t < CP; ++t) {
+                        const uint32_t df = pk_max(pk_adds(pk_subs(fsn[t], Hf[t]), ONE2), 0u), dq = pk_max(pk_adds(pk_subs(osn[t], Hf[t]), ONE2), 0u);
+                        dv[t] = df | (dq << 3);
+                    }
+                    if (tolds) {
+                        short* dh = ringH + (r & rmask) * lp + lc0 + 8;
+                        uint8_t* dl = ringD + (r & rmask) * lp + lc0 + 8;
+#pragma unroll
+                        for (int t = 0; t < CP; ++t) { dh[t] = (short)Hf[t]; dh[CP + t] = (short)(Hf[t] >> 16); dl[t] = (uint8_t)dv[t]; dl[CP + t] = (uint8_t)(dv[t] >> 16); }
+                    }
+                    if (keep) {
+                        short* hd = w.keepH + (size_t)ki * gp + col0 + 8;
+                        uint8_t* hb = w.keepD + (size_t)ki * gp + col0 + 8;
+#pragma unroll
+                        for (int t = 0; t < CP; ++t) { hd[t] = (short)Hf[t]; hd[CP + t] = (short)(Hf[t] >> 16); hb[t] = (uint8_t)dv[t]; hb[CP + t] = (uint8_t)(dv[t] >> 16); }
+                    }
+                }
+            }
+            if (tolds && lane == 0) ringH[(r & rmask) * lp + 7] = (short)cinH;     // element of local column 0
+            if (keep && pass == 0 && lane == 0) w.keepH[(size_t)ki * gp + 7] = (short)cinH;
+            if (!sw) {
+#pragma unroll
+                for (int t = 0; t < CP; ++t) lowP = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, lowP), __builtin_bit_cast(s16x2, bfi(pk_sra15(sbP[t] << 9), 0x7fff7fffu, Hf[t]))));
+            }
+            // ---- end cell: first strict maximum in (rank, column) order --------------------------------------------
+            if (sw | (!nw & sink)) {
+                // columns beyond the sequence do not count
+                uint32_t hv2[CP];
+#pragma unroll
+                for (int t = 0; t < CP; ++t) hv2[t] = bfi(pk_sra15(sbP[t] << 9), 0x80008000u, Hf[t]);
+                uint32_t rm = hv2[0];
+#pragma unroll
+                for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
+                const uint32_t imp = pk_sra15(pk_subs(bsP, rm));                  // halves whose best is exceeded (strictly: the first row stays)
+                if (__builtin_amdgcn_ballot_w64(imp != 0u)) {
+                    uint32_t colP = 0;
+#pragma unroll
+                    for (int t = CP - 1; t >= 0; --t) {
+                        const uint32_t eqm = pk_subu(pk_minu(pk_subs(rm, hv2[t]), ONE2), ONE2);   // 0xFFFF where this column holds the maximum
+                        colP = bfi(eqm, dup16(t), colP);
+                    }
+                    bsP = bfi(imp, rm, bsP); brP = bfi(imp, dup16(r), brP); bcP = bfi(imp, colP, bcP);
+                }
+            } else if (nw & sink & last) {
+                uint32_t pick = 0;
+#pragma unroll
+                for (int t = 0; t < CP; ++t) if (t == tm) pick = (uint32_t)__builtin_amdgcn_readlane((int)Hf[t], lm);
+                const int val = hm ? (int)pick >> 16 : (int)(short)(pick & 0xffffu);
+                if (val > nbest) { nbest = val; nrow = r; }
+            }
+            if (more) {
+                const int rH = (int)__builtin_amdgcn_readlane((int)Hf[CP - 1], 63) >> 16, rE = (int)__builtin_amdgcn_readlane((int)E[CP - 1], 63) >> 16,
+                          rQ = (int)__builtin_amdgcn_readlane((int)qhat[CP - 1], 63) >> 16;
+                cobH = lane == i ? rH : cobH; cobE = lane == i ? (rE < POA_NEG ? POA_NEG : rE) : cobE; cobQ = lane == i ? (rQ < POA_NEG ? POA_NEG : rQ) : cobQ;
+            }
+            asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
         }
-        if (more) phase_sync();
+        if (more && lane < cnt) { cnext[rb + lane] = (short)cobH; cnext[w.cpitch + rb + lane] = (short)cobE; cnext[2 * w.cpitch + rb + lane] = (short)cobQ; }
+        blk = nblk; xblk = nxblk; cH = nH; cE = nE; cQ = nQ;
+    }
+    if (more) phase_sync();
+    {   // a cell at the floor of the int16 range may have been cut off there: the caller reports it (status 6)
+        const int lo2 = (int)(short)(lowP & 0xffffu), hi2 = (int)lowP >> 16;
+        if (__builtin_amdgcn_ballot_w64((lo2 < hi2 ? lo2 : hi2) <= POA_NEG)) bs_io = -(1 << 29), br_io = -1;
+    }
+    if (br_io < 0) return;
+    // best of this pass: value descending, rank ascending, column ascending -- then against the earlier passes' (their columns
+    // are smaller: on equal value and rank the earlier pass stays)
+    {
+        const int vlo = (int)(short)(bsP & 0xffffu), vhi = (int)bsP >> 16;
+        const int rlo = (int)(brP & 0xffffu), rhi = (int)(brP >> 16);
+        const int clo = col0 + (int)(bcP & 0xffffu) + 1, chi = col0 + CP + (int)(bcP >> 16) + 1;
+        int bs = vlo, br = rlo, bc = clo;
+        if (vhi > vlo || (vhi == vlo && rhi < rlo)) { bs = vhi; br = rhi; bc = chi; }
+        if (br == 0) bs = -(1 << 30);                                             // nothing recorded in this virtual lane
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int s2 = __shfl_xor(bs, d), r2 = __shfl_xor(br, d), c2x = __shfl_xor(bc, d);
+            if (s2 > bs || (s2 == bs && (r2 < br || (r2 == br && c2x < bc)))) { bs = s2; br = r2; bc = c2x; }
+        }
+        if (nw) { bs = nbest; br = nrow; bc = m; }
+        if (br > 0 && (bs > bs_io || (bs == bs_io && br < br_io))) { bs_io = bs; br_io = br; bc_io = bc; }
     }
 }
 
-// DP rows of one sequence: passes of 256 columns (4 per lane); the last pass takes 2..4 columns per lane by its width
-__device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out, int& bc_out)
+// DP rows of one sequence: passes of 512 columns (8 per lane, two per register); the last pass takes 2, 4, 6 or 8 columns
+// per lane by its width (a row step costs a fixed part plus a part per register)
+__device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out, int& bc_out DBGARG)
 {
-    constexpr int NEGB = -(1 << 30);
-    constexpr int WMAX = 64 * POA_MAXC;
+    constexpr int WMAX = 128 * POA_MAXCP;
     const int RING = poa_ring(m);
-    int bs = S.algorithm == 0 ? 0 : NEGB, br = 0, bc = 0;
+    int bs = S.algorithm == 0 ? 0 : -(1 << 30), br = 0, bc = 0;
     int pass = 0;
     for (int colbase = 0; colbase < m; colbase += WMAX, ++pass) {
         const int rem = m - colbase;
         const bool more = rem > WMAX;
-        const int cw = more ? POA_MAXC : poa_cols(rem);
-        switch (cw) {
-            case 2: dp_pass<2>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
-            case 3: dp_pass<3>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
-#if POA_MAXC > 4
-            case 4: dp_pass<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
-            case 5: dp_pass<5>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
-            case 6: dp_pass<6>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
-            case 7: dp_pass<7>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
-            default: dp_pass<8>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
-#else
-            default: dp_pass<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc); break;
-#endif
+        const int cp = more ? POA_MAXCP : poa_cols(rem);
+        switch (cp) {
+            case 1: dp_pass_pk<1>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
+            case 2: dp_pass_pk<2>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
+            case 3: dp_pass_pk<3>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
+            default: dp_pass_pk<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
         }
-    }
-    // best over the lanes: value descending, rank ascending, column ascending
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int s2 = __shfl_xor(bs, d), r2 = __shfl_xor(br, d), c2 = __shfl_xor(bc, d);
-        if (s2 > bs || (s2 == bs && (r2 < br || (r2 == br && c2 < bc)))) { bs = s2; br = r2; bc = c2; }
+        if (br < 0) break;                               // a cell left the int16 range
     }
     bs_out = bs; br_out = br; bc_out = bc;
 }
@@ -727,7 +798,8 @@ __device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& 
     }
 }
 
-// returns the new node count; -1 graph limits, -2 workspace.  *score_out = end-cell score.
+// returns the new node count; -1 graph limits, -2 workspace, -3 back-track guard, -4 a cell at the floor of the int16 range
+// (global / overlap modes with costly gaps).  *score_out = end-cell score.
 // path_out (may be null): node of every base (for the MSA)
 __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8_t* seq, int m_, int lane, int* score_out, int32_t* path_out, unsigned long long* tacc)
 {
@@ -803,13 +875,22 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
                 f += S.e; o += S.c;
                 w.score[r] = f; w.bp[r] = o;
                 const int h = f > o ? f : o;
-                w.col0[r] = (short)(h < POA_NEG ? POA_NEG : h);
+                if (h <= POA_NEG) return -4;                 // column 0 leaves the int16 range (wave-uniform)
+                w.col0[r] = (short)h;
                 __syncthreads();
             }
         }
         phase_sync();
-        dp_rows(w, S, N, m, seq, lane, bs, br, bc);
+        dp_rows(w, S, N, m, seq, lane, bs, br, bc DBGPASS);
         phase_sync();
+        if (br < 0) return -4;                               // a cell at the floor of the int16 range: no exact answer from this kernel
+#ifdef CLH_DEBUG_POA
+        {   // row steps by register count of the pass (x16: the reader undoes the >>4 of the clocks)
+            constexpr int WMAX = 128 * POA_MAXCP;
+            for (int cb = 0; cb < m; cb += WMAX) { const int rem = m - cb; const int cp = rem > WMAX ? POA_MAXCP : poa_cols(rem); tacc[5] += (unsigned long long)N << 4; tacc[6] += (unsigned long long)N * cp << 4; }
+            tacc[7] += (unsigned long long)N * m;      // cells / 16
+        }
+#endif
     }
     *score_out = bs;
     TSTAMP(0);
@@ -1206,7 +1287,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
             }
             PoaWs w = carve(ws, ws_bytes, ncap, mcap);
             phase_sync();
-            unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             N = 0; b = 0;
             int si = 0;
             for (int i = 0; i <= ncuts && N >= 0; ++i) {
@@ -1233,13 +1314,15 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
                     for (int t = lane; t < L; t += 64) p.msa_col[off + t] = w.bp[p.msa_col[off + t]];
                 }
 #ifdef CLH_DEBUG_POA
-                if (lane == 0) for (int k = 0; k < 5; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
+                if (lane == 0) for (int k = 0; k < 8; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
+                if (lane == 0) for (int k = 8; k < 14; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (41 + k)] = (int)(tacc[k] >> 4);
 #endif
             }
             break;
         }
         if (N == -2) res.status = 1;
         else if (N == -3) res.status = 5;
+        else if (N == -4) res.status = 6;
         else if (N < 0) res.status = 2;
         else if (len < 0) res.status = 3;
         else { res.nseg = nseg; res.ccs_len = len; }

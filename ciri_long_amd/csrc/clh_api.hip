@@ -1110,6 +1110,8 @@ static int poa_check_opts(const clh_poa_opts* o, clh::PoaScores* s)
     if (d.m < 1 || d.m > 11 || d.n > d.m || d.n < -100) return fail(CLH_E_UNSUPPORTED, "poa: match score must be 1..11, mismatch -100..match (16-bit cells)");
     if (d.e - d.g > 6 || d.c - d.q > 30) return fail(CLH_E_UNSUPPORTED, "poa: e - g <= 6 and c - q <= 30 required (vertical gap states are kept as small differences)");
     if (std::max(d.g + 2799 * d.e, d.q + 2799 * d.c) < -30000) return fail(CLH_E_UNSUPPORTED, "poa: gap extension too costly for 16-bit cells");
+    // the row scans run in frames H - j*e and H - j*c over the <= 512 columns of a pass
+    if (d.m * 2800 + 512 * std::max(-d.e, -d.c) > 32767) return fail(CLH_E_UNSUPPORTED, "poa: match * 2800 + 512 * gap extension must fit 16 bits");
     if (d.min_coverage < 0) return fail(CLH_E_ARG, "poa: min_coverage must be >= 0");
     s->algorithm = d.algorithm; s->m = d.m; s->n = d.n; s->g = d.g; s->e = d.e; s->q = d.q; s->c = d.c; s->min_cov = d.min_coverage;
     return 0;

@@ -6,6 +6,7 @@ back to the CPU: a missing library or GPU raises ``HipUnavailable``.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -162,11 +163,20 @@ def pack(seqs):
     return np.ascontiguousarray(data, dtype=np.int8), off
 
 
+def _torch_first():
+    """torch ships its own HIP runtime; when a process uses both, torch's must open the device before libclh's does
+    (the other order leaves torch with "No HIP GPUs are available").  Only acts when the caller already imported torch."""
+    t = sys.modules.get('torch')
+    if t is not None and t.cuda.is_available() and not t.cuda.is_initialized():
+        t.cuda.init()
+
+
 class Context(object):
     """One per (process, GPU)."""
 
     def __init__(self, device=0):
         L = lib()
+        _torch_first()
         self._h = L.clh_create(int(device))
         if not self._h:
             raise HipUnavailable('clh_create(%d) failed: %s (there is no CPU fallback)' % (device, last_error()))
@@ -255,7 +265,7 @@ class Context(object):
         for k in range(ng):
             if lens[k] < 0:
                 raise ClhError('poa: no consensus for group %d (status %d: 1 workspace, 2 graph limits -- more than 12 in-edges or '
-                               '65000 nodes, 3 output, 4 sequence above 2800 bases)' % (k, -1 - int(lens[k])))
+                               '65000 nodes, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 a cell left the 16-bit score range)' % (k, -1 - int(lens[k])))
             o = int(seq_off[group_off[k]])
             cons = bases[np.minimum(out[o:o + int(lens[k])], 4)].tobytes().decode()
             if not genmsa and not with_scores:

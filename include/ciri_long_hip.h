@@ -121,7 +121,8 @@ typedef struct {
     int32_t nseg;      /* 0: no tandem repeat / no consensus (find_consensus would return (None, None)) */
     int32_t ccs_len;
     int32_t period;
-    int32_t status;    /* 0 ok; >0 treated as no consensus: 1 workspace, 2 graph limits (12 in-edges, 65000 rows), 3 output, 4 sequence longer than 2800 bases */
+    int32_t status;    /* 0 ok; >0 treated as no consensus: 1 workspace, 2 graph limits (12 in-edges, 65000 rows), 3 output, 4 sequence longer than 2800 bases,
+                          5 back-track guard, 6 a DP cell left the 16-bit range (global / overlap modes with costly gaps) */
 } clh_ccs_t;
 typedef struct clh_ccs_plan clh_ccs_plan;
 clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off);

@@ -38,3 +38,12 @@ def testfa():
     with open(os.path.join(HERE, 'golden', 'test.fa')) as f:
         f.readline(); seq1 = f.readline().rstrip(); f.readline(); seq2 = f.readline().rstrip()
     return seq1, seq2
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _torch_opens_the_gpu_first(request):
+    """GPU sessions mix libclh and torch (bench pieces, device views): torch's bundled HIP runtime has to initialise first."""
+    if request.config.getoption('-m') == 'gpu':
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()

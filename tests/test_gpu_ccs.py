@@ -210,6 +210,15 @@ def test_poa_batch_of_groups_large_clusters_and_limits():
         assert got[k] == oracle_lib.oracle_poa(g, 2, False, *PARS[0]), k
     with pytest.raises(hip.ClhError):
         spoa.poa(['ACGT' * 701, 'ACGT' * 700], 2, False, 10, -4, -8, -2, -24, -1)
+    # 16-bit cells: a score set whose row frames cannot fit is refused up front ...
+    with pytest.raises(hip.ClhError):
+        spoa.poa(['ACGTACGT', 'ACGTTCGT'], 0, False, 11, -4, -8, -6, -10, -5)
+    # ... and a global alignment that does reach the floor of the range says so (status 6) instead of answering inexactly:
+    # two unrelated 2600-base sequences under an affine cost of 6 per gap base sink below -30000; the same pair fits in local mode
+    a = ''.join(rng.choice('AC') for _ in range(2600)); b = ''.join(rng.choice('GT') for _ in range(2600))
+    with pytest.raises(hip.ClhError, match='status 6'):
+        spoa.poa([a, b], 1, False, 2, -100, -9, -6, -9, -6)
+    assert spoa.poa([a, b], 0, False, 2, -100, -9, -6, -9, -6)[0] == oracle_lib.oracle_poa([a, b], 0, False, 2, -100, -9, -6, -9, -6)
 
 
 def test_find_ccs_reads_files_and_resume(tmp_path):

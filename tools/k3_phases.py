@@ -23,4 +23,8 @@ names = ['dp rows', 'walk back', 'graph update', 'rerank', 'consensus']
 tot = t[ok].sum()
 for k, nm in enumerate(names):
     print('%-13s %6.1f %%   mean %8.1f us per read' % (nm, 100 * t[ok, k].sum() / tot, t[ok, k].mean() / 100.0))
+x = segs[:, 60:63, 0].astype(np.float64)
+print('row steps %.4g, register-rows %.4g (mean %.2f per step), cells %.4g' % (x[ok, 0].sum(), x[ok, 1].sum(), x[ok, 1].sum() / x[ok, 0].sum(), x[ok, 2].sum() * 16))
+y = segs[:, 49:55, 0].astype(np.float64)[ok].sum(0)
+print('rows with several in-edges %.3g, to ring %.3g, kept %.3g; sources: ring %.3g, kept %.3g, previous row %.3g' % tuple(y))
 print('reads with consensus %d, mean total %.1f us' % (ok.sum(), t[ok].sum(1).mean() / 100.0))

@@ -165,7 +165,7 @@ def roofline_of(launches, traffic_file=True):
             'note': 'integer DP kernels: hundreds of cell updates per compulsory byte; the VALU issue rate binds, not HBM (DESIGN.md section 3)'}
 
 
-def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False):
+def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1):
     """per read-length class HIP-event durations of K1 (and K1b), with their algorithmic bytes and cell counts"""
     ssw_plan.set_profiling(True)
     acc, accb = None, [0.0, 0.0]
@@ -181,17 +181,19 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False):
     classes = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32]
     rows16 = ((qlen + 15) // 16) * 16
     cls = np.array([next((c for c in classes if 128 * c >= r), 32) for r in rows16]) if len(qlen) else np.zeros(0, dtype=int)
+    if len(qlen) and not os.environ.get('CLH_NO_SCAN'):      # class 0 = K1s, the row-scan kernel (clh_api.hip: scan_class_ok)
+        cls[(qlen <= 240) & (max_match * qlen + bias < 255)] = 0
     out, cells_total, k1ms = [], 0, 0.0
     for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
         sel = cls == rv
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv, 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv else 'ssw_scan_kernel', 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_kernel[small window]', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         out.append({'kernel': 'ssw_traceback_kernel[large window, outliers]', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0})
-    valu = {'bound': 'valu', 'kernel': 'ssw_align_kernel (all classes)', 'unit': 'GCUPS',
+    valu = {'bound': 'valu', 'kernel': 'ssw_scan_kernel + ssw_align_kernel (all classes)', 'unit': 'GCUPS',
             'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
             'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,
             'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / 6 packed ops per cell pair (gapO == gapE path)'}

@@ -168,6 +168,15 @@ static int rv_class_for(int rows)
     return clh::kRvStrips;      // longer than 4096 rows: RV = 32 kernel with row strips
 }
 
+// K1s (ssw_scan.hip) takes the alignments whose scores provably fit the reference's 8-bit pass (ssw.c:804-806 chooses it and
+// it cannot overflow), with the read short enough for its (score, row) keys and the gap extension for its 16-bit frames.
+// CLH_NO_SCAN=1 in the environment sends everything to the anti-diagonal kernels (A/B measurements).
+static bool scan_class_ok(int64_t L, const clh_ssw_opts* o, int max_match, int bias)
+{
+    static const bool off = getenv("CLH_NO_SCAN") != nullptr;
+    return !off && L <= 240 && o->score_size != 1 && (int64_t)max_match * L + bias < 255 && o->gap_extend >= 0 && o->gap_extend <= 16 && o->gap_open <= 255;
+}
+
 // ref_off != nullptr: packed references, alignment a against [ref_off[a], ref_off[a+1]).  Otherwise windows of a resident
 // genome: win_off[a], win_len[a], win_rc[a] (1 = read backwards and complemented).
 static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
@@ -212,7 +221,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         if (L < 1 || R < 0 || L > 0x7fffffff || R > 0x7fffffff) { fail(CLH_E_ARG, "empty read or negative length in batch"); delete pl; return nullptr; }
         const int rc = (!ref_off && win_rc && win_rc[a]) ? 1 : 0;
         const int rows = (int)((L + 15) / 16) * 16;
-        const int rv = rv_class_for(rows);
+        const int rv = scan_class_ok(L, o, mx, -mn) ? clh::kRvScan : rv_class_for(rows);
         cls[a] = rv;
         clh::SswTask& t = pl->tasks[a];
         t.read_off = read_off[a]; t.ref_off = ref_off ? ref_off[a] : (rc ? win_off[a] + R - 1 : win_off[a]);
@@ -473,7 +482,8 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         hipStream_t ls = (fan && (q & 3)) ? c->side[(q & 3) - 1] : st;
         P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], ls));
-        HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
+        if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
+        else HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], ls));
         if (tb && !pl->profiling)
             HIPCHK(clh::launch_traceback_pool(0, P, s.count, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, ls));

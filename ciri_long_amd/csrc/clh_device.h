@@ -154,6 +154,8 @@ static constexpr int kRvStrips = 1000;   // pseudo class: RV = 32 with row strip
 extern const int kRvClasses[];
 extern const int kNumRvClasses;
 hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStream_t stream);
+static constexpr int kRvScan = 0;        // pseudo class: K1s, the row-scan kernel for short reads in the 8-bit regime (ssw_scan.hip)
+hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t stream);
 hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t* pool_base, unsigned long long* pool_head,
                                  unsigned long long pool_size, hipStream_t stream);
 

@@ -1,0 +1,347 @@
+// ssw_scan.hip -- K1s: Smith-Waterman scores and coordinates for SHORT reads, one alignment per wavefront (gfx950).
+//
+// Same answers as ssw_wavefront.hip (reference: libs/striped_smith_waterman/ssw.c:123-345 sw_sse2_byte and the
+// forward + reverse orchestration of ssw_align, ssw.c:779-849; row-major statement: oracle/rowmajor_spec.c), for the
+// alignments the host sorts into this class (clh_api.hip: scan_class_ok):
+//     read <= 240 bases,  max_match * readLen + bias < 255  (ssw.c:804-806 then runs the 8-bit pass and that pass cannot
+//     overflow: every score fits 8 bits, no 16-bit re-run, no stripe quirk),  gap_extend <= 16.
+// These are the 20..300-base clips of find_bsj.py:191-216 against windows of 2 kb .. 400 kb -- most of the SSW calls of
+// `call`.  The anti-diagonal kernel spends a fixed cost per step on handing three values down the lanes; with one row
+// per virtual lane (reads <= 128 bases) that fixed cost is most of the step, and 127 fill/drain steps per pass are wasted.
+//
+// Here the matrix is walked the other way round: the LANES own reference columns, the loop runs over the read's rows.
+//   * a wave is 128 virtual lanes (the 16-bit halves of every VGPR); virtual lane v owns CPR adjacent columns of a chunk
+//     of 128*CPR columns (CPR = 2, 4 or 8 by what is left of the window): register t, low halves = columns
+//     2*CPR*lane + t, high halves = columns 2*CPR*lane + CPR + t -- the left neighbour of a cell is the same half of the
+//     previous register;
+//   * one row step: diagonal + substitution score (profile of the chunk's columns in LDS, indexed by the row's base),
+//     the gap from the row above (F; registers), then the gap along the row (E) as a prefix maximum: a dependent chain
+//     inside the CPR columns of a virtual lane, one wave-wide scan (6 DPP max) of the per-lane "E leaving the lane"
+//     in the frame where a gap extension costs nothing, and the incoming E applied to the lane's columns;
+//   * per column the running maximum over the rows is kept as (H << 8 | 255 - row): one unsigned maximum gives the
+//     column maximum AND the smallest row that holds it (what ssw.c:299-308 searches at the end);
+//   * chunks follow each other left to right; the last column of a chunk (H and the E leaving it, per row) is handed to
+//     the next chunk through 1 KiB of LDS.  The reverse pass (ssw.c:834-849) ends at the first column whose maximum
+//     equals the forward score: it runs in chunks of 256 columns and stops after the chunk that holds that column.
+// No fill or drain, no per-cell hand-down: 9 packed operations per cell pair (gap_open == gap_extend) or 13, plus ~40 per
+// row step, against ~26 per 128 cells in the anti-diagonal form.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "clh_device.h"
+
+namespace clh {
+
+namespace {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_maxu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pk_subus(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pk_madu(uint32_t a, uint32_t b, uint32_t c) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c)); }
+__device__ __forceinline__ uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
+// hand a packed value to the next virtual lane: new low half = previous lane's high half (lane 0: lane0_lo), new high half = own low half
+__device__ __forceinline__ uint32_t hand_down(uint32_t v, int lane0_lo) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp((int)((uint32_t)lane0_lo << 16), (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __builtin_amdgcn_alignbit(v, x, 16);
+}
+__device__ __forceinline__ int dpp_shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+// inclusive prefix maximum over the 64 lanes (v_max_i32 with the DPP modifier on the operand: 6 instructions)
+__device__ __forceinline__ int wave_prefix_max(int v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
+    return v;
+}
+
+#ifndef SCAN_WAVES
+#define SCAN_WAVES 3      // measured on the C3 clip batch: 2 -> 1.87 ms, 3 -> 1.76 ms, 4 -> 1.88 ms
+#endif
+static constexpr int SCAN_MAX_ROWS = 256;        // rows of a pass incl. the wildcard rows (reads <= 240 bases)
+static constexpr int SCAN_CPR_MAX = 8;
+static constexpr int SCAN_PROF_WORDS = 6 * SCAN_CPR_MAX * 64;      // uint32 per wave: [query code 0..5][register][lane]
+
+struct ScanIn {
+    const int8_t* read;   // first row's base
+    int rstep;            // +1 / -1
+    int L;                // rows of the read
+    int rows;             // rows processed: L, or L padded to a multiple of 16 with wildcard rows (score 0 against everything)
+    const int8_t* ref;    // first column's base
+    int cstep;            // +1 / -1
+    int comp;             // reference bytes are complemented as they are read
+    int ncols;
+    int terminate;        // column maximum that ends the pass (ssw.c:296); > 254 = never
+    uint16_t* colmax;     // per-column maxima in processing order, or nullptr
+};
+struct ScanOut { int max, col, row; };
+
+struct ScanLds {
+    uint32_t* prof;       // SCAN_PROF_WORDS
+    const int* mat;       // [6 reference codes][8 query codes]
+    short* bH;            // [2][SCAN_MAX_ROWS]: H of the chunk's last column per row (parity of the chunk)
+    short* bE;            // [2][SCAN_MAX_ROWS]: E entering the next chunk's first column per row
+};
+
+// one chunk of 128*CPR columns starting at column c0; returns through best_* the best cell so far (first column wins)
+// and through tcol the first column of the chunk whose maximum equals in.terminate (or INT_MAX)
+template <int CPR, bool GEQ>
+__device__ void scan_chunk(const ScanIn& in, const ScanLds& lds, const int c0, const int parity, const bool first, const bool more,
+                           const int gapO, const int gapE, int& best_score, int& best_col, int& best_row, int& tcol)
+{
+    constexpr int VEC = CPR < 4 ? CPR : 4;       // registers per LDS read
+    constexpr int NCH = CPR / VEC;
+    const int lane = threadIdx.x & 63;
+    const int K = CPR * gapE;                    // what a gap loses across one virtual lane
+    const int kLo = 2 * lane * K;
+    const uint32_t gO2 = dup16(gapO), gE2 = dup16(gapE);
+
+    // ---- profile of the chunk's columns: prof[q][c][lane][VEC], entry = scores of the row base q against the two columns
+    {
+        int rlo[CPR], rhi[CPR];
+#pragma unroll
+        for (int t = 0; t < CPR; ++t) {
+            const int jlo = c0 + 2 * CPR * lane + t, jhi = jlo + CPR;
+            const int blo = jlo < in.ncols ? (int)in.ref[(int64_t)jlo * in.cstep] : 0, bhi = jhi < in.ncols ? (int)in.ref[(int64_t)jhi * in.cstep] : 0;
+            rlo[t] = jlo < in.ncols ? ref_code(blo, in.comp) : 5;
+            rhi[t] = jhi < in.ncols ? ref_code(bhi, in.comp) : 5;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int t = 0; t < CPR; ++t) {
+                const int slo = lds.mat[rlo[t] * 8 + q], shi = lds.mat[rhi[t] * 8 + q];
+                lds.prof[((q * NCH + t / VEC) * 64 + lane) * VEC + (t % VEC)] = (uint32_t)(slo & 0xffff) | ((uint32_t)shi << 16);
+            }
+    }
+    const short* bHin = lds.bH + (parity ^ 1) * SCAN_MAX_ROWS;
+    const short* bEin = lds.bE + (parity ^ 1) * SCAN_MAX_ROWS;
+    short* bHout = lds.bH + parity * SCAN_MAX_ROWS;
+    short* bEout = lds.bE + parity * SCAN_MAX_ROWS;
+    __syncthreads();
+
+    uint32_t Hp[CPR], Fst[GEQ ? 1 : CPR], key[CPR];
+#pragma unroll
+    for (int t = 0; t < CPR; ++t) { Hp[t] = 0; key[t] = 0; if constexpr (!GEQ) Fst[t] = 0; }
+    int prev_hb = 0;                             // H[row - 1][c0 - 1]
+    for (int rb = 0; rb < in.rows; rb += 64) {
+        const int row = rb + lane;
+        int qv = 5;
+        if (row < in.L) { const int c = (int)in.read[(int64_t)row * in.rstep] & 7; qv = c > 5 ? 5 : c; }
+        int hbv = 0, ebv = 0;
+        if (!first && row < in.rows) { hbv = bHin[row]; ebv = bEin[row]; }
+        const int cnt = in.rows - rb < 64 ? in.rows - rb : 64;
+        int cobH = 0, cobE = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int q = __builtin_amdgcn_readlane(qv, i), hb = __builtin_amdgcn_readlane(hbv, i), eb = __builtin_amdgcn_readlane(ebv, i);
+            uint32_t P[CPR];
+            {
+                const uint32_t* pp = lds.prof + (q * NCH * 64 + lane) * VEC;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if constexpr (VEC == 4) { const uint4 v = *(const uint4*)(pp + c * 64 * VEC); P[4 * c] = v.x; P[4 * c + 1] = v.y; P[4 * c + 2] = v.z; P[4 * c + 3] = v.w; }
+                    else { const uint2 v = *(const uint2*)(pp + c * 64 * VEC); P[0] = v.x; P[1] = v.y; }
+                }
+            }
+            const uint32_t d0 = hand_down(Hp[CPR - 1], prev_hb);
+            uint32_t R[CPR];
+            uint32_t e = 0, U;
+#pragma unroll
+            for (int t = 0; t < CPR; ++t) {
+                const uint32_t tt = pk_adds(t == 0 ? d0 : Hp[t - 1], P[t]);
+                uint32_t Fv;
+                if constexpr (GEQ) Fv = pk_subus(Hp[t], gO2);
+                else { Fv = pk_max(pk_subus(Fst[t], gE2), pk_subus(Hp[t], gO2)); Fst[t] = Fv; }
+                const uint32_t X = pk_max(tt, Fv);                      // >= 0: Fv is
+                if (t == 0) R[0] = X;
+                else if constexpr (GEQ) R[t] = pk_max(X, pk_subus(R[t - 1], gO2));
+                else { e = pk_max(pk_subus(e, gE2), pk_subus(R[t - 1], gO2)); R[t] = pk_max(X, e); }
+            }
+            if (GEQ) U = pk_subus(R[CPR - 1], gO2);
+            else U = pk_max(pk_subus(e, gE2), pk_subus(R[CPR - 1], gO2));   // E leaving the virtual lane, from its own columns
+            // E entering every virtual lane: prefix maximum of U in the frame where crossing a virtual lane costs nothing
+            const int Blo = (int)(U & 0xffffu) + kLo, Bhi = (int)(U >> 16) + kLo + K;
+            const int inc = wave_prefix_max(Blo > Bhi ? Blo : Bhi);
+            const int fill = eb - K;                                    // the previous chunk, as virtual lane -1
+            int exc = dpp_shr1(fill, inc);
+            exc = exc > fill ? exc : fill;
+            const int einLo = exc - kLo + K;
+            const int m2 = exc > Blo ? exc : Blo;
+            const int einHi = m2 - kLo;
+            uint32_t Ein = ((uint32_t)einLo & 0xffffu) | ((uint32_t)einHi << 16);
+            const uint32_t rowc = dup16(255 - (rb + i));
+#pragma unroll
+            for (int t = 0; t < CPR; ++t) {
+                const uint32_t h = pk_max(R[t], Ein);
+                Ein = pk_subs(Ein, gE2);
+                Hp[t] = h;
+                key[t] = pk_maxu(key[t], pk_madu(h, 0x01000100u, rowc));
+            }
+            prev_hb = hb;
+            if (more) {   // the chunk's last column: H, and the E that enters the next chunk's first column
+                const int outH = (int)((uint32_t)__builtin_amdgcn_readlane((int)Hp[CPR - 1], 63) >> 16);
+                int outE = __builtin_amdgcn_readlane(inc, 63);
+                outE = (outE > fill ? outE : fill) - 127 * K;
+                outE = outE < 0 ? 0 : outE;
+                cobH = lane == i ? outH : cobH; cobE = lane == i ? outE : cobE;
+            }
+        }
+        if (more && lane < cnt) { bHout[rb + lane] = (short)cobH; bEout[rb + lane] = (short)cobE; }
+    }
+    __syncthreads();
+
+    // ---- the chunk's columns: column maxima out, terminate column, best cell (first column wins; smallest row in it) ----
+    int tmin = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < CPR; ++t)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int j = c0 + 2 * CPR * lane + hf * CPR + t;
+            const int k16 = hf ? (int)(key[t] >> 16) : (int)(key[t] & 0xffffu);
+            const int cm = k16 >> 8;
+            if (j < in.ncols) {
+                if (in.colmax) in.colmax[j] = (uint16_t)cm;
+                if (cm == in.terminate) tmin = j < tmin ? j : tmin;
+            }
+        }
+    tmin = wave_min(tmin);
+    int b32 = 0;
+#pragma unroll
+    for (int t = 0; t < CPR; ++t)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int jc = 2 * CPR * lane + hf * CPR + t, j = c0 + jc;
+            const int k16 = hf ? (int)(key[t] >> 16) : (int)(key[t] & 0xffffu);
+            const int v = ((k16 >> 8) << 20) | ((0xfff - jc) << 8) | (k16 & 0xff);
+            if (j < in.ncols && j <= tmin) b32 = v > b32 ? v : b32;
+        }
+    b32 = wave_max(b32);
+    const int sc = b32 >> 20;
+    if (sc > best_score) { best_score = sc; best_col = c0 + (0xfff - ((b32 >> 8) & 0xfff)); best_row = 255 - (b32 & 0xff); }
+    tcol = tmin;
+}
+
+template <bool GEQ>
+__device__ ScanOut scan_pass(const ScanIn& in, const ScanLds& lds, const int gapO, const int gapE)
+{
+    int best_score = 0, best_col = -1, best_row = 0;
+    const bool ends = in.terminate <= 254;       // reverse pass: stops at the first column whose maximum is the forward score
+    int parity = 0;
+    for (int c0 = 0; c0 < in.ncols; parity ^= 1) {
+        const int rem = in.ncols - c0;
+        int tcol = 0x7fffffff;
+        const bool first = c0 == 0;
+        if (ends || rem <= 256) { scan_chunk<2, GEQ>(in, lds, c0, parity, first, rem > 256, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 256; }
+        else if (rem <= 512) { scan_chunk<4, GEQ>(in, lds, c0, parity, first, false, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 512; }
+        else { scan_chunk<8, GEQ>(in, lds, c0, parity, first, rem > 1024, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 1024; }
+        if (tcol != 0x7fffffff) break;
+    }
+    ScanOut o;
+    o.max = best_score;
+    if (best_score == 0) { o.col = -1; o.row = 0; return o; }
+    o.col = best_col;
+    o.row = best_row < in.L - 1 ? best_row : in.L - 1;
+    return o;
+}
+
+// masked second-best column maximum, ssw.c:325-340 (8-bit pass); wave-parallel
+__device__ void second_best8(const uint16_t* colmax, int refLen, int end_ref, int maskLen, int& score2, int& ref_end2)
+{
+    const int lane = threadIdx.x & 63;
+    int e1 = end_ref - maskLen; if (e1 < 0) e1 = 0;
+    int e2 = end_ref + maskLen; if (e2 > refLen) e2 = refLen;
+    e2 += 1;
+    int bv = 0, bp = 0x7fffffff;
+    for (int i = lane; i < refLen; i += 64) {
+        if (i < e1 || i >= e2) {
+            const int v = colmax[i];
+            if (v > bv) { bv = v; bp = i; }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v2 = __shfl_xor(bv, d), p2 = __shfl_xor(bp, d);
+        const bool take = v2 > bv || (v2 == bv && p2 < bp);
+        bv = take ? v2 : bv; bp = take ? p2 : bp;
+    }
+    score2 = bv;
+    ref_end2 = bv > 0 ? bp : 0;
+}
+
+}  // namespace
+
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_kernel(const SswParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_prof[SCAN_PROF_WORDS];
+    __shared__ int s_mat[48];
+    __shared__ short s_bH[2 * SCAN_MAX_ROWS], s_bE[2 * SCAN_MAX_ROWS];
+    const int lane = threadIdx.x & 63;
+    if (lane < 48) {   // 6 reference codes x 8 read codes; anything outside the n x n matrix scores 0
+        const int b = lane >> 3, q = lane & 7;
+        s_mat[lane] = (b < p.n && q < p.n) ? (int)p.mat[b * p.n + q] : 0;
+    }
+    __syncthreads();
+    ScanLds lds; lds.prof = s_prof; lds.mat = s_mat; lds.bH = s_bH; lds.bE = s_bE;
+
+    const SswTask task = p.tasks[blockIdx.x];
+    const int8_t* read = p.reads + task.read_off;
+    const int8_t* ref = p.refs + task.ref_off;
+    const int L = task.read_len, refLen = task.ref_len;
+    uint16_t* colmax = p.colmax ? p.colmax + task.colmax_off : nullptr;
+    const int rdir = task.ref_rc ? -1 : 1;
+    SswResult res;
+    res.score2 = 0; res.ref_begin1 = -1; res.ref_end2 = 0; res.status = 0;
+
+    // ---- forward (ssw.c:804-822: the 8-bit pass; it cannot overflow in this class) ---------------------------------
+    ScanIn in;
+    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = task.ref_rc; in.ncols = refLen;
+    in.terminate = 1 << 30; in.colmax = colmax;
+    in.rows = colmax ? ((L + 15) / 16) * 16 : L;     // the wildcard rows only matter to the column maxima (rowmajor_spec.c)
+    const ScanOut fw = scan_pass<GEQ>(in, lds, p.gapO, p.gapE);
+    res.score1 = fw.max;
+    if (fw.max == 0) { res.ref_end1 = -1; res.read_end1 = 0; }
+    else { res.ref_end1 = fw.col; res.read_end1 = fw.row; }
+    if (task.mask_len >= 15 && colmax) { __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); second_best8(colmax, refLen, res.ref_end1, task.mask_len, res.score2, res.ref_end2); }
+    else { res.score2 = 0; res.ref_end2 = task.mask_len >= 15 ? 0 : -1; }
+
+    // ---- reverse: begin coordinates (ssw.c:834-849) ---------------------------------------------------------------
+    res.read_begin1 = -1;
+    const bool want_begin = !(p.flag == 0 || (p.flag == 2 && res.score1 < p.filters));
+    if (want_begin) {
+        ScanIn rv;
+        rv.L = res.read_end1 + 1; rv.rows = ((rv.L + 15) / 16) * 16; rv.read = read + res.read_end1; rv.rstep = -1;
+        rv.ncols = res.ref_end1 + 1; rv.ref = ref + (int64_t)res.ref_end1 * rdir; rv.cstep = -rdir; rv.comp = task.ref_rc;
+        rv.terminate = res.score1; rv.colmax = nullptr;
+        const ScanOut r = scan_pass<GEQ>(rv, lds, p.gapO, p.gapE);
+        if (r.max == 0) { res.ref_begin1 = -1; res.read_begin1 = res.read_end1; }
+        else { res.ref_begin1 = res.ref_end1 - r.col; res.read_begin1 = res.read_end1 - r.row; }
+    }
+    if (lane == 0) p.results[task.out_index] = res;
+}
+
+hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t stream)
+{
+    if (geq) hipLaunchKernelGGL((ssw_scan_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL((ssw_scan_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace clh

@@ -280,3 +280,45 @@ def test_ssw_wrap_mirror_behaves_like_the_reference_wrapper(golden_cases):
                 (x['score'], x['ref_begin'], x['ref_end'], x['query_begin'], x['query_end'], x['cigar_string'])
     batch = al.align_batch([c['query'], c['query'][2:], 'ACGT'])
     assert batch[0].score == c['score'] and len(batch) == 3
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (1, 1, 2, 1), (2, 3, 5, 2), (1, 2, 16, 16), (3, 1, 4, 4)])
+def test_row_scan_class_short_reads_vs_oracle(ctx, scheme):
+    """K1s (csrc/ssw_scan.hip) takes the alignments whose scores fit the 8-bit pass for certain (ssw.c:804-806): reads up to
+    240 bases against windows whose lengths sit on and around its column chunks (256 / 512 / 1024), windows of several
+    chunks, repeats that make a later column exceed the forward score in the reverse pass (ssw.c:296 ends at equality
+    only), N on both sides; with and without the second-best score (its column maxima include the wildcard rows)."""
+    from ciri_long_amd import hip
+    m, x, o, e = scheme
+    rng = np.random.default_rng(700 + sum(scheme))
+    refs, qs = [], []
+    for R in [1, 2, 100, 255, 256, 257, 300, 511, 512, 513, 767, 1023, 1024, 1025, 1300, 2047, 2048, 2049, 3100, 5000, 9000]:
+        for _ in range(6):
+            L = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 65, 100, 127, 128, 129, 200, 239, 240])) if m == 1 else int(rng.integers(1, 250 // m))
+            ref = _rnd(rng, R)
+            st = int(rng.integers(0, max(1, R - L)))
+            q = _mut(ref[st:st + L], rng, float(rng.choice([0.0, 0.05, 0.2])))[:L] or 'A'
+            u = rng.random()
+            if u < 0.2 and R > 3 * len(q) + 10:     # the clip occurs twice, the second copy cleaner: reverse passes that see larger maxima
+                ref = ref[:R // 2] + q + ref[R // 2:R - len(q)]
+            elif u < 0.3:
+                ref = ref[:R // 3] + 'N' * int(rng.integers(1, 9)) + ref[R // 3:]
+            elif u < 0.4:
+                q = q[:len(q) // 2] + 'N' + q[len(q) // 2 + 1:]
+            elif u < 0.5:
+                q = _rnd(rng, len(q))
+            refs.append(ref); qs.append(q)
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    for s2 in (True, False):
+        plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=s2, want_cigar=True)
+        n0 = sum(c for rv, c, _a, _b in plan.segments() if rv == 0)
+        assert n0 == sum(1 for q in qs if len(q) <= 240 and m * len(q) + x < 255) and n0 > 0.9 * len(qs)
+        plan.close()
+        rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(m, x), o, e, want_score2=s2, want_cigar=True)
+        for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
+            want = oracle_align(ref, q, *scheme)
+            got = _row_tuple(r)
+            exp = (want['score'], want['score2'] if s2 else 0, want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end'],
+                   want['ref_end2'] if s2 else got[6])
+            assert got == exp, (k, len(q), len(ref), got, exp)
+            assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref))

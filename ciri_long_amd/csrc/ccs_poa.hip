@@ -311,11 +311,15 @@ static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whos
 #define DBGARG , unsigned long long* tacc
 #define DBGPASS , tacc
 #define DBGCNT(k, v) do { tacc[k] += (unsigned long long)(v) << 4; } while (0)
+#define SEC0() unsigned long long sec_t = __builtin_amdgcn_s_memtime()
+#define SEC(k) do { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); tacc[k] += t2_ - sec_t; sec_t = t2_; } while (0)
 #define TSTAMP(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define DBGARG
 #define DBGPASS
 #define DBGCNT(k, v) do {} while (0)
+#define SEC0() do {} while (0)
+#define SEC(k) do {} while (0)
 #define TSTAMP(k) do {} while (0)
 #endif
 
@@ -456,6 +460,7 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
         int cobH = 0, cobE = 0, cobQ = 0;
         for (int i = 0; i < cnt; ++i) {
             const int r = rb + i;
+            SEC0();
             const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
             const uint32_t rxv = (uint32_t)__builtin_amdgcn_readlane((int)xblk, i);
             const int cinH = __builtin_amdgcn_readlane(cH, i), cinE = __builtin_amdgcn_readlane(cE, i), cinQ = __builtin_amdgcn_readlane(cQ, i);
@@ -482,7 +487,6 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                     }
                     hsh0 = pack16(row0_h(col0), row0_h(col0 + CP));
                 } else if (qr == r - 1) {
-                    DBGCNT(13, 1);
 #pragma unroll
                     for (int t = 0; t < CP; ++t) { h[t] = px[t]; fs[t] = pf[t]; os[t] = po[t]; }
                     hsh0 = hand_down(px[CP - 1], pcin);
@@ -490,14 +494,12 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                     uint32_t dd[CP];
                     int a0, a1;                                  // the two elements in front of the two halves
                     if (r - qr < RING) {
-                        DBGCNT(11, 1);
                         const short* sh = ringH + (qr & rmask) * lp + lc0 + 8;
                         const uint8_t* sd = ringD + (qr & rmask) * lp + lc0 + 8;
                         a0 = sh[-1]; a1 = sh[CP - 1];
 #pragma unroll
                         for (int t = 0; t < CP; ++t) { h[t] = pack16(sh[t], sh[CP + t]); dd[t] = (uint32_t)sd[t] | ((uint32_t)sd[CP + t] << 16); }
                     } else {
-                        DBGCNT(12, 1);
                         const int kq = (int)(__builtin_amdgcn_readfirstlane((int)w.rx[qr]) >> 16) & 0xffff;
                         const short* sh = w.keepH + (size_t)kq * gp + col0 + 8;
                         const uint8_t* sd = w.keepD + (size_t)kq * gp + col0 + 8;
@@ -523,7 +525,7 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                     }
                 }
             };
-            DBGCNT(8, np > 1); DBGCNT(9, tolds); DBGCNT(10, keep);
+            SEC(8);
             uint32_t best[CP], code[CP], fsn[CP], osn[CP], xb[CP];   // xb: bit 7 of each half = vstop; multi rows: bits 8.. = slot of the upward run
             if (np <= 1) {
                 uint32_t h[CP], hsh0, fs[CP], os[CP];
@@ -582,6 +584,7 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                     xb[t] = ((sel & ONE2) << 7) | (slot2 << 8);
                 }
             }
+            SEC(9);
             // horizontal states: two prefix maxima in the gap-free frames of the two pieces
             uint32_t ehat[CP], qhat[CP];
             {
@@ -601,6 +604,7 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
                 for (int t = 0; t < CP; ++t) qhat[t] = pk_adds(pk_adds(pe[t], jcP[t]), qc2);
             }
+            SEC(10);
             uint32_t Hf[CP], E[CP];
 #pragma unroll
             for (int t = 0; t < CP; ++t) Hf[t] = pk_max(pk_max(best[t], ehat[t]), qhat[t]);
@@ -619,6 +623,7 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                 const uint32_t both_lt = pk_sra15(pk_subs(c5, c6)) & pk_sra15(pk_subs(c7, c8));
                 out[t] = cd | (~both_lt & 0x00400040u) | (xb[t] & 0x00800080u);
             }
+            SEC(11);
             // ---- what later rows and the back-track read ------------------------------------------------------------------
 #pragma unroll
             for (int t = 0; t < CP; ++t) { px[t] = Hf[t]; pf[t] = fsn[t]; po[t] = osn[t]; }
@@ -664,6 +669,7 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
             }
             if (tolds && lane == 0) ringH[(r & rmask) * lp + 7] = (short)cinH;     // element of local column 0
             if (keep && pass == 0 && lane == 0) w.keepH[(size_t)ki * gp + 7] = (short)cinH;
+            SEC(12);
             if (!sw) {
 #pragma unroll
                 for (int t = 0; t < CP; ++t) lowP = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, lowP), __builtin_bit_cast(s16x2, bfi(pk_sra15(sbP[t] << 9), 0x7fff7fffu, Hf[t]))));
@@ -699,6 +705,7 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                           rQ = (int)__builtin_amdgcn_readlane((int)qhat[CP - 1], 63) >> 16;
                 cobH = lane == i ? rH : cobH; cobE = lane == i ? (rE < POA_NEG ? POA_NEG : rE) : cobE; cobQ = lane == i ? (rQ < POA_NEG ? POA_NEG : rQ) : cobQ;
             }
+            SEC(13);
             asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
         }
         if (more && lane < cnt) { cnext[rb + lane] = (short)cobH; cnext[w.cpitch + rb + lane] = (short)cobE; cnext[2 * w.cpitch + rb + lane] = (short)cobQ; }

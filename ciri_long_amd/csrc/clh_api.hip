@@ -171,6 +171,9 @@ static int rv_class_for(int rows)
 // K1s (ssw_scan.hip) takes the alignments whose scores provably fit the reference's 8-bit pass (ssw.c:804-806 chooses it and
 // it cannot overflow), with the read short enough for its (score, row) keys and the gap extension for its 16-bit frames.
 // CLH_NO_SCAN=1 in the environment sends everything to the anti-diagonal kernels (A/B measurements).
+// CLH_NO_TB_ROWS=1: CIGARs from the anti-diagonal traceback kernel only (A/B measurements)
+static bool tb_rows_on() { static const bool off = getenv("CLH_NO_TB_ROWS") != nullptr; return !off; }
+
 static bool scan_class_ok(int64_t L, const clh_ssw_opts* o, int max_match, int bias)
 {
     static const bool off = getenv("CLH_NO_SCAN") != nullptr;
@@ -240,12 +243,14 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
             t.cigar_cap = (int32_t)(2 * L + 2);
             if (cig + (size_t)t.cigar_cap > 0x7fffffffull) { fail(CLH_E_CAPACITY, "batch too large for 32-bit CIGAR offsets; split it"); delete pl; return nullptr; }
             cig += (size_t)t.cigar_cap;
-            // traceback workspace estimate: two band doublings of a 64-wide band over the anti-diagonals of an L x L problem
-            pool += (unsigned long long)(2 * L + 64) * 130ull * 2ull;
+            // traceback workspace: the row kernel keeps 4 bits per cell of the final band only, 64 bytes per read row for
+            // bands up to 128 cells, 128 up to 256 (ssw_traceback_rows.hip); the few wide bands and the anti-diagonal
+            // kernel's per-iteration byte planes come out of the fixed slack added below
+            pool += (unsigned long long)(L + 64) * 160ull;
         }
     }
     pl->colmax_elems = colmax; pl->cigar_elems = cig;
-    if (pl->do_cigar) pl->pool_bytes = std::min<unsigned long long>(std::max<unsigned long long>(pool, 64ull << 20), 16ull << 30);
+    if (pl->do_cigar) pl->pool_bytes = std::min<unsigned long long>(pool + (512ull << 20), 16ull << 30);
 
     // launch order: by row class, heaviest alignments first inside a class
     std::vector<int> order(n);
@@ -272,7 +277,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
     if (pl->do_cigar) {
         pl->d_cigars = ctx->alloc(sizeof(uint32_t) * std::max<size_t>(cig, 1));
         pl->d_pool = ctx->alloc((size_t)pl->pool_bytes);
-        pl->d_pool_head = ctx->alloc(256);
+        pl->d_pool_head = ctx->alloc(clh::tb_head_bytes(n));
     }
     if (pl->strip_bytes) pl->d_strips = ctx->alloc(pl->strip_bytes);
     if (!pl->d_tasks || !pl->d_results || !pl->d_cigar_len || (pl->strip_bytes && !pl->d_strips) || (o->want_score2 && !pl->d_colmax) ||
@@ -468,7 +473,7 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     const bool tb = pl->do_cigar && pl->n > 0;
     const bool fan = !pl->profiling && pl->segs.size() > 1;
     const size_t eb = pl->segs.size() * 2;
-    if (tb) HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 8, st));
+    if (tb) HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 16, st));     // bump pointer and the two hand-over counters
     if (fan) {
         HIPCHK(hipEventRecord(c->fork_ev, st));
         for (int i = 0; i < 3; ++i) HIPCHK(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
@@ -485,8 +490,10 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
         else HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], ls));
-        if (tb && !pl->profiling)
-            HIPCHK(clh::launch_traceback_pool(0, P, s.count, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, ls));
+        if (tb && !pl->profiling) {
+            if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows(P, s.count, s.begin, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, ls));
+            else HIPCHK(clh::launch_traceback_pool(0, P, s.count, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, ls, false, pl->n));
+        }
     }
     if (fan)
         for (int i = 0; i < 3; ++i) {
@@ -497,16 +504,21 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         P.tasks = (const clh::SswTask*)pl->d_tasks;
         if (pl->profiling) {   // profiling runs keep the two traceback phases as separate, serial launches
             HIPCHK(hipEventRecord(pl->ev[eb + 0], st));
-            HIPCHK(clh::launch_traceback_pool(0, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+            if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows(P, pl->n, 0, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+            else HIPCHK(clh::launch_traceback_pool(0, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st, false, pl->n));
             HIPCHK(hipEventRecord(pl->ev[eb + 1], st));
             HIPCHK(hipEventRecord(pl->ev[eb + 2], st));
         }
-        // alignments whose band outgrew the small window: one launch sized for the longest read class; workgroups of
-        // unmarked alignments return at once
-        int rvmax = 1;
+        // what the row kernel handed over: bands of 513..2048 cells in its wide form; then walks that leave the band (the
+        // reference reads stale direction bytes there) and wider bands in the anti-diagonal kernel, whose launch is sized for
+        // the longest read class; workgroups share the list of the few alignments left
+        int rvmax = 4;
         for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv == clh::kRvStrips ? 32 : s.rv);
-        if (rvmax > 4)   // below that the small window (514 rows) already covers every read
-            HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+        if (tb_rows_on()) {
+            HIPCHK(clh::launch_traceback_rows_wide(P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
+            HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st, true, pl->n));
+        } else if (rvmax > 4)   // below that the small window (514 rows) already covers every read
+            HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st, true, pl->n));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[eb + 3], st));
     }
     pl->last_stream = st;
@@ -551,7 +563,31 @@ extern "C" int clh_plan_timing(clh_plan* pl, int32_t cap, float* k1_ms, float* k
     return ns;
 }
 
+// counts[0] = alignments of the last run that the row traceback kernel handed to its wide form, counts[1] = alignments that
+// went on to the anti-diagonal kernel (walks that leave the band, bands above 2048 cells); waits for the run
+extern "C" int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts)
+{
+    if (!pl || !counts || !pl->ran) return fail(CLH_E_ARG, "clh_plan_traceback_counts: no run yet");
+    counts[0] = counts[1] = 0;
+    if (!pl->d_pool_head) return 0;
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    HIPCHK(hipMemcpy(counts, (const char*)pl->d_pool_head + 8, 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" const void* clh_ssw_results_dev(const clh_plan* pl) { return pl ? pl->d_results : nullptr; }
+
+// CIGARs sit in worst-case shares (2 * readLen + 2 words per alignment, ~100x what is used): they are gathered into one
+// dense run on the device and only that run crosses PCIe
+__global__ void cigar_gather_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ src_off, const int64_t* __restrict__ dst_off,
+                                    const int32_t* __restrict__ len, uint32_t* __restrict__ dst)
+{
+    const int a = blockIdx.x, L = len[a];
+    const uint32_t* s = src + src_off[a];
+    uint32_t* d = dst + dst_off[a];
+    for (int k = threadIdx.x; k < L; k += blockDim.x) d[k] = s[k];
+}
 
 extern "C" int clh_ssw_fetch(clh_plan* pl, clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used)
 {
@@ -563,15 +599,9 @@ extern "C" int clh_ssw_fetch(clh_plan* pl, clh_align_t* out, uint32_t* cigar_buf
     std::vector<clh::SswResult> res((size_t)std::max(n, 1));
     std::vector<int32_t> clen((size_t)std::max(n, 1), 0);
     if (n > 0) HIPCHK(hipMemcpy(res.data(), pl->d_results, sizeof(clh::SswResult) * (size_t)n, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> cig;
-    if (pl->do_cigar && n > 0) {
-        HIPCHK(hipMemcpy(clen.data(), pl->d_cigar_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
-        if (cigar_buf) {
-            cig.resize(pl->cigar_elems);
-            HIPCHK(hipMemcpy(cig.data(), pl->d_cigars, sizeof(uint32_t) * pl->cigar_elems, hipMemcpyDeviceToHost));
-        }
-    }
-    std::vector<int32_t> share_off((size_t)std::max(n, 1), 0);
+    if (pl->do_cigar && n > 0) HIPCHK(hipMemcpy(clen.data(), pl->d_cigar_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<int32_t> share_off((size_t)std::max(n, 1), 0), glen((size_t)std::max(n, 1), 0);
+    std::vector<int64_t> dst_off((size_t)std::max(n, 1), 0);
     for (const auto& t : pl->tasks) share_off[t.out_index] = t.cigar_off;
     int64_t used = 0;
     int rc = 0;
@@ -594,11 +624,32 @@ extern "C" int clh_ssw_fetch(clh_plan* pl, clh_align_t* out, uint32_t* cigar_buf
             o.cigar_len = len;
             if (cigar_buf) {
                 if (used + len > cigar_cap) { rc = CLH_E_CAPACITY; o.cigar_len = 0; continue; }
-                memcpy(cigar_buf + used, cig.data() + share_off[a], sizeof(uint32_t) * (size_t)len);
                 o.cigar_off = (int32_t)used;
+                dst_off[a] = used; glen[a] = len;
             }
             used += len;
         }
+    }
+    if (cigar_buf && pl->do_cigar && n > 0 && used > 0) {
+        clh_ctx* c = pl->ctx;
+        const size_t nb4 = sizeof(int32_t) * (size_t)n, nb8 = sizeof(int64_t) * (size_t)n;
+        void *d_src = c->alloc(nb4), *d_len = c->alloc(nb4), *d_dst = c->alloc(nb8), *d_out = c->alloc(sizeof(uint32_t) * (size_t)used);
+        int grc = 0;
+        if (!d_src || !d_len || !d_dst || !d_out) grc = fail(CLH_E_HIP, "out of device memory while gathering CIGARs");
+        hipStream_t st = c->stream;
+        if (!grc && (hipMemcpyAsync(d_src, share_off.data(), nb4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                     hipMemcpyAsync(d_len, glen.data(), nb4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                     hipMemcpyAsync(d_dst, dst_off.data(), nb8, hipMemcpyHostToDevice, st) != hipSuccess)) grc = fail(CLH_E_HIP, "H2D failed");
+        if (!grc) {
+            hipLaunchKernelGGL(cigar_gather_kernel, dim3(n), dim3(64), 0, st, (const uint32_t*)pl->d_cigars, (const int32_t*)d_src, (const int64_t*)d_dst,
+                               (const int32_t*)d_len, (uint32_t*)d_out);
+            if (hipGetLastError() != hipSuccess) grc = fail(CLH_E_HIP, "cigar gather launch failed");
+        }
+        if (!grc && hipMemcpyAsync(cigar_buf, d_out, sizeof(uint32_t) * (size_t)used, hipMemcpyDeviceToHost, st) != hipSuccess) grc = fail(CLH_E_HIP, "D2H failed");
+        const hipError_t se = hipStreamSynchronize(st);      // also before the buffers go back to the cache
+        if (!grc && se != hipSuccess) grc = fail(CLH_E_HIP, "cigar gather failed");
+        c->release(d_src); c->release(d_len); c->release(d_dst); c->release(d_out);
+        if (grc) return grc;
     }
     if (cigar_used) *cigar_used = used;
     if (rc) return fail(rc, "cigar buffer too small");

@@ -157,6 +157,19 @@ hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStr
 static constexpr int kRvScan = 0;        // pseudo class: K1s, the row-scan kernel for short reads in the 8-bit regime (ssw_scan.hip)
 hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t stream);
 hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t* pool_base, unsigned long long* pool_head,
+                                 unsigned long long pool_size, hipStream_t stream, bool only_marked, int n_total);
+// the words behind the pool's bump pointer: [2] alignments handed to the small-window launch, [3] to the large-window
+// launch; their task indices from word 64 on (n_total each).  kTbHeadBytes(n) = size of that buffer.
+inline size_t tb_head_bytes(int n_total) { return 256 + 2 * sizeof(int) * (size_t)(n_total > 0 ? n_total : 1); }
+inline void tb_lists_of(unsigned long long* head, int n_total, int** n_small, int** n_big, int** list_small, int** list_big)
+{
+    int* w = (int*)head;
+    *n_small = w + 2; *n_big = w + 3; *list_small = w + 64; *list_big = w + 64 + (n_total > 0 ? n_total : 1);
+}
+// K1b row form (ssw_traceback_rows.hip): every alignment; the ones it cannot take are marked CLH_STATUS_NEED_BIG and listed:
+// launch_traceback_rows_wide takes the list (bands up to 2048 cells) and lists what is left for launch_traceback_pool
+hipError_t launch_traceback_rows_wide(const SswParams& p, int n_total, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size, hipStream_t stream);
+hipError_t launch_traceback_rows(const SswParams& p, int ntasks, int task_base, int n_total, uint8_t* pool_base, unsigned long long* pool_head,
                                  unsigned long long pool_size, hipStream_t stream);
 
 }  // namespace clh

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "clh_device.h"
 
 namespace clh {
@@ -33,8 +34,10 @@ namespace clh {
 
 struct TbPool {
     uint8_t* base;
-    unsigned long long* head;   // bump pointer (bytes)
+    unsigned long long* head;   // bump pointer (bytes); the words behind it: hand-over counters and lists (tb_lists_of)
     unsigned long long size;
+    int* n_small; int* n_big;   // alignments handed to the small-window / large-window launch of this kernel
+    int* list_small; int* list_big;   // their task indices
 };
 
 __device__ __forceinline__ int wave_max(int v)
@@ -65,9 +68,10 @@ __device__ __forceinline__ int ad_stride(int w, int readLen, int refLen)
     return s > refLen ? refLen : s;
 }
 
-// big = 0: first attempt with a small LDS window (high occupancy); alignments whose band outgrows it are marked
-// CLH_STATUS_NEED_BIG.  big = 1: only the marked ones, with a window sized for the launch's read-length class.
-__global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp, int big, int seq_cap)
+// big = 0: every alignment, with a small LDS window (high occupancy); alignments whose band outgrows it are marked
+// CLH_STATUS_NEED_BIG.  big = 2: the same window, only the alignments the row kernel (ssw_traceback_rows.hip) marked.
+// big = 1: only the marked ones, with a window sized for the launch's read-length class.
+__device__ void tb_antidiagonal(const SswParams& p, const TbPool& pool, const int ws, const int wsp, const int big, const int seq_cap, const int task_index)
 {
     extern __shared__ __attribute__((aligned(16))) short tb_lds[];
     short* const H0 = tb_lds;                 // H[3][ws]
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
     const int nt = blockDim.x;
     if (lane < 25) smat[lane] = p.mat[lane];
     __syncthreads();
-    const SswTask task = p.tasks[blockIdx.x];
+    const SswTask task = p.tasks[task_index];
     SswResult res = p.results[task.out_index];
     // the result row is read with a vector load (this kernel also writes it): tell the compiler it is wave-uniform, or
     // every loop bound below sits in a VGPR behind exec-mask control flow
@@ -119,7 +123,10 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
     // would force s_waitcnt vmcnt(0), which also waits for the previous step's direction store (an HBM round trip per
     // anti-diagonal); with LDS-only reads the stores are fire-and-forget.
     if (readLen + refLen > seq_cap) {   // does not fit this launch's LDS: retry in the large configuration, or give up
-        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | (big ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG); }
+        if (lane == 0) {
+            *cig_len = 0; p.results[task.out_index].status = res.status | (big == 1 ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG);
+            if (big != 1) pool.list_big[atomicAdd(pool.n_big, 1)] = task_index;
+        }
         return;
     }
     for (int k = lane; k < readLen; k += nt) sseq[k] = read[k];
@@ -148,7 +155,7 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
             continue;
         }
         const bool ring = w + 3 <= wsp;   // the active rows of an anti-diagonal span <= w+1 rows
-        if (!ring && readLen + 1 > ws) { status = big ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG; break; }
+        if (!ring && readLen + 1 > ws) { status = big == 1 ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG; break; }
         const int imask = ring ? wsp - 1 : -1;
         unsigned long long need = ((unsigned long long)nAD * (unsigned long long)stride_w + 63ull) & ~63ull;
         unsigned long long at = 0;
@@ -211,7 +218,10 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
         if (!(maxv < score && w < 2 * readLen)) break;
     }
     if (status) {
-        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | status; }
+        if (lane == 0) {
+            *cig_len = 0; p.results[task.out_index].status = res.status | status;
+            if (status == CLH_STATUS_NEED_BIG) pool.list_big[atomicAdd(pool.n_big, 1)] = task_index;
+        }
         return;
     }
     w /= 2;
@@ -308,11 +318,25 @@ __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, 
     if (lane == 0) *cig_len = nops;
 }
 
+// big = 0: workgroup k takes task k.  Otherwise the workgroups share the list of handed-over alignments (a few of many
+// thousand: a workgroup per task would spend the launch on workgroups that only find out they have nothing to do).
+__global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp, int big, int seq_cap)
+{
+    if (big == 0) { tb_antidiagonal(p, pool, ws, wsp, big, seq_cap, (int)blockIdx.x); return; }
+    const int* list = big == 2 ? pool.list_small : pool.list_big;
+    const int n = __builtin_amdgcn_readfirstlane(*(big == 2 ? pool.n_small : pool.n_big));
+    for (int k = (int)blockIdx.x; k < n; k += (int)gridDim.x) {
+        tb_antidiagonal(p, pool, ws, wsp, big, seq_cap, __builtin_amdgcn_readfirstlane(list[k]));
+        __syncthreads();
+    }
+}
+
 // rv = read-length class of every task in the launch (rows <= 128*rv)
 hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t* pool_base, unsigned long long* pool_head,
-                                 unsigned long long pool_size, hipStream_t stream)
+                                 unsigned long long pool_size, hipStream_t stream, bool only_marked, int n_total)
 {
     TbPool pool; pool.base = pool_base; pool.head = pool_head; pool.size = pool_size;
+    tb_lists_of(pool_head, n_total, &pool.n_small, &pool.n_big, &pool.list_small, &pool.list_big);
     // rv == 0: the small-window first attempt (any read length)
     const int ws = rv > 0 ? 128 * rv + 2 : 514;
     int wsp = 1;
@@ -324,7 +348,9 @@ hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t
         const char* a = getenv("CLH_TB_SMALL_NT"); const char* b = getenv("CLH_TB_BIG_NT");
         nt_small = a ? atoi(a) : 128; nt_big = b ? atoi(b) : 1024;
     }
-    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(ntasks), dim3(rv > 0 ? nt_big : nt_small), lds, stream, p, pool, ws, wsp, rv > 0 ? 1 : 0, seq_cap);
+    const int big = rv > 0 ? 1 : (only_marked ? 2 : 0);
+    const int grid = big == 0 ? ntasks : std::min(ntasks, big == 1 ? 512 : 2048);
+    hipLaunchKernelGGL(ssw_traceback_kernel, dim3(grid), dim3(rv > 0 ? nt_big : nt_small), lds, stream, p, pool, ws, wsp, big, seq_cap);
     return hipGetLastError();
 }
 

@@ -1,0 +1,449 @@
+// ssw_traceback_rows.hip -- K1b, row form: banded Smith-Waterman traceback (CIGAR), one alignment per wavefront (gfx950).
+//
+// Same answers as ssw_traceback.hip (reference: banded_sw, libs/striped_smith_waterman/ssw.c:548-735; literal statement:
+// oracle/ssw_oracle.c:banded_traceback) for every alignment whose band stays within 512 cells and whose walk stays inside
+// the final band; the others are marked CLH_STATUS_NEED_BIG and redone by the anti-diagonal kernel (which also reproduces
+// the reference's reads of stale direction bytes outside the band).
+//
+// The anti-diagonal kernel pays an LDS barrier per anti-diagonal: ~2000 dependent steps per band iteration, latency-bound.
+// Here a band ROW is one step of one wave: the 128*CP virtual lanes (16-bit halves of CP registers, CP = 1, 2, 4) hold the
+// band offsets o = j - i + w, right-aligned, so that
+//   * the diagonal neighbour (i-1, j-1) has the same offset: the same register of the previous row;
+//   * the upper neighbour (i-1, j) is offset o+1: the previous row shifted by one virtual lane (one DPP wave_shl + one
+//     v_alignbit per value, for H, E and the reference bases, which slide through the band the same way);
+//   * the left neighbour (i, j-1) is offset o-1 of the SAME row: F is a prefix maximum (ssw.c:613-616 is
+//     f = max(h_left - gapO, f_left - gapE); with gapO >= gapE that is max over k < j of X_k - gapO - (j-1-k) gapE,
+//     X = the cell's value without its horizontal gap), one wave scan per row as in ssw_scan.hip.
+// Cells outside the band or the reference read as H = E = F = 0 exactly as the sentinel slots of ssw.c:596 make them;
+// the one exception (the sentinel at `edge` overwriting the live last reference column, see ssw_traceback.hip) is a
+// per-row fix-up.  The band doubling loop (ssw.c:560,631-632: running maximum not reset) runs score-only passes; only the
+// final band is computed with direction codes, 4 bits per cell (H move: diagonal / E / F; E opened; F opened), row-major:
+// ~16 kB per C2 alignment instead of one byte per cell for every band iteration.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "clh_device.h"
+
+namespace clh {
+
+namespace {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_sra15(uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) >> (short)15); }
+__device__ __forceinline__ uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
+// value of offset o-1: new low half = previous lane's high half (lane 0: lane0_lo), new high half = own low half
+__device__ __forceinline__ uint32_t hand_down(uint32_t v, int lane0_lo) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp((int)((uint32_t)lane0_lo << 16), (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __builtin_amdgcn_alignbit(v, x, 16);
+}
+// value of offset o+1: new low half = own high half, new high half = next lane's low half (lane 63: top_hi)
+__device__ __forceinline__ uint32_t hand_up(uint32_t v, int top_hi) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp((int)((uint32_t)top_hi & 0xffffu), (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    return __builtin_amdgcn_alignbit(x, v, 16);
+}
+__device__ __forceinline__ int dpp_shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_prefix_max(int v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+
+static constexpr uint32_t SEL_NONE = 0x0c0c0c0cu;      // v_perm selector 0x0c = constant 0: "no reference base here"
+
+struct TbIn {
+    const int8_t* read;     // first base of the aligned part of the read
+    const int8_t* ref;      // first base of the aligned part of the reference (physical address of that base)
+    int rdir, rc;           // physical direction / complement of the reference
+    int readLen, refLen;
+    int gO, gE, bias;
+    const uint2* tab;       // LDS: per read code q, the 5 scores + bias against reference codes 0..4 as bytes {0..3},{4}
+};
+
+// One band iteration with band half-width w (2w+1 <= 128*CP).  DIRS: direction nibbles of every cell, row-major:
+// row i = 64*CP bytes at dir + i*64*CP, cell at offset o' = j - i + w + (128*CP - 1 - 2w) in nibble o' of the row.
+// Returns the maximum H of the iteration.
+// COLS: the virtual lanes own reference COLUMNS instead (cell j in nibble j; refLen <= 128*CP, any w) -- the layout for
+// bands that are wider than 2048 cells only on paper (a row never has more than refLen cells): the upper neighbour is then
+// the same register, the diagonal one is the shifted one, the bases stay put and the band is a per-row mask.
+template <int CP, bool DIRS, bool COLS>
+__device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
+{
+    constexpr int NV = 128 * CP;
+    const int lane = threadIdx.x & 63;
+    const int shiftc = COLS ? 0 : NV - 1 - 2 * w;
+    const int gO = in.gO, gE = in.gE;
+    const uint32_t gO2 = dup16(gO), gE2 = dup16(gE), bias2 = dup16(in.bias), xfix = dup16(gO - gE), dG2 = dup16(gO - gE);
+    const int K = CP * gE, kLo = 2 * lane * K;
+    uint32_t inb[CP], refsel[CP], Hp[CP], Ep[CP];      // inb: offsets inside the band (COLS: the lane's two column numbers)
+#pragma unroll
+    for (int t = 0; t < CP; ++t) {
+        const int olo = lane * 2 * CP + t, ohi = olo + CP;
+        inb[t] = COLS ? ((uint32_t)olo | ((uint32_t)ohi << 16)) : ((olo >= shiftc ? 0xffffu : 0u) | (ohi >= shiftc ? 0xffff0000u : 0u));
+        const int jlo = COLS ? olo : olo - shiftc - w, jhi = COLS ? ohi : ohi - shiftc - w;   // row 0: j = o' - shiftc - w
+        const bool vlo = olo >= shiftc && jlo >= 0 && jlo < in.refLen, vhi = ohi >= shiftc && jhi >= 0 && jhi < in.refLen;
+        const int clo = vlo ? ref_code((int)in.ref[(int64_t)jlo * in.rdir], in.rc) : 0x0c, chi = vhi ? ref_code((int)in.ref[(int64_t)jhi * in.rdir], in.rc) : 0x0c;
+        refsel[t] = (uint32_t)clo | 0x0c00u | ((uint32_t)chi << 16) | 0x0c000000u;
+        Hp[t] = 0; Ep[t] = 0;
+    }
+    uint32_t itmaxP = 0;
+    const int rowbytes = 64 * CP;
+    for (int rb = 0; rb < in.readLen; rb += 64) {
+        const int row = rb + lane;
+        const int qv = row < in.readLen ? ((int)in.read[row] & 7) : 0;
+        int nv = 0x0c;                                                        // the base entering at the top offset: ref[row + w]
+        if (!COLS && row < in.readLen && row + w < in.refLen) nv = ref_code((int)in.ref[(int64_t)(row + w) * in.rdir], in.rc);
+        const int cnt = in.readLen - rb < 64 ? in.readLen - rb : 64;
+        for (int k = 0; k < cnt; ++k) {
+            const int i = rb + k;
+            const int q = __builtin_amdgcn_readlane(qv, k);
+            const uint2 tb = in.tab[q];
+            uint32_t Hu[CP], Eu[CP], Hd[CP], bandinv[COLS ? CP : 1];
+            if constexpr (COLS) {
+                const uint32_t d0 = hand_down(Hp[CP - 1], 0);
+                const uint32_t lo2 = dup16(i - w), hi2 = dup16(i + w);
+#pragma unroll
+                for (int t = 0; t < CP; ++t) {
+                    Hu[t] = Hp[t]; Eu[t] = Ep[t]; Hd[t] = t == 0 ? d0 : Hp[t - 1];
+                    bandinv[t] = pk_sra15(pk_subs(inb[t], lo2)) | pk_sra15(pk_subs(hi2, inb[t]));      // j < i - w or i + w < j
+                }
+            } else {   // the previous row seen from one offset lower; the reference bases slide the same way
+                const uint32_t h0 = hand_up(Hp[0], 0), e0 = hand_up(Ep[0], 0);
+#pragma unroll
+                for (int t = 0; t < CP; ++t) Hd[t] = Hp[t];
+#pragma unroll
+                for (int t = 0; t + 1 < CP; ++t) { Hu[t] = Hp[t + 1]; Eu[t] = Ep[t + 1]; }
+                Hu[CP - 1] = h0; Eu[CP - 1] = e0;
+                if (i > 0) {
+                    const uint32_t r0 = hand_up(refsel[0], __builtin_amdgcn_readlane(nv, k) | 0x0c00);
+#pragma unroll
+                    for (int t = 0; t + 1 < CP; ++t) refsel[t] = bfi(inb[t], refsel[t + 1], SEL_NONE);
+                    refsel[CP - 1] = bfi(inb[CP - 1], r0, SEL_NONE);
+                }
+            }
+            // ssw.c:596: in a row i <= w+1 whose band is cut by the reference end, the sentinel sits on the live entry of
+            // the last reference column: its upper neighbour reads as 0
+            if (i >= 1 && i - 1 <= w && in.refLen - 1 < i + w) {
+                const int oc = COLS ? in.refLen - 1 : in.refLen - 1 - i + w + shiftc;     // where column refLen-1 sits in this row
+#pragma unroll
+                for (int t = 0; t < CP; ++t) {
+                    const int olo = lane * 2 * CP + t, ohi = olo + CP;
+                    const uint32_t keep = (olo == oc ? 0u : 0xffffu) | (ohi == oc ? 0u : 0xffff0000u);
+                    Hu[t] &= keep; Eu[t] &= keep;
+                }
+            }
+            uint32_t X[CP], e[CP], c[CP], inv[CP], td[CP], e1[CP], mde[CP];
+#pragma unroll
+            for (int t = 0; t < CP; ++t) {
+                const uint32_t t1 = pk_subs(Hu[t], gO2), t2 = pk_subs(Eu[t], gE2);
+                e[t] = pk_max(t1, t2);
+                if (DIRS) mde[t] = pk_sra15(pk_subs(t2, t1));                 // E opened: t1 > t2 (ssw.c:611)
+                e1[t] = pk_max(e[t], 0u);
+                const uint32_t T = __builtin_amdgcn_perm(tb.y, tb.x, refsel[t]);
+                td[t] = pk_subs(pk_adds(Hd[t], T), bias2);
+                X[t] = pk_max(e1[t], td[t]);
+                inv[t] = pk_sra15(refsel[t] << 12);                           // selector bit 3: no base in this cell
+                if constexpr (COLS) inv[t] |= bandinv[t];
+                c[t] = pk_subs(bfi(inv[t], xfix, X[t]), gO2);                 // what the cell offers its right neighbour's F; an absent cell: -gapE
+            }
+            // F: prefix maximum over the offsets (frame in which crossing a virtual lane costs nothing)
+            uint32_t f[CP];
+            {
+                uint32_t floc[CP];
+                floc[0] = 0x80008000u;
+#pragma unroll
+                for (int t = 1; t < CP; ++t) floc[t] = pk_max(c[t - 1], pk_subs(floc[t - 1], gE2));
+                const uint32_t U = CP == 1 ? c[0] : pk_max(c[CP - 1], pk_subs(floc[CP - 1], gE2));
+                const int Blo = (int)(short)(U & 0xffffu) + kLo, Bhi = ((int)U >> 16) + kLo + K;
+                const int inc = wave_prefix_max(Blo > Bhi ? Blo : Bhi);
+                const int fill = -gE - K;                                     // the cell left of offset 0: H = F = 0
+                int exc = dpp_shr1(fill, inc);
+                exc = exc > fill ? exc : fill;
+                int finLo = exc - kLo + K;
+                const int m2 = exc > Blo ? exc : Blo;
+                int finHi = m2 - kLo;
+                finLo = finLo < -32768 ? -32768 : finLo; finHi = finHi < -32768 ? -32768 : finHi;
+                uint32_t fin = ((uint32_t)finLo & 0xffffu) | ((uint32_t)finHi << 16);
+#pragma unroll
+                for (int t = 0; t < CP; ++t) { f[t] = t == 0 ? fin : pk_max(floc[t], fin); fin = pk_subs(fin, gE2); }
+            }
+            uint32_t hn[CP], nib[CP], dd[CP];
+#pragma unroll
+            for (int t = 0; t < CP; ++t) {
+                const uint32_t h = bfi(inv[t], 0u, pk_max(X[t], f[t]));
+                hn[t] = h;
+                itmaxP = pk_max(itmaxP, h);
+                if (DIRS) dd[t] = pk_subs(pk_subs(h, bfi(inv[t], 0u, f[t])), dG2);   // (h - gapO) - (f - gapE), what the right neighbour compares
+            }
+            if (DIRS) {
+                const uint32_t d0 = hand_down(dd[CP - 1], -(gO - gE));
+                uint32_t x[CP];
+#pragma unroll
+                for (int t = 0; t < CP; ++t) {
+                    const uint32_t ddl = t == 0 ? d0 : dd[t - 1];
+                    const uint32_t mdf = pk_sra15(pk_subs(0u, ddl));          // F opened: h_left - gapO > f_left - gapE (ssw.c:616)
+                    const uint32_t f1 = pk_max(f[t], 0u);
+                    const uint32_t t1h = pk_max(e1[t], f1);
+                    const uint32_t mgt = pk_sra15(pk_subs(td[t], t1h));       // not the diagonal: max(e1, f1) > diagonal + score (ssw.c:626)
+                    const uint32_t mef = pk_sra15(pk_subs(f1, e1[t]));        // E rather than F: e1 > f1 (ssw.c:627)
+                    x[t] = (mgt & bfi(mef, 0x00010001u, 0x00020002u)) | (mde[t] & 0x00040004u) | (mdf & 0x00080008u);
+                }
+                uint8_t* drow = dir + (size_t)i * rowbytes + (size_t)lane * CP;
+                if constexpr (CP == 1) { *drow = (uint8_t)((x[0] & 0xfu) | ((x[0] >> 12) & 0xf0u)); }
+                else if constexpr (CP == 2) { const uint32_t y = x[0] | (x[1] << 4); *(uint16_t*)drow = (uint16_t)((y & 0xffu) | ((y >> 8) & 0xff00u)); }
+                else {
+                    // bytes of the lane: the low halves' offsets (two per byte), then the high halves'
+                    uint32_t y[CP / 2], wd[CP / 4];
+#pragma unroll
+                    for (int m = 0; m < CP / 2; ++m) y[m] = x[2 * m] | (x[2 * m + 1] << 4);
+                    if constexpr (CP == 4) wd[0] = __builtin_amdgcn_perm(y[1], y[0], 0x06020400u);
+                    else {
+#pragma unroll
+                        for (int g = 0; g < CP / 8; ++g) {
+                            wd[g] = __builtin_amdgcn_perm(y[4 * g + 1], y[4 * g], 0x0c0c0400u) | __builtin_amdgcn_perm(y[4 * g + 3], y[4 * g + 2], 0x04000c0cu);
+                            wd[CP / 8 + g] = __builtin_amdgcn_perm(y[4 * g + 1], y[4 * g], 0x0c0c0602u) | __builtin_amdgcn_perm(y[4 * g + 3], y[4 * g + 2], 0x06020c0cu);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < CP / 4; ++g) ((uint32_t*)drow)[g] = wd[g];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < CP; ++t) { Hp[t] = hn[t]; Ep[t] = bfi(inv[t], 0u, e[t]); }
+        }
+    }
+    const int lo = (int)(short)(itmaxP & 0xffffu), hi = (int)itmaxP >> 16;
+    return __builtin_amdgcn_readfirstlane(wave_max(lo > hi ? lo : hi));
+}
+
+template <int MAXCP, bool DIRS>
+__device__ int tb_rows_iter(const TbIn& in, int w, uint8_t* dir)
+{
+    if (2 * w + 1 <= 128) return tb_rows_pass<1, DIRS, false>(in, w, dir);
+    if (2 * w + 1 <= 256) return tb_rows_pass<2, DIRS, false>(in, w, dir);
+    if (MAXCP <= 4 || 2 * w + 1 <= 512) return tb_rows_pass<4, DIRS, false>(in, w, dir);
+    if constexpr (MAXCP > 4) {
+        if (2 * w + 1 <= 1024) return tb_rows_pass<8, DIRS, false>(in, w, dir);
+        if (2 * w + 1 <= 2048) return tb_rows_pass<16, DIRS, false>(in, w, dir);
+        if (in.refLen <= 1024) return tb_rows_pass<8, DIRS, true>(in, w, dir);
+        return tb_rows_pass<16, DIRS, true>(in, w, dir);
+    }
+    return 0;
+}
+// registers per lane of the iteration with band w, and whether it is laid out by reference column
+__device__ __forceinline__ int cp_of(int w) { const int c = 2 * w + 1; return c <= 128 ? 1 : (c <= 256 ? 2 : (c <= 512 ? 4 : (c <= 1024 ? 8 : 16))); }
+__device__ __forceinline__ bool fits(int maxcp, int w, int refLen, int readLen)
+{
+    if (2 * w + 1 <= 128 * maxcp) return true;
+    return maxcp > 4 && refLen <= 2048 && w + readLen < 32000;       // by column: i + w must fit 16 bits
+}
+
+}  // namespace
+
+namespace {
+
+// One alignment.  MAXCP = 4: bands up to 512 cells (the launch over all alignments, 4 waves per SIMD); MAXCP = 16: up to
+// 2048 cells (the few wide ones, one wave per SIMD).  What this width cannot take goes on `next_list`.
+template <int MAXCP>
+__device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                            const int task_index, int* next_n, int* next_list)
+{
+    const int lane = threadIdx.x & 63;
+    const SswTask task = p.tasks[task_index];
+    SswResult res = p.results[task.out_index];
+    res.score1 = __builtin_amdgcn_readfirstlane(res.score1); res.status = __builtin_amdgcn_readfirstlane(res.status);
+    res.ref_begin1 = __builtin_amdgcn_readfirstlane(res.ref_begin1); res.ref_end1 = __builtin_amdgcn_readfirstlane(res.ref_end1);
+    res.read_begin1 = __builtin_amdgcn_readfirstlane(res.read_begin1); res.read_end1 = __builtin_amdgcn_readfirstlane(res.read_end1);
+    if (MAXCP > 4) res.status &= ~CLH_STATUS_NEED_BIG;      // set by the narrow launch that handed this alignment over
+    uint32_t* cig = p.cigars + task.cigar_off;
+    int* cig_len = p.cigar_len + task.out_index;
+    const bool no_cigar = (res.status & CLH_STATUS_OVERFLOW8) || (7 & p.flag) == 0 ||
+                          ((2 & p.flag) != 0 && res.score1 < p.filters) ||
+                          ((4 & p.flag) != 0 && (res.ref_end1 - res.ref_begin1 > p.filterd || res.read_end1 - res.read_begin1 > p.filterd));
+    if (no_cigar) {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_NO_CIGAR; }
+        return;
+    }
+    if (res.ref_begin1 < 0) {   // score 0: the reference's 1x1 problem never enters its traceback loop -> 1M
+        if (lane == 0) { cig[0] = (1u << 4); *cig_len = 1; }
+        return;
+    }
+    auto hand_over = [&]() {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_NEED_BIG; next_list[atomicAdd(next_n, 1)] = task_index; }
+    };
+    TbIn in;
+    in.rdir = task.ref_rc ? -1 : 1; in.rc = task.ref_rc;
+    in.ref = p.refs + task.ref_off + (int64_t)res.ref_begin1 * in.rdir;
+    in.read = p.reads + task.read_off + res.read_begin1;
+    in.refLen = res.ref_end1 - res.ref_begin1 + 1; in.readLen = res.read_end1 - res.read_begin1 + 1;
+    in.gO = p.gapO; in.gE = p.gapE; in.bias = p.bias; in.tab = s_tab;
+    const int readLen = in.readLen, refLen = in.refLen, score = res.score1;
+    if (p.gapE > 60 || p.gapO > 255) { hand_over(); return; }       // the frames of the F scan are 16-bit
+
+    // ---- band doubling (ssw.c:560-632), score-only: which band is the final one ------------------------------------
+    int w = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+    int maxv = 0;
+    bool covered = false;
+    for (;;) {
+        if (!covered) {
+            if (!fits(MAXCP, w, refLen, readLen)) { hand_over(); return; }
+            const int it = tb_rows_iter<MAXCP, false>(in, w, nullptr);
+            maxv = it > maxv ? it : maxv;
+            covered = w >= readLen && w >= refLen;      // a wider band holds the same cells: same values
+        }
+        w *= 2;
+        if (!(maxv < score && w < 2 * readLen)) break;
+    }
+    w /= 2;
+    if (!fits(MAXCP, w, refLen, readLen)) { hand_over(); return; }
+    // ---- the final band once more, with direction codes -------------------------------------------------------------
+    const bool by_col = 2 * w + 1 > 128 * MAXCP;
+    const int CPf = by_col ? (refLen <= 1024 ? 8 : 16) : cp_of(w), rowbytes = 64 * CPf, shiftc = by_col ? 0 : 128 * CPf - 1 - 2 * w;
+    const unsigned long long need = ((unsigned long long)readLen * (unsigned long long)rowbytes + 63ull) & ~63ull;
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(pool_head, need);
+    at = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffull)) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32);
+    if (at + need > pool_size) {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
+        return;
+    }
+    uint8_t* dir = pool_base + at;
+    (void)tb_rows_iter<MAXCP, true>(in, w, dir);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+    // ---- walk back from the bottom-right corner (ssw.c:636-696), wave-uniform; lane r holds 32 nibbles of row ib - r ----
+    int i = readLen - 1, j = refLen - 1, state = 2, run = 0, nops = 0, fail = 0;
+    int op = 0, prev_op = 0;             // 0 M, 1 I, 2 D
+    int ib = -1, pb = 0;
+    uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
+    while (i > 0) {
+        if (!(j >= 0 && j <= i + w && j >= i - w && j < refLen)) { fail = 2; break; }   // outside the band: the reference reads stale bytes
+        const int o = by_col ? j : j - i + w + shiftc;
+        if (ib < 0 || i > ib || i <= ib - 64 || o < pb || o >= pb + 32) {
+            ib = i; pb = o - 16; pb = pb < 0 ? 0 : pb; pb &= ~1;
+            if (pb + 32 > 128 * CPf) pb = 128 * CPf - 32;
+            const int rr = ib - lane;
+            pw0 = pw1 = pw2 = pw3 = 0;
+            if (rr >= 0) {
+                uint32_t t4[4];
+                __builtin_memcpy(t4, dir + (size_t)rr * rowbytes + (pb >> 1), 16);
+                pw0 = t4[0]; pw1 = t4[1]; pw2 = t4[2]; pw3 = t4[3];
+            }
+        }
+        const int kk = o - pb, src = ib - i;
+        const uint32_t wsel = (kk >> 3) == 0 ? pw0 : ((kk >> 3) == 1 ? pw1 : ((kk >> 3) == 2 ? pw2 : pw3));
+        const int nb = ((uint32_t)__builtin_amdgcn_readlane((int)wsel, src) >> ((kk & 7) * 4)) & 15;
+        const int sel = nb & 3;
+        const int cE = (nb & 4) ? 3 : 2, cF = (nb & 8) ? 5 : 4;
+        const int c = state == 2 ? (sel == 0 ? 1 : (sel == 1 ? cE : cF)) : (state == 0 ? cE : cF);
+        switch (c) {
+            case 1: --i; --j; state = 2; op = 0; break;
+            case 2: --i; state = 0; op = 1; break;
+            case 3: --i; state = 2; op = 1; break;
+            case 4: --j; state = 1; op = 2; break;
+            default: --j; state = 2; op = 2; break;
+        }
+        if (op == prev_op) ++run;
+        else {
+            if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)run << 4) | (uint32_t)prev_op;
+            ++nops; prev_op = op; run = 1;
+        }
+    }
+    if (fail) { hand_over(); return; }
+    if (op == 0) {                                   // ssw.c:697-714
+        if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)(run + 1) << 4);
+        ++nops;
+    } else {
+        if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)run << 4) | (uint32_t)op;
+        ++nops;
+        if (nops < task.cigar_cap && lane == 0) cig[nops] = (1u << 4);
+        ++nops;
+    }
+    if (nops > task.cigar_cap) {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int k = lane; k < nops / 2; k += 64) {      // reverse in place, ssw.c:716-725
+        const uint32_t x = cig[k], y = cig[nops - 1 - k];
+        cig[k] = y; cig[nops - 1 - k] = x;
+    }
+    if (lane == 0) *cig_len = nops;
+}
+
+}  // namespace
+
+__device__ __forceinline__ void tb_rows_table(const SswParams& p, uint2* s_tab)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < 8) {
+        uint32_t b[5];
+        for (int c = 0; c < 5; ++c) b[c] = (uint32_t)(((c < p.n && lane < p.n) ? (int)p.mat[c * p.n + lane] : 0) + p.bias) & 0xffu;
+        s_tab[lane] = make_uint2(b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4]);
+    }
+    __syncthreads();
+}
+
+// every alignment of the launch, one per workgroup (= one wave)
+__global__ void __launch_bounds__(64, 4) ssw_traceback_rows_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                                                                   int task_base, int* n_small, int* list_small)
+{
+    __shared__ uint2 s_tab[8];
+    tb_rows_table(p, s_tab);
+    SswParams q = p;
+    q.tasks = p.tasks - task_base;          // the lists hold indices into the plan's task table
+    tb_rows_one<4>(q, s_tab, pool_base, pool_head, pool_size, task_base + (int)blockIdx.x, n_small, list_small);
+}
+
+// the alignments the narrow launch handed over: the workgroups share the list
+__global__ void __launch_bounds__(64, 1) ssw_traceback_rows_wide_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                                                                        const int* n_small, const int* list_small, int* n_big, int* list_big)
+{
+    __shared__ uint2 s_tab[8];
+    tb_rows_table(p, s_tab);
+    const int n = __builtin_amdgcn_readfirstlane(*n_small);
+    for (int k = (int)blockIdx.x; k < n; k += (int)gridDim.x) {
+        tb_rows_one<16>(p, s_tab, pool_base, pool_head, pool_size, __builtin_amdgcn_readfirstlane(list_small[k]), n_big, list_big);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_traceback_rows(const SswParams& p, int ntasks, int task_base, int n_total, uint8_t* pool_base, unsigned long long* pool_head,
+                                 unsigned long long pool_size, hipStream_t stream)
+{
+    int *n_small, *n_big, *list_small, *list_big;
+    tb_lists_of(pool_head, n_total, &n_small, &n_big, &list_small, &list_big);
+    hipLaunchKernelGGL(ssw_traceback_rows_kernel, dim3(ntasks), dim3(64), 0, stream, p, pool_base, pool_head, pool_size, task_base, n_small, list_small);
+    return hipGetLastError();
+}
+
+// p.tasks = the plan's whole task table
+hipError_t launch_traceback_rows_wide(const SswParams& p, int n_total, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size, hipStream_t stream)
+{
+    int *n_small, *n_big, *list_small, *list_big;
+    tb_lists_of(pool_head, n_total, &n_small, &n_big, &list_small, &list_big);
+    hipLaunchKernelGGL(ssw_traceback_rows_wide_kernel, dim3(std::min(n_total, 1024)), dim3(64), 0, stream, p, pool_base, pool_head, pool_size, n_small, list_small, n_big, list_big);
+    return hipGetLastError();
+}
+
+}  // namespace clh

@@ -115,6 +115,7 @@ def lib():
         L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.clh_plan_traceback_counts.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -215,7 +216,7 @@ class Context(object):
         o, _keep = self._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar, filters, filterd)
         out = np.zeros(n, dtype=ALIGN_DTYPE)
         cap = int(2 * (read_off[-1] if n else 0) + 2 * n + 8) if want_cigar else 1
-        cig = np.zeros(cap, dtype=np.uint32)
+        cig = np.empty(cap, dtype=np.uint32)     # worst-case capacity; only the used prefix is written
         used = C.c_int64(0)
         ml = None
         if mask_len is not None:
@@ -510,7 +511,7 @@ class Genome(object):
         o, _keep = self.ctx._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar)
         out = np.zeros(n, dtype=ALIGN_DTYPE)
         cap = int(2 * (read_off[-1] if n else 0) + 2 * n + 8) if want_cigar else 1
-        cig = np.zeros(cap, dtype=np.uint32)
+        cig = np.empty(cap, dtype=np.uint32)     # worst-case capacity; only the used prefix is written
         used = C.c_int64(0)
         ml = np.ascontiguousarray(mask_len, dtype=np.int32) if mask_len is not None else None
         rc = lib().clh_ssw_windows_batch(self._h, n, reads.ctypes.data, read_off.ctypes.data, off.ctypes.data, ln32.ctypes.data, rcf.ctypes.data,
@@ -554,7 +555,7 @@ class Plan(object):
     def fetch(self):
         out = np.zeros(self.n, dtype=ALIGN_DTYPE)
         cap = int(2 * (self.read_off[-1] if self.n else 0) + 2 * self.n + 8) if self.want_cigar else 1
-        cig = np.zeros(cap, dtype=np.uint32)
+        cig = np.empty(cap, dtype=np.uint32)     # worst-case capacity; only the used prefix is ever written or touched
         used = C.c_int64(0)
         rc = lib().clh_ssw_fetch(self._h, out.ctypes.data, cig.ctypes.data if self.want_cigar else None, cap, C.byref(used))
         if rc != 0:
@@ -570,6 +571,13 @@ class Plan(object):
         rb = np.zeros(32, dtype=np.int64); fb = np.zeros(32, dtype=np.int64)
         ns = lib().clh_plan_segments(self._h, 32, rv.ctypes.data, cnt.ctypes.data, rb.ctypes.data, fb.ctypes.data)
         return [(int(rv[k]), int(cnt[k]), int(rb[k]), int(fb[k])) for k in range(ns)]
+
+    def traceback_counts(self):
+        """(alignments handed to the wide row traceback, alignments handed on to the anti-diagonal traceback) of the last run"""
+        c = np.zeros(2, dtype=np.int32)
+        if lib().clh_plan_traceback_counts(self._h, c.ctypes.data) != 0:
+            raise ClhError('clh_plan_traceback_counts: %s' % last_error())
+        return int(c[0]), int(c[1])
 
     def timing(self):
         """([K1 ms per segment], (K1b small-window ms, K1b large-window ms)) for the last run"""

@@ -83,6 +83,11 @@ clh_plan* clh_ssw_plan(clh_ctx* ctx, int32_t n, const int64_t* read_off, const i
                        const int32_t* mask_len, const clh_ssw_opts* opts);
 void clh_plan_destroy(clh_plan* plan);
 
+/* Diagnostics of the last run's CIGAR step (K1b): counts[0] = alignments the row traceback kernel handed to its wide form
+ * (bands of 513..2048 cells), counts[1] = alignments that went on to the anti-diagonal kernel (walks that leave the final band,
+ * where banded_sw, ssw.c:636-696, reads direction bytes of earlier band iterations; bands above 2048 cells).  Waits for the run. */
+int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts);
+
 /* Launch the batch on packed code arrays that already live in HBM (device pointers).  Asynchronous on `stream`
  * (a hipStream_t).  NULL selects the context's own, private, non-blocking stream -- NOT the legacy default stream: work
  * a caller has queued on the default stream (or on any other stream) is then unordered with these kernels.  A caller

@@ -322,3 +322,46 @@ def test_row_scan_class_short_reads_vs_oracle(ctx, scheme):
                    want['ref_end2'] if s2 else got[6])
             assert got == exp, (k, len(q), len(ref), got, exp)
             assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref))
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (2, 2, 3, 1), (10, 4, 8, 2)])
+def test_cigars_of_wide_bands_row_traceback_vs_oracle(ctx, scheme):
+    """K1b's row form (csrc/ssw_traceback_rows.hip) by band width: reads with one or two long insertions or deletions start
+    their band at |refLen - readLen| + 1 (ssw.c:560) -- up to 512 cells in the launch over all alignments, up to 2048 in the
+    wide form, beyond that laid out by reference column; whatever is left (walks that leave the band) goes to the
+    anti-diagonal kernel.  CIGARs and coordinates equal the oracle's in every class, and the classes are all populated."""
+    from ciri_long_amd import hip
+    m, x, o, e = scheme
+    rng = np.random.default_rng(900 + sum(scheme))
+    refs, qs = [], []
+    for blk, gap in [(500, 0), (500, 60), (600, 200), (700, 300), (800, 420), (1300, 600), (1500, 900), (1600, 1100)]:
+        for _ in range(5):
+            R = 2 * blk + gap + 200
+            ref = _rnd(rng, R)
+            a = int(rng.integers(0, 100)); L1 = blk - int(rng.integers(0, 60)); L2 = blk - int(rng.integers(0, 60))
+            mode = rng.random()
+            if mode < 0.45:                                 # deletion in the read: two blocks of the reference, `gap` apart
+                q = ref[a:a + L1] + ref[a + L1 + gap:a + L1 + gap + L2]
+            elif mode < 0.9:                                # insertion in the read
+                q = ref[a:a + L1] + _rnd(rng, gap) + ref[a + L1:a + L1 + L2]
+            else:                                           # both, on either side of a third block
+                g2 = gap // 2
+                q = ref[a:a + L1] + _rnd(rng, g2) + ref[a + L1:a + L1 + 300] + ref[a + L1 + 300 + g2:a + L1 + 300 + g2 + L2 // 2]
+            refs.append(ref); qs.append(_mut(q, rng, float(rng.choice([0.0, 0.03, 0.08])))[:4090] or 'A')
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    import torch
+    d_r = torch.from_numpy(rd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
+    ts = torch.cuda.Stream()
+    plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=True, want_cigar=True)
+    plan.run(d_r.data_ptr(), d_f.data_ptr(), ts.cuda_stream)
+    rows, cig = plan.fetch()
+    wide, anti = plan.traceback_counts()
+    plan.close()
+    nwide = 0
+    for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
+        want = oracle_align(ref, q, *scheme)
+        assert _row_tuple(r) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
+                                 want['query_end'], want['ref_end2']), (k, len(q), len(ref))
+        assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref), int(r['status']))
+        nwide += abs((want['ref_end'] - want['ref_begin']) - (want['query_end'] - want['query_begin'])) + 1 > 255
+    assert wide >= nwide > 5 and anti <= wide // 2 + 2, (wide, anti, nwide)

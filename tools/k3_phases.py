@@ -26,5 +26,5 @@ for k, nm in enumerate(names):
 x = segs[:, 60:63, 0].astype(np.float64)
 print('row steps %.4g, register-rows %.4g (mean %.2f per step), cells %.4g' % (x[ok, 0].sum(), x[ok, 1].sum(), x[ok, 1].sum() / x[ok, 0].sum(), x[ok, 2].sum() * 16))
 y = segs[:, 49:55, 0].astype(np.float64)[ok].sum(0)
-print('rows with several in-edges %.3g, to ring %.3g, kept %.3g; sources: ring %.3g, kept %.3g, previous row %.3g' % tuple(y))
+print('row step sections (%% of the DP clock): decode+score %.1f, sources+candidates %.1f, scans %.1f, H/E+horizontal codes %.1f, stores %.1f, end cell+carry %.1f' % tuple(100 * y / y.sum()))
 print('reads with consensus %d, mean total %.1f us' % (ok.sum(), t[ok].sum(1).mean() / 100.0))

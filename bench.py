@@ -191,8 +191,9 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         cells_total += cells; k1ms += k1 / PROF
         out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv else 'ssw_scan_kernel', 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
-        out.append({'kernel': 'ssw_traceback_kernel[small window]', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
-        out.append({'kernel': 'ssw_traceback_kernel[large window, outliers]', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0})
+        out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
+        out.append({'kernel': 'ssw_traceback_rows_wide_kernel + ssw_traceback_kernel (handed-over alignments)', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0,
+                    'note': 'latency of the few wide-band alignments, one wave or workgroup each'})
     valu = {'bound': 'valu', 'kernel': 'ssw_scan_kernel + ssw_align_kernel (all classes)', 'unit': 'GCUPS',
             'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
             'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,

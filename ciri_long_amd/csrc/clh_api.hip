@@ -480,7 +480,13 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     }
     std::vector<size_t> ord(pl->segs.size());
     for (size_t k = 0; k < ord.size(); ++k) ord[k] = k;
-    std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return pl->segs[x].count > pl->segs[y].count; });   // heaviest first
+    // launch order: the class whose single alignments take longest first (a pass is a serial chain of reference columns,
+    // longer per column the more rows a lane holds), the short-read scan class last: its many small workgroups would
+    // otherwise fill every slot of the GPU and the long chains would start only when they drain
+    std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+        const int rx = pl->segs[x].rv == clh::kRvStrips ? 1000 : pl->segs[x].rv, ry = pl->segs[y].rv == clh::kRvStrips ? 1000 : pl->segs[y].rv;
+        return rx > ry;
+    });
     for (size_t q = 0; q < ord.size(); ++q) {
         const size_t k = ord[q];
         const auto& s = pl->segs[k];

@@ -182,14 +182,17 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
     rows16 = ((qlen + 15) // 16) * 16
     cls = np.array([next((c for c in classes if 128 * c >= r), 32) for r in rows16]) if len(qlen) else np.zeros(0, dtype=int)
     if len(qlen) and not os.environ.get('CLH_NO_SCAN'):      # class 0 = K1s, the row-scan kernel (clh_api.hip: scan_class_ok)
-        cls[(qlen <= 240) & (max_match * qlen + bias < 255)] = 0
+        scan = (qlen <= 254) & (max_match * qlen + bias < 255)
+        cls[scan] = 0
+        if not os.environ.get('CLH_NO_SLICES'):                  # class -1 = K1s with the forward pass cut into window slices
+            cls[scan & (np.asarray(wlen) >= 32768)] = -1
     out, cells_total, k1ms = [], 0, 0.0
     for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
         sel = cls == rv
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv else 'ssw_scan_kernel', 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else ('ssw_scan_kernel' if rv == 0 else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel'), 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         out.append({'kernel': 'ssw_traceback_rows_wide_kernel + ssw_traceback_kernel (handed-over alignments)', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0,

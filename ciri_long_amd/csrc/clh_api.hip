@@ -136,6 +136,8 @@ struct clh_plan {
     bool quirk = false, do_cigar = false;
     std::vector<clh::SswTask> tasks;    // launch order
     struct Seg { int rv, begin, count; };
+    std::vector<clh::ScanSlice> slices;      // window slices of the sliced scan class (one segment at most)
+    void *d_slices = nullptr, *d_parts = nullptr;
     std::vector<Seg> segs;
     void *d_tasks = nullptr, *d_results = nullptr, *d_colmax = nullptr, *d_cigars = nullptr, *d_cigar_len = nullptr,
          *d_pool = nullptr, *d_pool_head = nullptr, *d_reads = nullptr, *d_refs = nullptr;
@@ -155,7 +157,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     (void)hipSetDevice(c->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
-                    pl->d_reads, pl->d_refs, pl->d_strips};
+                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts};
     for (void* b : bufs) c->release(b);
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
     delete pl;
@@ -177,7 +179,17 @@ static bool tb_rows_on() { static const bool off = getenv("CLH_NO_TB_ROWS") != n
 static bool scan_class_ok(int64_t L, const clh_ssw_opts* o, int max_match, int bias)
 {
     static const bool off = getenv("CLH_NO_SCAN") != nullptr;
-    return !off && L <= 240 && o->score_size != 1 && (int64_t)max_match * L + bias < 255 && o->gap_extend >= 0 && o->gap_extend <= 16 && o->gap_open <= 255;
+    return !off && L <= 254 && o->score_size != 1 && (int64_t)max_match * L + bias < 255 && o->gap_extend >= 0 && o->gap_extend <= 16 && o->gap_open <= 255;
+}
+
+// K1s on long windows: the forward pass runs as slices of >= 8192 owned columns (at most 64 per alignment), each started
+// `overlap` columns early (ssw_scan.hip: ssw_scan_slice_kernel).  Needs a positive gap extension (else a local alignment has
+// no bounded span).  CLH_NO_SLICES=1 switches it off (A/B measurements).
+static const int kSliceMinWindow = 32768, kSliceMinCols = 8192;
+static bool scan_sliced(int64_t R, const clh_ssw_opts* o)
+{
+    static const bool off = getenv("CLH_NO_SLICES") != nullptr;
+    return !off && R >= kSliceMinWindow && o->gap_extend >= 1;
 }
 
 // ref_off != nullptr: packed references, alignment a against [ref_off[a], ref_off[a+1]).  Otherwise windows of a resident
@@ -224,7 +236,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         if (L < 1 || R < 0 || L > 0x7fffffff || R > 0x7fffffff) { fail(CLH_E_ARG, "empty read or negative length in batch"); delete pl; return nullptr; }
         const int rc = (!ref_off && win_rc && win_rc[a]) ? 1 : 0;
         const int rows = (int)((L + 15) / 16) * 16;
-        const int rv = scan_class_ok(L, o, mx, -mn) ? clh::kRvScan : rv_class_for(rows);
+        const int rv = scan_class_ok(L, o, mx, -mn) ? (scan_sliced(R, o) ? clh::kRvScanSliced : clh::kRvScan) : rv_class_for(rows);
         cls[a] = rv;
         clh::SswTask& t = pl->tasks[a];
         t.read_off = read_off[a]; t.ref_off = ref_off ? ref_off[a] : (rc ? win_off[a] + R - 1 : win_off[a]);
@@ -269,6 +281,25 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         k = e;
     }
     pl->tasks.swap(sorted);
+    for (const auto& sg : pl->segs) {
+        if (sg.rv != clh::kRvScanSliced) continue;
+        for (int k = 0; k < sg.count; ++k) {
+            clh::SswTask& t = pl->tasks[sg.begin + k];
+            const int64_t R = t.ref_len, L = t.read_len;
+            const int64_t overlap = L + (L * mx + o->gap_extend - 1) / o->gap_extend + 32;    // span of a local alignment + wildcard rows + slack
+            const int64_t own = std::max<int64_t>(kSliceMinCols, (R + 63) / 64);
+            t.dir_off = (int64_t)pl->slices.size();
+            int ns = 0;
+            for (int64_t b = 0; b < R; b += own, ++ns) {
+                clh::ScanSlice sl;
+                memset(&sl, 0, sizeof(sl));
+                sl.task = k; sl.own_begin = (int32_t)b; sl.c_begin = (int32_t)std::max<int64_t>(0, b - overlap); sl.c_end = (int32_t)std::min<int64_t>(R, b + own);
+                sl.part = (int32_t)pl->slices.size();
+                pl->slices.push_back(sl);
+            }
+            t.pad = ns;
+        }
+    }
 
     pl->d_tasks = ctx->alloc(sizeof(clh::SswTask) * (size_t)std::max(n, 1));
     pl->d_results = ctx->alloc(sizeof(clh::SswResult) * (size_t)std::max(n, 1));
@@ -280,6 +311,14 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         pl->d_pool_head = ctx->alloc(clh::tb_head_bytes(n));
     }
     if (pl->strip_bytes) pl->d_strips = ctx->alloc(pl->strip_bytes);
+    if (!pl->slices.empty()) {
+        pl->d_slices = ctx->alloc(sizeof(clh::ScanSlice) * pl->slices.size());
+        pl->d_parts = ctx->alloc(sizeof(clh::ScanPart) * pl->slices.size());
+        if (!pl->d_slices || !pl->d_parts || hipMemcpy(pl->d_slices, pl->slices.data(), sizeof(clh::ScanSlice) * pl->slices.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            fail(CLH_E_HIP, "out of device memory while building the plan");
+            clh_plan_destroy(pl); return nullptr;
+        }
+    }
     if (!pl->d_tasks || !pl->d_results || !pl->d_cigar_len || (pl->strip_bytes && !pl->d_strips) || (o->want_score2 && !pl->d_colmax) ||
         (pl->do_cigar && (!pl->d_cigars || !pl->d_pool || !pl->d_pool_head))) {
         fail(CLH_E_HIP, "out of device memory while building the plan");
@@ -493,7 +532,10 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         hipStream_t ls = (fan && (q & 3)) ? c->side[(q & 3) - 1] : st;
         P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], ls));
-        if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
+        if (s.rv == clh::kRvScanSliced) {
+            P.slices = (const clh::ScanSlice*)pl->d_slices; P.parts = (clh::ScanPart*)pl->d_parts;
+            HIPCHK(clh::launch_ssw_scan_sliced(pl->quirk, P, s.count, (int)pl->slices.size(), ls));
+        } else if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
         else HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], ls));
         if (tb && !pl->profiling) {

@@ -44,6 +44,10 @@ struct SswResult {        // 32 bytes; the s_align fields of ssw.h:42-52 minus t
     int32_t score1, score2, ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, status;
 };
 
+// K1s on long windows (ssw_scan.hip): one forward pass cut into slices of the window
+struct ScanSlice { int32_t task, c_begin, own_begin, c_end, part, pad0, pad1, pad2; };   // columns [c_begin, c_end) computed, [own_begin, c_end) counted
+struct ScanPart { int32_t max, col, row, pad; };                                        // best cell of one slice
+
 struct SswParams {
     const int8_t* reads;
     const int8_t* refs;
@@ -56,6 +60,8 @@ struct SswParams {
     int8_t mat[32];       // n*n substitution matrix (n <= 5)
     int32_t n, gapO, gapE, bias, max_match, score_size, flag, filters, filterd;
     int32_t null_code;    // 4 if mat scores code 4 as 0 against everything (then fill/drain columns reuse it), else 5
+    const ScanSlice* slices;   // sliced scan class only
+    ScanPart* parts;
 };
 
 // ---- cyclic consensus (K2/K3, csrc/ccs_poa.hip) ----------------------------------------------------------------
@@ -156,6 +162,8 @@ extern const int kNumRvClasses;
 hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStream_t stream);
 static constexpr int kRvScan = 0;        // pseudo class: K1s, the row-scan kernel for short reads in the 8-bit regime (ssw_scan.hip)
 hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t stream);
+static constexpr int kRvScanSliced = -1; // pseudo class: K1s with the forward pass cut into window slices (task.dir_off = first part, task.pad = slices)
+hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int nslices, hipStream_t stream);
 hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t* pool_base, unsigned long long* pool_head,
                                  unsigned long long pool_size, hipStream_t stream, bool only_marked, int n_total);
 // the words behind the pool's bump pointer: [2] alignments handed to the small-window launch, [3] to the large-window

@@ -3,7 +3,7 @@
 // Same answers as ssw_wavefront.hip (reference: libs/striped_smith_waterman/ssw.c:123-345 sw_sse2_byte and the
 // forward + reverse orchestration of ssw_align, ssw.c:779-849; row-major statement: oracle/rowmajor_spec.c), for the
 // alignments the host sorts into this class (clh_api.hip: scan_class_ok):
-//     read <= 240 bases,  max_match * readLen + bias < 255  (ssw.c:804-806 then runs the 8-bit pass and that pass cannot
+//     read <= 254 bases,  max_match * readLen + bias < 255  (ssw.c:804-806 then runs the 8-bit pass and that pass cannot
 //     overflow: every score fits 8 bits, no 16-bit re-run, no stripe quirk),  gap_extend <= 16.
 // These are the 20..300-base clips of find_bsj.py:191-216 against windows of 2 kb .. 400 kb -- most of the SSW calls of
 // `call`.  The anti-diagonal kernel spends a fixed cost per step on handing three values down the lanes; with one row
@@ -75,7 +75,7 @@ __device__ __forceinline__ int wave_min(int v) {
 #ifndef SCAN_WAVES
 #define SCAN_WAVES 3      // measured on the C3 clip batch: 2 -> 1.87 ms, 3 -> 1.76 ms, 4 -> 1.88 ms
 #endif
-static constexpr int SCAN_MAX_ROWS = 256;        // rows of a pass incl. the wildcard rows (reads <= 240 bases)
+static constexpr int SCAN_MAX_ROWS = 256;        // rows of a pass incl. the wildcard rows (reads <= 254 bases)
 static constexpr int SCAN_CPR_MAX = 8;
 static constexpr int SCAN_PROF_WORDS = 6 * SCAN_CPR_MAX * 64;      // uint32 per wave: [query code 0..5][register][lane]
 
@@ -89,7 +89,9 @@ struct ScanIn {
     int comp;             // reference bytes are complemented as they are read
     int ncols;
     int terminate;        // column maximum that ends the pass (ssw.c:296); > 254 = never
-    uint16_t* colmax;     // per-column maxima in processing order, or nullptr
+    uint16_t* colmax;     // per-column maxima in processing order (indexed by col_base + column), or nullptr
+    int own0;             // columns below this one are computed but do not count (the overlap of a window slice); 0 otherwise
+    int col_base;         // column number of the first column handed in (a window slice); 0 otherwise
 };
 struct ScanOut { int max, col, row; };
 
@@ -216,8 +218,8 @@ __device__ void scan_chunk(const ScanIn& in, const ScanLds& lds, const int c0, c
             const int j = c0 + 2 * CPR * lane + hf * CPR + t;
             const int k16 = hf ? (int)(key[t] >> 16) : (int)(key[t] & 0xffffu);
             const int cm = k16 >> 8;
-            if (j < in.ncols) {
-                if (in.colmax) in.colmax[j] = (uint16_t)cm;
+            if (j < in.ncols && j >= in.own0) {
+                if (in.colmax) in.colmax[in.col_base + j] = (uint16_t)cm;
                 if (cm == in.terminate) tmin = j < tmin ? j : tmin;
             }
         }
@@ -230,7 +232,7 @@ __device__ void scan_chunk(const ScanIn& in, const ScanLds& lds, const int c0, c
             const int jc = 2 * CPR * lane + hf * CPR + t, j = c0 + jc;
             const int k16 = hf ? (int)(key[t] >> 16) : (int)(key[t] & 0xffffu);
             const int v = ((k16 >> 8) << 20) | ((0xfff - jc) << 8) | (k16 & 0xff);
-            if (j < in.ncols && j <= tmin) b32 = v > b32 ? v : b32;
+            if (j < in.ncols && j <= tmin && j >= in.own0) b32 = v > b32 ? v : b32;
         }
     b32 = wave_max(b32);
     const int sc = b32 >> 20;
@@ -256,7 +258,7 @@ __device__ ScanOut scan_pass(const ScanIn& in, const ScanLds& lds, const int gap
     ScanOut o;
     o.max = best_score;
     if (best_score == 0) { o.col = -1; o.row = 0; return o; }
-    o.col = best_col;
+    o.col = in.col_base + best_col;
     o.row = best_row < in.L - 1 ? best_row : in.L - 1;
     return o;
 }
@@ -285,37 +287,18 @@ __device__ void second_best8(const uint16_t* colmax, int refLen, int end_ref, in
     ref_end2 = bv > 0 ? bp : 0;
 }
 
-}  // namespace
-
+// everything after the forward pass: second best, reverse pass (begin coordinates), the result row
 template <bool GEQ>
-__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_kernel(const SswParams p)
+__device__ void scan_finish(const SswParams& p, const SswTask& task, const ScanOut& fw, const ScanLds& lds)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_prof[SCAN_PROF_WORDS];
-    __shared__ int s_mat[48];
-    __shared__ short s_bH[2 * SCAN_MAX_ROWS], s_bE[2 * SCAN_MAX_ROWS];
     const int lane = threadIdx.x & 63;
-    if (lane < 48) {   // 6 reference codes x 8 read codes; anything outside the n x n matrix scores 0
-        const int b = lane >> 3, q = lane & 7;
-        s_mat[lane] = (b < p.n && q < p.n) ? (int)p.mat[b * p.n + q] : 0;
-    }
-    __syncthreads();
-    ScanLds lds; lds.prof = s_prof; lds.mat = s_mat; lds.bH = s_bH; lds.bE = s_bE;
-
-    const SswTask task = p.tasks[blockIdx.x];
     const int8_t* read = p.reads + task.read_off;
     const int8_t* ref = p.refs + task.ref_off;
-    const int L = task.read_len, refLen = task.ref_len;
+    const int refLen = task.ref_len;
     uint16_t* colmax = p.colmax ? p.colmax + task.colmax_off : nullptr;
     const int rdir = task.ref_rc ? -1 : 1;
     SswResult res;
     res.score2 = 0; res.ref_begin1 = -1; res.ref_end2 = 0; res.status = 0;
-
-    // ---- forward (ssw.c:804-822: the 8-bit pass; it cannot overflow in this class) ---------------------------------
-    ScanIn in;
-    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = task.ref_rc; in.ncols = refLen;
-    in.terminate = 1 << 30; in.colmax = colmax;
-    in.rows = colmax ? ((L + 15) / 16) * 16 : L;     // the wildcard rows only matter to the column maxima (rowmajor_spec.c)
-    const ScanOut fw = scan_pass<GEQ>(in, lds, p.gapO, p.gapE);
     res.score1 = fw.max;
     if (fw.max == 0) { res.ref_end1 = -1; res.read_end1 = 0; }
     else { res.ref_end1 = fw.col; res.read_end1 = fw.row; }
@@ -329,7 +312,7 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_kernel(const SswParam
         ScanIn rv;
         rv.L = res.read_end1 + 1; rv.rows = ((rv.L + 15) / 16) * 16; rv.read = read + res.read_end1; rv.rstep = -1;
         rv.ncols = res.ref_end1 + 1; rv.ref = ref + (int64_t)res.ref_end1 * rdir; rv.cstep = -rdir; rv.comp = task.ref_rc;
-        rv.terminate = res.score1; rv.colmax = nullptr;
+        rv.terminate = res.score1; rv.colmax = nullptr; rv.own0 = 0; rv.col_base = 0;
         const ScanOut r = scan_pass<GEQ>(rv, lds, p.gapO, p.gapE);
         if (r.max == 0) { res.ref_begin1 = -1; res.read_begin1 = res.read_end1; }
         else { res.ref_begin1 = res.ref_end1 - r.col; res.read_begin1 = res.read_end1 - r.row; }
@@ -337,10 +320,92 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_kernel(const SswParam
     if (lane == 0) p.results[task.out_index] = res;
 }
 
+// forward pass over columns [c_begin, c_end) of the task's window, counting from own_begin on (ssw.c:804-822: the 8-bit
+// pass; it cannot overflow in this class)
+template <bool GEQ>
+__device__ ScanOut scan_forward(const SswParams& p, const SswTask& task, const ScanLds& lds, int c_begin, int own_begin, int c_end)
+{
+    const int rdir = task.ref_rc ? -1 : 1;
+    uint16_t* colmax = p.colmax ? p.colmax + task.colmax_off : nullptr;
+    ScanIn in;
+    in.read = p.reads + task.read_off; in.rstep = 1; in.L = task.read_len;
+    in.ref = p.refs + task.ref_off + (int64_t)c_begin * rdir; in.cstep = rdir; in.comp = task.ref_rc; in.ncols = c_end - c_begin;
+    in.terminate = 1 << 30; in.colmax = colmax; in.own0 = own_begin - c_begin; in.col_base = c_begin;
+    in.rows = colmax ? ((in.L + 15) / 16) * 16 : in.L;     // the wildcard rows only matter to the column maxima (rowmajor_spec.c)
+    return scan_pass<GEQ>(in, lds, p.gapO, p.gapE);
+}
+
+#define SCAN_LDS_SETUP \
+    __shared__ __attribute__((aligned(16))) uint32_t s_prof[SCAN_PROF_WORDS]; \
+    __shared__ int s_mat[48]; \
+    __shared__ short s_bH[2 * SCAN_MAX_ROWS], s_bE[2 * SCAN_MAX_ROWS]; \
+    { const int lane_ = threadIdx.x & 63; \
+      if (lane_ < 48) { const int b_ = lane_ >> 3, q_ = lane_ & 7; s_mat[lane_] = (b_ < p.n && q_ < p.n) ? (int)p.mat[b_ * p.n + q_] : 0; } } \
+    __syncthreads(); \
+    ScanLds lds; lds.prof = s_prof; lds.mat = s_mat; lds.bH = s_bH; lds.bE = s_bE;
+
+}  // namespace
+
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_kernel(const SswParams p)
+{
+    SCAN_LDS_SETUP
+    const SswTask task = p.tasks[blockIdx.x];
+    const ScanOut fw = scan_forward<GEQ>(p, task, lds, 0, 0, task.ref_len);
+    scan_finish<GEQ>(p, task, fw, lds);
+}
+
+// Long windows (clh_api.hip: scan_slices): the forward pass of one alignment is cut into slices of the window that run as
+// separate workgroups.  A local alignment of an L-base read spans at most L * (1 + max_match / gap_extend) columns (every
+// deleted reference base costs at least gap_extend, the read can earn at most L * max_match), so a slice that starts that many
+// columns (+ the 16 wildcard rows) before the columns it owns computes exactly the H of the whole-window pass there.  Each
+// slice leaves its best cell; the finishing kernel takes the largest (first column on ties, ssw.c:283) and goes on as usual.
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_slice_kernel(const SswParams p)
+{
+    SCAN_LDS_SETUP
+    const ScanSlice sl = p.slices[blockIdx.x];
+    const SswTask task = p.tasks[sl.task];
+    const ScanOut fw = scan_forward<GEQ>(p, task, lds, sl.c_begin, sl.own_begin, sl.c_end);
+    if ((threadIdx.x & 63) == 0) { ScanPart pt; pt.max = fw.max; pt.col = fw.col; pt.row = fw.row; pt.pad = 0; p.parts[sl.part] = pt; }
+}
+
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_finish_kernel(const SswParams p)
+{
+    SCAN_LDS_SETUP
+    const int lane = threadIdx.x & 63;
+    const SswTask task = p.tasks[blockIdx.x];
+    const int first = (int)task.dir_off, ns = task.pad;       // this task's slices (clh_api.hip: at most 64)
+    int v = 0, c = 0x7fffffff, r = 0;
+    if (lane < ns) { const ScanPart pt = p.parts[first + lane]; v = pt.max; c = pt.max > 0 ? pt.col : 0x7fffffff; r = pt.row; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v2 = __shfl_xor(v, d), c2 = __shfl_xor(c, d), r2 = __shfl_xor(r, d);
+        const bool take = v2 > v || (v2 == v && c2 < c);
+        v = take ? v2 : v; c = take ? c2 : c; r = take ? r2 : r;
+    }
+    ScanOut fw; fw.max = v; fw.col = v > 0 ? c : -1; fw.row = v > 0 ? r : 0;
+    scan_finish<GEQ>(p, task, fw, lds);
+}
+
 hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t stream)
 {
     if (geq) hipLaunchKernelGGL((ssw_scan_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
     else hipLaunchKernelGGL((ssw_scan_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+// p.slices / p.parts set; p.tasks = the sliced class's tasks
+hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int nslices, hipStream_t stream)
+{
+    if (geq) {
+        hipLaunchKernelGGL((ssw_scan_slice_kernel<true>), dim3(nslices), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((ssw_scan_finish_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((ssw_scan_slice_kernel<false>), dim3(nslices), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((ssw_scan_finish_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+    }
     return hipGetLastError();
 }
 

@@ -285,7 +285,7 @@ def test_ssw_wrap_mirror_behaves_like_the_reference_wrapper(golden_cases):
 @pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (1, 1, 2, 1), (2, 3, 5, 2), (1, 2, 16, 16), (3, 1, 4, 4)])
 def test_row_scan_class_short_reads_vs_oracle(ctx, scheme):
     """K1s (csrc/ssw_scan.hip) takes the alignments whose scores fit the 8-bit pass for certain (ssw.c:804-806): reads up to
-    240 bases against windows whose lengths sit on and around its column chunks (256 / 512 / 1024), windows of several
+    254 bases against windows whose lengths sit on and around its column chunks (256 / 512 / 1024), windows of several
     chunks, repeats that make a later column exceed the forward score in the reverse pass (ssw.c:296 ends at equality
     only), N on both sides; with and without the second-best score (its column maxima include the wildcard rows)."""
     from ciri_long_amd import hip
@@ -294,7 +294,7 @@ def test_row_scan_class_short_reads_vs_oracle(ctx, scheme):
     refs, qs = [], []
     for R in [1, 2, 100, 255, 256, 257, 300, 511, 512, 513, 767, 1023, 1024, 1025, 1300, 2047, 2048, 2049, 3100, 5000, 9000]:
         for _ in range(6):
-            L = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 65, 100, 127, 128, 129, 200, 239, 240])) if m == 1 else int(rng.integers(1, 250 // m))
+            L = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 65, 100, 127, 128, 129, 200, 239, 240, 241, 253])) if m == 1 else int(rng.integers(1, 250 // m))
             ref = _rnd(rng, R)
             st = int(rng.integers(0, max(1, R - L)))
             q = _mut(ref[st:st + L], rng, float(rng.choice([0.0, 0.05, 0.2])))[:L] or 'A'
@@ -312,7 +312,7 @@ def test_row_scan_class_short_reads_vs_oracle(ctx, scheme):
     for s2 in (True, False):
         plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=s2, want_cigar=True)
         n0 = sum(c for rv, c, _a, _b in plan.segments() if rv == 0)
-        assert n0 == sum(1 for q in qs if len(q) <= 240 and m * len(q) + x < 255) and n0 > 0.9 * len(qs)
+        assert n0 == sum(1 for q in qs if len(q) <= 254 and m * len(q) + x < 255) and n0 > 0.9 * len(qs)
         plan.close()
         rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(m, x), o, e, want_score2=s2, want_cigar=True)
         for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
@@ -365,3 +365,44 @@ def test_cigars_of_wide_bands_row_traceback_vs_oracle(ctx, scheme):
         assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref), int(r['status']))
         nwide += abs((want['ref_end'] - want['ref_begin']) - (want['query_end'] - want['query_begin'])) + 1 > 255
     assert wide >= nwide > 5 and anti <= wide // 2 + 2, (wide, anti, nwide)
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (2, 3, 5, 2), (1, 1, 3, 1)])
+def test_long_windows_in_slices_vs_oracle(ctx, scheme):
+    """Windows of 32 kb and more are cut into slices whose forward passes run as separate workgroups (ssw_scan.hip:
+    ssw_scan_slice_kernel): the clip placed across slice borders and inside the overlaps, twice in one window (first column
+    wins on ties, ssw.c:283), absent, and next to N runs -- scores, coordinates, second best and CIGAR equal the oracle's."""
+    from ciri_long_amd import hip
+    m, x, o, e = scheme
+    rng = np.random.default_rng(1200 + sum(scheme))
+    refs, qs = [], []
+    for R in [32768, 40000, 70000, 150000]:
+        own = max(8192, (R + 63) // 64)
+        for case in range(7):
+            L = int(rng.integers(20, min(240, 250 // m)))
+            ref = _rnd(rng, R)
+            border = own * int(rng.integers(1, max(2, R // own)))
+            pos = [border - L // 2, border - 3, border + 1, border - L - 40, int(rng.integers(0, R - L)), 0, R - L][case]
+            pos = max(0, min(R - L, pos))
+            q = _mut(ref[pos:pos + L], rng, float(rng.choice([0.0, 0.05, 0.15])))[:L] or 'A'
+            if case == 2 and pos > 2 * L + 10:        # an exact second copy earlier in the window: ties resolved by column
+                ref = ref[:pos - 2 * L] + ref[pos:pos + L] + ref[pos - L:]
+                ref = ref[:R]
+            if case == 4:
+                q = _rnd(rng, L)
+            if case == 3:
+                ref = ref[:pos] + 'N' * 7 + ref[pos + 7:]
+            refs.append(ref); qs.append(q)
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=True, want_cigar=True)
+    assert sum(c for rv, c, _a, _b in plan.segments() if rv == -1) == len(qs)
+    plan.close()
+    for s2 in (True, False):
+        rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(m, x), o, e, want_score2=s2, want_cigar=True)
+        for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
+            want = oracle_align(ref, q, *scheme)
+            got = _row_tuple(r)
+            exp = (want['score'], want['score2'] if s2 else 0, want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end'],
+                   want['ref_end2'] if s2 else got[6])
+            assert got == exp, (k, len(q), len(ref), got, exp)
+            assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref))

@@ -103,7 +103,8 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
         Hp[t] = 0; Ep[t] = 0;
     }
     uint32_t itmaxP = 0;
-    const int rowbytes = 64 * CP;
+    const int nb0 = COLS ? 0 : shiftc - shiftc % (2 * CP);      // first stored nibble of a row: the lane that holds the band's first offset
+    const int first_lane = nb0 / (2 * CP), rowbytes = (NV - nb0) / 2;
     for (int rb = 0; rb < in.readLen; rb += 64) {
         const int row = rb + lane;
         const int qv = row < in.readLen ? ((int)in.read[row] & 7) : 0;
@@ -204,8 +205,9 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
                     const uint32_t mef = pk_sra15(pk_subs(f1, e1[t]));        // E rather than F: e1 > f1 (ssw.c:627)
                     x[t] = (mgt & bfi(mef, 0x00010001u, 0x00020002u)) | (mde[t] & 0x00040004u) | (mdf & 0x00080008u);
                 }
-                uint8_t* drow = dir + (size_t)i * rowbytes + (size_t)lane * CP;
-                if constexpr (CP == 1) { *drow = (uint8_t)((x[0] & 0xfu) | ((x[0] >> 12) & 0xf0u)); }
+                uint8_t* drow = dir + (size_t)i * rowbytes + (size_t)(lane - first_lane) * CP;
+                if (lane < first_lane) {}
+                else if constexpr (CP == 1) { *drow = (uint8_t)((x[0] & 0xfu) | ((x[0] >> 12) & 0xf0u)); }
                 else if constexpr (CP == 2) { const uint32_t y = x[0] | (x[1] << 4); *(uint16_t*)drow = (uint16_t)((y & 0xffu) | ((y >> 8) & 0xff00u)); }
                 else {
                     // bytes of the lane: the low halves' offsets (two per byte), then the high halves'
@@ -314,8 +316,9 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
     if (!fits(MAXCP, w, refLen, readLen)) { hand_over(); return; }
     // ---- the final band once more, with direction codes -------------------------------------------------------------
     const bool by_col = 2 * w + 1 > 128 * MAXCP;
-    const int CPf = by_col ? (refLen <= 1024 ? 8 : 16) : cp_of(w), rowbytes = 64 * CPf, shiftc = by_col ? 0 : 128 * CPf - 1 - 2 * w;
-    const unsigned long long need = ((unsigned long long)readLen * (unsigned long long)rowbytes + 63ull) & ~63ull;
+    const int CPf = by_col ? (refLen <= 1024 ? 8 : 16) : cp_of(w), shiftc = by_col ? 0 : 128 * CPf - 1 - 2 * w;
+    const int nb0 = by_col ? 0 : shiftc - shiftc % (2 * CPf), nvb = 128 * CPf - nb0, rowbytes = nvb / 2;     // as in tb_rows_pass: only the band's lanes store
+    const unsigned long long need = ((unsigned long long)readLen * (unsigned long long)rowbytes + 64ull + 63ull) & ~63ull;   // + 64: the walk reads 16 bytes from a row's start
     unsigned long long at = 0;
     if (lane == 0) at = atomicAdd(pool_head, need);
     at = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffull)) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32);
@@ -336,10 +339,10 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
     uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
     while (i > 0) {
         if (!(j >= 0 && j <= i + w && j >= i - w && j < refLen)) { fail = 2; break; }   // outside the band: the reference reads stale bytes
-        const int o = by_col ? j : j - i + w + shiftc;
+        const int o = (by_col ? j : j - i + w + shiftc) - nb0;     // nibble within the stored row
         if (ib < 0 || i > ib || i <= ib - 64 || o < pb || o >= pb + 32) {
             ib = i; pb = o - 16; pb = pb < 0 ? 0 : pb; pb &= ~1;
-            if (pb + 32 > 128 * CPf) pb = 128 * CPf - 32;
+            if (pb + 32 > nvb) pb = nvb >= 32 ? nvb - 32 : 0;
             const int rr = ib - lane;
             pw0 = pw1 = pw2 = pw3 = 0;
             if (rr >= 0) {

@@ -338,7 +338,21 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
     int ib = -1, pb = 0;
     uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
     while (i > 0) {
-        if (!(j >= 0 && j <= i + w && j >= i - w && j < refLen)) { fail = 2; break; }   // outside the band: the reference reads stale bytes
+        int nb;
+        if (!(j >= 0 && j <= i + w && j >= i - w && j < refLen)) {
+            // outside the band the reference reads whatever sits at that flat index of its direction array (ssw.c:58,640): the
+            // codes of another cell.  If the final iteration wrote that cell the nibble is here; bytes only an earlier, narrower
+            // iteration wrote are the anti-diagonal kernel's business (it keeps every iteration)
+            const long long wd = 2ll * w + 1, xi = i - w > 0 ? i - w : 0, C = (long long)i * wd + ((long long)j - xi);
+            if (C < 0) { fail = 2; break; }
+            const long long ii = C / wd, pos = C % wd;
+            if (ii >= readLen) { fail = 2; break; }
+            const long long xk = ii - w > 0 ? ii - w : 0, jj = xk + pos, endk = ii + w < refLen - 1 ? ii + w : refLen - 1;
+            if (jj > endk) { fail = 2; break; }
+            const int o2 = (by_col ? (int)jj : (int)(jj - ii) + w + shiftc) - nb0;
+            const int byte = __builtin_amdgcn_readfirstlane((int)dir[(size_t)ii * rowbytes + (o2 >> 1)]);
+            nb = (byte >> ((o2 & 1) * 4)) & 15;
+        } else {
         const int o = (by_col ? j : j - i + w + shiftc) - nb0;     // nibble within the stored row
         if (ib < 0 || i > ib || i <= ib - 64 || o < pb || o >= pb + 32) {
             ib = i; pb = o - 16; pb = pb < 0 ? 0 : pb; pb &= ~1;
@@ -353,7 +367,8 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
         }
         const int kk = o - pb, src = ib - i;
         const uint32_t wsel = (kk >> 3) == 0 ? pw0 : ((kk >> 3) == 1 ? pw1 : ((kk >> 3) == 2 ? pw2 : pw3));
-        const int nb = ((uint32_t)__builtin_amdgcn_readlane((int)wsel, src) >> ((kk & 7) * 4)) & 15;
+        nb = ((uint32_t)__builtin_amdgcn_readlane((int)wsel, src) >> ((kk & 7) * 4)) & 15;
+        }
         const int sel = nb & 3;
         const int cE = (nb & 4) ? 3 : 2, cF = (nb & 8) ? 5 : 4;
         const int c = state == 2 ? (sel == 0 ? 1 : (sel == 1 ? cE : cF)) : (state == 0 ? cE : cF);

@@ -58,6 +58,19 @@ __device__ __forceinline__ int wave_prefix_max(int v) {
     return v;
 }
 
+// two independent scans, their steps interleaved: the other chain's instruction provides the wait states a DPP read needs
+// after a VALU write, so no s_nop inside
+__device__ __forceinline__ void wave_prefix_max2(int& a, int& b) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(a), "+v"(b));
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------------------
@@ -401,6 +414,26 @@ __device__ __forceinline__ void scan_left_pk(const uint32_t (&a)[CP], int left, 
     for (int t = 0; t < CP; ++t) pe[t] = pk_max(run[t], ex2);
 }
 
+// the two scans of a row (E frame, Q frame) with their wave-wide parts interleaved
+template <int CP>
+__device__ __forceinline__ void scan_left_pk2(const uint32_t (&a)[CP], int leftA, uint32_t (&pa)[CP], const uint32_t (&b)[CP], int leftB, uint32_t (&pb)[CP])
+{
+    constexpr int NEGB = -(1 << 30);
+    uint32_t runA[CP], runB[CP];
+    runA[0] = 0x80008000u; runB[0] = 0x80008000u;
+#pragma unroll
+    for (int t = 1; t < CP; ++t) { runA[t] = pk_max(runA[t - 1], a[t - 1]); runB[t] = pk_max(runB[t - 1], b[t - 1]); }
+    const uint32_t totA = pk_max(runA[CP - 1], a[CP - 1]), totB = pk_max(runB[CP - 1], b[CP - 1]);
+    const int loA = (int)(short)(totA & 0xffffu), hiA = (int)totA >> 16, loB = (int)(short)(totB & 0xffffu), hiB = (int)totB >> 16;
+    int incA = loA > hiA ? loA : hiA, incB = loB > hiB ? loB : hiB;
+    wave_prefix_max2(incA, incB);
+    int excA = dpp_shr1(NEGB, incA), excB = dpp_shr1(NEGB, incB);
+    excA = leftA > excA ? leftA : excA; excB = leftB > excB ? leftB : excB;
+    const uint32_t exA = pack16(excA, excA > loA ? excA : loA), exB = pack16(excB, excB > loB ? excB : loB);
+#pragma unroll
+    for (int t = 0; t < CP; ++t) { pa[t] = pk_max(runA[t], exA); pb[t] = pk_max(runB[t], exB); }
+}
+
 template <int CP>
 __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int pass, const int colbase,
                            const bool more, const int RING, int& bs_io, int& br_io, int& bc_io DBGARG)
@@ -588,21 +621,15 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
             // horizontal states: two prefix maxima in the gap-free frames of the two pieces
             uint32_t ehat[CP], qhat[CP];
             {
-                uint32_t a[CP], pe[CP];
+                uint32_t a[CP], b[CP], pe[CP], pq[CP];
                 const int leftE = cinH > cinE + e - g ? cinH : cinE + e - g;       // = E[first column of the pass] - g
-#pragma unroll
-                for (int t = 0; t < CP; ++t) a[t] = pk_subs(best[t], jeP[t]);
-                scan_left_pk<CP>(a, leftE, pe);
-                const uint32_t ge2 = dup16(g - e);
-#pragma unroll
-                for (int t = 0; t < CP; ++t) ehat[t] = pk_adds(pk_adds(pe[t], jeP[t]), ge2);
                 const int leftQ = cinH > cinQ + c - q ? cinH : cinQ + c - q;
 #pragma unroll
-                for (int t = 0; t < CP; ++t) a[t] = pk_subs(best[t], jcP[t]);
-                scan_left_pk<CP>(a, leftQ, pe);
-                const uint32_t qc2 = dup16(q - c);
+                for (int t = 0; t < CP; ++t) { a[t] = pk_subs(best[t], jeP[t]); b[t] = pk_subs(best[t], jcP[t]); }
+                scan_left_pk2<CP>(a, leftE, pe, b, leftQ, pq);
+                const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
 #pragma unroll
-                for (int t = 0; t < CP; ++t) qhat[t] = pk_adds(pk_adds(pe[t], jcP[t]), qc2);
+                for (int t = 0; t < CP; ++t) { ehat[t] = pk_adds(pk_adds(pe[t], jeP[t]), ge2); qhat[t] = pk_adds(pk_adds(pq[t], jcP[t]), qc2); }
             }
             SEC(10);
             uint32_t Hf[CP], E[CP];

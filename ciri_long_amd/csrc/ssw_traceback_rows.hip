@@ -260,6 +260,33 @@ __device__ __forceinline__ bool fits(int maxcp, int w, int refLen, int readLen)
 
 namespace {
 
+// the direction codes of one band iteration in the pool: geometry as in tb_rows_pass
+struct TbPlane { int w, by_col, shiftc, nb0, nvb, rowbytes; uint8_t* dir; };
+
+// computes iteration w with direction codes into fresh pool space; false: pool exhausted
+template <int MAXCP>
+__device__ bool tb_make_plane(const TbIn& in, const int w, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size, TbPlane& pl)
+{
+    const int lane = threadIdx.x & 63;
+    pl.w = w;
+    pl.by_col = 2 * w + 1 > 128 * MAXCP;
+    const int CPf = pl.by_col ? (in.refLen <= 1024 ? 8 : 16) : cp_of(w);
+    pl.shiftc = pl.by_col ? 0 : 128 * CPf - 1 - 2 * w;
+    pl.nb0 = pl.by_col ? 0 : pl.shiftc - pl.shiftc % (2 * CPf);       // as in tb_rows_pass: only the band's lanes store
+    pl.nvb = 128 * CPf - pl.nb0; pl.rowbytes = pl.nvb / 2;
+    const unsigned long long need = ((unsigned long long)in.readLen * (unsigned long long)pl.rowbytes + 64ull + 63ull) & ~63ull;   // + 64: the walk reads 16 bytes from a row's start
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(pool_head, need);
+    at = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffull)) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32);
+    if (at + need > pool_size) return false;
+    pl.dir = pool_base + at;
+    (void)tb_rows_iter<MAXCP, true>(in, w, pl.dir);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
 // One alignment.  MAXCP = 4: bands up to 512 cells (the launch over all alignments, 4 waves per SIMD); MAXCP = 16: up to
 // 2048 cells (the few wide ones, one wave per SIMD).  What this width cannot take goes on `next_list`.
 template <int MAXCP>
@@ -300,9 +327,11 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
 
     // ---- band doubling (ssw.c:560-632), score-only: which band is the final one ------------------------------------
     int w = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
-    int maxv = 0;
+    const int w0 = w;
+    int maxv = 0, niter = 0;
     bool covered = false;
     for (;;) {
+        ++niter;
         if (!covered) {
             if (!fits(MAXCP, w, refLen, readLen)) { hand_over(); return; }
             const int it = tb_rows_iter<MAXCP, false>(in, w, nullptr);
@@ -315,22 +344,15 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
     w /= 2;
     if (!fits(MAXCP, w, refLen, readLen)) { hand_over(); return; }
     // ---- the final band once more, with direction codes -------------------------------------------------------------
-    const bool by_col = 2 * w + 1 > 128 * MAXCP;
-    const int CPf = by_col ? (refLen <= 1024 ? 8 : 16) : cp_of(w), shiftc = by_col ? 0 : 128 * CPf - 1 - 2 * w;
-    const int nb0 = by_col ? 0 : shiftc - shiftc % (2 * CPf), nvb = 128 * CPf - nb0, rowbytes = nvb / 2;     // as in tb_rows_pass: only the band's lanes store
-    const unsigned long long need = ((unsigned long long)readLen * (unsigned long long)rowbytes + 64ull + 63ull) & ~63ull;   // + 64: the walk reads 16 bytes from a row's start
-    unsigned long long at = 0;
-    if (lane == 0) at = atomicAdd(pool_head, need);
-    at = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffull)) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32);
-    if (at + need > pool_size) {
+    TbPlane fin, old;
+    old.w = -1; old.dir = nullptr;
+    if (!tb_make_plane<MAXCP>(in, w, pool_base, pool_head, pool_size, fin)) {
         if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
         return;
     }
-    uint8_t* dir = pool_base + at;
-    (void)tb_rows_iter<MAXCP, true>(in, w, dir);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const bool by_col = fin.by_col != 0;
+    const int shiftc = fin.shiftc, nb0 = fin.nb0, nvb = fin.nvb, rowbytes = fin.rowbytes;
+    uint8_t* const dir = fin.dir;
 
     // ---- walk back from the bottom-right corner (ssw.c:636-696), wave-uniform; lane r holds 32 nibbles of row ib - r ----
     int i = readLen - 1, j = refLen - 1, state = 2, run = 0, nops = 0, fail = 0;
@@ -341,17 +363,32 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
         int nb;
         if (!(j >= 0 && j <= i + w && j >= i - w && j < refLen)) {
             // outside the band the reference reads whatever sits at that flat index of its direction array (ssw.c:58,640): the
-            // codes of another cell.  If the final iteration wrote that cell the nibble is here; bytes only an earlier, narrower
-            // iteration wrote are the anti-diagonal kernel's business (it keeps every iteration)
-            const long long wd = 2ll * w + 1, xi = i - w > 0 ? i - w : 0, C = (long long)i * wd + ((long long)j - xi);
-            if (C < 0) { fail = 2; break; }
-            const long long ii = C / wd, pos = C % wd;
-            if (ii >= readLen) { fail = 2; break; }
-            const long long xk = ii - w > 0 ? ii - w : 0, jj = xk + pos, endk = ii + w < refLen - 1 ? ii + w : refLen - 1;
-            if (jj > endk) { fail = 2; break; }
-            const int o2 = (by_col ? (int)jj : (int)(jj - ii) + w + shiftc) - nb0;
-            const int byte = __builtin_amdgcn_readfirstlane((int)dir[(size_t)ii * rowbytes + (o2 >> 1)]);
-            nb = (byte >> ((o2 & 1) * 4)) & 15;
+            // codes of another cell, written by the LAST band iteration that had a cell there (the array is reused across the
+            // doublings, each iteration laying its band out with its own width).  The final iteration's codes are here; an
+            // earlier iteration is computed once more with codes when the walk asks for it (rare: one plane is kept).
+            const long long wdF = 2ll * w + 1, xi = i - w > 0 ? i - w : 0, C = (long long)i * wdF + ((long long)j - xi);
+            if (C < 0) { fail = 1; break; }
+            nb = -1;
+            for (int k = niter - 1; k >= 0; --k) {
+                const long long wk = (long long)w0 << k, wd = 2 * wk + 1;
+                const long long ii = C / wd, pos = C % wd;
+                if (ii >= readLen) continue;
+                const long long xk = ii - wk > 0 ? ii - wk : 0, jj = xk + pos, endk = ii + wk < refLen - 1 ? ii + wk : refLen - 1;
+                if (jj > endk) continue;
+                const TbPlane* pl = &fin;
+                if (k != niter - 1) {
+                    if (old.w != (int)wk) {
+                        if (!fits(MAXCP, (int)wk, refLen, readLen) || !tb_make_plane<MAXCP>(in, (int)wk, pool_base, pool_head, pool_size, old)) { fail = 2; break; }
+                    }
+                    pl = &old;
+                }
+                const int o2 = (pl->by_col ? (int)jj : (int)(jj - ii) + pl->w + pl->shiftc) - pl->nb0;
+                const int byte = __builtin_amdgcn_readfirstlane((int)pl->dir[(size_t)ii * pl->rowbytes + (o2 >> 1)]);
+                nb = (byte >> ((o2 & 1) * 4)) & 15;
+                break;
+            }
+            if (fail) break;
+            if (nb < 0) { fail = 1; break; }             // no iteration wrote that byte: the reference reads uninitialised memory
         } else {
         const int o = (by_col ? j : j - i + w + shiftc) - nb0;     // nibble within the stored row
         if (ib < 0 || i > ib || i <= ib - 64 || o < pb || o >= pb + 32) {
@@ -385,7 +422,11 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
             ++nops; prev_op = op; run = 1;
         }
     }
-    if (fail) { hand_over(); return; }
+    if (fail == 2) { hand_over(); return; }        // pool exhausted or a band this launch cannot hold: the other kernels
+    if (fail) {
+        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_TRACE_ERR; }
+        return;
+    }
     if (op == 0) {                                   // ssw.c:697-714
         if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)(run + 1) << 4);
         ++nops;

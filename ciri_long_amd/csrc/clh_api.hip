@@ -512,20 +512,36 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     const bool tb = pl->do_cigar && pl->n > 0;
     const bool fan = !pl->profiling && pl->segs.size() > 1;
     const size_t eb = pl->segs.size() * 2;
-    if (tb) HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 16, st));     // bump pointer and the two hand-over counters
+    if (tb) HIPCHK(hipMemsetAsync(pl->d_pool_head, 0, 4 * 68, st));     // bump pointer and the classes' hand-over counters
     if (fan) {
         HIPCHK(hipEventRecord(c->fork_ev, st));
         for (int i = 0; i < 3; ++i) HIPCHK(hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
     }
-    std::vector<size_t> ord(pl->segs.size());
-    for (size_t k = 0; k < ord.size(); ++k) ord[k] = k;
     // launch order: the class whose single alignments take longest first (a pass is a serial chain of reference columns,
     // longer per column the more rows a lane holds), the short-read scan class last: its many small workgroups would
     // otherwise fill every slot of the GPU and the long chains would start only when they drain
+    std::vector<size_t> ord(pl->segs.size());
+    for (size_t k = 0; k < ord.size(); ++k) ord[k] = k;
     std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
         const int rx = pl->segs[x].rv == clh::kRvStrips ? 1000 : pl->segs[x].rv, ry = pl->segs[y].rv == clh::kRvStrips ? 1000 : pl->segs[y].rv;
         return rx > ry;
     });
+    clh::SswParams PG = P;                                  // the traceback launches index the whole task table
+    PG.tasks = (const clh::SswTask*)pl->d_tasks;
+    uint8_t* const pool = (uint8_t*)pl->d_pool;
+    unsigned long long* const head = (unsigned long long*)pl->d_pool_head;
+    // CIGARs of one class, all on one stream: the row kernel, its wide form for what it hands over, the anti-diagonal
+    // kernel for what is left (sized for the class; workgroups share the short lists).  Per class, so that the seconds-long
+    // tail of a few wide-band alignments of one class runs under the score kernels of the others.
+    auto traceback = [&](int first, int count, int seg, int rv, hipStream_t ls) -> int {
+        const int rvbig = std::max(4, rv == clh::kRvStrips ? 32 : rv);
+        if (tb_rows_on()) {
+            HIPCHK(clh::launch_traceback_rows(PG, first, count, pl->n, seg, pool, head, pl->pool_bytes, ls));
+            HIPCHK(clh::launch_traceback_rows_wide(PG, first, count, pl->n, seg, pool, head, pl->pool_bytes, ls));
+        } else HIPCHK(clh::launch_traceback_pool(0, PG, first, count, pl->n, seg, pool, head, pl->pool_bytes, ls));
+        HIPCHK(clh::launch_traceback_pool(rvbig, PG, first, count, pl->n, seg, pool, head, pl->pool_bytes, ls));
+        return 0;
+    };
     for (size_t q = 0; q < ord.size(); ++q) {
         const size_t k = ord[q];
         const auto& s = pl->segs[k];
@@ -538,36 +554,24 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         } else if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
         else HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], ls));
-        if (tb && !pl->profiling) {
-            if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows(P, s.count, s.begin, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, ls));
-            else HIPCHK(clh::launch_traceback_pool(0, P, s.count, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, ls, false, pl->n));
-        }
+        if (tb && !pl->profiling) { if (int rc = traceback(s.begin, s.count, (int)(k % clh::kTbMaxSeg), s.rv, ls)) return rc; }
     }
     if (fan)
         for (int i = 0; i < 3; ++i) {
             HIPCHK(hipEventRecord(c->join_ev[i], c->side[i]));
             HIPCHK(hipStreamWaitEvent(st, c->join_ev[i], 0));
         }
-    if (tb) {
-        P.tasks = (const clh::SswTask*)pl->d_tasks;
-        if (pl->profiling) {   // profiling runs keep the two traceback phases as separate, serial launches
-            HIPCHK(hipEventRecord(pl->ev[eb + 0], st));
-            if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows(P, pl->n, 0, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
-            else HIPCHK(clh::launch_traceback_pool(0, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st, false, pl->n));
-            HIPCHK(hipEventRecord(pl->ev[eb + 1], st));
-            HIPCHK(hipEventRecord(pl->ev[eb + 2], st));
-        }
-        // what the row kernel handed over: bands of 513..2048 cells in its wide form; then walks that leave the band (the
-        // reference reads stale direction bytes there) and wider bands in the anti-diagonal kernel, whose launch is sized for
-        // the longest read class; workgroups share the list of the few alignments left
+    if (tb && pl->profiling) {   // profiling runs: the traceback of all classes as serial launches after the score kernels
         int rvmax = 4;
         for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv == clh::kRvStrips ? 32 : s.rv);
-        if (tb_rows_on()) {
-            HIPCHK(clh::launch_traceback_rows_wide(P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st));
-            HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st, true, pl->n));
-        } else if (rvmax > 4)   // below that the small window (514 rows) already covers every read
-            HIPCHK(clh::launch_traceback_pool(rvmax, P, pl->n, (uint8_t*)pl->d_pool, (unsigned long long*)pl->d_pool_head, pl->pool_bytes, st, true, pl->n));
-        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[eb + 3], st));
+        HIPCHK(hipEventRecord(pl->ev[eb + 0], st));
+        if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows(PG, 0, pl->n, pl->n, 0, pool, head, pl->pool_bytes, st));
+        else HIPCHK(clh::launch_traceback_pool(0, PG, 0, pl->n, pl->n, 0, pool, head, pl->pool_bytes, st));
+        HIPCHK(hipEventRecord(pl->ev[eb + 1], st));
+        HIPCHK(hipEventRecord(pl->ev[eb + 2], st));
+        if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows_wide(PG, 0, pl->n, pl->n, 0, pool, head, pl->pool_bytes, st));
+        HIPCHK(clh::launch_traceback_pool(rvmax, PG, 0, pl->n, pl->n, 0, pool, head, pl->pool_bytes, st));
+        HIPCHK(hipEventRecord(pl->ev[eb + 3], st));
     }
     pl->last_stream = st;
     pl->ran = true;
@@ -620,7 +624,9 @@ extern "C" int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts)
     if (!pl->d_pool_head) return 0;
     HIPCHK(hipSetDevice(pl->ctx->device));
     HIPCHK(hipStreamSynchronize(pl->last_stream));
-    HIPCHK(hipMemcpy(counts, (const char*)pl->d_pool_head + 8, 8, hipMemcpyDeviceToHost));
+    int32_t w[64];
+    HIPCHK(hipMemcpy(w, (const char*)pl->d_pool_head + 16, sizeof(w), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 32; ++k) { counts[0] += w[k]; counts[1] += w[32 + k]; }
     return 0;
 }
 

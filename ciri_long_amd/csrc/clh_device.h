@@ -164,20 +164,28 @@ static constexpr int kRvScan = 0;        // pseudo class: K1s, the row-scan kern
 hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t stream);
 static constexpr int kRvScanSliced = -1; // pseudo class: K1s with the forward pass cut into window slices (task.dir_off = first part, task.pad = slices)
 hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int nslices, hipStream_t stream);
-hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t* pool_base, unsigned long long* pool_head,
-                                 unsigned long long pool_size, hipStream_t stream, bool only_marked, int n_total);
-// the words behind the pool's bump pointer: [2] alignments handed to the small-window launch, [3] to the large-window
-// launch; their task indices from word 64 on (n_total each).  kTbHeadBytes(n) = size of that buffer.
-inline size_t tb_head_bytes(int n_total) { return 256 + 2 * sizeof(int) * (size_t)(n_total > 0 ? n_total : 1); }
-inline void tb_lists_of(unsigned long long* head, int n_total, int** n_small, int** n_big, int** list_small, int** list_big)
+// K1b launches.  All take the plan's WHOLE task table in p.tasks and work on the tasks [task_base, task_base + ntasks) of launch
+// class `seg` (every class has its own hand-over counters and list regions, so the classes' launch chains run on different
+// streams at once).  Words behind the pool's bump pointer: [4 + seg] alignments the row kernel handed to its wide form,
+// [36 + seg] alignments handed on to the anti-diagonal kernel; the task indices from word 68 on, two arrays of n_total, a
+// class's entries at the offset of its first task.
+static constexpr int kTbMaxSeg = 32;
+inline size_t tb_head_bytes(int n_total) { return 4 * 68 + 2 * sizeof(int) * (size_t)(n_total > 0 ? n_total : 1); }
+inline void tb_lists_of(unsigned long long* head, int n_total, int seg, int task_base, int** n_small, int** n_big, int** list_small, int** list_big)
 {
     int* w = (int*)head;
-    *n_small = w + 2; *n_big = w + 3; *list_small = w + 64; *list_big = w + 64 + (n_total > 0 ? n_total : 1);
+    *n_small = w + 4 + seg; *n_big = w + 36 + seg;
+    *list_small = w + 68 + task_base; *list_big = w + 68 + (n_total > 0 ? n_total : 1) + task_base;
 }
-// K1b row form (ssw_traceback_rows.hip): every alignment; the ones it cannot take are marked CLH_STATUS_NEED_BIG and listed:
-// launch_traceback_rows_wide takes the list (bands up to 2048 cells) and lists what is left for launch_traceback_pool
-hipError_t launch_traceback_rows_wide(const SswParams& p, int n_total, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size, hipStream_t stream);
-hipError_t launch_traceback_rows(const SswParams& p, int ntasks, int task_base, int n_total, uint8_t* pool_base, unsigned long long* pool_head,
+// row form, bands up to 512 cells: every alignment of the class; what it cannot take goes on the class's first list
+hipError_t launch_traceback_rows(const SswParams& p, int task_base, int ntasks, int n_total, int seg, uint8_t* pool_base, unsigned long long* pool_head,
+                                 unsigned long long pool_size, hipStream_t stream);
+// row form, bands up to 2048 cells / by reference column: the class's first list; what is left goes on its second list
+hipError_t launch_traceback_rows_wide(const SswParams& p, int task_base, int ntasks, int n_total, int seg, uint8_t* pool_base, unsigned long long* pool_head,
+                                      unsigned long long pool_size, hipStream_t stream);
+// anti-diagonal form.  rv = 0: every alignment of the class with the small LDS window (what outgrows it goes on the class's
+// second list); rv > 0: the class's second list, window sized for rows <= 128 * rv
+hipError_t launch_traceback_pool(int rv, const SswParams& p, int task_base, int ntasks, int n_total, int seg, uint8_t* pool_base, unsigned long long* pool_head,
                                  unsigned long long pool_size, hipStream_t stream);
 
 }  // namespace clh

@@ -36,8 +36,9 @@ struct TbPool {
     uint8_t* base;
     unsigned long long* head;   // bump pointer (bytes); the words behind it: hand-over counters and lists (tb_lists_of)
     unsigned long long size;
-    int* n_small; int* n_big;   // alignments handed to the small-window / large-window launch of this kernel
-    int* list_small; int* list_big;   // their task indices
+    int* n_small; int* n_big;   // this launch class's hand-over counters (clh_device.h: tb_lists_of)
+    int* list_small; int* list_big;   // its list regions (task indices into the plan's task table)
+    int task_base;              // first task of the class
 };
 
 __device__ __forceinline__ int wave_max(int v)
@@ -68,9 +69,8 @@ __device__ __forceinline__ int ad_stride(int w, int readLen, int refLen)
     return s > refLen ? refLen : s;
 }
 
-// big = 0: every alignment, with a small LDS window (high occupancy); alignments whose band outgrows it are marked
-// CLH_STATUS_NEED_BIG.  big = 2: the same window, only the alignments the row kernel (ssw_traceback_rows.hip) marked.
-// big = 1: only the marked ones, with a window sized for the launch's read-length class.
+// big = 0: every alignment of the class, with a small LDS window (high occupancy); alignments whose band outgrows it are
+// marked CLH_STATUS_NEED_BIG and listed.  big = 1: the listed ones, with a window sized for the read-length class.
 __device__ void tb_antidiagonal(const SswParams& p, const TbPool& pool, const int ws, const int wsp, const int big, const int seq_cap, const int task_index)
 {
     extern __shared__ __attribute__((aligned(16))) short tb_lds[];
@@ -322,21 +322,20 @@ __device__ void tb_antidiagonal(const SswParams& p, const TbPool& pool, const in
 // thousand: a workgroup per task would spend the launch on workgroups that only find out they have nothing to do).
 __global__ void __launch_bounds__(1024) ssw_traceback_kernel(const SswParams p, TbPool pool, int ws, int wsp, int big, int seq_cap)
 {
-    if (big == 0) { tb_antidiagonal(p, pool, ws, wsp, big, seq_cap, (int)blockIdx.x); return; }
-    const int* list = big == 2 ? pool.list_small : pool.list_big;
-    const int n = __builtin_amdgcn_readfirstlane(*(big == 2 ? pool.n_small : pool.n_big));
+    if (big == 0) { tb_antidiagonal(p, pool, ws, wsp, big, seq_cap, pool.task_base + (int)blockIdx.x); return; }
+    const int n = __builtin_amdgcn_readfirstlane(*pool.n_big);
     for (int k = (int)blockIdx.x; k < n; k += (int)gridDim.x) {
-        tb_antidiagonal(p, pool, ws, wsp, big, seq_cap, __builtin_amdgcn_readfirstlane(list[k]));
+        tb_antidiagonal(p, pool, ws, wsp, big, seq_cap, __builtin_amdgcn_readfirstlane(pool.list_big[k]));
         __syncthreads();
     }
 }
 
 // rv = read-length class of every task in the launch (rows <= 128*rv)
-hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t* pool_base, unsigned long long* pool_head,
-                                 unsigned long long pool_size, hipStream_t stream, bool only_marked, int n_total)
+hipError_t launch_traceback_pool(int rv, const SswParams& p, int task_base, int ntasks, int n_total, int seg, uint8_t* pool_base, unsigned long long* pool_head,
+                                 unsigned long long pool_size, hipStream_t stream)
 {
-    TbPool pool; pool.base = pool_base; pool.head = pool_head; pool.size = pool_size;
-    tb_lists_of(pool_head, n_total, &pool.n_small, &pool.n_big, &pool.list_small, &pool.list_big);
+    TbPool pool; pool.base = pool_base; pool.head = pool_head; pool.size = pool_size; pool.task_base = task_base;
+    tb_lists_of(pool_head, n_total, seg, task_base, &pool.n_small, &pool.n_big, &pool.list_small, &pool.list_big);
     // rv == 0: the small-window first attempt (any read length)
     const int ws = rv > 0 ? 128 * rv + 2 : 514;
     int wsp = 1;
@@ -348,8 +347,8 @@ hipError_t launch_traceback_pool(int rv, const SswParams& p, int ntasks, uint8_t
         const char* a = getenv("CLH_TB_SMALL_NT"); const char* b = getenv("CLH_TB_BIG_NT");
         nt_small = a ? atoi(a) : 128; nt_big = b ? atoi(b) : 1024;
     }
-    const int big = rv > 0 ? 1 : (only_marked ? 2 : 0);
-    const int grid = big == 0 ? ntasks : std::min(ntasks, big == 1 ? 512 : 2048);
+    const int big = rv > 0 ? 1 : 0;
+    const int grid = big == 0 ? ntasks : std::min(ntasks, 512);
     hipLaunchKernelGGL(ssw_traceback_kernel, dim3(grid), dim3(rv > 0 ? nt_big : nt_small), lds, stream, p, pool, ws, wsp, big, seq_cap);
     return hipGetLastError();
 }

@@ -463,15 +463,13 @@ __device__ __forceinline__ void tb_rows_table(const SswParams& p, uint2* s_tab)
     __syncthreads();
 }
 
-// every alignment of the launch, one per workgroup (= one wave)
+// every alignment of the launch class, one per workgroup (= one wave)
 __global__ void __launch_bounds__(64, 4) ssw_traceback_rows_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
                                                                    int task_base, int* n_small, int* list_small)
 {
     __shared__ uint2 s_tab[8];
     tb_rows_table(p, s_tab);
-    SswParams q = p;
-    q.tasks = p.tasks - task_base;          // the lists hold indices into the plan's task table
-    tb_rows_one<4>(q, s_tab, pool_base, pool_head, pool_size, task_base + (int)blockIdx.x, n_small, list_small);
+    tb_rows_one<4>(p, s_tab, pool_base, pool_head, pool_size, task_base + (int)blockIdx.x, n_small, list_small);
 }
 
 // the alignments the narrow launch handed over: the workgroups share the list
@@ -487,21 +485,21 @@ __global__ void __launch_bounds__(64, 1) ssw_traceback_rows_wide_kernel(const Ss
     }
 }
 
-hipError_t launch_traceback_rows(const SswParams& p, int ntasks, int task_base, int n_total, uint8_t* pool_base, unsigned long long* pool_head,
+hipError_t launch_traceback_rows(const SswParams& p, int task_base, int ntasks, int n_total, int seg, uint8_t* pool_base, unsigned long long* pool_head,
                                  unsigned long long pool_size, hipStream_t stream)
 {
     int *n_small, *n_big, *list_small, *list_big;
-    tb_lists_of(pool_head, n_total, &n_small, &n_big, &list_small, &list_big);
+    tb_lists_of(pool_head, n_total, seg, task_base, &n_small, &n_big, &list_small, &list_big);
     hipLaunchKernelGGL(ssw_traceback_rows_kernel, dim3(ntasks), dim3(64), 0, stream, p, pool_base, pool_head, pool_size, task_base, n_small, list_small);
     return hipGetLastError();
 }
 
-// p.tasks = the plan's whole task table
-hipError_t launch_traceback_rows_wide(const SswParams& p, int n_total, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size, hipStream_t stream)
+hipError_t launch_traceback_rows_wide(const SswParams& p, int task_base, int ntasks, int n_total, int seg, uint8_t* pool_base, unsigned long long* pool_head,
+                                      unsigned long long pool_size, hipStream_t stream)
 {
     int *n_small, *n_big, *list_small, *list_big;
-    tb_lists_of(pool_head, n_total, &n_small, &n_big, &list_small, &list_big);
-    hipLaunchKernelGGL(ssw_traceback_rows_wide_kernel, dim3(std::min(n_total, 1024)), dim3(64), 0, stream, p, pool_base, pool_head, pool_size, n_small, list_small, n_big, list_big);
+    tb_lists_of(pool_head, n_total, seg, task_base, &n_small, &n_big, &list_small, &list_big);
+    hipLaunchKernelGGL(ssw_traceback_rows_wide_kernel, dim3(std::min(std::max(ntasks, 1), 1024)), dim3(64), 0, stream, p, pool_base, pool_head, pool_size, n_small, list_small, n_big, list_big);
     return hipGetLastError();
 }
 

@@ -364,7 +364,9 @@ def test_cigars_of_wide_bands_row_traceback_vs_oracle(ctx, scheme):
                                  want['query_end'], want['ref_end2']), (k, len(q), len(ref))
         assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref), int(r['status']))
         nwide += abs((want['ref_end'] - want['ref_begin']) - (want['query_end'] - want['query_begin'])) + 1 > 255
-    assert wide >= nwide > 5 and anti <= wide // 2 + 2, (wide, anti, nwide)
+    import os
+    if not os.environ.get('CLH_NO_TB_ROWS'):      # the A/B switch sends everything through the anti-diagonal kernel
+        assert wide >= nwide > 5 and anti <= wide // 2 + 2, (wide, anti, nwide)
 
 
 @pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (2, 3, 5, 2), (1, 1, 3, 1)])

@@ -319,6 +319,11 @@ static void u32_push(u32vec *a, uint32_t x)
     a->v[a->n++] = x;
 }
 
+/* test instrumentation: steps of the last traceback that read a direction byte outside the final band (the reads of stale bytes,
+ * ssw.c:58,640) -- lets the tests pick inputs that exercise that path */
+static int g_oob_steps = 0;
+int clo_last_oob_steps(void) { return g_oob_steps; }
+
 static int banded_traceback(const int8_t *ref, const int8_t *read, int refLen, int readLen, int score,
                             int gapO, int gapE, int band_width, const int8_t *mat, int n,
                             uint32_t **out, int *outLen)
@@ -396,8 +401,10 @@ static int banded_traceback(const int8_t *ref, const int8_t *read, int refLen, i
     int i = readLen - 1, j = refLen - 1, run = 0, state = 2, fail = 0;
     char op = 'M', prev_op = 'M';
     long lo = 0, hi = (long)s2;
+    g_oob_steps = 0;
     while (i > 0) {
         long idx = (direction_line - direction) + band_d(band_width, i, j, state);
+        if (j < imax(0, i - band_width) || j > imin(refLen - 1, i + band_width)) ++g_oob_steps;
         if (idx < lo || idx >= hi) { fail = 1; break; }
         switch (direction[idx]) {
             case 1: --i; --j; state = 2; direction_line -= (size_t)width_d * 3; op = 'M'; break;

@@ -408,3 +408,26 @@ def test_long_windows_in_slices_vs_oracle(ctx, scheme):
                    want['ref_end2'] if s2 else got[6])
             assert got == exp, (k, len(q), len(ref), got, exp)
             assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref))
+
+
+def test_stale_walk_goldens(ctx):
+    """the four alignments of tests/golden/stale_walk_golden.json.gz (the reference's traceback reads direction bytes outside
+    the final band): rows and CIGARs equal the reference library's, batched together with ordinary alignments"""
+    import gzip
+    import json
+    import os
+    from ciri_long_amd import hip
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stale_walk_golden.json.gz'), 'rt') as f:
+        cases = json.load(f)['cases']
+    rng = np.random.default_rng(4)
+    refs = [c['ref'] for c in cases]; qs = [c['query'] for c in cases]
+    for _ in range(12):
+        ref = _rnd(rng, 1500); refs.append(ref); qs.append(_mut(ref[200:1100], rng, 0.1))
+    rows, cig = _run(ctx, refs, qs, (1, 1, 1, 1))
+    for c, r in zip(cases, rows):
+        w = c['want']
+        assert _row_tuple(r) == (w['score'], w['score2'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end'], w['ref_end2']), (c['rank'], c['index'])
+        assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == w['cigar'], (c['rank'], c['index'], int(r['status']))
+    for ref, q, r in zip(refs[len(cases):], qs[len(cases):], rows[len(cases):]):
+        want = oracle_align(ref, q, 1, 1, 1, 1)
+        assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar']

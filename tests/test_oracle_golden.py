@@ -38,3 +38,23 @@ def test_zero_score_is_degenerate_but_deterministic(golden_cases):
     assert (z['score'], z['ref_begin'], z['ref_end'], z['query_begin'], z['query_end'], z['cigar_string']) == \
         (0, -1, -1, 0, 0, '1M7S')
     _check(z)
+
+
+def test_stale_walk_goldens_oracle_equals_the_reference_library():
+    """tests/golden/stale_walk_golden.json.gz: alignments whose traceback leaves the final band and reads direction bytes
+    of other cells / earlier band iterations (ssw.c:636-696).  Expected values are the reference library's; the oracle
+    reproduces them, and its instrumentation confirms the walks do take such steps."""
+    import ctypes as C
+    import gzip
+    import json
+    import os
+    import oracle_lib
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stale_walk_golden.json.gz'), 'rt') as f:
+        cases = json.load(f)['cases']
+    assert len(cases) >= 4
+    lib = oracle_lib.oracle(); lib.clo_last_oob_steps.restype = C.c_int
+    for c in cases:
+        w = oracle_lib.oracle_align(c['ref'], c['query'], c['match'], c['mismatch'], c['gap_open'], c['gap_extend'])
+        assert lib.clo_last_oob_steps() == c['stale_steps'] > 0
+        for k, v in c['want'].items():
+            assert w[k] == v, (c['rank'], c['index'], k)

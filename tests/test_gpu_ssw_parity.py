@@ -412,7 +412,8 @@ def test_long_windows_in_slices_vs_oracle(ctx, scheme):
 
 def test_stale_walk_goldens(ctx):
     """the four alignments of tests/golden/stale_walk_golden.json.gz (the reference's traceback reads direction bytes outside
-    the final band): rows and CIGARs equal the reference library's, batched together with ordinary alignments"""
+    the final band; in all four the byte belongs to an EARLIER band iteration, which the row kernel computes once more with
+    codes): rows and CIGARs equal the reference library's, batched together with ordinary alignments"""
     import gzip
     import json
     import os

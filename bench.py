@@ -192,7 +192,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else ('ssw_scan_kernel' if rv == 0 else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel'), 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         out.append({'kernel': 'ssw_traceback_rows_wide_kernel + ssw_traceback_kernel (handed-over alignments)', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0,

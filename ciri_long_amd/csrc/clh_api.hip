@@ -138,6 +138,9 @@ struct clh_plan {
     struct Seg { int rv, begin, count; };
     std::vector<clh::ScanSlice> slices;      // window slices of the sliced scan class (one segment at most)
     void *d_slices = nullptr, *d_parts = nullptr;
+    std::vector<int32_t> slice_base;         // task-level slices of the anti-diagonal classes: first window column of scratch row k
+    void* d_slice_base = nullptr;
+    int n_all = 0;                           // tasks incl. those slices (their result rows sit behind the n real ones)
     std::vector<Seg> segs;
     void *d_tasks = nullptr, *d_results = nullptr, *d_colmax = nullptr, *d_cigars = nullptr, *d_cigar_len = nullptr,
          *d_pool = nullptr, *d_pool_head = nullptr, *d_reads = nullptr, *d_refs = nullptr;
@@ -157,7 +160,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     (void)hipSetDevice(c->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
-                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts};
+                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base};
     for (void* b : bufs) c->release(b);
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
     delete pl;
@@ -261,22 +264,57 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
             pool += (unsigned long long)(L + 64) * 160ull;
         }
     }
+    // Long windows of the anti-diagonal classes (reads outside K1s's 8-bit class), call-path options (no second best): the
+    // alignment is cut into window slices that run as ordinary tasks of their class -- whole alignments of the read against
+    // [c_begin, c_end), results into scratch rows behind the n real ones -- and a combining kernel (class kRvCombine, after
+    // all classes have finished) takes the best slice: largest score, then smallest end column, then the earlier slice.
+    // Exact: a local alignment spans at most L (1 + max_match / gap_extend) columns, so the slice that OWNS the end column
+    // (started that far before its owned columns) computes the whole-window H there; a later slice that sees the same cell
+    // in its overlap can only underestimate, and loses the tie.  The reverse pass of the owning slice runs inside the slice.
+    int n_all = n;
+    if (!o->want_score2 && o->gap_extend >= 1 && !getenv("CLH_NO_SLICES")) {
+        for (int a = 0; a < n; ++a) {
+            if (cls[a] < 1 || cls[a] == clh::kRvStrips || pl->tasks[a].ref_len < kSliceMinWindow) continue;
+            const clh::SswTask par = pl->tasks[a];
+            const int64_t R = par.ref_len, L = par.read_len;
+            const int64_t overlap = L + (L * mx + o->gap_extend - 1) / o->gap_extend + 32;
+            const int64_t own = std::max<int64_t>(std::max<int64_t>(kSliceMinCols, 2 * overlap), (R + 63) / 64);
+            const int rdir = par.ref_rc ? -1 : 1;
+            pl->tasks[a].dir_off = (int64_t)pl->slice_base.size();       // first scratch row of this alignment (relative to n)
+            int ns = 0;
+            for (int64_t b = 0; b < R; b += own, ++ns) {
+                clh::SswTask t = par;
+                const int64_t cb = std::max<int64_t>(0, b - overlap), ce = std::min<int64_t>(R, b + own);
+                t.ref_off = par.ref_off + cb * rdir; t.ref_len = (int32_t)(ce - cb);
+                t.out_index = n + (int32_t)pl->slice_base.size();
+                t.cigar_cap = 0; t.pad = 0; t.dir_off = 0;
+                pl->slice_base.push_back((int32_t)cb);
+                pl->tasks.push_back(t);
+                cls.push_back(cls[a]);
+            }
+            pl->tasks[a].pad = ns;
+            cls[a] = clh::kRvCombine;
+        }
+        n_all = (int)pl->tasks.size();
+    }
+    pl->n_all = n_all;
+    P.n_real = n;
     pl->colmax_elems = colmax; pl->cigar_elems = cig;
     if (pl->do_cigar) pl->pool_bytes = std::min<unsigned long long>(pool + (512ull << 20), 16ull << 30);
 
     // launch order: by row class, heaviest alignments first inside a class
-    std::vector<int> order(n);
-    for (int a = 0; a < n; ++a) order[a] = a;
+    std::vector<int> order(n_all);
+    for (int a = 0; a < n_all; ++a) order[a] = a;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
         if (cls[x] != cls[y]) return cls[x] < cls[y];
         const int64_t wx = (int64_t)pl->tasks[x].read_len * pl->tasks[x].ref_len, wy = (int64_t)pl->tasks[y].read_len * pl->tasks[y].ref_len;
         return wx > wy;
     });
-    std::vector<clh::SswTask> sorted(n);
-    for (int k = 0; k < n; ++k) sorted[k] = pl->tasks[order[k]];
-    for (int k = 0; k < n;) {
+    std::vector<clh::SswTask> sorted(n_all);
+    for (int k = 0; k < n_all; ++k) sorted[k] = pl->tasks[order[k]];
+    for (int k = 0; k < n_all;) {
         int e = k;
-        while (e < n && cls[order[e]] == cls[order[k]]) ++e;
+        while (e < n_all && cls[order[e]] == cls[order[k]]) ++e;
         pl->segs.push_back({cls[order[k]], k, e - k});
         k = e;
     }
@@ -301,14 +339,21 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         }
     }
 
-    pl->d_tasks = ctx->alloc(sizeof(clh::SswTask) * (size_t)std::max(n, 1));
-    pl->d_results = ctx->alloc(sizeof(clh::SswResult) * (size_t)std::max(n, 1));
-    pl->d_cigar_len = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
+    pl->d_tasks = ctx->alloc(sizeof(clh::SswTask) * (size_t)std::max(n_all, 1));
+    pl->d_results = ctx->alloc(sizeof(clh::SswResult) * (size_t)std::max(n_all, 1));
+    pl->d_cigar_len = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n_all, 1));
+    if (!pl->slice_base.empty()) {
+        pl->d_slice_base = ctx->alloc(sizeof(int32_t) * pl->slice_base.size());
+        if (!pl->d_slice_base || hipMemcpy(pl->d_slice_base, pl->slice_base.data(), sizeof(int32_t) * pl->slice_base.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            fail(CLH_E_HIP, "out of device memory while building the plan");
+            clh_plan_destroy(pl); return nullptr;
+        }
+    }
     if (o->want_score2) pl->d_colmax = ctx->alloc(sizeof(uint16_t) * std::max<size_t>(colmax, 1));
     if (pl->do_cigar) {
         pl->d_cigars = ctx->alloc(sizeof(uint32_t) * std::max<size_t>(cig, 1));
         pl->d_pool = ctx->alloc((size_t)pl->pool_bytes);
-        pl->d_pool_head = ctx->alloc(clh::tb_head_bytes(n));
+        pl->d_pool_head = ctx->alloc(clh::tb_head_bytes(n_all));
     }
     if (pl->strip_bytes) pl->d_strips = ctx->alloc(pl->strip_bytes);
     if (!pl->slices.empty()) {
@@ -324,7 +369,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         fail(CLH_E_HIP, "out of device memory while building the plan");
         clh_plan_destroy(pl); return nullptr;
     }
-    if (n > 0 && hipMemcpy(pl->d_tasks, pl->tasks.data(), sizeof(clh::SswTask) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) {
+    if (n_all > 0 && hipMemcpy(pl->d_tasks, pl->tasks.data(), sizeof(clh::SswTask) * (size_t)n_all, hipMemcpyHostToDevice) != hipSuccess) {
         fail(CLH_E_HIP, "task upload failed");
         clh_plan_destroy(pl); return nullptr;
     }
@@ -536,15 +581,19 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     auto traceback = [&](int first, int count, int seg, int rv, hipStream_t ls) -> int {
         const int rvbig = std::max(4, rv == clh::kRvStrips ? 32 : rv);
         if (tb_rows_on()) {
-            HIPCHK(clh::launch_traceback_rows(PG, first, count, pl->n, seg, pool, head, pl->pool_bytes, ls));
-            HIPCHK(clh::launch_traceback_rows_wide(PG, first, count, pl->n, seg, pool, head, pl->pool_bytes, ls));
-        } else HIPCHK(clh::launch_traceback_pool(0, PG, first, count, pl->n, seg, pool, head, pl->pool_bytes, ls));
-        HIPCHK(clh::launch_traceback_pool(rvbig, PG, first, count, pl->n, seg, pool, head, pl->pool_bytes, ls));
+            HIPCHK(clh::launch_traceback_rows(PG, first, count, pl->n_all, seg, pool, head, pl->pool_bytes, ls));
+            HIPCHK(clh::launch_traceback_rows_wide(PG, first, count, pl->n_all, seg, pool, head, pl->pool_bytes, ls));
+        } else HIPCHK(clh::launch_traceback_pool(0, PG, first, count, pl->n_all, seg, pool, head, pl->pool_bytes, ls));
+        HIPCHK(clh::launch_traceback_pool(rvbig, PG, first, count, pl->n_all, seg, pool, head, pl->pool_bytes, ls));
         return 0;
     };
+    P.slice_base = (const int32_t*)pl->d_slice_base; PG.slice_base = P.slice_base;
+    int rv_all = 4;                                              // longest read class of the plan (the combined alignments have any length)
+    for (const auto& s : pl->segs) rv_all = std::max(rv_all, s.rv == clh::kRvStrips ? 32 : s.rv);
     for (size_t q = 0; q < ord.size(); ++q) {
         const size_t k = ord[q];
         const auto& s = pl->segs[k];
+        if (s.rv == clh::kRvCombine) continue;                   // after the join below: it reads the other classes' rows
         hipStream_t ls = (fan && (q & 3)) ? c->side[(q & 3) - 1] : st;
         P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], ls));
@@ -561,16 +610,25 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
             HIPCHK(hipEventRecord(c->join_ev[i], c->side[i]));
             HIPCHK(hipStreamWaitEvent(st, c->join_ev[i], 0));
         }
+    for (size_t k = 0; k < pl->segs.size(); ++k) {
+        const auto& s = pl->segs[k];
+        if (s.rv != clh::kRvCombine) continue;
+        P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
+        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], st));
+        HIPCHK(clh::launch_ssw_combine(P, s.count, st));
+        if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], st));
+        if (tb && !pl->profiling) { if (int rc = traceback(s.begin, s.count, (int)(k % clh::kTbMaxSeg), rv_all, st)) return rc; }
+    }
     if (tb && pl->profiling) {   // profiling runs: the traceback of all classes as serial launches after the score kernels
         int rvmax = 4;
         for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv == clh::kRvStrips ? 32 : s.rv);
         HIPCHK(hipEventRecord(pl->ev[eb + 0], st));
-        if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows(PG, 0, pl->n, pl->n, 0, pool, head, pl->pool_bytes, st));
-        else HIPCHK(clh::launch_traceback_pool(0, PG, 0, pl->n, pl->n, 0, pool, head, pl->pool_bytes, st));
+        if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows(PG, 0, pl->n_all, pl->n_all, 0, pool, head, pl->pool_bytes, st));
+        else HIPCHK(clh::launch_traceback_pool(0, PG, 0, pl->n_all, pl->n_all, 0, pool, head, pl->pool_bytes, st));
         HIPCHK(hipEventRecord(pl->ev[eb + 1], st));
         HIPCHK(hipEventRecord(pl->ev[eb + 2], st));
-        if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows_wide(PG, 0, pl->n, pl->n, 0, pool, head, pl->pool_bytes, st));
-        HIPCHK(clh::launch_traceback_pool(rvmax, PG, 0, pl->n, pl->n, 0, pool, head, pl->pool_bytes, st));
+        if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows_wide(PG, 0, pl->n_all, pl->n_all, 0, pool, head, pl->pool_bytes, st));
+        HIPCHK(clh::launch_traceback_pool(rvmax, PG, 0, pl->n_all, pl->n_all, 0, pool, head, pl->pool_bytes, st));
         HIPCHK(hipEventRecord(pl->ev[eb + 3], st));
     }
     pl->last_stream = st;
@@ -656,7 +714,7 @@ extern "C" int clh_ssw_fetch(clh_plan* pl, clh_align_t* out, uint32_t* cigar_buf
     if (pl->do_cigar && n > 0) HIPCHK(hipMemcpy(clen.data(), pl->d_cigar_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     std::vector<int32_t> share_off((size_t)std::max(n, 1), 0), glen((size_t)std::max(n, 1), 0);
     std::vector<int64_t> dst_off((size_t)std::max(n, 1), 0);
-    for (const auto& t : pl->tasks) share_off[t.out_index] = t.cigar_off;
+    for (const auto& t : pl->tasks) if (t.out_index < n) share_off[t.out_index] = t.cigar_off;
     int64_t used = 0;
     int rc = 0;
     for (int a = 0; a < n; ++a) {

@@ -62,6 +62,9 @@ struct SswParams {
     int32_t null_code;    // 4 if mat scores code 4 as 0 against everything (then fill/drain columns reuse it), else 5
     const ScanSlice* slices;   // sliced scan class only
     ScanPart* parts;
+    int32_t n_real;            // result rows of real alignments; tasks with out_index >= n_real are window slices of the
+                               // anti-diagonal classes (scratch rows, no CIGAR), see clh_api.hip and ssw_combine_kernel
+    const int32_t* slice_base; // first window column of scratch row k (index out_index - n_real)
 };
 
 // ---- cyclic consensus (K2/K3, csrc/ccs_poa.hip) ----------------------------------------------------------------
@@ -162,6 +165,9 @@ extern const int kNumRvClasses;
 hipError_t launch_ssw(int rv, bool quirk, const SswParams& p, int ntasks, hipStream_t stream);
 static constexpr int kRvScan = 0;        // pseudo class: K1s, the row-scan kernel for short reads in the 8-bit regime (ssw_scan.hip)
 hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t stream);
+static constexpr int kRvCombine = -2;    // pseudo class: alignments whose score pass ran as window-slice tasks of an anti-diagonal class;
+                                         // their "score kernel" takes the best slice (task.dir_off = first scratch row, task.pad = slices)
+hipError_t launch_ssw_combine(const SswParams& p, int ntasks, hipStream_t stream);
 static constexpr int kRvScanSliced = -1; // pseudo class: K1s with the forward pass cut into window slices (task.dir_off = first part, task.pad = slices)
 hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int nslices, hipStream_t stream);
 // K1b launches.  All take the plan's WHOLE task table in p.tasks and work on the tasks [task_base, task_base + ntasks) of launch

@@ -396,6 +396,42 @@ hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t
     return hipGetLastError();
 }
 
+// class kRvCombine: the best of an alignment's window-slice tasks (clh_api.hip) becomes its result row: largest score, then
+// smallest end column in the whole window, then the earlier slice (the one that owns that column)
+__global__ void __launch_bounds__(64) ssw_combine_kernel(const SswParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const SswTask task = p.tasks[blockIdx.x];
+    const int first = (int)task.dir_off, ns = task.pad;
+    int v = -1, c = 0x7fffffff, k = 0x7fffffff;
+    if (lane < ns) {
+        const SswResult r = p.results[p.n_real + first + lane];
+        v = r.score1; k = lane;
+        c = r.score1 > 0 ? r.ref_end1 + p.slice_base[first + lane] : 0x7fffffff;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v2 = __shfl_xor(v, d), c2 = __shfl_xor(c, d), k2 = __shfl_xor(k, d);
+        const bool take = v2 > v || (v2 == v && (c2 < c || (c2 == c && k2 < k)));
+        v = take ? v2 : v; c = take ? c2 : c; k = take ? k2 : k;
+    }
+    if (lane == 0) {
+        SswResult r = p.results[p.n_real + first + k];
+        if (r.score1 > 0) {
+            const int base = p.slice_base[first + k];
+            r.ref_end1 += base;
+            if (r.ref_begin1 >= 0) r.ref_begin1 += base;
+        }
+        p.results[task.out_index] = r;
+    }
+}
+
+hipError_t launch_ssw_combine(const SswParams& p, int ntasks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssw_combine_kernel, dim3(ntasks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
 // p.slices / p.parts set; p.tasks = the sliced class's tasks
 hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int nslices, hipStream_t stream)
 {

@@ -89,6 +89,7 @@ __device__ void tb_antidiagonal(const SswParams& p, const TbPool& pool, const in
     if (lane < 25) smat[lane] = p.mat[lane];
     __syncthreads();
     const SswTask task = p.tasks[task_index];
+    if (task.out_index >= p.n_real) return;            // a window slice of an anti-diagonal class: scratch row, no CIGAR
     SswResult res = p.results[task.out_index];
     // the result row is read with a vector load (this kernel also writes it): tell the compiler it is wave-uniform, or
     // every loop bound below sits in a VGPR behind exec-mask control flow

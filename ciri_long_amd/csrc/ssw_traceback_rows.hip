@@ -295,6 +295,7 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
 {
     const int lane = threadIdx.x & 63;
     const SswTask task = p.tasks[task_index];
+    if (task.out_index >= p.n_real) return;            // a window slice of an anti-diagonal class: scratch row, no CIGAR
     SswResult res = p.results[task.out_index];
     res.score1 = __builtin_amdgcn_readfirstlane(res.score1); res.status = __builtin_amdgcn_readfirstlane(res.status);
     res.ref_begin1 = __builtin_amdgcn_readfirstlane(res.ref_begin1); res.ref_end1 = __builtin_amdgcn_readfirstlane(res.ref_end1);

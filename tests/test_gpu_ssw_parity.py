@@ -432,3 +432,61 @@ def test_stale_walk_goldens(ctx):
     for ref, q, r in zip(refs[len(cases):], qs[len(cases):], rows[len(cases):]):
         want = oracle_align(ref, q, 1, 1, 1, 1)
         assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar']
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (10, 4, 8, 2), (2, 2, 3, 1)])
+def test_long_windows_of_the_anti_diagonal_classes_in_slices_vs_oracle(ctx, scheme):
+    """Reads outside K1s's 8-bit class against windows of 32 kb and more, call-path options (no second best): the alignment
+    runs as window-slice tasks of its anti-diagonal class and `ssw_combine_kernel` takes the best slice (clh_api.hip).  The
+    read placed across slice borders, inside overlaps, twice (first end column wins), absent; forward windows as packed
+    references and minus-strand windows of a resident genome.  Scores, coordinates and CIGARs equal the oracle's."""
+    from ciri_long_amd import hip, utils
+    m, x, o, e = scheme
+    rng = np.random.default_rng(1500 + sum(scheme))
+    refs, qs = [], []
+    for R in [32768, 50000, 120000]:
+        for case in range(6):
+            L = int(rng.integers(260, 900)) if m == 1 else int(rng.integers(30, 500))
+            ref = _rnd(rng, R)
+            overlap = L + (L * m + e - 1) // e + 32
+            own = max(8192, 2 * overlap, (R + 63) // 64)
+            border = own * int(rng.integers(1, max(2, R // own)))
+            pos = [border - L // 2, border - 5, border + 2, border - overlap + 3, int(rng.integers(0, R - L)), R - L][case]
+            pos = max(0, min(R - L, pos))
+            q = _mut(ref[pos:pos + L], rng, float(rng.choice([0.0, 0.05, 0.12]))) or 'A'
+            if case == 2 and pos > 2 * L + 10:
+                ref = (ref[:pos - 2 * L] + ref[pos:pos + L] + ref[pos - L:])[:R]      # an exact earlier copy
+            if case == 4:
+                q = _rnd(rng, L)
+            refs.append(ref); qs.append(q[:4000])
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=True)
+    assert sum(c for rv, c, _a, _b in plan.segments() if rv == -2) >= len(qs) - 6      # nearly all: reads outside the 8-bit class
+    plan.close()
+    rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(m, x), o, e, want_score2=False, want_cigar=True)
+    for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
+        want = oracle_align(ref, q, *scheme)
+        got = (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1']))
+        assert got == (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end']), (k, len(q), len(ref), got)
+        assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref), int(r['status']))
+    # minus-strand windows of a resident genome: the slices walk the genome backwards
+    text = _rnd(rng, 140000)
+    g = hip.Genome(ctx, {'chr1': text})
+    wins, minus, queries, strings = [], [], [], []
+    for k in range(8):
+        s = int(rng.integers(0, 20000)); e2 = s + int(rng.integers(40000, 110000))
+        w = text[s:e2]
+        mstrand = k % 2 == 1
+        wstr = utils.revcomp(w) if mstrand else w
+        L = int(rng.integers(270, 700)) if m == 1 else int(rng.integers(40, 300))
+        p0 = int(rng.integers(0, len(wstr) - L))
+        queries.append(_mut(wstr[p0:p0 + L], rng, 0.06) or 'A'); strings.append(wstr)
+        wins.append(('chr1', s, e2)); minus.append(mstrand)
+    qd, qo = hip.pack(queries)
+    rows, cig = g.ssw_windows(qd, qo, wins, minus, hip.score_matrix(m, x), o, e, want_score2=False, want_cigar=True)
+    for k, (wstr, q, r) in enumerate(zip(strings, queries, rows)):
+        want = oracle_align(wstr, q, *scheme)
+        got = (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1']))
+        assert got == (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end']), ('window', k, got)
+        assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], ('window', k)
+    g.close()

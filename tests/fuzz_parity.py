@@ -56,6 +56,43 @@ while time.time() < t_end:
             np.save('gpurun_out/fuzz_fail_q.npy', qs[k]); np.save('gpurun_out/fuzz_fail_r.npy', refs[k])
             print('SSW MISMATCH seed', seed + it - 1, 'k', k, scheme, len(qs[k]), len(refs[k]), got, exp, int(r['status'])); sys.exit(1)
     n_ssw += len(qs)
+    # ---- SSW: long windows (slices), reads with long gaps (wide traceback bands), call-path options every other round ----
+    refs, qs = [], []
+    for _ in range(10):
+        R = int(rng.choice([33000, 45000, 70000])); L = int(rng.choice([25, 120, 250, 300, 700]))
+        ref = rng.integers(0, 4, R, dtype=np.int8)
+        st = int(rng.integers(0, R - L))
+        q = synth.mutate(ref[st:st + L], rng, sub=float(rng.choice([0.0, 0.05])), ins=0.03, dele=0.03)
+        refs.append(ref); qs.append(q.astype(np.int8) if len(q) else np.zeros(3, dtype=np.int8))
+    for _ in range(10):
+        blk = int(rng.choice([300, 600, 1100])); gap = int(rng.choice([40, 150, 320, 700])); R = 2 * blk + gap + 300
+        ref = rng.integers(0, 4, R, dtype=np.int8)
+        a = int(rng.integers(0, 100))
+        if rng.random() < 0.5:
+            q = np.concatenate([ref[a:a + blk], ref[a + blk + gap:a + 2 * blk + gap]])
+        else:
+            q = np.concatenate([ref[a:a + blk], rng.integers(0, 4, gap, dtype=np.int8), ref[a + blk:a + 2 * blk]])
+        refs.append(ref); qs.append(synth.mutate(q, rng, sub=0.03, ins=0.02, dele=0.02).astype(np.int8)[:4000])
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    s2 = bool(it & 1)
+    rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(scheme[0], scheme[1]), scheme[2], scheme[3], want_score2=s2, want_cigar=True)
+    for k in range(len(qs)):
+        w = oracle_lib.oracle_align(refs[k], qs[k], *scheme)
+        r = rows[k]
+        if w is None:
+            if not (int(r['status']) & 4):
+                print('SSW(long): reference NULL but no TRACE_ERR status, seed', seed + it - 1, 'k', k, scheme); sys.exit(1)
+            n_null += 1
+            continue
+        got = [int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])]
+        exp = [w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']]
+        ok = got == exp and [int(x) for x in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == w['cigar']
+        if s2:
+            ok = ok and [int(r['score2']), int(r['ref_end2'])] == [w['score2'], w['ref_end2']]
+        if not ok:
+            np.save('gpurun_out/fuzz_fail_q.npy', qs[k]); np.save('gpurun_out/fuzz_fail_r.npy', refs[k])
+            print('SSW(long) MISMATCH seed', seed + it - 1, 'k', k, scheme, s2, len(qs[k]), len(refs[k]), got, exp, int(r['status'])); sys.exit(1)
+    n_ssw += len(qs)
     # ---- consensus: random periods / lengths / error rates ----
     reads = []
     for _ in range(120):

@@ -579,7 +579,9 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     // kernel for what is left (sized for the class; workgroups share the short lists).  Per class, so that the seconds-long
     // tail of a few wide-band alignments of one class runs under the score kernels of the others.
     auto traceback = [&](int first, int count, int seg, int rv, hipStream_t ls) -> int {
-        const int rvbig = std::max(4, rv == clh::kRvStrips ? 32 : rv);
+        // the anti-diagonal fallback stages both aligned sequences in LDS: always the largest configuration (12 kB of sequence,
+        // 4098 rows) -- a short read can align against thousands of reference bases; its few workgroups share the list
+        const int rvbig = 32; (void)rv;
         if (tb_rows_on()) {
             HIPCHK(clh::launch_traceback_rows(PG, first, count, pl->n_all, seg, pool, head, pl->pool_bytes, ls));
             HIPCHK(clh::launch_traceback_rows_wide(PG, first, count, pl->n_all, seg, pool, head, pl->pool_bytes, ls));
@@ -620,8 +622,7 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         if (tb && !pl->profiling) { if (int rc = traceback(s.begin, s.count, (int)(k % clh::kTbMaxSeg), rv_all, st)) return rc; }
     }
     if (tb && pl->profiling) {   // profiling runs: the traceback of all classes as serial launches after the score kernels
-        int rvmax = 4;
-        for (const auto& s : pl->segs) rvmax = std::max(rvmax, s.rv == clh::kRvStrips ? 32 : s.rv);
+        const int rvmax = 32;
         HIPCHK(hipEventRecord(pl->ev[eb + 0], st));
         if (tb_rows_on()) HIPCHK(clh::launch_traceback_rows(PG, 0, pl->n_all, pl->n_all, 0, pool, head, pl->pool_bytes, st));
         else HIPCHK(clh::launch_traceback_pool(0, PG, 0, pl->n_all, pl->n_all, 0, pool, head, pl->pool_bytes, st));

@@ -490,3 +490,21 @@ def test_long_windows_of_the_anti_diagonal_classes_in_slices_vs_oracle(ctx, sche
         assert got == (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end']), ('window', k, got)
         assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], ('window', k)
     g.close()
+
+
+def test_short_read_spanning_thousands_of_reference_bases(ctx):
+    """tests/golden/stale_walk_golden.json.gz, `wide_reference_cases` (found by the fuzz harness): a 315-base read aligned over
+    2603 reference bases with 5/4/6/6 -- a band above 2048 cells on a reference above 2048 bases, i.e. the anti-diagonal
+    traceback, whose LDS must hold both aligned sequences whatever the read-length class is"""
+    import gzip
+    import json
+    import os
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stale_walk_golden.json.gz'), 'rt') as f:
+        cases = json.load(f)['wide_reference_cases']
+    for c in cases:
+        scheme = (c['match'], c['mismatch'], c['gap_open'], c['gap_extend'])
+        rows, cig = _run(ctx, [c['ref']] * 3, [c['query'], c['query'][:100], c['query']], scheme)
+        for r in (rows[0], rows[2]):
+            w = c['want']
+            assert _row_tuple(r) == (w['score'], w['score2'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end'], w['ref_end2'])
+            assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == w['cigar'], int(r['status'])

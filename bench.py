@@ -250,6 +250,7 @@ class FullStep(object):
         self.ctg_len = np.full(len(has), self.glen, dtype=np.int64)
         self.t_k5 = self.t_k6 = self.t_fetch = 0.0
         self.last = None
+        self.ccs_queued = False
         if expect is not None:   # parity spot check outside the timed region, against the answers the CPU leg left
             self.step()
             srow = self.last['rows']
@@ -263,9 +264,15 @@ class FullStep(object):
                     r = srow[pos[k]]
                     assert [int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])] == want_row, k
 
-    def step(self):
+    def step(self, launch_next=False):
+        """one batch through the whole device part of `call`.  launch_next: queue K2+K3 of the NEXT step behind this step's K1
+        before waiting for this step's rows, so that the GPU is not idle while the host downloads rows, builds candidates
+        and calls K6 (the timed loop does this for all steps but the last: the region still holds exactly `steps` of every
+        launch)"""
         torch = self.torch
-        self.ccs_plan.run(self.d_reads.data_ptr(), self.stream)                       # 1. K2 + K3
+        if not self.ccs_queued:
+            self.ccs_plan.run(self.d_reads.data_ptr(), self.stream)                   # 1. K2 + K3
+        self.ccs_queued = False
         with torch.cuda.stream(self.tstream):
             d_clips = self.d_ccs[self.d_idx]                                          # 2. clips out of this step's K3 output
         t0 = time.perf_counter()
@@ -273,7 +280,10 @@ class FullStep(object):
         keep = ncount < 0.3 * self.win_len
         t1 = time.perf_counter()
         self.ssw_plan.run(d_clips.data_ptr(), self.genome.codes_ptr, self.stream)     # 4. K1, windows read in place
-        rows, _ = self.ssw_plan.fetch()                                               # 5. rows to the host
+        if launch_next:
+            self.ccs_plan.run(self.d_reads.data_ptr(), self.stream)                   # (1. of the next step)
+            self.ccs_queued = True
+        rows, _ = self.ssw_plan.fetch()                                               # 5. rows to the host (waits for K1 only)
         t2 = time.perf_counter()
         start = self.win_off + rows['ref_begin1'].astype(np.int64)
         end = self.win_off + rows['ref_end1'].astype(np.int64) + 1
@@ -324,8 +334,8 @@ def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmu
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        fs.step()
+    for k in range(steps):
+        fs.step(launch_next=k + 1 < steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -148,6 +148,7 @@ struct clh_plan {
     unsigned long long pool_bytes = 0;
     void* d_strips = nullptr;
     hipStream_t last_stream = nullptr;
+    hipEvent_t done_ev = nullptr;           // recorded behind the run's last launch: fetch waits for the RUN, not for what the caller queued later
     bool ran = false;
     bool profiling = false;
     std::vector<hipEvent_t> ev;     // per segment: K1 start, K1 stop; then K1b small-window start/stop, large-window start/stop
@@ -163,6 +164,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
                     pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base};
     for (void* b : bufs) c->release(b);
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
+    if (pl->done_ev) (void)hipEventDestroy(pl->done_ev);
     delete pl;
 }
 
@@ -632,6 +634,8 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         HIPCHK(clh::launch_traceback_pool(rvmax, PG, 0, pl->n_all, pl->n_all, 0, pool, head, pl->pool_bytes, st));
         HIPCHK(hipEventRecord(pl->ev[eb + 3], st));
     }
+    if (!pl->done_ev) HIPCHK(hipEventCreateWithFlags(&pl->done_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(pl->done_ev, st));
     pl->last_stream = st;
     pl->ran = true;
     return 0;
@@ -707,7 +711,7 @@ extern "C" int clh_ssw_fetch(clh_plan* pl, clh_align_t* out, uint32_t* cigar_buf
     if (!pl || !out) return fail(CLH_E_ARG, "clh_ssw_fetch: null argument");
     if (!pl->ran) return fail(CLH_E_ARG, "clh_ssw_fetch before clh_ssw_run");
     HIPCHK(hipSetDevice(pl->ctx->device));
-    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    HIPCHK(pl->done_ev ? hipEventSynchronize(pl->done_ev) : hipStreamSynchronize(pl->last_stream));
     const int n = pl->n;
     std::vector<clh::SswResult> res((size_t)std::max(n, 1));
     std::vector<int32_t> clen((size_t)std::max(n, 1), 0);

@@ -96,7 +96,9 @@ int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts);
  * for the stream of the last run.  The same holds for every `stream` argument of this header. */
 int clh_ssw_run(clh_plan* plan, const void* d_reads, const void* d_refs, void* stream);
 
-/* Wait for the last run and copy results out.  cigar_buf may be NULL.  *cigar_used receives the u32 count. */
+/* Wait for the last run and copy results out.  cigar_buf may be NULL.  *cigar_used receives the u32 count (the CIGARs come back
+ * as one dense array).  It waits for the completion of the plan's last clh_ssw_run (an event recorded behind its last launch),
+ * not for work the caller queued on the stream afterwards. */
 int clh_ssw_fetch(clh_plan* plan, clh_align_t* out, uint32_t* cigar_buf, int64_t cigar_cap, int64_t* cigar_used);
 
 /* Device pointer of the raw result table of the last run (8 x int32 per alignment: score1 score2 ref_begin1 ref_end1

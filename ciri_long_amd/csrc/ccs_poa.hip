@@ -75,15 +75,19 @@ __device__ __forceinline__ void wave_prefix_max2(int& a, int& b) {
 // K2
 // ------------------------------------------------------------------------------------------------------------
 // LDS layout for a batch whose longest read has lcap bases (lcap a multiple of 64):
-//   head[K2_BUCKETS] int32 | cnt[lcap/2+2] int32 | sm[lcap/2+2] int32 | code[lcap] uint16 | next[lcap] int16
-static constexpr int K2_BUCKETS = 2048;
+//   head[k2_buckets(lcap)] int32 | cnt[lcap/2+2] int32 | sm[lcap/2+2] int32 | code[lcap] uint16 | next[lcap] int16
+static constexpr int K2_BUCKETS = 2048;         // most buckets (the HBM-workspace kernel for reads above K2_LDS_MAX)
+// buckets of a launch whose longest read has lcap bases: fewer for short reads -- the LDS block shrinks (more waves per CU hide
+// the LDS latency of the chain walks; measured on ~1 kb reads: 2048 -> 1.24 ms, 1024 -> 1.19, 512 -> 1.06, 256 -> 1.15, 128 -> 1.39)
+// at ~2 positions per bucket.  The counts do not depend on it: equal k-mers share a bucket whatever the number of buckets.
+__host__ __device__ inline int k2_buckets(int lcap) { return lcap <= 1536 ? 512 : (lcap <= 3072 ? 1024 : 2048); }
 static constexpr int K2_LDS_MAX = 16000;       // longest read scanned out of LDS (8 bytes per base + 8 KiB of 160 KiB)
-__host__ __device__ inline size_t k2_lds_bytes(int lcap) { return 4 * (size_t)K2_BUCKETS + 8 * ((size_t)lcap / 2 + 2) + 4 * (size_t)lcap; }
+__host__ __device__ inline size_t k2_lds_bytes(int lcap) { return 4 * (size_t)k2_buckets(lcap) + 8 * ((size_t)lcap / 2 + 2) + 4 * (size_t)lcap; }
 
 // The scan of one read.  NextT = int16_t with every array in LDS (reads up to K2_LDS_MAX bases), int32_t with cnt/sm/
 // code/next in an HBM workspace (longer reads: rare, so the slower memory does not matter; no length limit).
 template <typename NextT>
-__device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, int32_t* head, int32_t* cnt, int32_t* sm, uint16_t* code, NextT* next)
+__device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, int32_t* head, const int nbuckets, int32_t* cnt, int32_t* sm, uint16_t* code, NextT* next)
 {
     const int64_t off = p.read_off[rd];
     const int L = (int)(p.read_off[rd + 1] - off);
@@ -98,7 +102,7 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
     // PAIR of equal k-mers.  A read of L bases has O(L * copies) such pairs, not O(L^2/4): the positions are chained per
     // hash bucket and every pair is visited once, instead of comparing all (i, d).
     const int dmax = L / 2;
-    for (int i = lane; i < K2_BUCKETS; i += 64) head[i] = -1;
+    for (int i = lane; i < nbuckets; i += 64) head[i] = -1;
     for (int d = lane; d <= dmax + 1; d += 64) cnt[d] = 0;
     sync();
     for (int i = lane; i < L; i += 64) {
@@ -110,7 +114,7 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
                 c = (c << 2) | (b & 3);
             }
         code[i] = (uint16_t)c;
-        next[i] = ok ? (NextT)atomicExch(&head[(c ^ (c >> 5)) & (K2_BUCKETS - 1)], i) : (NextT)-2;
+        next[i] = ok ? (NextT)atomicExch(&head[(c ^ (c >> 5)) & (nbuckets - 1)], i) : (NextT)-2;
     }
     sync();
     for (int i = lane; i < L; i += 64) {
@@ -165,7 +169,7 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
         for (int i = b + lane; i < b + W && i < L; i += 64) {
             if (next[i] == -2) continue;
             const int ci = code[i];
-            int j = head[(ci ^ (ci >> 5)) & (K2_BUCKETS - 1)];
+            int j = head[(ci ^ (ci >> 5)) & (nbuckets - 1)];
             while (j >= 0) {
                 const int delta = j - i;
                 if (delta >= dlo && delta < dlo + nd && code[j] == ci) atomicAdd(&dh[delta - dlo], 1);
@@ -202,14 +206,15 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t k2_lds[];
     const int lane = threadIdx.x & 63;
-    const int rd = blockIdx.x;
+    const int rd = p.work_order[p.k2_begin + blockIdx.x];   // launch classes by read length: a short read gets a small LDS block
     if ((int)(p.read_off[rd + 1] - p.read_off[rd]) > p.k2_lds_max) return;        // ccs_scan_long_kernel takes it
     int32_t* head = k2_lds;                         // bucket -> last inserted position, -1 = empty
-    int32_t* cnt = head + K2_BUCKETS;               // matches per offset, [lcap/2 + 2]
+    const int nb = k2_buckets(p.lcap);
+    int32_t* cnt = head + nb;                       // matches per offset, [lcap/2 + 2]
     int32_t* sm = cnt + p.lcap / 2 + 2;             // smoothed counts; later the per-cut histogram of offsets
     uint16_t* code = (uint16_t*)(sm + p.lcap / 2 + 2);
     int16_t* next = (int16_t*)(code + p.lcap);      // chain of the positions of a bucket; -1 = end (invalid k-mers are in no chain)
-    ccs_scan_read<int16_t>(p, rd, lane, head, cnt, sm, code, next);
+    ccs_scan_read<int16_t>(p, rd, lane, head, nb, cnt, sm, code, next);
 }
 
 __global__ void __launch_bounds__(64) ccs_scan_long_kernel(const CcsParams p)
@@ -223,7 +228,7 @@ __global__ void __launch_bounds__(64) ccs_scan_long_kernel(const CcsParams p)
     int32_t* sm = cnt + half;
     int32_t* next = sm + half;
     uint16_t* code = (uint16_t*)(next + p.k2_lmax);
-    ccs_scan_read<int32_t>(p, rd, lane, head, cnt, sm, code, next);
+    ccs_scan_read<int32_t>(p, rd, lane, head, K2_BUCKETS, cnt, sm, code, next);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1373,7 +1378,9 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
     }
 }
 
-hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream)
+// one launch class of K2: `count` reads from p.work_order[p.k2_begin ...], none longer than p.lcap (reads above p.k2_lds_max
+// return at once); with_long: also the HBM-workspace kernel for those
+hipError_t launch_ccs_scan(const CcsParams& p, int count, bool with_long, hipStream_t stream)
 {
     const size_t lds = k2_lds_bytes(p.lcap);
     static bool attr = false;
@@ -1382,8 +1389,8 @@ hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(ccs_scan_kernel, dim3(p.n), dim3(64), lds, stream, p);
-    if (p.n_long > 0) hipLaunchKernelGGL(ccs_scan_long_kernel, dim3(p.n_long), dim3(64), 0, stream, p);
+    if (count > 0) hipLaunchKernelGGL(ccs_scan_kernel, dim3(count), dim3(64), lds, stream, p);
+    if (with_long && p.n_long > 0) hipLaunchKernelGGL(ccs_scan_long_kernel, dim3(p.n_long), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

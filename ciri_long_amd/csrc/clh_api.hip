@@ -1063,6 +1063,8 @@ struct clh_ccs_plan {
     clh_ctx* ctx = nullptr;
     int n = 0, lcap = 0, lmax = 0, n_long = 0, nslots = 0, nslots_big = 0;
     void *d_long = nullptr, *d_k2ws = nullptr, *d_busy = nullptr;
+    struct K2Class { int begin, count, lcap; };
+    std::vector<K2Class> k2_classes;
     int64_t total = 0;
     size_t slot_bytes = 0, slot_bytes_big = 0;      // second tier: a few slots sized for the worst case of the batch
     void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr, *d_ws_big = nullptr,
@@ -1104,6 +1106,17 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     }
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return read_off[x + 1] - read_off[x] > read_off[y + 1] - read_off[y]; });
     pl->lcap = (std::min(lmax, clh::kK2LdsMax) + 63) & ~63;
+    {   // K2 launch classes over the length-sorted order: the LDS block of a launch is sized for its longest read
+        static const int T[] = {1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384};
+        auto cls_of = [&](int64_t L) { for (int t : T) if (L <= t) return std::min(t, pl->lcap); return pl->lcap; };
+        for (int k = 0; k < n;) {
+            const int c = cls_of(std::min<int64_t>(read_off[order[k] + 1] - read_off[order[k]], clh::kK2LdsMax));
+            int e = k;
+            while (e < n && cls_of(std::min<int64_t>(read_off[order[e] + 1] - read_off[order[e]], clh::kK2LdsMax)) == c) ++e;
+            pl->k2_classes.push_back({k, e - k, c});
+            k = e;
+        }
+    }
     pl->lmax = lmax; pl->n_long = (int)long_idx.size();
     // Workspace.  The worst case of a read of L bases is a graph of L+8 nodes against copies of L/2 + L/16 bases (period
     // <= L/2, tolerance period/8; sequences above 2800 bases are refused by the kernel), every row kept and with several
@@ -1196,7 +1209,12 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     HIPCHK(hipMemsetAsync(pl->d_counter, 0, 8, st));
     const bool trace = getenv("CLH_TRACE") != nullptr;
     HIPCHK(hipEventRecord(pl->ev[0], st));
-    HIPCHK(clh::launch_ccs_scan(P, st));
+    P.work_order = (const int32_t*)pl->d_order;
+    for (size_t k = 0; k < pl->k2_classes.size(); ++k) {
+        P.k2_begin = pl->k2_classes[k].begin; P.lcap = pl->k2_classes[k].lcap;
+        HIPCHK(clh::launch_ccs_scan(P, pl->k2_classes[k].count, k == 0, st));
+    }
+    P.lcap = pl->lcap;
     if (trace) { fprintf(stderr, "[clh] K2 launched (n=%d lcap=%d)\n", pl->n, pl->lcap); HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[clh] K2 done\n"); }
     HIPCHK(hipEventRecord(pl->ev[1], st));
     if (int rc = launch_poa_tiers(pl, P, st)) return rc;

@@ -110,6 +110,7 @@ struct CcsParams {
     uint8_t* k2_ws;
     unsigned long long k2_slot;
     int32_t n_long, k2_lmax, k2_lds_max;
+    int32_t k2_begin;          // K2 launch class: workgroup b scans read work_order[k2_begin + b] with an LDS block for lcap bases
     uint8_t* big_ws;           // K3: large slots that first-tier waves may claim for a read that does not fit their own
     unsigned long long big_slot_bytes;
     int* big_busy;
@@ -125,7 +126,7 @@ struct CcsParams {
     int32_t* aln_score;        // optional, [n][CCS_SEG_CAP]: end-cell score of the alignment of each of the first 65 sequences (tests)
 };
 
-hipError_t launch_ccs_scan(const CcsParams& p, hipStream_t stream);
+hipError_t launch_ccs_scan(const CcsParams& p, int count, bool with_long, hipStream_t stream);
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream);
 size_t poa_slot_bytes_host(int ncap, int mcap);
 size_t poa_slot_min_bytes_host(int ncap, int mcap);

@@ -123,9 +123,9 @@ __device__ void tb_antidiagonal(const SswParams& p, const TbPool& pool, const in
     // the DP touches read[i] and ref[j] once per cell: both are staged in LDS.  A vector-memory LOAD inside the loop
     // would force s_waitcnt vmcnt(0), which also waits for the previous step's direction store (an HBM round trip per
     // anti-diagonal); with LDS-only reads the stores are fire-and-forget.
-    if (readLen + refLen > seq_cap) {   // does not fit this launch's LDS: retry in the large configuration, or give up
+    if (readLen + refLen > seq_cap) {   // does not fit this launch's LDS: retry in the large configuration, or report the capacity limit
         if (lane == 0) {
-            *cig_len = 0; p.results[task.out_index].status = res.status | (big == 1 ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG);
+            *cig_len = 0; p.results[task.out_index].status = res.status | (big == 1 ? CLH_STATUS_CIGAR_TRUNC : CLH_STATUS_NEED_BIG);
             if (big != 1) pool.list_big[atomicAdd(pool.n_big, 1)] = task_index;
         }
         return;
@@ -156,7 +156,7 @@ __device__ void tb_antidiagonal(const SswParams& p, const TbPool& pool, const in
             continue;
         }
         const bool ring = w + 3 <= wsp;   // the active rows of an anti-diagonal span <= w+1 rows
-        if (!ring && readLen + 1 > ws) { status = big == 1 ? CLH_STATUS_TRACE_ERR : CLH_STATUS_NEED_BIG; break; }
+        if (!ring && readLen + 1 > ws) { status = big == 1 ? CLH_STATUS_CIGAR_TRUNC : CLH_STATUS_NEED_BIG; break; }
         const int imask = ring ? wsp - 1 : -1;
         unsigned long long need = ((unsigned long long)nAD * (unsigned long long)stride_w + 63ull) & ~63ull;
         unsigned long long at = 0;

@@ -36,7 +36,9 @@ extern "C" {
 #define CLH_ST_NULL        2    /* the reference would have returned NULL (ssw.c:810-813: score_size 0 overflow) */
 #define CLH_ST_TRACE_ERR   4    /* the reference's "Trace back error" (ssw.c:674-682) */
 #define CLH_ST_NO_CIGAR    8    /* CIGAR not produced because of flag/filters (ssw.c:834,850) */
-#define CLH_ST_CIGAR_TRUNC 16   /* internal CIGAR/traceback workspace exhausted (retry with a smaller batch) */
+#define CLH_ST_CIGAR_TRUNC 16   /* no CIGAR for a capacity reason, scores and coordinates are valid: the traceback workspace ran out
+                                 * (retry with a smaller batch), or the band is wider than 2048 cells on an aligned reference of more than
+                                 * 2048 bases AND read + reference of the aligned part exceed 12 kB (or the read 4096 rows) */
 
 /* One result row: the fields of s_align (ssw.h:42-52) with the cigar pointer replaced by a slice of the
  * caller's cigar buffer. */

@@ -508,3 +508,35 @@ def test_short_read_spanning_thousands_of_reference_bases(ctx):
             w = c['want']
             assert _row_tuple(r) == (w['score'], w['score2'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end'], w['ref_end2'])
             assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == w['cigar'], int(r['status'])
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 3, 0), (2, 2, 0, 0), (1, 3, 255, 16), (4, 4, 9, 3)])
+def test_row_scan_and_row_traceback_unusual_gap_costs(ctx, scheme):
+    """free extensions, free gaps, the largest opening K1s accepts, and a 4 x 4 matrix (no N row) -- score kernel K1s, window
+    slices only with a positive extension, row traceback with its 16-bit frames"""
+    from ciri_long_amd import hip
+    m, x, o, e = scheme
+    rng = np.random.default_rng(77 + sum(scheme))
+    refs, qs = [], []
+    for R in [60, 300, 1100, 34000]:
+        for _ in range(5):
+            L = int(rng.integers(5, min(250, 250 // m)))
+            ref = _rnd(rng, R)
+            st = int(rng.integers(0, max(1, R - L)))
+            refs.append(ref); qs.append(_mut(ref[st:st + L], rng, float(rng.choice([0.0, 0.1, 0.3]))) or 'A')
+    for nmat in (5, 4):
+        mat = hip.score_matrix(m, x)
+        qq = qs
+        if nmat == 4:
+            mat = np.array([m if i == j else -x for i in range(4) for j in range(4)], dtype=np.int8)
+        rd, ro = hip.pack(qq); fd, fo = hip.pack(refs)
+        rows, cig = ctx.ssw_batch(rd, ro, fd, fo, mat, o, e, want_score2=True, want_cigar=True)
+        for k, (ref, q, r) in enumerate(zip(refs, qq, rows)):
+            want = oracle_align(ref, q, m, x, o, e, mat=mat)
+            assert _row_tuple(r) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
+                                     want['query_end'], want['ref_end2']), (nmat, k, len(q), len(ref))
+            span = (want['ref_end'] - want['ref_begin'] + 1) + (want['query_end'] - want['query_begin'] + 1)
+            if int(r['status']) & 16:        # the stated capacity limit of the CIGAR step (include/ciri_long_hip.h): only beyond 12 kB
+                assert span > 12000 and e == 0, (nmat, k, span)
+                continue
+            assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (nmat, k, int(r['status']))

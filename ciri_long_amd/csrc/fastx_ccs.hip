@@ -5,8 +5,9 @@
 // without its leading '>' / '@' characters, consensus of every read, and the two tmp files in the reference's format
 // (find_ccs.py:94-95):  tmp/{prefix}.ccs.fa  ">{header}\t{segments}\t{len(ccs)}\n{ccs}\n"   and
 //                       tmp/{prefix}.raw.fa  ">{header}\n{raw sequence}\n"   -- reads with a consensus only, input order.
-// The Python loop handles ~10^5 reads/s; K2+K3 handle ~7*10^6.  Here a reader thread parses and encodes the next batch
-// (zlib's gzread serves plain and gzip files alike) while the calling thread runs the previous one on the GPU and writes.
+// The Python loop handles ~10^5 reads/s; K2+K3 handle ~4*10^6.  Here three threads work on three rotating batches: a reader
+// parses and encodes (zlib's gzread serves plain and gzip files alike), the calling thread runs the batch on the GPU, a writer
+// formats and writes the two files.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -56,7 +56,7 @@ def iter_reads(in_file):
 def find_ccs_reads(in_file, out_dir, prefix, threads, debugging):
     """-> (total_reads, ro_reads, {header: [segments, ccs, raw]}); writes the two tmp FASTA files (find_ccs.py:21-103).
     Parsing, encoding, the kernels and the two output files are native code (`clh_ccs_file`: a reader thread keeps the
-    GPU fed); the returned dict is read back from the files the way the reference's own resume path does."""
+    GPU fed, a writer thread takes the results); the returned dict is read back from the files the way the reference's own resume path does."""
     from . import hip
     from .logger import ProgressBar
     prog = ProgressBar()

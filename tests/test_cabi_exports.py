@@ -94,3 +94,27 @@ def test_product_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 txt = open(os.path.join(dp, f)).read()
                 assert 'oracle_lib' not in txt and 'liboracle' not in txt and '_ref/libssw' not in txt, os.path.join(dp, f)
+
+
+def test_fastx_count_is_host_only_and_counts_like_the_reference_loop(tmp_path):
+    """clh_fastx_count needs no GPU: records of FASTA / FASTQ files as find_ccs.py:51-64 counts them (a trailing header
+    without its sequence line is a record), across refills of the 4 MiB read buffer, plain and gzipped"""
+    import gzip
+    from ciri_long_amd import hip
+    fa = tmp_path / 'a.fa'
+    fa.write_text(''.join('>r%d\r\n%s\r\n' % (k, 'ACGT' * (k % 7 + 1)) for k in range(1000)) + '>dangling')
+    assert hip.fastx_count(str(fa), 0) == 1001
+    fq = tmp_path / 'b.fq'
+    with open(fq, 'w') as f:
+        for k in range(9000):
+            s = 'ACGTTGCA' * 70
+            f.write('@q%d\n%s\n+\n%s\n' % (k, s, 'I' * len(s)))
+    assert fq.stat().st_size > 2 * (4 << 20) and hip.fastx_count(str(fq), 1) == 9000
+    gz = tmp_path / 'c.fastq.gz'
+    with gzip.open(gz, 'wt') as f:
+        for k in range(300):
+            f.write('@q%d\nACGT\n+\nIIII\n' % k)
+    assert hip.fastx_count(str(gz), 1) == 300
+    empty = tmp_path / 'e.fa'
+    empty.write_text('')
+    assert hip.fastx_count(str(empty), 0) == 0

@@ -287,3 +287,29 @@ def test_native_file_stage_equals_the_python_loop(tmp_path):
             assert (tmp_path / 'a' / 'tmp' / name).read_bytes() == (tmp_path / 'b' / 'tmp' / name).read_bytes(), (str(path), name)
         tot_d, ro_d, d_d = find_ccs.find_ccs_reads(str(path), str(tmp_path / 'a'), 'x', 1, False)
         assert (tot_d, ro_d) == (tot_p, ro_p) and d_d == d_p
+
+
+def test_native_file_stage_buffer_borders_and_a_trailing_header(tmp_path):
+    """a file larger than the reader's 4 MiB buffer (lines split across refills take the assembling path), a last header
+    without its sequence line, batches of 1000 rotating through the three threads: byte-identical to the Python loop"""
+    from ciri_long_amd import find_ccs, hip, synth
+    rng = np.random.Generator(np.random.PCG64(23))
+    recs = []
+    for k in range(6500):
+        tm = synth.template(rng)
+        r = synth.rolling_circle_read(rng, tm, int(rng.integers(500, 1100))) if k % 2 else synth.mutate(rng.integers(0, 4, 800, dtype=np.int8), rng)
+        recs.append(('q%05d' % k, oracle_lib.decode(r)))
+    for sub in ('a', 'b'):
+        (tmp_path / sub / 'tmp').mkdir(parents=True)
+    fq = tmp_path / 'in.fq'
+    with open(fq, 'w') as f:
+        for h, s in recs:
+            f.write('@%s\n%s\n+\n%s\n' % (h, s, '#' * len(s)))
+        f.write('@dangling')
+    assert fq.stat().st_size > 2 * (4 << 20)
+    tot_n, ro_n, long_n = hip.default_context().ccs_file(str(fq), 1, str(tmp_path / 'a' / 'tmp' / 'x.ccs.fa'), str(tmp_path / 'a' / 'tmp' / 'x.raw.fa'), 1000)
+    tot_p, ro_p, d_p = find_ccs.find_ccs_reads_py(str(fq), str(tmp_path / 'b'), 'x', 1, False)
+    assert (tot_n, ro_n, long_n) == (tot_p, ro_p, 0) and tot_n == 6501
+    for name in ('x.ccs.fa', 'x.raw.fa'):
+        assert (tmp_path / 'a' / 'tmp' / name).read_bytes() == (tmp_path / 'b' / 'tmp' / name).read_bytes(), name
+    assert hip.fastx_count(str(fq), 1) == 6501

@@ -672,14 +672,25 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                                               w1 = __builtin_amdgcn_perm(out[2], out[1], 0x0c0c0602u); }
                 else { w0 = __builtin_amdgcn_perm(out[1], out[0], 0x0c0c0400u) | __builtin_amdgcn_perm(out[3], out[2], 0x04000c0cu);
                        w1 = __builtin_amdgcn_perm(out[1], out[0], 0x0c0c0602u) | __builtin_amdgcn_perm(out[3], out[2], 0x06020c0cu); }
+#ifndef POA_EXPERIMENT_NO_DIR_STORE      // traffic experiment only (results are wrong without the codes): what K3 writes besides them
                 if constexpr (C == 8) *(uint2*)dd = make_uint2(w0, w1);
                 else if constexpr (C == 6) { __builtin_memcpy(dd, &w0, 4); const uint16_t x2 = (uint16_t)w1; __builtin_memcpy(dd + 4, &x2, 2); }
                 else if constexpr (C == 4) __builtin_memcpy(dd, &w0, 4);
                 else { const uint16_t x2 = (uint16_t)w0; __builtin_memcpy(dd, &x2, 2); }
-                if (np > 1) {
+#endif
+                if (np > 1) {   // second plane: bytes 1 and 3 of xb, packed like the first plane's (byte stores would touch every sector of the row C times)
                     uint8_t* db = w.dirB + (size_t)mi * gp + col0 + 8;
-#pragma unroll
-                    for (int t = 0; t < CP; ++t) { db[t] = (uint8_t)(xb[t] >> 8); db[CP + t] = (uint8_t)(xb[t] >> 24); }
+                    uint32_t s0 = 0, s1 = 0;
+                    if constexpr (CP == 1) s0 = __builtin_amdgcn_perm(0u, xb[0], 0x0c0c0301u);
+                    else if constexpr (CP == 2) s0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x07030501u);
+                    else if constexpr (CP == 3) { s0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x0c0c0501u) | __builtin_amdgcn_perm(xb[2], xb[0], 0x03050c0cu);
+                                                  s1 = __builtin_amdgcn_perm(xb[2], xb[1], 0x0c0c0703u); }
+                    else { s0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x0c0c0501u) | __builtin_amdgcn_perm(xb[3], xb[2], 0x05010c0cu);
+                           s1 = __builtin_amdgcn_perm(xb[1], xb[0], 0x0c0c0703u) | __builtin_amdgcn_perm(xb[3], xb[2], 0x07030c0cu); }
+                    if constexpr (C == 8) *(uint2*)db = make_uint2(s0, s1);
+                    else if constexpr (C == 6) { __builtin_memcpy(db, &s0, 4); const uint16_t y2 = (uint16_t)s1; __builtin_memcpy(db + 4, &y2, 2); }
+                    else if constexpr (C == 4) __builtin_memcpy(db, &s0, 4);
+                    else { const uint16_t y2 = (uint16_t)s0; __builtin_memcpy(db, &y2, 2); }
                 }
                 if (tolds | keep) {
                     uint32_t dv[CP];

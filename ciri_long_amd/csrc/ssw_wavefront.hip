@@ -440,6 +440,9 @@ __global__ void __launch_bounds__(64, waves_per_simd(RV)) ssw_align_kernel(const
     PassOut fw;
     bool byte_overflowed = false;
     int job_word = (p.score_size == 1 || (p.score_size == 2 && p.max_match * L + bias >= 255)) ? 1 : 0;
+    // a window-slice task (clh_api.hip) mostly sees background: in the reference's own order -- 8-bit pass first, 16-bit on overflow
+    // (ssw.c:804-809) -- it needs one pass instead of two; a slice that does overflow ends in the 16-bit regime either way
+    if (task.out_index >= p.n_real && p.score_size == 2) job_word = 0;
     PassIn in;
     const int rdir = task.ref_rc ? -1 : 1;       // physical direction of the reference in memory
     in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = task.ref_rc; in.ncols = refLen; in.terminate = 1 << 30;

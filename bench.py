@@ -325,23 +325,23 @@ class FullStep(object):
         return out, valu
 
 
-def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmup, expect):
+def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmup, expect, use_dist=False):
     fs = FullStep(torch, hip, synth, ctx, wl, nreads, rank, expect)
     for _ in range(warmup):
         fs.step()
     fs.t_k5 = fs.t_k6 = fs.t_fetch = 0.0
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
         fs.step(launch_next=k + 1 < steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     el = time.perf_counter() - t0
     counters = fs.counters()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -360,7 +360,7 @@ def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmu
     return res
 
 
-def run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, steps, warmup, expect):
+def run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, steps, warmup, expect, use_dist=False):
     reads, wins = make_batch(synth, 'c2', nreads, rank)
     rd, ro = hip.pack(reads)
     fd, fo = hip.pack(wins)
@@ -387,17 +387,17 @@ def run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, steps, warmup, exp
 
     for _ in range(warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -512,6 +512,32 @@ def extra_stage1(hip, synth, ctx, n=100000):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """`bench.py --gpus N` started without a launcher: run the N ranks as children of this process, one per GPU, through
+    torch.distributed.run on 127.0.0.1.  This process has not touched the GPU (no HIP call, no torch.cuda call) and does
+    not exec; rank 0's JSON line is passed through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                     # a free port for the rendezvous
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line)
+    return rc if rc != 0 or line is not None else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -527,9 +553,18 @@ def main():
     full = wl != 'c2'            # c3 / c4: the whole device part of `call`; c2: Smith-Waterman only
     nreads = args.reads or {'c3': 100000, 'c2': 10000, 'c4': 125000}[wl]
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts the N ranks as CHILD
+        # processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) before anything here has touched the GPU,
+        # never execs, relays rank 0's JSON line and exits with the children's code.
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    # under a launcher the process group exists even for one rank, so the RCCL exchange of `call` runs wherever a launcher does
+    use_dist = 'WORLD_SIZE' in os.environ
     # The CPU leg spawns one process per host core.  It runs BEFORE this process touches the GPU (a child of a process
     # that has initialised the GPU must not exec), and not at all under rocprofv3, whose preloaded library initialises
     # the GPU before Python starts (and again in every child).
@@ -543,18 +578,21 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')   # RCCL
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
 
     from ciri_long_amd import hip, synth
     expect = cpu.pop('_expect') if cpu else None     # None: no CPU leg in this run (multi-GPU, --no-cpu, profiler): no spot check
     ctx = hip.Context(local_rank)
     if full:
-        res = run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, args.steps, args.warmup, expect)
+        res = run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, args.steps, args.warmup, expect, use_dist)
     else:
-        res = run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, args.steps, args.warmup, expect)
+        res = run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, args.steps, args.warmup, expect, use_dist)
 
     step_text = ('through the device part of the call path, start to finish in every timed step: cyclic consensus (K2+K3) of every '
                  'read; the clipped part of each consensus gathered on the device from that step\'s K3 output; N count of the candidate '
@@ -597,7 +635,7 @@ def main():
         out['extra'] = extra
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -31,7 +31,7 @@ static constexpr int CCS_SMOOTH = 3;
 static constexpr int CCS_MAX_CUTS = 64;
 static constexpr int CCS_MIN_TAIL = 20;
 static constexpr int POA_MAXP = 12;                  // in-edges a node can hold (implementation limit)
-static constexpr int POA_MAXA = 4;                   // other members of an aligned set (5 letter codes)
+static constexpr int POA_MAXA = 7;                   // other members of an aligned set: 8 different letters in one column (implementation limit)
 static constexpr int POA_MAX_COPY = 2800;            // longest sequence: cells are int16 (match score <= 11)
 
 // Phase boundary inside one wave that exchanges data between lanes through HBM: complete the stores, then drop the
@@ -248,8 +248,9 @@ static constexpr int POA_NEG = -30000;               // "minus infinity" of a st
 static constexpr int POA_MAX_ROWS = 65000;           // ranks travel in 16 bits
 
 struct PoaWs {            // views into one wave's workspace slot
-    int8_t* base; int8_t* np; int32_t* pred; int32_t* pw; int32_t* aligned; int32_t* cov; int32_t* nout; int32_t* order; int32_t* rank;
-    int32_t* pn; int32_t* pj; long long* key; int32_t* bnd;                  // per base of the sequence being added
+    int8_t* base; int8_t* np; int8_t* na; int32_t* pred; int32_t* pw; int32_t* aligned; int32_t* cov; int32_t* nout; int32_t* order; int32_t* rank;
+    int32_t* root; uint32_t* rsz; int32_t* ntr; uint8_t* st;                 // the topological sort (poa_sort)
+    int32_t* pn; int32_t* pj;                                                // per base of the sequence being added
     uint2* ri; uint32_t* rx; uint32_t* tab; int32_t* score; int32_t* bp; short* col0;     // rank space
     short* carry; int cpitch;
     uint8_t* dp; size_t dp_bytes;                                            // the rest of the slot: DP planes of the current sequence
@@ -268,13 +269,13 @@ __host__ __device__ inline size_t poa_fixed_bytes(int ncap, int mcap, int* cpitc
     add(sizeof(int32_t) * (size_t)ncap * POA_MAXA);                                                        // aligned
     add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap);   // cov nout order rank
     add(sizeof(int32_t) * (size_t)(ncap + mcap + 2)); add(sizeof(int32_t) * (size_t)(ncap + mcap + 2));    // pn pj (pn doubles as the consensus path)
-    add(sizeof(long long) * (size_t)(mcap + 2)); add(sizeof(int32_t) * (size_t)(mcap + 2));                // key bnd
+    add(sizeof(int32_t) * ncap); add(sizeof(uint32_t) * ncap); add(sizeof(int32_t) * ncap); add(ncap);    // root rsz ntr st
     add(sizeof(uint2) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));   // ri rx tab
     add(sizeof(int32_t) * (size_t)(ncap + 2)); add(sizeof(int32_t) * (size_t)(ncap + 2)); add(sizeof(short) * (size_t)(ncap + 2));        // score bp col0
     const int cp = (ncap + 2 + 7) & ~7;
     if (cpitch_out) *cpitch_out = cp;
     add(sizeof(short) * 6 * (size_t)cp);                                                                    // carries: 2 x (H, E, Q)
-    add(ncap); add(ncap);                                                                                  // base np
+    add(ncap); add(ncap); add(ncap);                                                                       // base np na
     return o;
 }
 // DP planes of one sequence against N rows: byte plane, slot plane (one byte) of nm rows, kept rows (H int16 + vertical states int8)
@@ -302,8 +303,10 @@ __device__ PoaWs carve(uint8_t* slot, size_t slot_bytes, int ncap, int mcap)
     w.rank = (int32_t*)take(sizeof(int32_t) * ncap);
     w.pn = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
     w.pj = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + mcap + 2));
-    w.key = (long long*)take(sizeof(long long) * (size_t)(mcap + 2));
-    w.bnd = (int32_t*)take(sizeof(int32_t) * (size_t)(mcap + 2));
+    w.root = (int32_t*)take(sizeof(int32_t) * ncap);
+    w.rsz = (uint32_t*)take(sizeof(uint32_t) * ncap);
+    w.ntr = (int32_t*)take(sizeof(int32_t) * ncap);
+    w.st = (uint8_t*)take(ncap);
     w.ri = (uint2*)take(sizeof(uint2) * (size_t)(ncap + 2));
     w.rx = (uint32_t*)take(sizeof(uint32_t) * (size_t)(ncap + 2));
     w.tab = (uint32_t*)take(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));
@@ -314,6 +317,7 @@ __device__ PoaWs carve(uint8_t* slot, size_t slot_bytes, int ncap, int mcap)
     w.carry = (short*)take(sizeof(short) * 6 * (size_t)w.cpitch);
     w.base = (int8_t*)take(ncap);
     w.np = (int8_t*)take(ncap);
+    w.na = (int8_t*)take(ncap);
     w.dp = slot + o;
     w.dp_bytes = slot_bytes > o ? slot_bytes - o : 0;
     w.dirA = nullptr; w.dirB = nullptr; w.keepH = nullptr; w.keepD = nullptr;
@@ -459,11 +463,11 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
     const int lm = mc / C, tm = (mc % C) % CP, hm = (mc % C) / CP;
     uint32_t sbP[CP], jeP[CP], jcP[CP];
 #pragma unroll
-    // a column beyond the sequence has base code 100 (bit 6): pk_sra15(sbP << 9) is 0xFFFF in those halves -- recomputed
-    // where needed, a register per pair held across the row loop costs more (measured)
+    // letters are bytes; a column beyond the sequence holds 0x100 (bit 8): pk_sra15(sbP << 7) is 0xFFFF in those halves --
+    // recomputed where needed, a register per pair held across the row loop costs more (measured)
     for (int t = 0; t < CP; ++t) {
         const int jlo = col0 + t + 1, jhi = jlo + CP;
-        sbP[t] = pack16(jlo <= m ? (int)seq[jlo - 1] : 100, jhi <= m ? (int)seq[jhi - 1] : 100);
+        sbP[t] = pack16(jlo <= m ? (int)(uint8_t)seq[jlo - 1] : 0x100, jhi <= m ? (int)(uint8_t)seq[jhi - 1] : 0x100);
         jeP[t] = pack16((lc0 + t + 1) * e, (lc0 + CP + t + 1) * e);
         jcP[t] = pack16((lc0 + t + 1) * c, (lc0 + CP + t + 1) * c);
     }
@@ -718,15 +722,15 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
             SEC(12);
             if (!sw) {
 #pragma unroll
-                for (int t = 0; t < CP; ++t) lowP = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, lowP), __builtin_bit_cast(s16x2, bfi(pk_sra15(sbP[t] << 9), 0x7fff7fffu, Hf[t]))));
+                for (int t = 0; t < CP; ++t) lowP = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, lowP), __builtin_bit_cast(s16x2, bfi(pk_sra15(sbP[t] << 7), 0x7fff7fffu, Hf[t]))));
             }
             // ---- end cell: first strict maximum in (rank, column) order --------------------------------------------
             if (sw | (!nw & sink)) {
-                // columns beyond the sequence (base code 100: bit 6) do not count.  (Leaving the mask off where no such cell can win
+                // columns beyond the sequence (letter 0x100: bit 8) do not count.  (Leaving the mask off where no such cell can win
                 // -- local mode, negative mismatch, lanes entirely beyond the sequence switched off -- measured 0.5 ms SLOWER.)
                 uint32_t hv2[CP];
 #pragma unroll
-                for (int t = 0; t < CP; ++t) hv2[t] = bfi(pk_sra15(sbP[t] << 9), 0x80008000u, Hf[t]);
+                for (int t = 0; t < CP; ++t) hv2[t] = bfi(pk_sra15(sbP[t] << 7), 0x80008000u, Hf[t]);
                 uint32_t rm = hv2[0];
 #pragma unroll
                 for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
@@ -806,37 +810,109 @@ __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const i
     bs_out = bs; br_out = br; bc_out = bc;
 }
 
-// merge the nodes created by the last sequence ([n_old, n_new), keys ascending in creation order) into the rank order.
-// key of a new node = ((s * 4 + class) << 24) + position, s = the old rank it goes in front of; an old node of rank r
-// compares as (r * 4 + 2) << 24.  returns 0, or -1 if the order would violate an edge (cannot happen: aligned sets stay
-// contiguous; checked because everything downstream relies on it)
-__device__ int poa_rerank(const PoaWs& w, int n_old, int n_new, int lane)
+// Graph::TopologicalSort -- the order spoa's sequential depth-first search produces (oracle/poa_oracle.c: topo_sort), from
+// independent pieces (tools/poa_model.py: topo_sort states and tests the derivation on the CPU):
+//  1. root[x] = the smallest node id among everything that depends on x (descendants over the edges, the members of their
+//     aligned sets, and so on).  spoa's outer loop takes the ids in ascending order and a visit emits exactly the unfinished
+//     ancestors of that id, so x is emitted during the visit of id root[x].  The values of the graph before this sequence
+//     are kept; the new path lowers them by a suffix minimum along the path, the rest is relaxation to the fixed point.
+//  2. every id r with root[r] == r starts one search over the nodes with root == r, independent of all others (a dependency
+//     with a smaller root is finished by then, one with a larger root cannot occur); its nodes go behind the nodes of all
+//     smaller roots.  One search per LANE; frames (node | cursor << 16) grow down from the end of the root's own stretch of
+//     `order`, emitted nodes up from its start (an unfinished node is in neither, so they never meet).
+// st[v]: bit 0 finished, bit 1 "ignored" (pushed as a member of an aligned set: emitted with the member the search met first).
+__device__ void poa_dfs_root(const PoaWs& w, const int r, const int lo, const int size)
 {
-    const int added = n_new - n_old;
-    long long* lkeys = (long long*)poa_lds;
-    const bool in_lds = added <= POA_RERANK_LDS_KEYS;
-    if (in_lds) {
-        for (int i = lane; i < added; i += 64) lkeys[i] = w.key[i];
-        __syncthreads();
+    const int hi = lo + size;
+    int sp = hi, k = lo;
+    w.order[--sp] = r;
+    while (sp < hi) {
+        const uint32_t fr = (uint32_t)w.order[sp];
+        const int v = (int)(fr & 0xffffu);
+        int cur = (int)(fr >> 16);
+        const int npv = w.np[v], nav = w.na[v];
+        const bool ign = (w.st[v] & 2) != 0;
+        if (cur == 0 && !ign) for (int t = 0; t < nav; ++t) w.st[w.aligned[v * POA_MAXA + t]] |= 2;
+        // the order spoa's stack hands the dependencies out: aligned members last to first, then in-edge tails last to first
+        const int na2 = ign ? 0 : nav, nd = na2 + npv;
+        int nxt = -1;
+        while (cur < nd) {
+            const int d = cur < na2 ? w.aligned[v * POA_MAXA + na2 - 1 - cur] : w.pred[v * POA_MAXP + npv - 1 - (cur - na2)];
+            ++cur;
+            if (w.root[d] == r && !(w.st[d] & 1)) { nxt = d; break; }
+        }
+        if (nxt >= 0) { w.order[sp] = (int)((uint32_t)v | ((uint32_t)cur << 16)); w.order[--sp] = nxt; continue; }
+        w.st[v] |= 1;
+        ++sp;
+        if (!ign) {
+            w.order[k++] = v;
+            for (int t = 0; t < nav; ++t) w.order[k++] = w.aligned[v * POA_MAXA + t];
+        }
     }
-    for (int r = 1 + lane; r <= n_old; r += 64) {
-        const int v = w.order[r - 1];
-        const long long k = ((long long)r * 4 + 2) << 24;
-        int lo = 0, hi = added;                      // lower_bound over new keys
-        if (in_lds) while (lo < hi) { const int mid = (lo + hi) >> 1; if (lkeys[mid] < k) lo = mid + 1; else hi = mid; }
-        else while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.key[mid] < k) lo = mid + 1; else hi = mid; }
-        w.rank[v] = r + lo;
+}
+
+// sort the graph after a sequence of m bases (nodes w.pj[0..m)) has been fused; nodes [n_old, n) are new.  returns 0, or -1 if
+// the order violates an edge (cannot happen; checked because everything downstream relies on it)
+__device__ int poa_sort(const PoaWs& w, const int n_old, const int n, const int m, const int lane)
+{
+    for (int v = n_old + lane; v < n; v += 64) w.root[v] = v;
+    for (int v = lane; v < n; v += 64) { w.rsz[v] = 0; w.st[v] = 0; }
+    phase_sync();
+    {   // everything behind a base of the new path depends on it: suffix minimum of root along the path
+        int smin = 0x7fffffff;
+        for (int i0 = ((m - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
+            const int i = i0 + lane;
+            const int x = i < m ? w.pj[i] : -1;
+            int val = x >= 0 ? w.root[x] : 0x7fffffff;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_down(val, d); if (lane + d < 64) val = o < val ? o : val; }
+            val = val < smin ? val : smin;
+            if (x >= 0) atomicMin(&w.root[x], val);
+            smin = __builtin_amdgcn_readlane(val, 0);
+        }
     }
-    for (int i = lane; i < added; i += 64) w.rank[n_old + i] = i + (int)(w.key[i] >> 26);      // i new nodes + (s - 1) old nodes in front, 1-based
+    phase_sync();
+    for (int sweep = 0; sweep <= n; ++sweep) {            // relaxation; a sweep that changes nothing ends it
+        int changed = 0;
+        for (int v = lane; v < n; v += 64) {
+            const int r0 = w.root[v];
+            int rv = r0;
+            const int nav = w.na[v], npv = w.np[v];
+            for (int t = 0; t < nav; ++t) { const int ra = w.root[w.aligned[v * POA_MAXA + t]]; rv = ra < rv ? ra : rv; }
+            if (rv < r0) { atomicMin(&w.root[v], rv); changed = 1; }
+            for (int t = 0; t < npv; ++t) { const int u = w.pred[v * POA_MAXP + t]; if (rv < w.root[u]) { atomicMin(&w.root[u], rv); changed = 1; } }
+        }
+        phase_sync();
+        if (!__builtin_amdgcn_ballot_w64(changed != 0)) break;
+    }
+    for (int v = lane; v < n; v += 64) atomicAdd(&w.rsz[w.root[v]], 1u);
+    phase_sync();
+    int acc = 0, nnt = 0;                                  // positions before the current block of ids; searches collected so far
+    for (int r0 = 0; r0 < n; r0 += 64) {
+        const int r = r0 + lane;
+        const int sz = r < n ? (int)w.rsz[r] : 0;
+        int inc = sz;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        const int base = acc + inc - sz;
+        if (sz == 1) w.order[base] = r;
+        const bool nt = sz > 1;
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(nt);
+        if (nt) { w.rsz[r] = (uint32_t)base; w.ntr[nnt + __builtin_popcountll(bm & (((unsigned long long)1 << lane) - 1))] = r | (sz << 16); }
+        nnt += __builtin_popcountll(bm);
+        acc += __builtin_amdgcn_readlane(inc, 63);
+    }
+    phase_sync();
+    for (int t = lane; t < nnt; t += 64) { const int e = w.ntr[t]; const int r = e & 0xffff; poa_dfs_root(w, r, (int)w.rsz[r], (int)((uint32_t)e >> 16)); }
+    phase_sync();
+    for (int i = lane; i < n; i += 64) w.rank[w.order[i]] = i + 1;
     phase_sync();
     int bad = 0;
-    for (int v = lane; v < n_new; v += 64) {
+    for (int v = lane; v < n; v += 64) {
         const int r = w.rank[v];
-        w.order[r - 1] = v;
         const int np = w.np[v];
         for (int s2 = 0; s2 < np; ++s2) bad |= (w.rank[w.pred[v * POA_MAXP + s2]] >= r);
     }
-    phase_sync();
     return __builtin_amdgcn_ballot_w64(bad != 0) ? -1 : 0;
 }
 
@@ -844,10 +920,9 @@ __device__ int poa_rerank(const PoaWs& w, int n_old, int n_new, int lane)
 __device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& hi)
 {
     lo = hi = w.rank[v];
-    for (int t = 0; t < POA_MAXA; ++t) {
-        const int x = w.aligned[v * POA_MAXA + t];
-        if (x < 0) break;
-        const int rr = w.rank[x];
+    const int nav = w.na[v];
+    for (int t = 0; t < nav; ++t) {
+        const int rr = w.rank[w.aligned[v * POA_MAXA + t]];
         lo = rr < lo ? rr : lo; hi = rr > hi ? rr : hi;
     }
 }
@@ -952,8 +1027,11 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
     // The lanes hold a 32x32 patch of the byte plane (ranks r0..r0-31, columns j0..j0-31; 16 bytes per lane), of the slot
     // plane for the rows that have one, and the graph rows of those ranks, so the chain runs on v_readlane until it leaves
     // the patch.  pn[j] = rank aligned to base j (0: none), staged in one register per lane, stored 64 bases at a time.
+    bool moved = false;                                    // the alignment holds at least one step
+    int jb = 0, je = -1;                                   // ... and the bases [jb, je]
     {
         int r = __builtin_amdgcn_readfirstlane(br), j = br > 0 ? __builtin_amdgcn_readfirstlane(bc) : 0;
+        je = j - 1;
         for (int t = j + lane; t < m; t += 64) w.pn[t] = 0;                     // bases behind the end cell
         const int gp = poa_pitch(m);
         int r0 = -64, j0 = -64;
@@ -1020,6 +1098,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
             }
             const int code = d & 63;
             if (code == CODE_ZERO) break;                        // local mode only: nothing else carries this code
+            moved = true;
             if (code > CODE_VERT) {                              // diagonal through in-edge CODE_DIAG - code
                 --j;
                 buf = lane == (j & 63) ? r : buf;
@@ -1037,6 +1116,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
                 mode = code != CODE_HORZ - 1 ? 2 : 0;
             }
         }
+        jb = S.algorithm == 1 ? 0 : j;                           // global mode: spoa walks on along the border to (0, 0)
         int fill_to = j;
         if (j & 63) { fill_to = j & ~63; const int q = fill_to + lane; if (q < m && q >= 0) w.pn[q] = q < j ? 0 : buf; }
         for (int q = lane; q < fill_to; q += 64) w.pn[q] = 0;
@@ -1045,71 +1125,57 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
     TSTAMP(1);
     // ---- fuse the path into the graph (Graph::AddAlignment), data-parallel over the bases -------------------------------
     // Base i touches only its own aligned node's set and the in-edge list of the node it ends on, and the nodes of one
-    // path are distinct, so the sequential rule is evaluated per lane; ids of new nodes are a prefix count in base order.
+    // path are distinct, so the sequential rule is evaluated per lane.  Node ids as AddAlignment gives them: the bases in
+    // front of the alignment [0, jb), the bases behind it (je, m), then the new nodes among the bases [jb, je] it holds.
     int n = N, fail = 0;
     {
-        // old rank in front of which a run of unaligned bases goes: first rank of the aligned set of the next aligned base
-        int nextb = N + 1;
-        for (int i0 = ((m - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
-            const int i = i0 + lane;
-            const int rk = i < m ? w.pn[i] : 0;
-            int lo = 0, hi = 0;
-            if (rk > 0) group_span(w, w.order[rk - 1], lo, hi);
-            const unsigned long long mb = __builtin_amdgcn_ballot_w64(rk > 0);
-            const unsigned long long at_or_above = ~(((unsigned long long)1 << lane) - 1);
-            const unsigned long long up = mb & at_or_above;
-            const int src = up ? __builtin_ctzll(up) : 0;
-            const int lo_src = __shfl(lo, src);
-            if (i < m) w.bnd[i] = up ? lo_src : nextb;
-            if (mb) nextb = __shfl(lo, __builtin_ctzll(mb));
-        }
+        if (!moved) { jb = m; je = m - 1; }                // empty alignment: the whole sequence is a chain of new nodes
+        else if (jb > je) return -5;                       // steps but no base (overlap mode, vertical steps only): spoa throws
+        const int nlead = jb, ntrail = m - 1 - je;
+        n = N + nlead + ntrail;
         for (int i0 = 0; i0 < m; i0 += 64) {
             const int i = i0 + lane;
-            const bool act = i < m;
-            const int rk = act ? w.pn[i] : 0;
+            const bool act = i < m, mid = act && i >= jb && i <= je;
+            const int rk = mid ? w.pn[i] : 0;
             const int v = rk > 0 ? w.order[rk - 1] : -1;
             const int b = act ? (int)seq[i] : 0;
             int use = -1;
             if (v >= 0) {
                 if (w.base[v] == b) use = v;
-                else for (int t = 0; t < POA_MAXA; ++t) { const int x = w.aligned[v * POA_MAXA + t]; if (x < 0) break; if (w.base[x] == b) { use = x; break; } }
+                else { const int nav = w.na[v]; for (int t = 0; t < nav; ++t) { const int x = w.aligned[v * POA_MAXA + t]; if (w.base[x] == b) { use = x; break; } } }
             }
-            const bool isnew = act && use < 0;
-            const unsigned long long nb = __builtin_amdgcn_ballot_w64(isnew);
+            const bool newmid = mid && use < 0;
+            const unsigned long long nb = __builtin_amdgcn_ballot_w64(newmid);
             const unsigned long long below = ((unsigned long long)1 << lane) - 1;
-            if (isnew) use = n + __builtin_popcountll(nb & below);
+            if (newmid) use = n + __builtin_popcountll(nb & below);
+            else if (act && !mid) use = i < jb ? N + i : N + nlead + (i - je - 1);
             n += __builtin_popcountll(nb);
-            if (isnew && use < ncap) {
-                long long key;
-                int al[POA_MAXA];
-#pragma unroll
-                for (int t = 0; t < POA_MAXA; ++t) al[t] = -1;
-                if (v >= 0) {                                  // a new member of the aligned set of v: directly behind the set
-                    int lo, hi;
-                    group_span(w, v, lo, hi);
-                    key = ((long long)(hi + 1) * 4 + 0) << 24;
-                    int nm2 = 0;
-                    for (int t = 0; t < POA_MAXA; ++t) {
-                        const int x = w.aligned[v * POA_MAXA + t];
-                        if (x < 0) break;
-                        al[nm2++] = x;
-                        int u = 0;
-                        while (u < POA_MAXA && w.aligned[x * POA_MAXA + u] >= 0) ++u;
-                        if (u < POA_MAXA) w.aligned[x * POA_MAXA + u] = use; else fail = 1;
+            if (act && use >= N && use < ncap) {           // a new node
+                int nal = 0;
+                if (v >= 0) {                              // a new member of the aligned set of v: every member's list gains it; its own
+                    const int nav = w.na[v];               // list is v's list followed by v
+                    if (nav >= POA_MAXA) fail = 1;
+                    else {
+                        for (int t = 0; t < nav; ++t) {
+                            const int x = w.aligned[v * POA_MAXA + t];
+                            w.aligned[use * POA_MAXA + t] = x;
+                            const int u = w.na[x];
+                            w.aligned[x * POA_MAXA + u] = use; w.na[x] = (int8_t)(u + 1);       // u == nav < POA_MAXA: the lists of a set are equally long
+                        }
+                        w.aligned[use * POA_MAXA + nav] = v;
+                        w.aligned[v * POA_MAXA + nav] = use; w.na[v] = (int8_t)(nav + 1);
+                        nal = nav + 1;
                     }
-                    if (nm2 < POA_MAXA) { al[nm2] = v; w.aligned[v * POA_MAXA + nm2] = use; } else fail = 1;
-                } else key = (((long long)w.bnd[i] * 4 + 1) << 24) + i;
-                w.base[use] = (int8_t)b; w.np[use] = 0; w.cov[use] = 0; w.nout[use] = 0; w.key[use - N] = key;
-#pragma unroll
-                for (int t = 0; t < POA_MAXA; ++t) w.aligned[use * POA_MAXA + t] = al[t];
+                }
+                w.base[use] = (int8_t)b; w.np[use] = 0; w.na[use] = (int8_t)nal; w.cov[use] = 0; w.nout[use] = 0;
             }
             if (act) { w.pj[i] = use; if (path_out) path_out[i] = use; }
         }
-        if (n > ncap) return -1;
+        if (n > ncap || n > POA_MAX_ROWS) return -1;
         phase_sync();
         for (int i = lane; i < m; i += 64) {
             const int x = w.pj[i];
-            w.cov[x] += 1;
+            if (m >= 2) w.cov[x] += 1;                     // Node::Coverage counts the sequences with an edge at the node
             if (i == 0) continue;
             const int u = w.pj[i - 1];
             const int cnt = w.np[x];
@@ -1123,10 +1189,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
     }
     phase_sync();
     TSTAMP(2);
-    if (N == 0) {
-        for (int v = lane; v < n; v += 64) { w.order[v] = v; w.rank[v] = v + 1; }
-        phase_sync();
-    } else if (poa_rerank(w, N, n, lane) != 0) return -1;
+    if (poa_sort(w, N, n, m, lane) != 0) return -1;
     TSTAMP(3);
     return n;
 }
@@ -1377,6 +1440,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
         if (N == -2) res.status = 1;
         else if (N == -3) res.status = 5;
         else if (N == -4) res.status = 6;
+        else if (N == -5) res.status = 7;
         else if (N < 0) res.status = 2;
         else if (len < 0) res.status = 3;
         else { res.nseg = nseg; res.ccs_len = len; }

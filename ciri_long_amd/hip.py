@@ -145,6 +145,17 @@ def encode(seq):
     return _LUT[np.frombuffer(seq, dtype=np.uint8)]
 
 
+def pack_raw(seqs):
+    """list of str / bytes -> (the letters as they are, one byte each, int64 offsets[n+1]): the partial-order aligner compares
+    letters for equality only (spoa's alphabet is the set of raw characters)"""
+    arrs = [np.frombuffer(s.encode('latin-1') if isinstance(s, str) else bytes(s), dtype=np.int8) for s in seqs]
+    off = np.zeros(len(arrs) + 1, dtype=np.int64)
+    if arrs:
+        np.cumsum([len(a) for a in arrs], out=off[1:])
+    data = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.int8)
+    return np.ascontiguousarray(data, dtype=np.int8), off
+
+
 def score_matrix(match, mismatch):
     """ssw_wrap.py:146-159: match on the diagonal, -mismatch elsewhere, 0 for N."""
     m = np.full((5, 5), -int(mismatch), dtype=np.int8)
@@ -242,10 +253,12 @@ class Context(object):
         return out, segs, ccs
 
     def poa_batch(self, seqs, seq_off, group_off, algorithm=0, scores=(10, -4, -8, -2, -24, -1), min_coverage=0, genmsa=False,
-                  with_scores=False):
+                  with_scores=False, raw=False):
         """spoa.poa per group of sequences: -> list of consensus str, or list of (consensus, msa rows[, end-cell scores of
-        the first 65 sequences]) with genmsa / with_scores.  Raises ClhError when a group has no consensus (a sequence above
-        2800 bases, a node with more than 12 in-edges) or the scores are outside what the kernel honours."""
+        the first 65 sequences]) with genmsa / with_scores.  The letters of `seqs` are bytes compared for equality only;
+        raw=False reads them as the codes 0..4 of `encode` and writes ACGTN, raw=True hands them through as characters
+        (`pack_raw`).  Raises ClhError when a group has no consensus (a sequence above 2800 bases, a node with more than 12
+        in-edges, more than 8 different letters in a column) or the scores are outside what the kernel honours."""
         seqs = np.ascontiguousarray(seqs, dtype=np.int8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
         group_off = np.ascontiguousarray(group_off, dtype=np.int64)
@@ -265,10 +278,12 @@ class Context(object):
         res = []
         for k in range(ng):
             if lens[k] < 0:
-                raise ClhError('poa: no consensus for group %d (status %d: 1 workspace, 2 graph limits -- more than 12 in-edges or '
-                               '65000 nodes, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 a cell left the 16-bit score range)' % (k, -1 - int(lens[k])))
+                raise ClhError('poa: no consensus for group %d (status %d: 1 workspace, 2 graph limits -- more than 12 in-edges, more than 8 '
+                               'letters in a column or 65000 nodes, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 a cell left the '
+                               '16-bit score range, 7 an alignment without a base: spoa throws)' % (k, -1 - int(lens[k])))
             o = int(seq_off[group_off[k]])
-            cons = bases[np.minimum(out[o:o + int(lens[k])], 4)].tobytes().decode()
+            text = (lambda a: a.view(np.uint8).tobytes().decode('latin-1')) if raw else (lambda a: bases[np.minimum(a, 4)].tobytes().decode())
+            cons = text(out[o:o + int(lens[k])])
             if not genmsa and not with_scores:
                 res.append(cons)
                 continue
@@ -277,8 +292,8 @@ class Context(object):
                 for i in range(int(group_off[k]), int(group_off[k + 1])):
                     row = np.full(int(ncols[k]), ord('-'), dtype=np.uint8)
                     a, b = int(seq_off[i]), int(seq_off[i + 1])
-                    row[col[a:b]] = bases[np.minimum(seqs[a:b], 4)]
-                    rows.append(row.tobytes().decode())
+                    row[col[a:b]] = seqs[a:b].view(np.uint8) if raw else bases[np.minimum(seqs[a:b], 4)]
+                    rows.append(row.tobytes().decode('latin-1'))
             item = (cons, rows)
             if with_scores:
                 item = item + ([int(x) for x in asc[k, :min(CCS_SEG_CAP, int(group_off[k + 1] - group_off[k]))]],)

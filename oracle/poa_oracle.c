@@ -11,18 +11,23 @@
  * github.com/rvaser/spoa, the 4.0 line pyspoa bundles), itself an implementation of Lee, Grasso, Sharlow:
  * Bioinformatics 18:452-464 (2002) -- from the author's knowledge of that code base:
  * `AlignmentEngine::Create` (sub-type selection), `SisdAlignmentEngine::Initialize/Linear/Affine/Convex`
- * (recurrences, end cell, back-track order), `Graph::AddAlignment`, `Graph::TraverseHeaviestBundle/BranchCompletion`,
- * `Graph::GenerateMultipleSequenceAlignment`.  Every rule below that could not be checked against the sources here is
- * a recollection: [UNVERIFIED] applies to the whole file.  Known, deliberate departures are marked DEPARTURE.
+ * (recurrences, end cell, back-track order), `Graph::AddAlignment` (node numbering, aligned lists, edge weights),
+ * `Graph::TopologicalSort` (the depth-first order every alignment and the consensus run in),
+ * `Graph::TraverseHeaviestBundle/BranchCompletion`, `Graph::GenerateMultipleSequenceAlignment`.  Every rule below that
+ * could not be checked against the sources here is a recollection: [UNVERIFIED] applies to the whole file.
+ * "clh-poa v3": the three departures of v2 (five letter codes, incremental rank rule, node ids in sequence order) are
+ * gone -- letters are raw bytes, node ids follow AddAlignment, the rank order is spoa's depth-first sort after every
+ * sequence.
  *
  * Model
  * -----
- * poa(seqs, algorithm, genmsa, m, n, g, e, q, c): sequences are added one by one: align to the graph, fuse the path.
+ * poa(seqs, algorithm, genmsa, m, n, g, e, q, c): sequences are added one by one: align to the graph, fuse the path,
+ * sort the graph.  An empty sequence is skipped (it gets no MSA row either).
  * algorithm: 0 local (Smith-Waterman), 1 global (Needleman-Wunsch), 2 overlap (sequence end to end, graph ends free).
  * m match, n mismatch (n < 0), gap of k bases costs max(g + (k-1) e, q + (k-1) c) (all <= 0).
  * Sub-type as spoa selects it: g >= e -> linear (e := g); else g <= q or e >= c -> affine (one piece); else convex.
- * Letters: codes 0..4 (A C G T other); two letters match iff their codes are equal (spoa compares letter codes, so an
- * N matches an N).  DEPARTURE: spoa's alphabet is the set of raw characters; the C ABI here hands over 5 codes.
+ * Letters: bytes.  Two letters match iff the bytes are equal (spoa numbers the characters in order of first appearance and
+ * compares the numbers): 'a' is not 'A', an N matches an N, every IUPAC letter is a letter of its own.
  *
  * Alignment of a sequence s[1..L] to the graph, rows i = 1..N in topological order ("rank"), row 0 = no node:
  *   pred(i) = in-edges of the row's node in insertion order; a node without in-edges has the single predecessor row 0.
@@ -46,23 +51,23 @@
  *   further vertical steps: at (i, j) the first p with F[i][j] == H[p][j] + g (last step), F[i][j] == F[p][j] + e,
  *   O[i][j] == H[p][j] + q (last step), O[i][j] == O[p][j] + c is taken, ending after a last step or in row 0.
  *   Affine: the same without O and Q.  Linear: H only; diagonal, then vertical (H == H[p][j] + g), then horizontal.
+ *   The alignment is the list of pairs (node | none, base | none) of the steps.  An alignment that holds steps but no base
+ *   (overlap mode: a path of vertical steps only) makes AddAlignment throw; here: return -3.
  *
- * Fusing (Graph::AddAlignment): every base of the sequence ends on a node -- a base aligned to a node with the same
- * code re-uses it; with another code it re-uses the member of that node's aligned set holding its code, else a new node
- * joins the set (every member learns the new node; the new node's list is the matched node's list followed by the
- * matched node); bases that are not aligned to a node (insertions, the parts before and after the alignment, the whole
- * sequence when the alignment is empty) get new nodes.  Consecutive bases get an edge; an existing edge gains weight;
- * with unit base weights one sequence contributes 2 per edge (weight of the two bases it joins).
- * Implementation limits (not spoa's): a node keeps at most 12 in-edges, more -> error; sequences <= 2800 bases on the GPU.
+ * Fusing (Graph::AddAlignment).  The bases of the alignment are a contiguous stretch [jb, je] of the sequence.  Node ids
+ * are given in this order: the bases in front of jb (a chain of new nodes), the bases behind je (another chain), then the
+ * stretch itself base by base -- a base aligned to a node with the same letter re-uses it; with another letter it re-uses
+ * the first member of that node's aligned list holding its letter, else a new node joins the set (every member's list
+ * gains the new node; the new node's list is the matched node's list followed by the matched node); a base without a
+ * node (insertion) gets a new node.  An empty alignment: the whole sequence is one chain of new nodes.  Consecutive
+ * bases get an edge (an existing edge gains weight and the sequence's label; a new edge goes to the end of the in-edge
+ * list of its head); with unit base weights one sequence contributes 2 per edge.
  *
- * Rank order.  DEPARTURE: spoa re-sorts the whole graph depth-first after every sequence (by node id, predecessors
- * and aligned nodes first), a sequential pass; any topological order that keeps aligned sets contiguous yields the same
- * DP values, the order matters only for ties (end cell, heaviest bundle) and for the MSA column order of independent
- * insertions.  Here the order is updated incrementally, by a rule that places new nodes where spoa's sort places them in
- * the common cases: old nodes keep their relative order; a new member of an aligned set goes directly behind the set; a run
- * of new unaligned nodes goes directly in front of the aligned set of the next base of the sequence that is on an old
- * set (behind a new member of the previous set, if any); with no such base, at the end.  Node ids are given in
- * sequence order (spoa: leading part, trailing part, then the rest; ids are not observable).
+ * Rank order (Graph::TopologicalSort, after every sequence).  Iterative depth-first search over the node ids in ascending
+ * order with an explicit stack: a node on top of the stack pushes its in-edge tails that are not finished (in list order),
+ * then -- unless it was itself pushed as an aligned node ("ignored") -- the unfinished members of its aligned list (in list
+ * order, each flagged ignored); if it pushed nothing it is finished and, unless ignored, emitted followed by its whole
+ * aligned list in list order.  So an aligned set is contiguous in the order, led by the member the search met first.
  *
  * Consensus (Graph::TraverseHeaviestBundle): in rank order, a node takes the in-edge with the largest weight, on
  * equal weight the later edge if the score of its tail is not smaller; score = weight + score(tail), a node without
@@ -71,24 +76,30 @@
  * ranks are recomputed (barred tails skipped; a node all of whose tails are barred becomes barred) and the best later
  * node is taken.  The path is followed back over the chosen edges.
  * min_coverage > 0 (GenerateConsensus(min_coverage) of later spoa releases; pyspoa 0.0.5's poa() has no such argument
- * and passes 0 here; find_consensus uses it, see ccs_oracle.c): nodes of the path crossed by fewer sequences are left out.
+ * and passes 0 here; find_consensus uses it, see ccs_oracle.c): nodes of the path whose coverage -- the number of
+ * sequences with an edge at the node (Node::Coverage: a one-base sequence has no edge) -- is smaller are left out.
  * MSA (GenerateMultipleSequenceAlignment): one column per aligned set in rank order, one row per sequence, '-' elsewhere.
  */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-#define POA_MAXP 12
-#define POA_MAXA 4
 #define NEG (-(1 << 29))
+
+typedef struct { int32_t *v; int n, cap; } ivec;
+static void iv_push(ivec *a, int32_t x)
+{
+    if (a->n == a->cap) { a->cap = a->cap ? 2 * a->cap : 4; a->v = (int32_t *)realloc(a->v, sizeof(int32_t) * (size_t)a->cap); }
+    a->v[a->n++] = x;
+}
 
 typedef struct {
     int n, cap;
-    int8_t *code, *np, *na;
-    int32_t *pred, *pw;       /* [cap][POA_MAXP] in-edges in insertion order */
-    int32_t *aligned;         /* [cap][POA_MAXA] */
+    uint8_t *code;
+    ivec *tail, *wt;          /* in-edges in insertion order: tail node, weight */
+    ivec *al;                 /* aligned_nodes, in list order */
     int32_t *nout;
-    int32_t *cov;             /* sequences through the node (Node::Coverage) */
+    int32_t *cov;             /* Node::Coverage: sequences with an edge at the node */
     int32_t *order, *rank;    /* order[r-1] = node of rank r; rank[node] = 1..n */
 } graph;
 
@@ -99,10 +110,8 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 static void g_init(graph *g, int cap)
 {
     g->n = 0; g->cap = cap;
-    g->code = (int8_t *)malloc((size_t)cap); g->np = (int8_t *)calloc((size_t)cap, 1); g->na = (int8_t *)calloc((size_t)cap, 1);
-    g->pred = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap * POA_MAXP);
-    g->pw = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap * POA_MAXP);
-    g->aligned = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap * POA_MAXA);
+    g->code = (uint8_t *)malloc((size_t)cap);
+    g->tail = (ivec *)calloc((size_t)cap, sizeof(ivec)); g->wt = (ivec *)calloc((size_t)cap, sizeof(ivec)); g->al = (ivec *)calloc((size_t)cap, sizeof(ivec));
     g->nout = (int32_t *)calloc((size_t)cap, sizeof(int32_t));
     g->cov = (int32_t *)calloc((size_t)cap, sizeof(int32_t));
     g->order = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
@@ -110,43 +119,87 @@ static void g_init(graph *g, int cap)
 }
 static void g_free(graph *g)
 {
-    free(g->code); free(g->np); free(g->na); free(g->pred); free(g->pw); free(g->aligned); free(g->nout); free(g->cov); free(g->order); free(g->rank);
+    for (int v = 0; v < g->cap; ++v) { free(g->tail[v].v); free(g->wt[v].v); free(g->al[v].v); }
+    free(g->code); free(g->tail); free(g->wt); free(g->al); free(g->nout); free(g->cov); free(g->order); free(g->rank);
 }
-static int g_new(graph *g, int code)
+static int g_new(graph *g, int code)                      /* Graph::AddNode */
 {
     if (g->n >= g->cap) return -1;
     const int v = g->n++;
-    g->code[v] = (int8_t)code; g->np[v] = 0; g->na[v] = 0; g->nout[v] = 0; g->cov[v] = 0; g->rank[v] = 0;
+    g->code[v] = (uint8_t)code; g->rank[v] = 0;
     return v;
 }
-static int g_edge(graph *g, int u, int v, int w)          /* Graph::AddEdge */
+static void g_edge(graph *g, int u, int v, int w)         /* Graph::AddEdge */
 {
-    for (int k = 0; k < g->np[v]; ++k)
-        if (g->pred[v * POA_MAXP + k] == u) { g->pw[v * POA_MAXP + k] += w; return 0; }
-    if (g->np[v] >= POA_MAXP) return -1;
-    g->pred[v * POA_MAXP + g->np[v]] = u; g->pw[v * POA_MAXP + g->np[v]] = w; g->np[v] += 1;
+    for (int k = 0; k < g->tail[v].n; ++k)
+        if (g->tail[v].v[k] == u) { g->wt[v].v[k] += w; return; }
+    iv_push(&g->tail[v], u); iv_push(&g->wt[v], w);
     g->nout[u] += 1;
-    return 0;
+}
+static int max_indegree(const graph *g)
+{
+    int m = 1;
+    for (int v = 0; v < g->n; ++v) m = imax(m, g->tail[v].n);
+    return m;
 }
 /* rows of the predecessors of row i (1..N): count, list; a source row has the single predecessor 0 */
 static int preds_of(const graph *g, int i, int *pr)
 {
     const int v = g->order[i - 1];
-    if (g->np[v] == 0) { pr[0] = 0; return 1; }
-    for (int k = 0; k < g->np[v]; ++k) pr[k] = g->rank[g->pred[v * POA_MAXP + k]];
-    return g->np[v];
+    if (g->tail[v].n == 0) { pr[0] = 0; return 1; }
+    for (int k = 0; k < g->tail[v].n; ++k) pr[k] = g->rank[g->tail[v].v[k]];
+    return g->tail[v].n;
+}
+
+/* Graph::TopologicalSort */
+static void topo_sort(graph *g)
+{
+    const int N = g->n;
+    uint8_t *marks = (uint8_t *)calloc((size_t)N + 1, 1), *ignored = (uint8_t *)calloc((size_t)N + 1, 1);   /* 0 unmarked, 1 temporarily, 2 permanently marked */
+    ivec st = {0, 0, 0};
+    int nord = 0;
+    for (int i = 0; i < N; ++i) {
+        if (marks[i] != 0) continue;
+        iv_push(&st, i);
+        while (st.n) {
+            const int curr = st.v[st.n - 1];
+            int valid = 1;
+            if (marks[curr] != 2) {
+                for (int k = 0; k < g->tail[curr].n; ++k) {
+                    const int t = g->tail[curr].v[k];
+                    if (marks[t] != 2) { iv_push(&st, t); valid = 0; }
+                }
+                if (!ignored[curr])
+                    for (int k = 0; k < g->al[curr].n; ++k) {
+                        const int a = g->al[curr].v[k];
+                        if (marks[a] != 2) { iv_push(&st, a); ignored[a] = 1; valid = 0; }
+                    }
+                if (valid) {
+                    marks[curr] = 2;
+                    if (!ignored[curr]) {
+                        g->order[nord++] = curr;
+                        for (int k = 0; k < g->al[curr].n; ++k) g->order[nord++] = g->al[curr].v[k];
+                    }
+                } else marks[curr] = 1;
+            }
+            if (valid) --st.n;
+        }
+    }
+    for (int r = 0; r < nord; ++r) g->rank[g->order[r]] = r + 1;
+    free(marks); free(ignored); free(st.v);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
- * alignment.  pn[j] (j = 0..L-1) = node the base j is aligned to, or -1.  Pairs (node, no base) do not change the graph
- * (AddAlignment skips them) and are not returned.  *score = end-cell score.  returns 0. */
-static int align_linear(const graph *g, const int8_t *s, int L, const par *P, int32_t *pn, int *score)
+ * alignment.  pn[j] (j = 0..L-1) = node the base j is aligned to, or -1.  [*jb, *je] = the bases the alignment holds
+ * (jb > je: none), *steps = its number of pairs.  Pairs (node, no base) do not change the graph (AddAlignment skips them)
+ * and are only counted.  *score = end-cell score. */
+static void align_linear(const graph *g, const uint8_t *s, int L, const par *P, int32_t *pn, int *score, int *jb, int *je, int *steps)
 {
     const int N = g->n, W = L + 1, sw = P->algorithm == 0, nw = P->algorithm == 1;
     int32_t *H = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N + 1) * W);
+    int *pr = (int *)malloc(sizeof(int) * (size_t)(max_indegree(g) + 1));
     H[0] = 0;
     for (int j = 1; j <= L; ++j) H[j] = sw ? 0 : j * P->g;
-    int pr[POA_MAXP];
     for (int i = 1; i <= N; ++i) {
         if (!nw) { H[(size_t)i * W] = 0; continue; }
         const int np = preds_of(g, i, pr);
@@ -170,7 +223,7 @@ static int align_linear(const graph *g, const int8_t *s, int L, const par *P, in
     }
     for (int j = 0; j < L; ++j) pn[j] = -1;
     *score = best;
-    int i = bi, j = bj;
+    int i = bi, j = bj, ns = 0;
     while ((sw && H[(size_t)i * W + j] != 0) || (nw && (i != 0 || j != 0)) || (P->algorithm == 2 && i != 0 && j != 0)) {
         const int h = H[(size_t)i * W + j];
         int pi = i, pj = j, found = 0;
@@ -185,28 +238,29 @@ static int align_linear(const graph *g, const int8_t *s, int L, const par *P, in
         if (!found && j != 0 && h == H[(size_t)i * W + j - 1] + P->g) { pi = i; pj = j - 1; found = 1; }
         if (!found) break;                                   /* cannot happen */
         if (pj != j && pi != i) pn[j - 1] = g->order[i - 1];
+        ++ns;
         i = pi; j = pj;
     }
-    free(H);
-    return 0;
+    *jb = j; *je = bj - 1; *steps = ns;
+    free(H); free(pr);
 }
 
-static int align_gotoh(const graph *g, const int8_t *s, int L, const par *P, int32_t *pn, int *score)
+static void align_gotoh(const graph *g, const uint8_t *s, int L, const par *P, int32_t *pn, int *score, int *jb, int *je, int *steps)
 {
     const int N = g->n, W = L + 1, sw = P->algorithm == 0, nw = P->algorithm == 1, ov = P->algorithm == 2, cx = P->subtype == 2;
     const int ge = P->g, ee = P->e, qq = P->q, cc = P->c;
     const size_t cells = (size_t)(N + 1) * W;
     int32_t *H = (int32_t *)malloc(sizeof(int32_t) * cells), *F = (int32_t *)malloc(sizeof(int32_t) * cells), *E = (int32_t *)malloc(sizeof(int32_t) * cells);
     int32_t *O = (int32_t *)malloc(sizeof(int32_t) * cells), *Q = (int32_t *)malloc(sizeof(int32_t) * cells);
-    int pr[POA_MAXP];
+    int *pr = (int *)malloc(sizeof(int) * (size_t)(max_indegree(g) + 1));
     /* Initialize */
     O[0] = 0; Q[0] = 0; F[0] = 0; E[0] = 0; H[0] = 0;
     for (int j = 1; j <= L; ++j) { O[j] = NEG; Q[j] = cx ? qq + (j - 1) * cc : NEG; F[j] = NEG; E[j] = ge + (j - 1) * ee; }
     for (int i = 1; i <= N; ++i) {
         const int v = g->order[i - 1];
-        int penF = g->np[v] == 0 ? ge - ee : NEG, penO = g->np[v] == 0 ? qq - cc : NEG;
-        for (int k = 0; k < g->np[v]; ++k) {
-            const int p = g->rank[g->pred[v * POA_MAXP + k]];
+        int penF = g->tail[v].n == 0 ? ge - ee : NEG, penO = g->tail[v].n == 0 ? qq - cc : NEG;
+        for (int k = 0; k < g->tail[v].n; ++k) {
+            const int p = g->rank[g->tail[v].v[k]];
             penF = imax(penF, F[(size_t)p * W]); penO = imax(penO, O[(size_t)p * W]);
         }
         F[(size_t)i * W] = penF + ee; E[(size_t)i * W] = NEG;
@@ -242,7 +296,7 @@ static int align_gotoh(const graph *g, const int8_t *s, int L, const par *P, int
     for (int j = 0; j < L; ++j) pn[j] = -1;
     *score = best;
     /* back-track */
-    int i = bi, j = bj;
+    int i = bi, j = bj, ns = 0;
     while ((sw && H[(size_t)i * W + j] != 0) || (nw && (i != 0 || j != 0)) || (ov && i != 0 && j != 0)) {
         const int h = H[(size_t)i * W + j];
         int pi = i, pj = j, found = 0, ext_left = 0, ext_up = 0;
@@ -271,10 +325,11 @@ static int align_gotoh(const graph *g, const int8_t *s, int L, const par *P, int
         }
         if (!found) break;                                   /* cannot happen */
         if (pi != i && pj != j) pn[j - 1] = g->order[i - 1];
+        ++ns;
         i = pi; j = pj;
         if (ext_left) {
             for (;;) {
-                --j;                                          /* one more base without a node */
+                --j; ++ns;                                    /* one more base without a node */
                 const size_t b = (size_t)i * W + j;
                 if (E[b] + ee != E[b + 1] && (!cx || Q[b] + cc != Q[b + 1])) break;
             }
@@ -293,82 +348,55 @@ static int align_gotoh(const graph *g, const int8_t *s, int L, const par *P, int
                     else stop = 0;
                     if (hit) { ni = pr[k]; break; }
                 }
-                i = ni;                                       /* one more node without a base */
+                i = ni; ++ns;                                 /* one more node without a base */
                 if (stop || i == 0) break;
             }
         }
     }
-    free(H); free(F); free(E); free(O); free(Q);
-    return 0;
+    *jb = j; *je = bj - 1; *steps = ns;
+    free(H); free(F); free(E); free(O); free(Q); free(pr);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Graph::AddAlignment + the incremental rank rule.  used[j] receives the node of base j.  returns 0 / -1 (limits). */
-typedef struct { int64_t key; int32_t node; } keyed;
-static int keyed_cmp(const void *a, const void *b)
+ * Graph::AddAlignment.  used[j] receives the node of base j.  The alignment holds the bases [jb, je] (steps == 0: it is
+ * empty).  returns 0, -1 (node capacity), -3 (an alignment without a base: spoa throws). */
+static int fuse(graph *g, const uint8_t *s, int L, const int32_t *pn, int jb, int je, int steps, int32_t *used)
 {
-    const keyed *x = (const keyed *)a, *y = (const keyed *)b;
-    return x->key < y->key ? -1 : (x->key > y->key);
-}
-static void group_span(const graph *g, int v, int *lo, int *hi)      /* ranks of the aligned set of v */
-{
-    int a = g->rank[v], b = g->rank[v];
-    for (int k = 0; k < g->na[v]; ++k) {
-        const int r = g->rank[g->aligned[v * POA_MAXA + k]];
-        if (r < a) a = r;
-        if (r > b) b = r;
+    if (steps == 0) { jb = L; je = L - 1; }                   /* AddSequence(0, L) */
+    else if (jb > je) return -3;
+    /* the bases in front of the alignment, then the bases behind it: two chains of new nodes (Graph::AddSequence) */
+    for (int j = 0; j < jb; ++j) {
+        if ((used[j] = g_new(g, s[j])) < 0) return -1;
+        if (j > 0) g_edge(g, used[j - 1], used[j], 2);
     }
-    *lo = a; *hi = b;
-}
-static int fuse(graph *g, const int8_t *s, int L, const int32_t *pn, int32_t *used)
-{
-    const int N = g->n;
-    keyed *ks = (keyed *)malloc(sizeof(keyed) * (size_t)(N + L + 1));
-    int nk = 0;
-    for (int r = 1; r <= N; ++r) { ks[nk].key = ((int64_t)r * 4 + 2) << 24; ks[nk].node = g->order[r - 1]; ++nk; }
-    /* boundary (old rank in front of which a run of unaligned bases goes): start of the aligned set of the next aligned base */
-    int32_t *bnd = (int32_t *)malloc(sizeof(int32_t) * (size_t)(L + 1));
-    int nextb = N + 1;
-    for (int j = L - 1; j >= 0; --j) {
-        if (pn[j] >= 0) { int lo, hi; group_span(g, pn[j], &lo, &hi); nextb = lo; }
-        bnd[j] = nextb;
+    if (steps == 0) return 0;
+    for (int j = je + 1; j < L; ++j) {
+        if ((used[j] = g_new(g, s[j])) < 0) return -1;
+        if (j > je + 1) g_edge(g, used[j - 1], used[j], 2);
     }
-    int rc = 0;
-    for (int j = 0; j < L && rc == 0; ++j) {
+    for (int j = jb; j <= je; ++j) {
         const int b = s[j], v = pn[j];
         int use = -1;
-        if (v >= 0) {
-            if (g->code[v] == b) use = v;
-            else for (int k = 0; k < g->na[v]; ++k) { const int w = g->aligned[v * POA_MAXA + k]; if (g->code[w] == b) { use = w; break; } }
+        if (v < 0) use = g_new(g, b);
+        else if (g->code[v] == b) use = v;
+        else {
+            for (int k = 0; k < g->al[v].n; ++k) { const int w = g->al[v].v[k]; if (g->code[w] == b) { use = w; break; } }
             if (use < 0) {
-                int lo, hi;
-                group_span(g, v, &lo, &hi);
                 use = g_new(g, b);
-                if (use < 0 || g->na[v] >= POA_MAXA) { rc = -1; break; }
-                for (int k = 0; k < g->na[v]; ++k) {
-                    const int w = g->aligned[v * POA_MAXA + k];
-                    g->aligned[w * POA_MAXA + g->na[w]++] = use;
-                    g->aligned[use * POA_MAXA + g->na[use]++] = w;
+                if (use < 0) return -1;
+                for (int k = 0; k < g->al[v].n; ++k) {
+                    const int w = g->al[v].v[k];
+                    iv_push(&g->al[w], use); iv_push(&g->al[use], w);
                 }
-                g->aligned[v * POA_MAXA + g->na[v]++] = use;
-                g->aligned[use * POA_MAXA + g->na[use]++] = v;
-                ks[nk].key = (((int64_t)(hi + 1) * 4 + 0) << 24); ks[nk].node = use; ++nk;
+                iv_push(&g->al[v], use); iv_push(&g->al[use], v);
             }
-        } else {
-            use = g_new(g, b);
-            if (use < 0) { rc = -1; break; }
-            ks[nk].key = (((int64_t)bnd[j] * 4 + 1) << 24) + j; ks[nk].node = use; ++nk;
         }
+        if (use < 0) return -1;
         used[j] = use;
-        g->cov[use] += 1;
-        if (j > 0 && g_edge(g, used[j - 1], use, 2) != 0) rc = -1;
+        if (j > 0) g_edge(g, used[j - 1], use, 2);          /* j == jb: from the last node of the leading chain, if there is one */
     }
-    if (rc == 0) {
-        qsort(ks, (size_t)nk, sizeof(keyed), keyed_cmp);      /* keys are distinct */
-        for (int r = 0; r < nk; ++r) { g->order[r] = ks[r].node; g->rank[ks[r].node] = r + 1; }
-    }
-    free(ks); free(bnd);
-    return rc;
+    if (je + 1 < L) g_edge(g, used[je], used[je + 1], 2);
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -382,8 +410,8 @@ static int consensus(const graph *g, int32_t *path, int cap)
     int top = -1;
     for (int r = 1; r <= N; ++r) {
         const int v = g->order[r - 1];
-        for (int k = 0; k < g->np[v]; ++k) {
-            const int u = g->pred[v * POA_MAXP + k], w = g->pw[v * POA_MAXP + k];
+        for (int k = 0; k < g->tail[v].n; ++k) {
+            const int u = g->tail[v].v[k], w = g->wt[v].v[k];
             if (score[v] < w || (score[v] == w && score[bp[v]] <= score[u])) { score[v] = w; bp[v] = u; }
         }
         if (bp[v] >= 0) score[v] += score[bp[v]];
@@ -393,16 +421,16 @@ static int consensus(const graph *g, int32_t *path, int cap)
         const int start = top, r0 = g->rank[start];
         for (int h = 0; h < N; ++h) {
             int is_succ = 0;
-            for (int k = 0; k < g->np[h]; ++k) if (g->pred[h * POA_MAXP + k] == start) is_succ = 1;
+            for (int k = 0; k < g->tail[h].n; ++k) if (g->tail[h].v[k] == start) is_succ = 1;
             if (!is_succ) continue;
-            for (int k = 0; k < g->np[h]; ++k) if (g->pred[h * POA_MAXP + k] != start) score[g->pred[h * POA_MAXP + k]] = -1;
+            for (int k = 0; k < g->tail[h].n; ++k) if (g->tail[h].v[k] != start) score[g->tail[h].v[k]] = -1;
         }
         top = -1;
         for (int r = r0 + 1; r <= N; ++r) {
             const int v = g->order[r - 1];
             score[v] = -1; bp[v] = -1;
-            for (int k = 0; k < g->np[v]; ++k) {
-                const int u = g->pred[v * POA_MAXP + k], w = g->pw[v * POA_MAXP + k];
+            for (int k = 0; k < g->tail[v].n; ++k) {
+                const int u = g->tail[v].v[k], w = g->wt[v].v[k];
                 if (score[u] == -1) continue;
                 if (score[v] < w || (score[v] == w && score[bp[v]] <= score[u])) { score[v] = w; bp[v] = u; }
             }
@@ -431,13 +459,16 @@ static int parse_par(const int32_t *pp, par *P)
     return 0;
 }
 
-/* poa(seqs, algorithm, genmsa, m, n, g, e, q, c): nseq sequences (packed codes, off[nseq+1]); params = {algorithm, m, n, g,
- * e, q, c, min_coverage}.  cons receives the consensus codes (capacity cap); returns its length, -1 on an implementation limit, -2 on
- * invalid parameters.  msa (may be NULL) receives nseq rows of *ncols characters ('-' = 45, else the code), row-major,
- * if nseq * ncols <= msa_cap (else -1).  scores (may be NULL) receives the end-cell score of every alignment. */
-int clo_poa(int32_t nseq, const int8_t *seqs, const int32_t *off, const int32_t *params, int8_t *cons, int32_t cap,
-            int8_t *msa, int64_t msa_cap, int32_t *ncols, int32_t *scores)
+/* poa(seqs, algorithm, genmsa, m, n, g, e, q, c): nseq sequences (packed letters = bytes, off[nseq+1]); params = {algorithm,
+ * m, n, g, e, q, c, min_coverage}.  cons receives the consensus letters (capacity cap); returns its length, -1 on an
+ * implementation limit, -2 on invalid parameters, -3 where spoa throws (an alignment without a base).  msa (may be NULL)
+ * receives one row of *ncols characters ('-' = 45, else the letter) per NON-EMPTY sequence, row-major, if it fits msa_cap
+ * (else -1).  scores (may be NULL) receives the end-cell score of every alignment (0 for an empty sequence).
+ * rank_out (may be NULL): node ids in the final rank order, preceded by their count (capacity: total letters + 1). */
+int clo_poa_ranked(int32_t nseq, const int8_t *seqs_, const int32_t *off, const int32_t *params, int8_t *cons, int32_t cap,
+                   int8_t *msa, int64_t msa_cap, int32_t *ncols, int32_t *scores, int32_t *rank_out)
 {
+    const uint8_t *seqs = (const uint8_t *)seqs_;
     par P;
     if (parse_par(params, &P) != 0) return -2;
     const int total = off[nseq];
@@ -447,40 +478,53 @@ int clo_poa(int32_t nseq, const int8_t *seqs, const int32_t *off, const int32_t 
     int rc = 0;
     for (int s = 0; s < nseq && rc == 0; ++s) {
         const int L = off[s + 1] - off[s];
+        if (scores) scores[s] = 0;
         if (L == 0) continue;
-        int sc = 0;
-        if (g.n == 0) for (int j = 0; j < L; ++j) pn[j] = -1;
-        else if (P.subtype == 0) align_linear(&g, seqs + off[s], L, &P, pn, &sc);
-        else align_gotoh(&g, seqs + off[s], L, &P, pn, &sc);
+        int sc = 0, jb = 0, je = -1, steps = 0;
+        if (g.n == 0) { for (int j = 0; j < L; ++j) pn[j] = -1; }
+        else if (P.subtype == 0) align_linear(&g, seqs + off[s], L, &P, pn, &sc, &jb, &je, &steps);
+        else align_gotoh(&g, seqs + off[s], L, &P, pn, &sc, &jb, &je, &steps);
         if (scores) scores[s] = sc;
-        rc = fuse(&g, seqs + off[s], L, pn, used + off[s]);
+        rc = fuse(&g, seqs + off[s], L, pn, jb, je, steps, used + off[s]);
+        if (rc == 0) {
+            if (L >= 2) for (int j = 0; j < L; ++j) g.cov[used[off[s] + j]] += 1;
+            topo_sort(&g);
+        }
     }
-    int len = -1;
+    int len = rc;
     if (rc == 0) {
         int32_t *path = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g.n + 1));
         len = consensus(&g, path, g.n + 1);
         if (len > cap) len = -1;
         if (len >= 0) {                                        /* GenerateConsensus(min_coverage): nodes below it are left out */
             int k2 = 0;
-            for (int k = 0; k < len; ++k) if (g.cov[path[k]] >= P.min_cov) cons[k2++] = g.code[path[k]];
+            for (int k = 0; k < len; ++k) if (g.cov[path[k]] >= P.min_cov) cons[k2++] = (int8_t)g.code[path[k]];
             len = k2;
         }
         free(path);
     }
+    if (len >= 0 && rank_out) { rank_out[0] = g.n; for (int i = 0; i < g.n; ++i) rank_out[1 + i] = g.order[i]; }
     if (len >= 0 && ncols) {
         int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g.n + 1));
         int nc = 0;
         for (int i = 0; i < g.n; ++i, ++nc) {
             const int v = g.order[i];
             col[v] = nc;
-            for (int k = 0; k < g.na[v]; ++k) { col[g.aligned[v * POA_MAXA + k]] = nc; ++i; }
+            for (int k = 0; k < g.al[v].n; ++k) { col[g.al[v].v[k]] = nc; ++i; }
         }
         *ncols = nc;
         if (msa) {
-            if ((int64_t)nseq * nc > msa_cap) len = -1;
+            int rows = 0;
+            for (int s = 0; s < nseq; ++s) rows += off[s + 1] > off[s];
+            if ((int64_t)rows * nc > msa_cap) len = -1;
             else {
-                memset(msa, '-', (size_t)nseq * nc);
-                for (int s = 0; s < nseq; ++s) for (int j = off[s]; j < off[s + 1]; ++j) msa[(size_t)s * nc + col[used[j]]] = g.code[used[j]];
+                memset(msa, '-', (size_t)rows * nc);
+                int r = 0;
+                for (int s = 0; s < nseq; ++s) {
+                    if (off[s + 1] == off[s]) continue;
+                    for (int j = off[s]; j < off[s + 1]; ++j) msa[(size_t)r * nc + col[used[j]]] = (int8_t)g.code[used[j]];
+                    ++r;
+                }
             }
         }
         free(col);
@@ -488,4 +532,10 @@ int clo_poa(int32_t nseq, const int8_t *seqs, const int32_t *off, const int32_t 
     free(pn); free(used);
     g_free(&g);
     return len;
+}
+
+int clo_poa(int32_t nseq, const int8_t *seqs, const int32_t *off, const int32_t *params, int8_t *cons, int32_t cap,
+            int8_t *msa, int64_t msa_cap, int32_t *ncols, int32_t *scores)
+{
+    return clo_poa_ranked(nseq, seqs, off, params, cons, cap, msa, msa_cap, ncols, scores, NULL);
 }

@@ -197,31 +197,51 @@ def oracle_find_consensus(seq):
 POA_DEFAULT = (10, -4, -8, -2, -24, -1)       # the scores of every reference call site (collapse.py:267,504; tests/test_poa.py:30)
 
 
-def oracle_poa(seqs, algorithm=0, genmsa=False, m=10, n=-4, g=-8, e=-2, q=-24, c=-1, with_scores=False, min_coverage=0):
-    """oracle/poa_oracle.c: spoa.poa(seqs, algorithm, genmsa, m, n, g, e, q, c) -> consensus | (consensus, msa[, scores]).
-    None where an implementation limit was hit; ValueError on invalid parameters."""
-    arrs = [np.ascontiguousarray(encode(s) if not isinstance(s, np.ndarray) else s, dtype=np.int8) for s in seqs]
+def oracle_poa(seqs, algorithm=0, genmsa=False, m=10, n=-4, g=-8, e=-2, q=-24, c=-1, with_scores=False, min_coverage=0, with_order=False):
+    """oracle/poa_oracle.c: spoa.poa(seqs, algorithm, genmsa, m, n, g, e, q, c) -> consensus | (consensus, msa[, scores[, order]]).
+    str / bytes sequences are taken letter by letter as they are (spoa's alphabet is the set of raw characters); int8 arrays
+    are taken as letters 0..4 and come back as 'ACGTN'.  msa holds one row per non-empty sequence.  None where an
+    implementation limit was hit; ValueError on invalid parameters or where spoa throws (an alignment without a base)."""
+    raw = all(not isinstance(s, np.ndarray) for s in seqs)
+    if raw:
+        arrs = [np.frombuffer(s.encode('latin-1') if isinstance(s, str) else bytes(s), dtype=np.int8) for s in seqs]
+        dec = lambda a: bytes(np.asarray(a, dtype=np.int8).view(np.uint8)).decode('latin-1')
+    else:
+        arrs = [np.ascontiguousarray(encode(s) if not isinstance(s, np.ndarray) else s, dtype=np.int8) for s in seqs]
+        dec = lambda a: ''.join('-' if x == 45 else 'ACGTN'[x] for x in a)
     off = np.zeros(len(arrs) + 1, dtype=np.int32)
     np.cumsum([len(a) for a in arrs], out=off[1:])
-    data = np.concatenate(arrs) if arrs else np.zeros(1, dtype=np.int8)
+    data = np.ascontiguousarray(np.concatenate(arrs)) if arrs and off[-1] else np.zeros(1, dtype=np.int8)
     out = np.zeros(int(off[-1]) + 8, dtype=np.int8)
     par = np.array([algorithm, m, n, g, e, q, c, min_coverage], dtype=np.int32)
     ncols = C.c_int32(0)
     msa_cap = (int(off[-1]) + 8) * max(len(arrs), 1)
     msa = np.zeros(msa_cap, dtype=np.int8)
     scores = np.zeros(len(arrs) + 1, dtype=np.int32)
-    k = _ccs_lib().clo_poa(len(arrs), data.ctypes.data, off.ctypes.data, par.ctypes.data, out.ctypes.data, len(out),
-                           msa.ctypes.data if genmsa else None, msa_cap, C.byref(ncols), scores.ctypes.data)
+    order = np.zeros(int(off[-1]) + 2, dtype=np.int32)
+    lib = _ccs_lib()
+    lib.clo_poa_ranked.restype = C.c_int
+    lib.clo_poa_ranked.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    k = lib.clo_poa_ranked(len(arrs), data.ctypes.data, off.ctypes.data, par.ctypes.data, out.ctypes.data, len(out),
+                           msa.ctypes.data if genmsa else None, msa_cap, C.byref(ncols), scores.ctypes.data, order.ctypes.data)
     if k == -2:
         raise ValueError('invalid poa parameters')
-    cons = None if k < 0 else decode(out[:k])
-    if not genmsa and not with_scores:
+    if k == -3:
+        raise ValueError('alignment without a base (spoa throws)')
+    cons = None if k < 0 else dec(out[:k])
+    if not genmsa and not with_scores and not with_order:
         return cons
     rows = []
     if genmsa and k >= 0:
         nc = ncols.value
-        rows = [''.join('-' if x == 45 else 'ACGTN'[x] for x in msa[r * nc:(r + 1) * nc]) for r in range(len(arrs))]
-    return (cons, rows, [int(x) for x in scores[:len(arrs)]]) if with_scores else (cons, rows)
+        rows = [dec(msa[r * nc:(r + 1) * nc]) for r in range(sum(1 for a in arrs if len(a)))]
+    res = (cons, rows)
+    if with_scores or with_order:
+        res += ([int(x) for x in scores[:len(arrs)]],)
+    if with_order:
+        res += ([int(x) for x in order[1:1 + int(order[0])]] if k >= 0 else None,)
+    return res
 
 
 def oracle_edit_distance(x, y):

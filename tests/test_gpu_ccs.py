@@ -193,6 +193,48 @@ def test_poa_modes_scores_msa_equal_the_oracle(algorithm):
         assert got[1] == want[1], (it, 'msa')
 
 
+def test_poa_letters_are_raw_characters_and_spoa_corner_cases():
+    """spoa's alphabet is the set of raw characters: 'a' is not 'A', every IUPAC letter is its own letter (columns of up to 8
+    different letters; a ninth is this kernel's stated limit); empty sequences are skipped (no MSA row), a one-base sequence
+    has no edge and so no coverage; all three modes; rank order = spoa's depth-first sort (MSA columns show it)."""
+    import random
+    from ciri_long_amd import hip, spoa
+    rng = random.Random(31)
+    n = 0
+    for it in range(60):
+        alpha = ['ACGTacgt', 'ACGTNRYK', 'ACGTN', 'AaCc', 'ACGT'][it % 5]
+        t = ''.join(rng.choice(alpha) for _ in range(rng.choice([8, 20, 60, 150])))
+        seqs = []
+        for _k in range(rng.randint(2, 14)):
+            s = ''.join(rng.choice(alpha) if rng.random() < 0.1 else ch for ch in t if rng.random() > 0.05)
+            if rng.random() < 0.25:
+                s = s[rng.randrange(0, max(1, len(s) // 2)):]
+            if rng.random() < 0.08:
+                s = ''
+            if rng.random() < 0.08:
+                s = rng.choice(alpha)
+            seqs.append(s)
+        if not any(seqs):
+            seqs.append('ACGT')
+        algorithm = it % 3
+        par = PARS[(it // 3) % len(PARS)]
+        try:
+            want = oracle_lib.oracle_poa(seqs, algorithm, True, *par)
+        except ValueError:                      # an alignment without a base: spoa throws, the kernel reports status 7
+            with pytest.raises(hip.ClhError, match='status 7'):
+                spoa.poa(seqs, algorithm, True, *par)
+            continue
+        assert spoa.poa(seqs, algorithm, True, *par) == tuple(want), (it, seqs)
+        n += 1
+    assert n >= 50
+    # nine different letters in one column: beyond the kernel's aligned-set capacity, said aloud
+    col9 = ['GG' + ch + 'TT' for ch in 'ACGTNRYKM']
+    assert oracle_lib.oracle_poa(col9, 1, False, *PARS[0]) is not None
+    with pytest.raises(hip.ClhError, match='status 2'):
+        spoa.poa(col9, 1, False, *PARS[0])
+    assert spoa.poa(col9[:8], 1, True, *PARS[0]) == tuple(oracle_lib.oracle_poa(col9[:8], 1, True, *PARS[0]))
+
+
 def test_poa_batch_of_groups_large_clusters_and_limits():
     """Several groups in one call (the batch form of collapse.py:504), a cluster of 150 sequences (the reference's
     correct_cluster takes up to 200 reads), and the stated limits: a sequence above 2800 bases raises."""

@@ -19,6 +19,14 @@ PARS = [(10, -4, -8, -2, -24, -1),      # every call site of the reference (coll
         (3, -5, -4, -3, -9, -1), (2, -1, -2, -1, -3, -1)]
 
 
+def _letters(s):
+    return np.frombuffer(s.encode('latin-1'), dtype=np.uint8).astype(np.int64)
+
+
+def _text(a):
+    return bytes(int(x) for x in a).decode('latin-1')
+
+
 def _mutate(rng, t, rate):
     out = []
     for ch in t:
@@ -56,12 +64,17 @@ def test_row_formulation_equals_matrix_statement(algorithm):
     for rng, seqs in _families(100 + algorithm, 40):
         par = rng.choice(PARS)
         mc = rng.choice([0, 0, (len(seqs) + 1) // 2])
-        want = oracle_lib.oracle_poa(seqs, algorithm, True, *par, with_scores=True, min_coverage=mc)
-        cons, rows, scores = poa_model.poa([oracle_lib.encode(s) for s in seqs], algorithm, True, *par, min_coverage=mc)
-        got = (oracle_lib.decode(cons), [''.join('-' if x == 45 else 'ACGTN'[x] for x in r) for r in rows], scores)
+        try:
+            want = oracle_lib.oracle_poa(seqs, algorithm, True, *par, with_scores=True, min_coverage=mc, with_order=True)
+        except ValueError:                                   # an alignment without a base: spoa throws, so does the model
+            with pytest.raises(ValueError):
+                poa_model.poa([_letters(s) for s in seqs], algorithm, True, *par, min_coverage=mc)
+            continue
+        cons, rows, scores, order = poa_model.poa([_letters(s) for s in seqs], algorithm, True, *par, min_coverage=mc)
+        got = (_text(cons), [_text(r) for r in rows], scores, order)
         assert got == tuple(want), (seqs, par, mc)
         n += 1
-    assert n == 40
+    assert n >= 38
 
 
 def test_gap_model_of_the_call_sites():

@@ -128,15 +128,16 @@ def dp_row(P, code, seq, srcs, col0):
 
 
 class Graph(object):
-    MAXP, MAXA = 12, 4
+    MAXP, MAXA = 12, 15          # the kernel's limits: in-edges of a node, other members of an aligned set
 
     def __init__(self):
         self.code, self.pred, self.pw, self.aligned, self.cov, self.nout = [], [], [], [], [], []
         self.order, self.rank = [], []            # order[r-1] = node; rank[node] = r
+        self.root = []                            # smallest node id among the node's descendants and their aligned sets (topo_sort)
 
     def new(self, code):
         self.code.append(int(code)); self.pred.append([]); self.pw.append([]); self.aligned.append([]); self.cov.append(0)
-        self.nout.append(0); self.rank.append(0)
+        self.nout.append(0); self.rank.append(0); self.root.append(len(self.code) - 1)
         return len(self.code) - 1
 
     def edge(self, u, v, w):
@@ -147,9 +148,87 @@ class Graph(object):
                 raise OverflowError('in-degree')
             self.pred[v].append(u); self.pw[v].append(w); self.nout[u] += 1
 
-    def span(self, v):
-        rs = [self.rank[v]] + [self.rank[a] for a in self.aligned[v]]
-        return min(rs), max(rs)
+
+def topo_sort(G, path):
+    """Graph::TopologicalSort as the kernel computes it -- the same order as spoa's sequential depth-first search
+    (oracle/poa_oracle.c: topo_sort), from independent pieces:
+
+    1. root[x] = the smallest node id among everything that depends on x (its descendants over the edges, the members of
+       their aligned sets, and so on).  spoa's outer loop visits the ids in ascending order and a visit emits exactly the
+       unfinished ancestors of that id, so x is emitted during the visit of id root[x].  The values of the graph before
+       this sequence are kept; the new sequence's path lowers them by a suffix minimum along the path, the rest is
+       relaxation to the fixed point (a few sweeps).
+    2. every id r with root[r] == r is the start of one search over the nodes with root == r, independent of all others
+       (a dependency with a smaller root is finished by then, one with a larger root cannot occur); its nodes go to the
+       positions behind the nodes of all smaller roots.  The kernel runs these searches one per lane.
+    """
+    N = len(G.code)
+    root = G.root
+    smin = N
+    for v in reversed(path):                                 # along the new path: everything behind a base depends on it
+        smin = min(smin, root[v])
+        root[v] = smin
+    changed = True
+    while changed:
+        changed = False
+        for v in range(N):
+            for u in G.pred[v]:
+                if root[v] < root[u]:
+                    root[u] = root[v]; changed = True
+            for a in G.aligned[v]:
+                if root[a] < root[v]:
+                    root[v] = root[a]; changed = True
+    size = [0] * N
+    for v in range(N):
+        size[root[v]] += 1
+    base, acc = [0] * N, 0
+    for r in range(N):
+        base[r] = acc
+        acc += size[r]
+    order = [-1] * N
+    done, ignored = [False] * N, [False] * N
+    for r in range(N):
+        if size[r] == 0:
+            continue
+        assert root[r] == r
+        if size[r] == 1:
+            order[base[r]] = r
+            continue
+        # one search: frames (node, cursor) grow from the end of the root's own stretch of `order`, emitted nodes from its start
+        lo, hi = base[r], base[r] + size[r]
+        sp, k = hi, lo
+        sp -= 1; order[sp] = (r, 0)
+        while sp < hi:
+            v, cur = order[sp]
+            if cur == 0 and not ignored[v]:
+                for a in G.aligned[v]:
+                    assert not done[a]
+                    ignored[a] = True
+            deps = ([] if ignored[v] else G.aligned[v][::-1]) + G.pred[v][::-1]      # the order spoa's stack hands them out
+            nxt = -1
+            while cur < len(deps):
+                d = deps[cur]; cur += 1
+                if root[d] == r and not done[d]:
+                    nxt = d
+                    break
+                assert root[d] <= r
+            if nxt >= 0:
+                order[sp] = (v, cur)
+                sp -= 1
+                assert sp >= k
+                order[sp] = (nxt, 0)
+                continue
+            done[v] = True
+            sp += 1
+            if not ignored[v]:
+                order[k] = v; k += 1
+                for a in G.aligned[v]:
+                    order[k] = a; k += 1
+                assert k <= sp or sp == hi
+        assert k == hi
+    G.order = order
+    for i, v in enumerate(order):
+        G.rank[v] = i + 1
 
 
 def align(P, G, seq):
@@ -180,12 +259,14 @@ def align(P, G, seq):
             best, bi, bj = int(H[L]), r, L
     pn = [0] * L
     r, j = bi, bj
+    steps = 0
     while r > 0 and j > 0:
         bits, slots, pr = planes[r]
         b = int(bits[j - 1])
         code = b & 63
         if code == CODE_ZERO:
             break
+        steps += 1
         if code > CODE_VERT:
             pn[j - 1] = r
             r, j = pr[CODE_DIAG - code], j - 1
@@ -207,43 +288,46 @@ def align(P, G, seq):
                     j -= 1
                     if not (int(bits[c - 1]) & B_HX):
                         break
-    return pn, best
+    if P.algorithm == 1:
+        # global mode: the walk goes on to (0, 0) along the borders -- vertical steps in column 0 hold no base, horizontal
+        # steps in row 0 hold bases without a node: either way the whole sequence is inside the alignment
+        steps += r + j
+        j = 0
+    return pn, best, j, bj - 1, steps
 
 
-def fuse(G, seq, pn):
-    N, L = len(G.order), len(seq)
-    bnd, nextb = [0] * L, N + 1
-    for j in range(L - 1, -1, -1):
-        if pn[j] > 0:
-            nextb = G.span(G.order[pn[j] - 1])[0]
-        bnd[j] = nextb
-    keys = [((r * 4 + 2) << 24, G.order[r - 1]) for r in range(1, N + 1)]
-    used = []
-    for j in range(L):
+def fuse(G, seq, pn, jb, je, steps):
+    """Graph::AddAlignment: node ids go to the bases in front of the alignment, then to those behind it, then to the bases
+    [jb, je] it holds, one by one.  pn[j] = rank of the node base j is aligned to (0: none)."""
+    L = len(seq)
+    if steps == 0:
+        jb, je = L, L - 1
+    elif jb > je:
+        raise ValueError('alignment without a base (spoa throws)')
+    used = [-1] * L
+    for j in list(range(0, jb)) + list(range(je + 1, L)):
+        used[j] = G.new(int(seq[j]))
+    for j in range(jb, je + 1):
         b = int(seq[j])
         if pn[j] > 0:
             v = G.order[pn[j] - 1]
             use = v if G.code[v] == b else next((a for a in G.aligned[v] if G.code[a] == b), -1)
             if use < 0:
-                hi = G.span(v)[1]
                 use = G.new(b)
                 if len(G.aligned[v]) >= G.MAXA:
                     raise OverflowError('aligned set')
                 for a in G.aligned[v]:
                     G.aligned[a].append(use); G.aligned[use].append(a)
                 G.aligned[v].append(use); G.aligned[use].append(v)
-                keys.append((((hi + 1) * 4 + 0) << 24, use))
         else:
             use = G.new(b)
-            keys.append((((bnd[j] * 4 + 1) << 24) + j, use))
-        used.append(use)
-        G.cov[use] += 1
+        used[j] = use
+    for j in range(L):
+        if L >= 2:
+            G.cov[used[j]] += 1
         if j > 0:
-            G.edge(used[j - 1], use, 2)
-    keys.sort()
-    G.order = [v for _, v in keys]
-    for r, v in enumerate(G.order):
-        G.rank[v] = r + 1
+            G.edge(used[j - 1], used[j], 2)
+    topo_sort(G, used)
     return used
 
 
@@ -287,21 +371,22 @@ def consensus(G, min_cov=0):
 
 
 def poa(seqs, algorithm=0, genmsa=False, m=10, n=-4, g=-8, e=-2, q=-24, c=-1, min_coverage=0):
-    """seqs: int8 code arrays.  -> (consensus codes, msa rows (codes, 45 = '-'), end-cell scores)"""
+    """seqs: arrays of letters (any small integers; equality is all that matters).  -> (consensus letters, msa rows (letters,
+    45 = '-'; none for an empty sequence), end-cell scores)"""
     P = Params(algorithm, m, n, g, e, q, c)
     G = Graph()
     paths, scores = [], []
     for s in seqs:
         s = np.asarray(s, dtype=np.int64)
         if len(s) == 0:
-            paths.append([]); scores.append(0)
+            scores.append(0)
             continue
         if not G.order:
-            pn, sc = [0] * len(s), 0
+            pn, sc, jb, je, steps = [0] * len(s), 0, 0, -1, 0
         else:
-            pn, sc = align(P, G, s)
+            pn, sc, jb, je, steps = align(P, G, s)
         scores.append(sc)
-        paths.append(fuse(G, s, pn))
+        paths.append(fuse(G, s, pn, jb, je, steps))
     cons = consensus(G, min_coverage)
     rows = []
     if genmsa:
@@ -318,4 +403,4 @@ def poa(seqs, algorithm=0, genmsa=False, m=10, n=-4, g=-8, e=-2, q=-24, c=-1, mi
             for v in p:
                 row[col[v]] = G.code[v]
             rows.append(row)
-    return cons, rows, scores
+    return cons, rows, scores, list(G.order)

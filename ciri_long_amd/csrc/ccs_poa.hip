@@ -251,10 +251,10 @@ struct PoaWs {            // views into one wave's workspace slot
     int8_t* base; int8_t* np; int8_t* na; int32_t* pred; int32_t* pw; int32_t* aligned; int32_t* cov; int32_t* nout; int32_t* order; int32_t* rank;
     int32_t* root; uint32_t* rsz; int32_t* ntr; uint8_t* st;                 // the topological sort (poa_sort)
     int32_t* pn; int32_t* pj;                                                // per base of the sequence being added
-    uint2* ri; uint32_t* rx; uint32_t* tab; int32_t* score; int32_t* bp; short* col0;     // rank space
+    uint2* ri; uint32_t* tab; int32_t* score; int32_t* bp; short* col0;     // rank space
     short* carry; int cpitch;
     uint8_t* dp; size_t dp_bytes;                                            // the rest of the slot: DP planes of the current sequence
-    uint8_t* dirA; uint8_t* dirB; short* keepH; uint8_t* keepD;             // set per sequence (poa_add)
+    short* planeH; unsigned short* planeD;                                   // set per sequence (poa_add): H and the clamped differences
 };
 
 // row pitch (elements) of the DP planes for a sequence of m bases: column j sits at element j+7,
@@ -270,7 +270,7 @@ __host__ __device__ inline size_t poa_fixed_bytes(int ncap, int mcap, int* cpitc
     add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap); add(sizeof(int32_t) * ncap);   // cov nout order rank
     add(sizeof(int32_t) * (size_t)(ncap + mcap + 2)); add(sizeof(int32_t) * (size_t)(ncap + mcap + 2));    // pn pj (pn doubles as the consensus path)
     add(sizeof(int32_t) * ncap); add(sizeof(uint32_t) * ncap); add(sizeof(int32_t) * ncap); add(ncap);    // root rsz ntr st
-    add(sizeof(uint2) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));   // ri rx tab
+    add(sizeof(uint2) * (size_t)(ncap + 2)); add(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));   // ri tab
     add(sizeof(int32_t) * (size_t)(ncap + 2)); add(sizeof(int32_t) * (size_t)(ncap + 2)); add(sizeof(short) * (size_t)(ncap + 2));        // score bp col0
     const int cp = (ncap + 2 + 7) & ~7;
     if (cpitch_out) *cpitch_out = cp;
@@ -278,15 +278,12 @@ __host__ __device__ inline size_t poa_fixed_bytes(int ncap, int mcap, int* cpitc
     add(ncap); add(ncap); add(ncap);                                                                       // base np na
     return o;
 }
-// DP planes of one sequence against N rows: byte plane, slot plane (one byte) of nm rows, kept rows (H int16 + vertical states int8)
-__host__ __device__ inline size_t poa_dp_bytes(int N, int m, int nm, int nk)
+// DP planes of one sequence against N rows: H (int16) and the clamped differences (16 bits), one row more than the graph has
+__host__ __device__ inline size_t poa_plane_bytes(int N, int m) { return (((size_t)(N + 1) * (size_t)poa_pitch(m) * 2 + 15) & ~(size_t)15) + 64; }
+__host__ __device__ inline size_t poa_dp_bytes(int N, int m) { return 2 * poa_plane_bytes(N, m); }
+__host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)       // worst case
 {
-    const size_t gp = (size_t)poa_pitch(m);
-    return (((size_t)(N + 1) * gp + 15) & ~(size_t)15) + (((size_t)nm * gp + 15) & ~(size_t)15) + (size_t)nk * gp * 2 + (size_t)nk * gp + 64;
-}
-__host__ __device__ inline size_t poa_slot_bytes(int ncap, int mcap)       // worst case: every row has several in-edges and is kept
-{
-    return poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(ncap, mcap - 1, ncap, ncap) + 64;
+    return poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(ncap, mcap - 1) + 64;
 }
 
 __device__ PoaWs carve(uint8_t* slot, size_t slot_bytes, int ncap, int mcap)
@@ -308,7 +305,6 @@ __device__ PoaWs carve(uint8_t* slot, size_t slot_bytes, int ncap, int mcap)
     w.ntr = (int32_t*)take(sizeof(int32_t) * ncap);
     w.st = (uint8_t*)take(ncap);
     w.ri = (uint2*)take(sizeof(uint2) * (size_t)(ncap + 2));
-    w.rx = (uint32_t*)take(sizeof(uint32_t) * (size_t)(ncap + 2));
     w.tab = (uint32_t*)take(sizeof(uint32_t) * 3 * (size_t)(ncap + 2));
     w.score = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + 2));
     w.bp = (int32_t*)take(sizeof(int32_t) * (size_t)(ncap + 2));
@@ -320,13 +316,12 @@ __device__ PoaWs carve(uint8_t* slot, size_t slot_bytes, int ncap, int mcap)
     w.na = (int8_t*)take(ncap);
     w.dp = slot + o;
     w.dp_bytes = slot_bytes > o ? slot_bytes - o : 0;
-    w.dirA = nullptr; w.dirB = nullptr; w.keepH = nullptr; w.keepD = nullptr;
+    w.planeH = nullptr; w.planeD = nullptr;
     return w;
 }
 
 extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];     // K3's dynamic LDS block
-static constexpr int POA_LDS_BYTES = 9216;           // ring of recent rows (DP) / keys (re-rank) / score per rank (heaviest bundle)
-static constexpr int POA_RERANK_LDS_KEYS = POA_LDS_BYTES / 8;
+static constexpr int POA_LDS_BYTES = 9216;           // ring of recent rows (DP) / band of the planes + the sequence (back-track) / score per rank (heaviest bundle)
 static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whose scores fit the LDS block
 
 #ifdef CLH_DEBUG_POA
@@ -353,11 +348,11 @@ static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whos
 #define POA_WAVES 4
 #endif
 __device__ __forceinline__ int poa_cols(int m) { const int c = (m + 127) >> 7; return c < 1 ? 1 : (c > POA_MAXCP ? POA_MAXCP : c); }   // column pairs per lane
-__device__ __forceinline__ int poa_ring_pitch(int m) { const int W = 128 * poa_cols(m); return poa_pitch(m < W ? m : W); }   // LDS row pitch: the widest pass
+__device__ __forceinline__ int poa_ring_cp(int m) { return m > 128 * POA_MAXCP ? POA_MAXCP : poa_cols(m); }     // registers per lane of the widest pass
 __device__ __forceinline__ int poa_ring(int m) {
-    const int lp = poa_ring_pitch(m);
-    int ring = 16;                                   // power of two, so slot = rank & (ring-1); a ring row is 3 bytes per element
-    while (ring * lp * 3 > POA_LDS_BYTES) ring >>= 1;
+    const int row = 512 * poa_ring_cp(m) + 4;        // raw packed registers: H and differences, 64 lanes each, + the left-boundary H
+    int ring = 16;                                   // power of two, so slot = rank & (ring-1)
+    while (ring * row > POA_LDS_BYTES) ring >>= 1;
     return ring;
 }
 
@@ -443,28 +438,60 @@ __device__ __forceinline__ void scan_left_pk2(const uint32_t (&a)[CP], int leftA
     for (int t = 0; t < CP; ++t) { pa[t] = pk_max(runA[t], exA); pb[t] = pk_max(runB[t], exB); }
 }
 
+// lo half = half hx of x, hi half = half hy of y (one v_perm_b32)
+template <int HX, int HY>
+__device__ __forceinline__ uint32_t mix16(uint32_t x, uint32_t y) {
+    constexpr uint32_t sel = (uint32_t)(2 * HX) | ((uint32_t)(2 * HX + 1) << 8) | ((uint32_t)(4 + 2 * HY) << 16) | ((uint32_t)(4 + 2 * HY + 1) << 24);
+    return __builtin_amdgcn_perm(y, x, sel);
+}
+// packed registers (low halves = the lane's first CP columns, high halves the next CP) <-> natural column order (dword d = columns 2d, 2d+1)
 template <int CP>
-__device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int pass, const int colbase,
+__device__ __forceinline__ void to_natural(const uint32_t (&p)[CP], uint32_t (&nat)[CP]) {
+    if constexpr (CP == 1) nat[0] = p[0];
+    else if constexpr (CP == 2) { nat[0] = mix16<0, 0>(p[0], p[1]); nat[1] = mix16<1, 1>(p[0], p[1]); }
+    else if constexpr (CP == 3) { nat[0] = mix16<0, 0>(p[0], p[1]); nat[1] = mix16<0, 1>(p[2], p[0]); nat[2] = mix16<1, 1>(p[1], p[2]); }
+    else { nat[0] = mix16<0, 0>(p[0], p[1]); nat[1] = mix16<0, 0>(p[2], p[3]); nat[2] = mix16<1, 1>(p[0], p[1]); nat[3] = mix16<1, 1>(p[2], p[3]); }
+}
+template <int CP>
+__device__ __forceinline__ void to_packed(const uint32_t (&nat)[CP], uint32_t (&p)[CP]) {
+    if constexpr (CP == 1) p[0] = nat[0];
+    else if constexpr (CP == 2) { p[0] = mix16<0, 0>(nat[0], nat[1]); p[1] = mix16<1, 1>(nat[0], nat[1]); }
+    else if constexpr (CP == 3) { p[0] = mix16<0, 1>(nat[0], nat[1]); p[1] = mix16<1, 0>(nat[0], nat[2]); p[2] = mix16<0, 1>(nat[1], nat[2]); }
+    else { p[0] = mix16<0, 0>(nat[0], nat[2]); p[1] = mix16<1, 1>(nat[0], nat[2]); p[2] = mix16<0, 0>(nat[1], nat[3]); p[3] = mix16<1, 1>(nat[1], nat[3]); }
+}
+
+// ---- the lazy forward pass (round 3) ------------------------------------------------------------------------------------
+// A cell keeps no back-track code.  It leaves H (int16) and ONE 16-bit word of clamped differences -- the two vertical states
+// as the following rows read them (dF = max(F + e - g - H, -1) + 1 in 3 bits, dO likewise with c, q in 5) and the two horizontal
+// states the same way (dE, dQ) -- in two planes in HBM, natural column order; spoa's value-comparing back-track is replayed
+// from those on the few hundred cells of the path (poa_backtrack; tools/poa_model.py: backtrack_lazy is the derivation, checked
+// against the five-matrix oracle on the CPU).  Per cell pair: the maxima only -- no strictly-greater updates, no code selection.
+// A source row that is not the row before comes from the LDS ring (raw packed registers) or, older, from the planes.
+static constexpr int D_F = 0x0007, D_O_SHIFT = 3, D_E_SHIFT = 8, D_Q_SHIFT = 11;
+
+template <int CP>
+__device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int pass, const int colbase,
                            const bool more, const int RING, int& bs_io, int& br_io, int& bc_io DBGARG)
 {
     constexpr int C = 2 * CP;
     const int gp = poa_pitch(m);
-    const int lp = poa_ring_pitch(m);
     const int rmask = RING - 1;
     const bool sw = S.algorithm == 0, nw = S.algorithm == 1;
     const int g = S.g, e = S.e, q = S.q, c = S.c;
     const uint32_t g2 = dup16(g), e2 = dup16(e), q2 = dup16(q), c2 = dup16(c), sm2 = dup16(S.m), dsn2 = dup16(S.n - S.m);
+    const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
     const uint32_t NEG2 = dup16(POA_NEG), ONE2 = 0x00010001u;
-    short* ringH = (short*)poa_lds;
-    uint8_t* ringD = (uint8_t*)(ringH + RING * lp);
+    // ring row: CP dwords of H per lane, then CP dwords of differences per lane; behind the rows one left-boundary H per row
+    uint32_t* ring = poa_lds;
+    const int rrow = 128 * poa_ring_cp(m);
+    int* ringL = (int*)(poa_lds + RING * rrow);
     const bool last = !more;
     const int lc0 = C * lane, col0 = colbase + lc0;              // register t: low half = column col0+t+1, high half = column col0+CP+t+1
     const int mc = m - 1 - colbase;                              // last pass: where column m lives
     const int lm = mc / C, tm = (mc % C) % CP, hm = (mc % C) / CP;
     uint32_t sbP[CP], jeP[CP], jcP[CP];
 #pragma unroll
-    // letters are bytes; a column beyond the sequence holds 0x100 (bit 8): pk_sra15(sbP << 7) is 0xFFFF in those halves --
-    // recomputed where needed, a register per pair held across the row loop costs more (measured)
+    // letters are bytes; a column beyond the sequence holds 0x100 (bit 8): pk_sra15(sbP << 7) is 0xFFFF in those halves
     for (int t = 0; t < CP; ++t) {
         const int jlo = col0 + t + 1, jhi = jlo + CP;
         sbP[t] = pack16(jlo <= m ? (int)(uint8_t)seq[jlo - 1] : 0x100, jhi <= m ? (int)(uint8_t)seq[jhi - 1] : 0x100);
@@ -477,16 +504,19 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
     };
     const short* cprev = w.carry + (size_t)(pass & 1) * 3 * w.cpitch;
     short* cnext = w.carry + (size_t)((pass + 1) & 1) * 3 * w.cpitch;
-    uint2 blk = make_uint2(0, 0); uint32_t xblk = 0; int cH = 0, cE = POA_NEG, cQ = POA_NEG;
-    auto fetch = [&](int rr, uint2& b, uint32_t& x, int& h, int& ee, int& qq) {
-        b = make_uint2(0, 0); x = 0; h = 0; ee = POA_NEG; qq = POA_NEG;
+    const bool carried = pass > 0;
+    uint2 blk = make_uint2(0, 0); int cH = 0, cE = POA_NEG, cQ = POA_NEG;
+    auto fetch = [&](int rr, uint2& b, int& h, int& ee, int& qq) {
+        b = make_uint2(0, 0); h = 0; ee = POA_NEG; qq = POA_NEG;
         if (rr <= N) {
-            b = w.ri[rr]; x = w.rx[rr];
-            if (pass > 0) { h = (int)cprev[rr]; ee = (int)cprev[w.cpitch + rr]; qq = (int)cprev[2 * w.cpitch + rr]; }
+            b = w.ri[rr];
+            if (carried) { h = (int)cprev[rr]; ee = (int)cprev[w.cpitch + rr]; qq = (int)cprev[2 * w.cpitch + rr]; }
             else if (nw) h = (int)w.col0[rr];
         }
     };
-    fetch(1 + lane, blk, xblk, cH, cE, cQ);
+    // H of the column in front of the pass for a row that is not the row before
+    auto left_of = [&](int qr) -> int { return carried ? (int)cprev[qr] : (nw ? (int)w.col0[qr] : 0); };
+    fetch(1 + lane, blk, cH, cE, cQ);
     uint32_t px[CP], pf[CP], po[CP];                             // the previous row, still in registers (packed)
     int pcin = 0;
 #pragma unroll
@@ -495,27 +525,30 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
     uint32_t bsP = sw ? 0u : 0x80008000u, brP = 0, bcP = 0;
     int nbest = -(1 << 30), nrow = 0;                            // global mode: cells (sink row, column m), wave-uniform
     uint32_t lowP = 0x7fff7fffu;                                 // global / overlap: the lowest H of the pass (local cells are >= 0)
+    const bool stores = col0 + 1 <= m;
+    short* hrow = w.planeH + col0 + 8;                           // + r * gp per row
+    unsigned short* drow = w.planeD + col0 + 8;
     for (int rb = 1; rb <= N; rb += 64) {
-        uint2 nblk; uint32_t nxblk; int nH, nE, nQ;
-        fetch(rb + 64 + lane, nblk, nxblk, nH, nE, nQ);
+        uint2 nblk; int nH, nE, nQ;
+        fetch(rb + 64 + lane, nblk, nH, nE, nQ);
         const int cnt = N - rb + 1 < 64 ? N - rb + 1 : 64;
         int cobH = 0, cobE = 0, cobQ = 0;
         for (int i = 0; i < cnt; ++i) {
             const int r = rb + i;
             SEC0();
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
-            const uint32_t rxv = (uint32_t)__builtin_amdgcn_readlane((int)xblk, i);
-            const int cinH = __builtin_amdgcn_readlane(cH, i), cinE = __builtin_amdgcn_readlane(cE, i), cinQ = __builtin_amdgcn_readlane(cQ, i);
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i);
+            int cinH = 0, cinE = POA_NEG, cinQ = POA_NEG;
+            if (carried | nw) cinH = __builtin_amdgcn_readlane(cH, i);
+            if (carried) { cinE = __builtin_amdgcn_readlane(cE, i); cinQ = __builtin_amdgcn_readlane(cQ, i); }
             const int vb = (int)(d0 & 0xff), np = (int)((d0 >> 8) & 0xf);
-            const bool sink = (d0 & 0x1000u) != 0, tolds = (d0 & 0x4000u) != 0, keep = (d0 & 0x8000u) != 0;
-            const int p0 = (int)(d0 >> 16), p1 = (int)(d1 & 0xffff), p2 = (int)(d1 >> 16);
-            const int mi = (int)(rxv & 0xffff), ki = (int)(rxv >> 16);
+            const bool sink = (d0 & 0x1000u) != 0, tolds = (d0 & 0x4000u) != 0;
+            const int p0 = (int)(d0 >> 16);
             uint32_t ss[CP];
             {
                 const uint32_t vb2 = dup16(vb);
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
-                    const uint32_t nz = pk_minu(sbP[t] ^ vb2, ONE2);                 // 0 where the base equals the node's
+                    const uint32_t nz = pk_minu(sbP[t] ^ vb2, ONE2);                 // 0 where the letter equals the node's
                     ss[t] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, nz) * __builtin_bit_cast(u16x2, dsn2) + __builtin_bit_cast(u16x2, sm2));
                 }
             }
@@ -534,32 +567,27 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                     hsh0 = hand_down(px[CP - 1], pcin);
                 } else {
                     uint32_t dd[CP];
-                    int a0, a1;                                  // the two elements in front of the two halves
+                    int left;
                     if (r - qr < RING) {
-                        const short* sh = ringH + (qr & rmask) * lp + lc0 + 8;
-                        const uint8_t* sd = ringD + (qr & rmask) * lp + lc0 + 8;
-                        a0 = sh[-1]; a1 = sh[CP - 1];
+                        const uint32_t* rp = ring + (qr & rmask) * rrow + lane * CP;
 #pragma unroll
-                        for (int t = 0; t < CP; ++t) { h[t] = pack16(sh[t], sh[CP + t]); dd[t] = (uint32_t)sd[t] | ((uint32_t)sd[CP + t] << 16); }
+                        for (int t = 0; t < CP; ++t) { h[t] = rp[t]; dd[t] = rp[64 * CP + t]; }
+                        left = ringL[qr & rmask];
                     } else {
-                        const int kq = (int)(__builtin_amdgcn_readfirstlane((int)w.rx[qr]) >> 16) & 0xffff;
-                        const short* sh = w.keepH + (size_t)kq * gp + col0 + 8;
-                        const uint8_t* sd = w.keepD + (size_t)kq * gp + col0 + 8;
-                        int hv[C], dv[C];
-                        asm volatile("global_load_sshort %0, %1, off" : "=v"(a0) : "v"(sh - 1) : "memory");
+                        uint32_t nh[CP], nd[CP];
+                        const uint32_t* sh = (const uint32_t*)(hrow + (size_t)qr * gp);
+                        const uint32_t* sd = (const uint32_t*)(drow + (size_t)qr * gp);
 #pragma unroll
-                        for (int k = 0; k < C; ++k) asm volatile("global_load_sshort %0, %1, off" : "=v"(hv[k]) : "v"(sh + k) : "memory");
+                        for (int t = 0; t < CP; ++t) asm volatile("global_load_dword %0, %1, off" : "=v"(nh[t]) : "v"(sh + t) : "memory");
 #pragma unroll
-                        for (int k = 0; k < C; ++k) asm volatile("global_load_ubyte %0, %1, off" : "=v"(dv[k]) : "v"(sd + k) : "memory");
+                        for (int t = 0; t < CP; ++t) asm volatile("global_load_dword %0, %1, off" : "=v"(nd[t]) : "v"(sd + t) : "memory");
+                        left = left_of(qr);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                        for (int k = 0; k < C; ++k) asm volatile("" : "+v"(hv[k]), "+v"(dv[k]));
-                        asm volatile("" : "+v"(a0));
-                        a1 = hv[CP - 1];
-#pragma unroll
-                        for (int t = 0; t < CP; ++t) { h[t] = pack16(hv[t], hv[CP + t]); dd[t] = (uint32_t)dv[t] | ((uint32_t)dv[CP + t] << 16); }
+                        for (int t = 0; t < CP; ++t) asm volatile("" : "+v"(nh[t]), "+v"(nd[t]));
+                        to_packed<CP>(nh, h); to_packed<CP>(nd, dd);
                     }
-                    hsh0 = pack16(a0, a1);
+                    hsh0 = hand_down(h[CP - 1], left);
 #pragma unroll
                     for (int t = 0; t < CP; ++t) {
                         fs[t] = pk_adds(h[t], pk_subu(dd[t] & 0x00070007u, ONE2));
@@ -568,157 +596,89 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                 }
             };
             SEC(8);
-            uint32_t best[CP], code[CP], fsn[CP], osn[CP], xb[CP];   // xb: bit 7 of each half = vstop; multi rows: bits 8.. = slot of the upward run
-            if (np <= 1) {
+            uint32_t dg[CP], MF[CP], MO[CP];
+            {
                 uint32_t h[CP], hsh0, fs[CP], os[CP];
                 source(np == 0 ? 0 : p0, h, hsh0, fs, os);
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
-                    uint32_t b = sw ? 0u : NEG2, cd = dup16(CODE_ZERO);
-                    upd(b, cd, pk_adds(t == 0 ? hsh0 : h[t - 1], ss[t]), dup16(CODE_DIAG));
-                    upd(b, cd, pk_adds(fs[t], g2), dup16(CODE_VERT));
-                    upd(b, cd, pk_adds(h[t], g2), dup16(CODE_VERT - 1));
-                    upd(b, cd, pk_adds(os[t], q2), dup16(CODE_VERT - 2));
-                    best[t] = b; code[t] = cd;
-                    fsn[t] = pk_adds(pk_max(fs[t], h[t]), e2);
-                    osn[t] = pk_adds(pk_max(os[t], h[t]), c2);
-                    xb[t] = ~pk_sra15(pk_subs(h[t], fs[t])) & 0x00800080u;          // vstop: H_p >= Fs_p
+                    dg[t] = pk_adds(t == 0 ? hsh0 : h[t - 1], ss[t]);
+                    MF[t] = pk_max(h[t], fs[t]); MO[t] = pk_max(h[t], os[t]);
                 }
-            } else {
-                uint32_t bD[CP], cD[CP], bV[CP], cV[CP], MX[CP], MO[CP], XF[CP], cF[CP], XO[CP], cO[CP];
-#pragma unroll
-                for (int t = 0; t < CP; ++t) { bD[t] = NEG2; cD[t] = 0; bV[t] = NEG2; cV[t] = 0; MX[t] = NEG2; MO[t] = NEG2; XF[t] = 0x80008000u; cF[t] = 0; XO[t] = 0x80008000u; cO[t] = 0; }
-                auto add_source = [&](int slot, int qr) {
+            }
+            if (np > 1) {
+                const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
+                auto add_source = [&](int qr) {
                     uint32_t h[CP], hsh0, fs[CP], os[CP];
                     source(qr, h, hsh0, fs, os);
-                    const uint32_t xo = dup16(2 * (POA_MAXP - slot) + 1), xe = dup16(2 * (POA_MAXP - slot));
 #pragma unroll
                     for (int t = 0; t < CP; ++t) {
-                        upd(bD[t], cD[t], pk_adds(t == 0 ? hsh0 : h[t - 1], ss[t]), dup16(CODE_DIAG - slot));
-                        upd(bV[t], cV[t], pk_adds(fs[t], g2), dup16(CODE_VERT - 3 * slot));
-                        upd(bV[t], cV[t], pk_adds(h[t], g2), dup16(CODE_VERT - 3 * slot - 1));
-                        upd(bV[t], cV[t], pk_adds(os[t], q2), dup16(CODE_VERT - 3 * slot - 2));
-                        MX[t] = pk_max(MX[t], pk_max(fs[t], h[t]));
-                        MO[t] = pk_max(MO[t], pk_max(os[t], h[t]));
-                        upd(XF[t], cF[t], h[t], xo); upd(XF[t], cF[t], fs[t], xe);     // upward run: open before extend, earlier in-edge first
-                        upd(XO[t], cO[t], h[t], xo); upd(XO[t], cO[t], os[t], xe);
+                        dg[t] = pk_max(dg[t], pk_adds(t == 0 ? hsh0 : h[t - 1], ss[t]));
+                        MF[t] = pk_max(MF[t], pk_max(h[t], fs[t])); MO[t] = pk_max(MO[t], pk_max(h[t], os[t]));
                     }
                 };
-                add_source(0, p0);
-                add_source(1, p1);
-                if (np > 2) add_source(2, p2);
+                add_source((int)(d1 & 0xffff));
+                if (np > 2) add_source((int)(d1 >> 16));
                 if (np > 3) {                                    // rare: in-edges beyond the third come from HBM
                     const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
-                    for (int s2 = 3; s2 < np; ++s2) add_source(s2, __builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + s2]]));
-                }
-#pragma unroll
-                for (int t = 0; t < CP; ++t) {
-                    uint32_t b = sw ? 0u : NEG2, cd = dup16(CODE_ZERO);
-                    upd(b, cd, bD[t], cD[t]);                    // all diagonals before all verticals
-                    upd(b, cd, bV[t], cV[t]);
-                    best[t] = b; code[t] = cd;
-                    fsn[t] = pk_adds(MX[t], e2); osn[t] = pk_adds(MO[t], c2);
-                    // in-edge an upward run leaves through: the earlier of the two levels' first hits, F before O in one in-edge
-                    const uint32_t kF = pk_shr(cF[t], 1), kO = pk_shr(cO[t], 1);               // POA_MAXP - slot
-                    const uint32_t useO = pk_sra15(pk_subs(kF, kO));                             // 0xFFFF where F's in-edge comes later
-                    const uint32_t sel = bfi(useO, cO[t], cF[t]);
-                    const uint32_t slot2 = pk_subu(dup16(POA_MAXP), pk_shr(sel, 1));
-                    xb[t] = ((sel & ONE2) << 7) | (slot2 << 8);
+                    for (int s2 = 3; s2 < np; ++s2) add_source(__builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + s2]]));
                 }
             }
             SEC(9);
+            uint32_t M0[CP], fsn[CP], osn[CP];
+#pragma unroll
+            for (int t = 0; t < CP; ++t) {
+                fsn[t] = pk_adds(MF[t], e2); osn[t] = pk_adds(MO[t], c2);
+                uint32_t b = pk_max(dg[t], pk_max(pk_adds(MF[t], g2), pk_adds(MO[t], q2)));
+                if (sw) b = pk_max(b, 0u);
+                M0[t] = b;
+            }
             // horizontal states: two prefix maxima in the gap-free frames of the two pieces
-            uint32_t ehat[CP], qhat[CP];
+            uint32_t X[CP], Y[CP];                              // Ehat + e - g and Qhat + c - q: the states as the next column reads them
             {
                 uint32_t a[CP], b[CP], pe[CP], pq[CP];
                 const int leftE = cinH > cinE + e - g ? cinH : cinE + e - g;       // = E[first column of the pass] - g
                 const int leftQ = cinH > cinQ + c - q ? cinH : cinQ + c - q;
 #pragma unroll
-                for (int t = 0; t < CP; ++t) { a[t] = pk_subs(best[t], jeP[t]); b[t] = pk_subs(best[t], jcP[t]); }
+                for (int t = 0; t < CP; ++t) { a[t] = pk_subs(M0[t], jeP[t]); b[t] = pk_subs(M0[t], jcP[t]); }
                 scan_left_pk2<CP>(a, leftE, pe, b, leftQ, pq);
-                const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
 #pragma unroll
-                for (int t = 0; t < CP; ++t) { ehat[t] = pk_adds(pk_adds(pe[t], jeP[t]), ge2); qhat[t] = pk_adds(pk_adds(pq[t], jcP[t]), qc2); }
+                for (int t = 0; t < CP; ++t) { X[t] = pk_adds(pe[t], jeP[t]); Y[t] = pk_adds(pq[t], jcP[t]); }
             }
             SEC(10);
-            uint32_t Hf[CP], E[CP];
+            uint32_t Hf[CP], qhat[CP], Es[CP], D[CP];
 #pragma unroll
-            for (int t = 0; t < CP; ++t) Hf[t] = pk_max(pk_max(best[t], ehat[t]), qhat[t]);
+            for (int t = 0; t < CP; ++t) { qhat[t] = pk_adds(Y[t], qc2); Hf[t] = pk_max(pk_max(M0[t], pk_adds(X[t], ge2)), qhat[t]); }
             const uint32_t q0 = hand_down(qhat[CP - 1], cinQ);
 #pragma unroll
-            for (int t = 0; t < CP; ++t) E[t] = pk_max(ehat[t], pk_adds(t == 0 ? q0 : qhat[t - 1], g2));     // E as spoa holds it
-            const uint32_t h0 = hand_down(Hf[CP - 1], cinH), e0 = hand_down(E[CP - 1], cinE);
-            uint32_t out[CP];
-#pragma unroll
             for (int t = 0; t < CP; ++t) {
-                const uint32_t hl = t == 0 ? h0 : Hf[t - 1], ep = t == 0 ? e0 : E[t - 1], qp = t == 0 ? q0 : qhat[t - 1];
-                const uint32_t c5 = pk_adds(ep, e2), c6 = pk_adds(hl, g2), c7 = pk_adds(qp, c2), c8 = pk_adds(hl, q2);
-                // Hf = max(best, c5, c6, c7) (c8 <= c6: q <= g).  Where a horizontal move wins (best < Hf) the code is the first of
-                // c5, c6, c7 that equals Hf -- the same answer as three strictly-greater updates, three operations fewer
-                const uint32_t lt5 = pk_sra15(pk_subs(c5, Hf[t])), lt6 = pk_sra15(pk_subs(c6, Hf[t]));
-                const uint32_t hcode = bfi(lt5, bfi(lt6, dup16(CODE_HORZ - 2), dup16(CODE_HORZ - 1)), dup16(CODE_HORZ));
-                const uint32_t cd = bfi(pk_sra15(pk_subs(best[t], Hf[t])), hcode, code[t]);
-                // hx: E or Q of this column extends the previous column's (E[j-1]+e >= H[j-1]+g, Q[j-1]+c >= H[j-1]+q)
-                const uint32_t both_lt = pk_sra15(pk_subs(c5, c6)) & pk_sra15(pk_subs(c7, c8));
-                out[t] = cd | (~both_lt & 0x00400040u) | (xb[t] & 0x00800080u);
+                Es[t] = pk_max(X[t], pk_adds(t == 0 ? q0 : qhat[t - 1], e2));       // E + e - g with E = max(Ehat, Qhat[j-1] + g), spoa's array
+                const uint32_t Hm = pk_subs(Hf[t], ONE2);
+                const uint32_t dF = pk_max(pk_subs(fsn[t], Hm), 0u), dO = pk_max(pk_subs(osn[t], Hm), 0u);
+                const uint32_t dE = pk_max(pk_subs(Es[t], Hm), 0u), dQ = pk_max(pk_subs(Y[t], Hm), 0u);
+                D[t] = (dF | (dO << 3)) | ((dE | (dQ << 3)) << 8);
             }
             SEC(11);
             // ---- what later rows and the back-track read ------------------------------------------------------------------
 #pragma unroll
             for (int t = 0; t < CP; ++t) { px[t] = Hf[t]; pf[t] = fsn[t]; po[t] = osn[t]; }
             pcin = cinH;
-            if (col0 + 1 <= m) {
-                uint8_t* dd = w.dirA + (size_t)r * gp + col0 + 8;
-                uint32_t w0 = 0, w1 = 0;                         // C bytes: the low halves' columns, then the high halves' (v_perm_b32 picks bytes 0 and 2)
-                if constexpr (CP == 1) w0 = __builtin_amdgcn_perm(0u, out[0], 0x0c0c0200u);
-                else if constexpr (CP == 2) w0 = __builtin_amdgcn_perm(out[1], out[0], 0x06020400u);
-                else if constexpr (CP == 3) { w0 = __builtin_amdgcn_perm(out[1], out[0], 0x0c0c0400u) | __builtin_amdgcn_perm(out[2], out[0], 0x02040c0cu);
-                                              w1 = __builtin_amdgcn_perm(out[2], out[1], 0x0c0c0602u); }
-                else { w0 = __builtin_amdgcn_perm(out[1], out[0], 0x0c0c0400u) | __builtin_amdgcn_perm(out[3], out[2], 0x04000c0cu);
-                       w1 = __builtin_amdgcn_perm(out[1], out[0], 0x0c0c0602u) | __builtin_amdgcn_perm(out[3], out[2], 0x06020c0cu); }
-#ifndef POA_EXPERIMENT_NO_DIR_STORE      // traffic experiment only (results are wrong without the codes): what K3 writes besides them
-                if constexpr (C == 8) *(uint2*)dd = make_uint2(w0, w1);
-                else if constexpr (C == 6) { __builtin_memcpy(dd, &w0, 4); const uint16_t x2 = (uint16_t)w1; __builtin_memcpy(dd + 4, &x2, 2); }
-                else if constexpr (C == 4) __builtin_memcpy(dd, &w0, 4);
-                else { const uint16_t x2 = (uint16_t)w0; __builtin_memcpy(dd, &x2, 2); }
-#endif
-                if (np > 1) {   // second plane: bytes 1 and 3 of xb, packed like the first plane's (byte stores would touch every sector of the row C times)
-                    uint8_t* db = w.dirB + (size_t)mi * gp + col0 + 8;
-                    uint32_t s0 = 0, s1 = 0;
-                    if constexpr (CP == 1) s0 = __builtin_amdgcn_perm(0u, xb[0], 0x0c0c0301u);
-                    else if constexpr (CP == 2) s0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x07030501u);
-                    else if constexpr (CP == 3) { s0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x0c0c0501u) | __builtin_amdgcn_perm(xb[2], xb[0], 0x03050c0cu);
-                                                  s1 = __builtin_amdgcn_perm(xb[2], xb[1], 0x0c0c0703u); }
-                    else { s0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x0c0c0501u) | __builtin_amdgcn_perm(xb[3], xb[2], 0x05010c0cu);
-                           s1 = __builtin_amdgcn_perm(xb[1], xb[0], 0x0c0c0703u) | __builtin_amdgcn_perm(xb[3], xb[2], 0x07030c0cu); }
-                    if constexpr (C == 8) *(uint2*)db = make_uint2(s0, s1);
-                    else if constexpr (C == 6) { __builtin_memcpy(db, &s0, 4); const uint16_t y2 = (uint16_t)s1; __builtin_memcpy(db + 4, &y2, 2); }
-                    else if constexpr (C == 4) __builtin_memcpy(db, &s0, 4);
-                    else { const uint16_t y2 = (uint16_t)s0; __builtin_memcpy(db, &y2, 2); }
-                }
-                if (tolds | keep) {
-                    uint32_t dv[CP];
-#pragma unroll
-                    for (int t = 0; t < CP; ++t) {
-                        const uint32_t df = pk_max(pk_adds(pk_subs(fsn[t], Hf[t]), ONE2), 0u), dq = pk_max(pk_adds(pk_subs(osn[t], Hf[t]), ONE2), 0u);
-                        dv[t] = df | (dq << 3);
-                    }
-                    if (tolds) {
-                        short* dh = ringH + (r & rmask) * lp + lc0 + 8;
-                        uint8_t* dl = ringD + (r & rmask) * lp + lc0 + 8;
-#pragma unroll
-                        for (int t = 0; t < CP; ++t) { dh[t] = (short)Hf[t]; dh[CP + t] = (short)(Hf[t] >> 16); dl[t] = (uint8_t)dv[t]; dl[CP + t] = (uint8_t)(dv[t] >> 16); }
-                    }
-                    if (keep) {
-                        short* hd = w.keepH + (size_t)ki * gp + col0 + 8;
-                        uint8_t* hb = w.keepD + (size_t)ki * gp + col0 + 8;
-#pragma unroll
-                        for (int t = 0; t < CP; ++t) { hd[t] = (short)Hf[t]; hd[CP + t] = (short)(Hf[t] >> 16); hb[t] = (uint8_t)dv[t]; hb[CP + t] = (uint8_t)(dv[t] >> 16); }
-                    }
-                }
+            if (stores) {
+                uint32_t nh[CP], nd[CP];
+                to_natural<CP>(Hf, nh); to_natural<CP>(D, nd);
+                uint32_t* dh = (uint32_t*)(hrow + (size_t)r * gp);
+                uint32_t* dd = (uint32_t*)(drow + (size_t)r * gp);
+                if constexpr (CP == 1) { *dh = nh[0]; *dd = nd[0]; }
+                else if constexpr (CP == 2) { *(uint2*)dh = make_uint2(nh[0], nh[1]); *(uint2*)dd = make_uint2(nd[0], nd[1]); }
+                else if constexpr (CP == 3) { __builtin_memcpy(dh, nh, 12); __builtin_memcpy(dd, nd, 12); }
+                else { *(uint4*)dh = make_uint4(nh[0], nh[1], nh[2], nh[3]); *(uint4*)dd = make_uint4(nd[0], nd[1], nd[2], nd[3]); }
             }
-            if (tolds && lane == 0) ringH[(r & rmask) * lp + 7] = (short)cinH;     // element of local column 0
-            if (keep && pass == 0 && lane == 0) w.keepH[(size_t)ki * gp + 7] = (short)cinH;
+            if (tolds) {
+                uint32_t* rp = ring + (r & rmask) * rrow + lane * CP;
+#pragma unroll
+                for (int t = 0; t < CP; ++t) { rp[t] = Hf[t]; rp[64 * CP + t] = D[t]; }
+                if (lane == 0) ringL[r & rmask] = cinH;
+            }
             SEC(12);
             if (!sw) {
 #pragma unroll
@@ -726,8 +686,7 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
             }
             // ---- end cell: first strict maximum in (rank, column) order --------------------------------------------
             if (sw | (!nw & sink)) {
-                // columns beyond the sequence (letter 0x100: bit 8) do not count.  (Leaving the mask off where no such cell can win
-                // -- local mode, negative mismatch, lanes entirely beyond the sequence switched off -- measured 0.5 ms SLOWER.)
+                // columns beyond the sequence (letter 0x100: bit 8) do not count
                 uint32_t hv2[CP];
 #pragma unroll
                 for (int t = 0; t < CP; ++t) hv2[t] = bfi(pk_sra15(sbP[t] << 7), 0x80008000u, Hf[t]);
@@ -752,15 +711,16 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
                 if (val > nbest) { nbest = val; nrow = r; }
             }
             if (more) {
-                const int rH = (int)__builtin_amdgcn_readlane((int)Hf[CP - 1], 63) >> 16, rE = (int)__builtin_amdgcn_readlane((int)E[CP - 1], 63) >> 16,
+                const int rH = (int)__builtin_amdgcn_readlane((int)Hf[CP - 1], 63) >> 16, rEs = (int)__builtin_amdgcn_readlane((int)Es[CP - 1], 63) >> 16,
                           rQ = (int)__builtin_amdgcn_readlane((int)qhat[CP - 1], 63) >> 16;
+                const int rE = rEs - (e - g);
                 cobH = lane == i ? rH : cobH; cobE = lane == i ? (rE < POA_NEG ? POA_NEG : rE) : cobE; cobQ = lane == i ? (rQ < POA_NEG ? POA_NEG : rQ) : cobQ;
             }
             SEC(13);
             asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
         }
         if (more && lane < cnt) { cnext[rb + lane] = (short)cobH; cnext[w.cpitch + rb + lane] = (short)cobE; cnext[2 * w.cpitch + rb + lane] = (short)cobQ; }
-        blk = nblk; xblk = nxblk; cH = nH; cE = nE; cQ = nQ;
+        blk = nblk; cH = nH; cE = nE; cQ = nQ;
     }
     if (more) phase_sync();
     {   // a cell at the floor of the int16 range may have been cut off there: the caller reports it (status 6)
@@ -787,8 +747,8 @@ __device__ void dp_pass_pk(const PoaWs& w, const PoaScores S, int N, int m, cons
     }
 }
 
-// DP rows of one sequence: passes of 512 columns (8 per lane, two per register); the last pass takes 2, 4, 6 or 8 columns
-// per lane by its width (a row step costs a fixed part plus a part per register)
+// DP rows of one sequence: passes of 128 * POA_MAXCP columns; the last pass takes 2, 4 or 6 columns per lane by its width (a
+// row step costs a fixed part plus a part per register)
 __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out, int& bc_out DBGARG)
 {
     constexpr int WMAX = 128 * POA_MAXCP;
@@ -800,10 +760,10 @@ __device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const i
         const bool more = rem > WMAX;
         const int cp = more ? POA_MAXCP : poa_cols(rem);
         switch (cp) {
-            case 1: dp_pass_pk<1>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
-            case 2: dp_pass_pk<2>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
-            case 3: dp_pass_pk<3>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
-            default: dp_pass_pk<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
+            case 1: dp_pass_lz<1>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
+            case 2: dp_pass_lz<2>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
+            case 3: dp_pass_lz<3>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
+            default: dp_pass_lz<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
         }
         if (br < 0) break;                               // a cell left the int16 range
     }
@@ -927,6 +887,179 @@ __device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& 
     }
 }
 
+// Back-track of the lazy formulation (tools/poa_model.py: backtrack_lazy; oracle/poa_oracle.c: align_gotoh's loop).  spoa walks
+// from the end cell and at every cell takes the first of its value tests that holds: diagonal through the in-edges in order,
+// then per in-edge F+e / H+g / O+c / H+q, then E+e / H+g / Q+c / H+q to the left; runs of gap steps continue by the tests of its
+// two inner loops.  Every value those tests read follows from H and the clamped differences of the cell itself, of its sources'
+// cells in the same and the previous column, and of its left neighbour.
+//  * The cells around the path are staged in LDS: rows r0-63 .. r0 (lane k holds row r0-k), 24 columns of each around the
+//    diagonal through the anchor cell, both planes; the sequence's letters too.  A cell outside the band is read from HBM.
+//  * Most steps are "diagonal through the first in-edge, which is the row before": lanes a, a+1, ... test that for the cells
+//    (r-l, j-l) at once, the length of the run of successes is taken in one step.
+//  * Any other step is evaluated with the in-edges across the lanes (first hit in in-edge order = lowest lane).
+// returns the column the walk ends in (the bases in front of it are not part of the alignment), or -1 (guard: corrupt planes).
+static constexpr int BT_W = 24;                       // columns per band row
+__device__ int poa_backtrack(const PoaWs& w, const PoaScores S, const int N, const int m, const int8_t* seq, const int lane, int r, int j, bool& moved)
+{
+    const bool sw = S.algorithm == 0, nw = S.algorithm == 1;
+    const int g = S.g, e = S.e, q = S.q, c = S.c;
+    const int gp = poa_pitch(m);
+    short* Hb = (short*)poa_lds;
+    unsigned short* Db = (unsigned short*)poa_lds + 64 * BT_W;
+    uint8_t* lseq = (uint8_t*)poa_lds + 4 * 64 * BT_W;
+    for (int i = lane; i < m; i += 64) lseq[i] = (uint8_t)seq[i];
+    auto row0_h = [&](int jj) -> int {
+        const int l1 = g + (jj - 1) * e, l2 = q + (jj - 1) * c;
+        return (sw || jj == 0) ? 0 : (l1 > l2 ? l1 : l2);
+    };
+    int r0 = -(1 << 20), j0 = 0;
+    uint2 rim = make_uint2(0, 0);
+    auto cs_of = [&](int k) -> int { const int x = j0 - k - BT_W / 2; return (x & 1) ? x : x - 1; };    // first column of band row k: odd = a dword boundary of the planes
+    auto reload = [&](int rr0, int jj0) {
+        r0 = rr0; j0 = jj0;
+        const int rr = r0 - lane;
+        rim = make_uint2(0, 0);
+        if (rr >= 1) {
+            rim = w.ri[rr];
+            const int cs = cs_of(lane);
+            if (cs + BT_W > 1) {
+                uint32_t t[BT_W / 2];
+                __builtin_memcpy(t, (const uint32_t*)(w.planeH + (size_t)rr * gp + cs + 7), BT_W * 2);
+                __builtin_memcpy(Hb + lane * BT_W, t, BT_W * 2);
+                __builtin_memcpy(t, (const uint32_t*)(w.planeD + (size_t)rr * gp + cs + 7), BT_W * 2);
+                __builtin_memcpy(Db + lane * BT_W, t, BT_W * 2);
+            }
+        }
+        __syncthreads();
+    };
+    auto Hat = [&](int rr, int jj) -> int {
+        if (rr == 0) return row0_h(jj);
+        if (jj == 0) return nw ? (int)w.col0[rr] : 0;
+        const int k = r0 - rr, x = jj - cs_of(k);
+        if ((unsigned)k < 64u && (unsigned)x < (unsigned)BT_W) return (int)Hb[k * BT_W + x];
+        return (int)w.planeH[(size_t)rr * gp + jj + 7];
+    };
+    auto Dat = [&](int rr, int jj) -> int {
+        if (rr == 0 || jj == 0) return 0;
+        const int k = r0 - rr, x = jj - cs_of(k);
+        if ((unsigned)k < 64u && (unsigned)x < (unsigned)BT_W) return (int)Db[k * BT_W + x];
+        return (int)w.planeD[(size_t)rr * gp + jj + 7];
+    };
+    // the graph row of rank rr (wave-uniform): from the staged block or from HBM
+    auto meta = [&](int rr, uint32_t& d0, uint32_t& d1) {
+        const int k = r0 - rr;
+        if ((unsigned)k < 64u) { d0 = (uint32_t)__builtin_amdgcn_readlane((int)rim.x, k); d1 = (uint32_t)__builtin_amdgcn_readlane((int)rim.y, k); }
+        else { const uint2 t = w.ri[rr]; d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.x); d1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.y); }
+    };
+    // rank of in-edge `s` of the row with graph row (d0, d1), per lane
+    auto pred_of = [&](int rr, uint32_t d0, uint32_t d1, int s) -> int {
+        const int np = (int)((d0 >> 8) & 0xf);
+        if (np == 0) return 0;
+        if (s == 0) return (int)(d0 >> 16);
+        if (s == 1) return (int)(d1 & 0xffff);
+        if (s == 2) return (int)(d1 >> 16);
+        return w.rank[w.pred[w.order[rr - 1] * POA_MAXP + s]];
+    };
+    __syncthreads();
+    int guard = 2 * (N + m) + 64;                           // every step lowers r or j: a longer walk means corrupt planes
+    while (r > 0 && j > 0) {
+        if (--guard < 0) return -1;
+        int a = r0 - r;
+        {
+            const int drift = j - (j0 - a);
+            if ((unsigned)a > 48u || drift < -8 || drift > 7) { reload(r, j); a = 0; }
+        }
+        {   // a run of diagonal steps through first in-edges that are the row before
+            const int l = lane - a, myr = r0 - lane, myc = j - l;
+            bool ok = l >= 0 && lane < 63 && myr >= 1 && myc >= 1;
+            if (ok) {
+                const int np = (int)((rim.x >> 8) & 0xf);
+                ok = (np == 0 ? 0 : (int)(rim.x >> 16)) == myr - 1;
+                if (ok) {
+                    const int hc = Hat(myr, myc), hd = Hat(myr - 1, myc - 1);
+                    const int sc = (int)(rim.x & 0xff) == (int)lseq[myc - 1] ? S.m : S.n;
+                    ok = hc == hd + sc && !(sw && hc == 0);
+                }
+            }
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok) >> a;
+            const int run = ~okm ? __builtin_ctzll(~okm) : 64;
+            if (run > 0) {
+                if (l >= 0 && l < run) w.pn[myc - 1] = myr;
+                r -= run; j -= run; moved = true;
+                continue;
+            }
+        }
+        // one step by spoa's full list of tests; lane s looks at in-edge s
+        uint32_t d0, d1;
+        meta(r, d0, d1);
+        const int h = Hat(r, j);
+        if (sw && h == 0) break;
+        moved = true;
+        {
+            const int np = (int)((d0 >> 8) & 0xf), npp = np ? np : 1;
+            const bool act = lane < npp;
+            int ps = 0, hp1 = 0, hp = 0, dp = 0;
+            if (act) { ps = pred_of(r, d0, d1, lane); hp1 = Hat(ps, j - 1); hp = Hat(ps, j); dp = Dat(ps, j); }
+            const int sc = (int)(d0 & 0xff) == (int)lseq[j - 1] ? S.m : S.n;
+            unsigned long long bm = __builtin_amdgcn_ballot_w64(act && h == hp1 + sc);
+            if (bm) {
+                if (lane == 0) w.pn[j - 1] = r;
+                r = __builtin_amdgcn_readlane(ps, __builtin_ctzll(bm)); --j;
+                continue;
+            }
+            const int fs = hp + (dp & 7) - 1, os = hp + ((dp >> 3) & 31) - 1;
+            const int kind = !act ? 0 : (h == fs + g ? 1 : (h == hp + g ? 2 : (h == os + q ? 3 : (h == hp + q ? 4 : 0))));
+            bm = __builtin_amdgcn_ballot_w64(kind != 0);
+            if (bm) {
+                const int s = __builtin_ctzll(bm);
+                const int kd = __builtin_amdgcn_readlane(kind, s);
+                r = __builtin_amdgcn_readlane(ps, s);
+                if (kd & 1) {                                 // by F + e or O + c: the run goes on upwards
+                    while (r > 0) {
+                        if (--guard < 0) return -1;
+                        uint32_t e0, e1;
+                        meta(r, e0, e1);
+                        const int np2 = (int)((e0 >> 8) & 0xf), npp2 = np2 ? np2 : 1;
+                        const bool act2 = lane < npp2;
+                        int ps2 = 0, xf = -(1 << 30), xo = -(1 << 30), hp2 = 0, fs2 = 0, os2 = 0;
+                        if (act2) {
+                            ps2 = pred_of(r, e0, e1, lane); hp2 = Hat(ps2, j);
+                            const int dp2 = Dat(ps2, j);
+                            fs2 = hp2 + (dp2 & 7) - 1; os2 = hp2 + ((dp2 >> 3) & 31) - 1;
+                            xf = hp2 > fs2 ? hp2 : fs2; xo = hp2 > os2 ? hp2 : os2;
+                        }
+#pragma unroll
+                        for (int d = 1; d < 16; d <<= 1) { const int f2 = __shfl_xor(xf, d), o2 = __shfl_xor(xo, d); xf = f2 > xf ? f2 : xf; xo = o2 > xo ? o2 : xo; }
+                        const int mf = __builtin_amdgcn_readlane(xf, 0), mo = __builtin_amdgcn_readlane(xo, 0);
+                        const int k2 = !act2 ? 0 : (hp2 == mf ? 1 : (fs2 == mf ? 2 : (hp2 == mo ? 3 : (os2 == mo ? 4 : 0))));
+                        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(k2 != 0);
+                        if (!b2) return -1;                   // cannot happen: some in-edge attains the maximum
+                        const int s2 = __builtin_ctzll(b2);
+                        const int kk = __builtin_amdgcn_readlane(k2, s2);
+                        r = __builtin_amdgcn_readlane(ps2, s2);
+                        if (kk & 1) break;                    // the gap opened here
+                    }
+                }
+                continue;
+            }
+        }
+        {   // to the left
+            const int hl = Hat(r, j - 1), dl = Dat(r, j - 1);
+            const int es = hl + ((dl >> 8) & 7) - 1, qs = hl + ((dl >> 11) & 31) - 1;
+            int ext;
+            if (h == es + g) ext = 1; else if (h == hl + g) ext = 0; else if (h == qs + q) ext = 1; else if (h == hl + q) ext = 0; else return -1;
+            --j;
+            if (ext) for (;;) {                               // by E + e or Q + c: the run goes on to the left
+                if (--guard < 0) return -1;
+                --j;
+                const int dj = Dat(r, j);
+                if (!(dj >> 8)) break;                        // neither E nor Q of this column feeds the next
+            }
+        }
+    }
+    return j;
+}
+
 // returns the new node count; -1 graph limits, -2 workspace, -3 back-track guard, -4 a cell at the floor of the int16 range
 // (global / overlap modes with costly gaps).  *score_out = end-cell score.
 // path_out (may be null): node of every base (for the MSA)
@@ -956,40 +1089,21 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
             w.ri[r] = make_uint2((uint32_t)(w.base[v] & 0xff) | ((uint32_t)np << 8) | (w.nout[v] == 0 ? 0x1000u : 0u) | (pr[0] << 16), pr[1] | (pr[2] << 16));
         }
         phase_sync();
-        // where will row r read source p from?  the row before it: registers; another recent row: the LDS ring (0x4000);
-        // an older one: its kept row in HBM (0x8000)
+        // where will row r read source p from?  the row before it: registers; another recent row: the LDS ring (0x4000 on
+        // the source row: it leaves a copy there); an older one: the planes in HBM
         for (int r = 1 + lane; r <= N; r += 64) {
             const uint2 d = w.ri[r];
             const int np = (int)((d.x >> 8) & 0xf);
             const int p0 = (int)(d.x >> 16), p1 = (int)(d.y & 0xffff), p2 = (int)(d.y >> 16);
-            auto mark = [&](int q) { if (q == 0) return; if (r - q >= RING) atomicOr(&ri32[q * 2], 0x8000u); else if (r - q >= 2) atomicOr(&ri32[q * 2], 0x4000u); };
+            auto mark = [&](int q) { if (q != 0 && r - q >= 2 && r - q < RING) atomicOr(&ri32[q * 2], 0x4000u); };
             if (np > 0) mark(p0);
             if (np > 1) mark(p1);
             if (np > 2) mark(p2);
             if (np > 3) { const int v = w.order[r - 1]; for (int s2 = 3; s2 < np; ++s2) mark(w.rank[w.pred[v * POA_MAXP + s2]]); }
         }
-        phase_sync();
-        // plane indices: rows with several in-edges (slot plane) and kept rows, counted in rank order
-        int nm = 0, nk = 0;
-        for (int r0 = 1; r0 <= N; r0 += 64) {
-            const int r = r0 + lane;
-            const uint32_t d = r <= N ? ri32[r * 2] : 0u;
-            const bool multi = ((d >> 8) & 0xf) > 1, kp = (d & 0x8000u) != 0;
-            const unsigned long long bm = __builtin_amdgcn_ballot_w64(multi), bk = __builtin_amdgcn_ballot_w64(kp);
-            const unsigned long long below = ((unsigned long long)1 << lane) - 1;
-            if (r <= N) w.rx[r] = (uint32_t)(nm + __builtin_popcountll(bm & below)) | ((uint32_t)(nk + __builtin_popcountll(bk & below)) << 16);
-            nm += __builtin_popcountll(bm); nk += __builtin_popcountll(bk);
-        }
-        if (nm > 65535 || nk > 65535) return -1;
-        if (poa_dp_bytes(N, m, nm, nk) > w.dp_bytes) return -2;
-        {
-            const size_t gp = (size_t)pitch;
-            size_t o = ((size_t)(N + 1) * gp + 15) & ~(size_t)15;
-            w.dirA = w.dp;
-            w.dirB = w.dp + o; o += (((size_t)nm * gp + 15) & ~(size_t)15);
-            w.keepH = (short*)(w.dp + o); o += (size_t)nk * gp * 2;
-            w.keepD = w.dp + o;
-        }
+        if (poa_dp_bytes(N, m) > w.dp_bytes) return -2;
+        w.planeH = (short*)w.dp;
+        w.planeD = (unsigned short*)(w.dp + poa_plane_bytes(N, m));
         if (S.algorithm == 1) {
             // global mode: H[i][0] = max(F, O)[i][0], F[i][0] = e + max over sources (a node without in-edges: g), O likewise.
             // A chain over the ranks, wave-uniform (every lane computes and stores the same values); not a hot path.
@@ -1023,103 +1137,20 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
     }
     *score_out = bs;
     TSTAMP(0);
-    // ---- back-track (sequential by nature, wave-uniform) ----------------------------------------------------------
-    // The lanes hold a 32x32 patch of the byte plane (ranks r0..r0-31, columns j0..j0-31; 16 bytes per lane), of the slot
-    // plane for the rows that have one, and the graph rows of those ranks, so the chain runs on v_readlane until it leaves
-    // the patch.  pn[j] = rank aligned to base j (0: none), staged in one register per lane, stored 64 bases at a time.
+    // ---- back-track: spoa's value comparisons, replayed on the cells of the path from the two planes ---------------------------
     bool moved = false;                                    // the alignment holds at least one step
     int jb = 0, je = -1;                                   // ... and the bases [jb, je]
+    for (int t = lane; t < m; t += 64) w.pn[t] = 0;        // pn[j] = rank aligned to base j (0: none); only diagonal steps write
     {
-        int r = __builtin_amdgcn_readfirstlane(br), j = br > 0 ? __builtin_amdgcn_readfirstlane(bc) : 0;
+        int j = br > 0 ? __builtin_amdgcn_readfirstlane(bc) : 0;
         je = j - 1;
-        for (int t = j + lane; t < m; t += 64) w.pn[t] = 0;                     // bases behind the end cell
-        const int gp = poa_pitch(m);
-        int r0 = -64, j0 = -64;
-        uint32_t pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, ri = 0;     // lane l: row r0-(l>>1), columns j0-16*(l&1)-15 .. j0-16*(l&1)
-        uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;
-        int buf = 0, mode = 0;                                   // mode 1: inside an upward run, 2: inside a leftward run
-        const bool sw = S.algorithm == 0;
-        int guard = 2 * (N + m) + 64;                           // every step lowers r or j: a longer walk means corrupt planes
-        while (j > 0 && r > 0) {
-            if (--guard < 0) return -3;
-            int a = r0 - r, b = j0 - j;
-            if ((unsigned)a >= 32u || (unsigned)b >= 32u) {
-                r0 = r; j0 = j;
-                const int rr = r - (lane >> 1), jlo = j - 16 * (lane & 1) - 15;       // lowest column of this lane's 16
-                pa0 = pa1 = pa2 = pa3 = 0; pb0 = pb1 = pb2 = pb3 = 0; ri = 0;
-                if (rr >= 1) {
-                    const uint2 gr = w.ri[rr];
-                    ri = (lane & 1) ? gr.y : gr.x;
-                    if (jlo + 15 >= 1) {
-                        // bytes at columns jlo..jlo+15 (columns below 0 belong to the previous row: in bounds, never looked at)
-                        const uint8_t* src = w.dirA + (size_t)rr * gp + 7 + jlo;
-                        uint32_t t[4];
-                        __builtin_memcpy(t, src, 16);
-                        pa0 = t[0]; pa1 = t[1]; pa2 = t[2]; pa3 = t[3];
-                        if (((gr.x >> 8) & 0xf) > 1) {
-                            const uint8_t* sb2 = w.dirB + (size_t)(w.rx[rr] & 0xffff) * gp + 7 + jlo;
-                            __builtin_memcpy(t, sb2, 16);
-                            pb0 = t[0]; pb1 = t[1]; pb2 = t[2]; pb3 = t[3];
-                        }
-                    }
-                }
-                a = 0; b = 0;
-            }
-            // column j0-b sits in lane 2a+(b>>4) at byte 15-(b&15)
-            const int idx = 15 - (b & 15), src_lane = a * 2 + (b >> 4);
-            const uint32_t sela = (idx >> 2) == 0 ? pa0 : ((idx >> 2) == 1 ? pa1 : ((idx >> 2) == 2 ? pa2 : pa3));
-            const int d = (__builtin_amdgcn_readlane((int)sela, src_lane) >> ((idx & 3) * 8)) & 0xff;
-            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2), g1 = (uint32_t)__builtin_amdgcn_readlane((int)ri, a * 2 + 1);
-            const int np = (int)((g0 >> 8) & 0xf);
-            auto pred_rank = [&](int s2) -> int {
-                if (np == 0) return 0;
-                if (s2 == 0) return (int)(g0 >> 16);
-                if (s2 == 1) return (int)(g1 & 0xffff);
-                if (s2 == 2) return (int)(g1 >> 16);
-                const int v = w.order[r - 1];
-                return __builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + s2]]);
-            };
-            if (mode == 1) {                                     // upward run: one more node without a base
-                int sl = 0;
-                if (np > 1) {
-                    const uint32_t selb = (idx >> 2) == 0 ? pb0 : ((idx >> 2) == 1 ? pb1 : ((idx >> 2) == 2 ? pb2 : pb3));
-                    sl = (__builtin_amdgcn_readlane((int)selb, src_lane) >> ((idx & 3) * 8)) & 0xff;
-                }
-                r = pred_rank(sl);
-                if (d & B_VSTOP) mode = 0;
-                continue;
-            }
-            if (mode == 2) {                                     // leftward run: one more base without a node
-                --j;
-                buf = lane == (j & 63) ? 0 : buf;
-                if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
-                if (!(d & B_HX)) mode = 0;
-                continue;
-            }
-            const int code = d & 63;
-            if (code == CODE_ZERO) break;                        // local mode only: nothing else carries this code
-            moved = true;
-            if (code > CODE_VERT) {                              // diagonal through in-edge CODE_DIAG - code
-                --j;
-                buf = lane == (j & 63) ? r : buf;
-                if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
-                r = pred_rank(CODE_DIAG - code);
-            } else if (code > CODE_HORZ) {                       // vertical: in-edge v / 3, by F+e, H+g, O+c (v % 3)
-                const int v = CODE_VERT - code;
-                const int slot = v / 3;
-                r = pred_rank(slot);
-                mode = (v - 3 * slot) != 1 ? 1 : 0;
-            } else {                                             // horizontal by E+e, H+g, Q+c
-                --j;
-                buf = lane == (j & 63) ? 0 : buf;
-                if ((j & 63) == 0) { if (j + lane < m) w.pn[j + lane] = buf; buf = 0; }
-                mode = code != CODE_HORZ - 1 ? 2 : 0;
-            }
+        if (br > 0) {
+            phase_sync();
+            const int rc = poa_backtrack(w, S, N, m, seq, lane, __builtin_amdgcn_readfirstlane(br), j, moved);
+            if (rc < 0) return -3;
+            j = rc;
         }
         jb = S.algorithm == 1 ? 0 : j;                           // global mode: spoa walks on along the border to (0, 0)
-        int fill_to = j;
-        if (j & 63) { fill_to = j & ~63; const int q = fill_to + lane; if (q < m && q >= 0) w.pn[q] = q < j ? 0 : buf; }
-        for (int q = lane; q < fill_to; q += 64) w.pn[q] = 0;
     }
     phase_sync();
     TSTAMP(1);
@@ -1385,7 +1416,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
         uint8_t* ws = slot;
         size_t ws_bytes = p.slot_bytes;
         int big = -1;
-        const size_t need_min = poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(maxlen + 8, maxlen, 0, 0) + 64;
+        const size_t need_min = poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(maxlen + 8, maxlen) + 64;
         bool use_big = need_min > p.slot_bytes;
         int N = 0, len = -1, ncols = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1476,6 +1507,6 @@ hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream)
 }
 
 size_t poa_slot_bytes_host(int ncap, int mcap) { return poa_slot_bytes(ncap, mcap); }
-size_t poa_slot_min_bytes_host(int ncap, int mcap) { return poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(mcap + 8, mcap - 1, 0, 0) + 64; }
+size_t poa_slot_min_bytes_host(int ncap, int mcap) { return poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(mcap + 8, mcap - 1) + 64; }
 
 }  // namespace clh

@@ -103,3 +103,11 @@ def test_parameter_rules():
     assert oracle_lib.oracle_poa(['ACGTACGTAC', 'ACGTTCGTAC', 'ACGTACGTAC'], 1, False, 5, -4, -8, -8, -8, -8) == 'ACGTACGTAC'
     with pytest.raises(NotImplementedError):
         poa_model.Params(0, 5, -4, -8, -8, -8, -8)
+
+
+@pytest.mark.parametrize('algorithm', [0, 1, 2])
+def test_lazy_back_track_from_h_and_differences(algorithm, monkeypatch):
+    """the same families with the back-track replayed from H and the four clamped differences a cell keeps in the lazy forward
+    pass (no code byte): K3's formulation since round 3"""
+    monkeypatch.setattr(poa_model, 'LAZY', True)
+    test_row_formulation_equals_matrix_statement(algorithm)

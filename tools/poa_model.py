@@ -124,7 +124,13 @@ def dp_row(P, code, seq, srcs, col0):
     dF[1:] = np.maximum(fs_new - h1, -1)
     dO[1:] = np.maximum(os_new - h1, -1)
     assert dF.max() <= P.e - P.g and dO.max() <= P.c - P.q
-    return H, dF, dO, bits, slots
+    # the same for the horizontal states of this row (what the lazy back-track reads instead of a code byte): Es = E + e - g,
+    # Qs = Q + c - q relative to H, clamped at -1 (column 0: E = Q = -inf)
+    dE = np.full(L + 1, -1, dtype=np.int64); dQ = np.full(L + 1, -1, dtype=np.int64)
+    dE[1:] = np.maximum(E[1:] + P.e - P.g - h1, -1)
+    dQ[1:] = np.maximum(Q[1:] + P.c - P.q - h1, -1)
+    assert dE.max() <= P.e - P.g and dQ.max() <= P.c - P.q
+    return H, dF, dO, bits, slots, dE, dQ
 
 
 class Graph(object):
@@ -236,6 +242,8 @@ def align(P, G, seq):
     N, L = len(G.order), len(seq)
     rows = [row0(P, L)]
     planes = [None]
+    h0 = rows[0][0]
+    lazy = [(h0, np.full(L + 1, -1), np.full(L + 1, -1), np.full(L + 1, -1), np.full(L + 1, -1), [], -1)]   # row 0: no vertical state; never a current row
     sinks = []
     # column 0 of the global mode: H[i][0] = max(F, O)[i][0] with F[i][0] = e + max over sources (a source row: g)
     f0, o0 = [0], [0]
@@ -248,8 +256,8 @@ def align(P, G, seq):
         else:
             f0.append(P.g); o0.append(P.q)
         col0 = max(f0[r], o0[r]) if P.algorithm == 1 else 0
-        H, dF, dO, bits, slots = dp_row(P, G.code[v], seq, [rows[p] for p in pr], col0)
-        rows.append((H, dF, dO)); planes.append((bits, slots, pr))
+        H, dF, dO, bits, slots, dE, dQ = dp_row(P, G.code[v], seq, [rows[p] for p in pr], col0)
+        rows.append((H, dF, dO)); planes.append((bits, slots, pr)); lazy.append((H, dF, dO, dE, dQ, pr, G.code[v]))
         sink = G.nout[v] == 0
         if P.algorithm == 0 or (sink and P.algorithm == 2):
             jm = int(np.argmax(H[1:])) + 1
@@ -257,6 +265,9 @@ def align(P, G, seq):
                 best, bi, bj = int(H[jm]), r, jm
         elif sink and H[L] > best:
             best, bi, bj = int(H[L]), r, L
+    if LAZY:
+        pn, jfin, steps = backtrack_lazy(P, lazy, seq, bi, bj)
+        return pn, best, (0 if P.algorithm == 1 else jfin), bj - 1, steps + (1 if P.algorithm == 1 and steps == 0 else 0)
     pn = [0] * L
     r, j = bi, bj
     steps = 0
@@ -294,6 +305,93 @@ def align(P, G, seq):
         steps += r + j
         j = 0
     return pn, best, j, bj - 1, steps
+
+
+LAZY = False        # align(): replay the back-track from the code bytes (False) or from H and the clamped differences (True)
+
+
+def backtrack_lazy(P, rows, seq, bi, bj):
+    """spoa's back-track (oracle/poa_oracle.c: align_gotoh) from what the lazy forward pass keeps per cell: H and the four
+    clamped differences dF, dO (vertical states, as the next rows read them) and dE, dQ (horizontal states); -1 = below H - 1
+    in its frame, where the state can neither win nor tie.  rows[r] = (H, dF, dO, dE, dQ, source ranks, letter)."""
+    g, e, q, c = P.g, P.e, P.q, P.c
+    pn = [0] * len(seq)
+    r, j, steps = bi, bj, 0
+    while r > 0 and j > 0:
+        H, dF, dO, dE, dQ, pr, code = rows[r]
+        pr = pr or [0]
+        h = int(H[j])
+        if P.algorithm == 0 and h == 0:
+            break
+        steps += 1
+        sc = P.m if code == seq[j - 1] else P.n
+        hit = None
+        for p in pr:
+            if h == int(rows[p][0][j - 1]) + sc:
+                hit = ('d', p)
+                break
+        if hit is None:
+            for p in pr:
+                hp, fs, os_ = int(rows[p][0][j]), int(rows[p][0][j] + rows[p][1][j]), int(rows[p][0][j] + rows[p][2][j])
+                if h == fs + g:
+                    hit = ('v', p, True)
+                elif h == hp + g:
+                    hit = ('v', p, False)
+                elif h == os_ + q:
+                    hit = ('v', p, True)
+                elif h == hp + q:
+                    hit = ('v', p, False)
+                if hit:
+                    break
+        if hit is None:
+            hl, es, qs = int(H[j - 1]), int(H[j - 1] + dE[j - 1]), int(H[j - 1] + dQ[j - 1])
+            if h == es + g:
+                hit = ('h', True)
+            elif h == hl + g:
+                hit = ('h', False)
+            elif h == qs + q:
+                hit = ('h', True)
+            elif h == hl + q:
+                hit = ('h', False)
+        assert hit is not None
+        if hit[0] == 'd':
+            pn[j - 1] = r
+            r, j = hit[1], j - 1
+        elif hit[0] == 'v':
+            r = hit[1]
+            if hit[2]:
+                while r > 0:
+                    prr = rows[r][5] or [0]
+                    mf = max(max(int(rows[p][0][j]), int(rows[p][0][j] + rows[p][1][j])) for p in prr)
+                    mo = max(max(int(rows[p][0][j]), int(rows[p][0][j] + rows[p][2][j])) for p in prr)
+                    stop, ni = False, 0
+                    for p in prr:
+                        hp, fs, os_ = int(rows[p][0][j]), int(rows[p][0][j] + rows[p][1][j]), int(rows[p][0][j] + rows[p][2][j])
+                        if hp == mf:
+                            stop, ni = True, p
+                            break
+                        if fs == mf:
+                            stop, ni = False, p
+                            break
+                        if hp == mo:
+                            stop, ni = True, p
+                            break
+                        if os_ == mo:
+                            stop, ni = False, p
+                            break
+                    r = ni
+                    steps += 1
+                    if stop:
+                        break
+        else:
+            j -= 1
+            if hit[1]:
+                while True:
+                    j -= 1
+                    steps += 1
+                    if not (dE[j] >= 0 or dQ[j] >= 0):
+                        break
+    return pn, j, steps
 
 
 def fuse(G, seq, pn, jb, je, steps):

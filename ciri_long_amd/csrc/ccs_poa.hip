@@ -321,7 +321,10 @@ __device__ PoaWs carve(uint8_t* slot, size_t slot_bytes, int ncap, int mcap)
 }
 
 extern __shared__ __attribute__((aligned(16))) uint32_t poa_lds[];     // K3's dynamic LDS block
-static constexpr int POA_LDS_BYTES = 9216;           // ring of recent rows (DP) / band of the planes + the sequence (back-track) / score per rank (heaviest bundle)
+#ifndef POA_LDS_KB
+#define POA_LDS_KB 9
+#endif
+static constexpr int POA_LDS_BYTES = POA_LDS_KB * 1024;           // ring of recent rows (DP) / band of the planes + the sequence (back-track) / score per rank (heaviest bundle)
 static constexpr int POA_LDS_SCORES = POA_LDS_BYTES / 4 - 1;   // most rows whose scores fit the LDS block
 
 #ifdef CLH_DEBUG_POA
@@ -438,6 +441,11 @@ __device__ __forceinline__ void scan_left_pk2(const uint32_t (&a)[CP], int leftA
     for (int t = 0; t < CP; ++t) { pa[t] = pk_max(runA[t], exA); pb[t] = pk_max(runB[t], exB); }
 }
 
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t b) {   // (a << sh) | b as ONE instruction (the compiler reassociates a tree of them into shifts and ors)
+    uint32_t d;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(sh), "v"(b));
+    return d;
+}
 // lo half = half hx of x, hi half = half hy of y (one v_perm_b32)
 template <int HX, int HY>
 __device__ __forceinline__ uint32_t mix16(uint32_t x, uint32_t y) {
@@ -481,6 +489,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     const uint32_t g2 = dup16(g), e2 = dup16(e), q2 = dup16(q), c2 = dup16(c), sm2 = dup16(S.m), dsn2 = dup16(S.n - S.m);
     const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
     const uint32_t NEG2 = dup16(POA_NEG), ONE2 = 0x00010001u;
+    const uint32_t floor2 = sw ? 0u : 0x80008000u;           // local mode: a cell is at least 0
     // ring row: CP dwords of H per lane, then CP dwords of differences per lane; behind the rows one left-boundary H per row
     uint32_t* ring = poa_lds;
     const int rrow = 128 * poa_ring_cp(m);
@@ -577,14 +586,14 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                         uint32_t nh[CP], nd[CP];
                         const uint32_t* sh = (const uint32_t*)(hrow + (size_t)qr * gp);
                         const uint32_t* sd = (const uint32_t*)(drow + (size_t)qr * gp);
+                        // compiler-visible loads: its own wait counts (an asm block here made it wait for every store in flight on the
+                        // ring path too).  The cells were written by these very lanes earlier in this pass.
 #pragma unroll
-                        for (int t = 0; t < CP; ++t) asm volatile("global_load_dword %0, %1, off" : "=v"(nh[t]) : "v"(sh + t) : "memory");
-#pragma unroll
-                        for (int t = 0; t < CP; ++t) asm volatile("global_load_dword %0, %1, off" : "=v"(nd[t]) : "v"(sd + t) : "memory");
+                        for (int t = 0; t < CP; ++t) {      // agent-scope loads: served by L2 (a line of the CU's L1 may predate the row next to it)
+                            nh[t] = __hip_atomic_load(sh + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            nd[t] = __hip_atomic_load(sd + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         left = left_of(qr);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                        for (int t = 0; t < CP; ++t) asm volatile("" : "+v"(nh[t]), "+v"(nd[t]));
                         to_packed<CP>(nh, h); to_packed<CP>(nd, dd);
                     }
                     hsh0 = hand_down(h[CP - 1], left);
@@ -629,9 +638,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
             for (int t = 0; t < CP; ++t) {
                 fsn[t] = pk_adds(MF[t], e2); osn[t] = pk_adds(MO[t], c2);
-                uint32_t b = pk_max(dg[t], pk_max(pk_adds(MF[t], g2), pk_adds(MO[t], q2)));
-                if (sw) b = pk_max(b, 0u);
-                M0[t] = b;
+                M0[t] = pk_max(pk_max(dg[t], floor2), pk_max(pk_adds(MF[t], g2), pk_adds(MO[t], q2)));
             }
             // horizontal states: two prefix maxima in the gap-free frames of the two pieces
             uint32_t X[CP], Y[CP];                              // Ehat + e - g and Qhat + c - q: the states as the next column reads them
@@ -656,7 +663,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 const uint32_t Hm = pk_subs(Hf[t], ONE2);
                 const uint32_t dF = pk_max(pk_subs(fsn[t], Hm), 0u), dO = pk_max(pk_subs(osn[t], Hm), 0u);
                 const uint32_t dE = pk_max(pk_subs(Es[t], Hm), 0u), dQ = pk_max(pk_subs(Y[t], Hm), 0u);
-                D[t] = (dF | (dO << 3)) | ((dE | (dQ << 3)) << 8);
+                D[t] = lshl_or(lshl_or(dQ, 3, dE), 8, lshl_or(dO, 3, dF));
             }
             SEC(11);
             // ---- what later rows and the back-track read ------------------------------------------------------------------
@@ -876,6 +883,120 @@ __device__ int poa_sort(const PoaWs& w, const int n_old, const int n, const int 
     return __builtin_amdgcn_ballot_w64(bad != 0) ? -1 : 0;
 }
 
+// The same sort with its arrays in LDS (graphs of up to POA_SORT_LDS nodes: the common case): root (32 bits, LDS atomics), the
+// number of nodes per root, the order and the per-node search state (bits 0-1 as st[], bits 2-6 the cursor of the node's frame --
+// a node is on the stack of its search at most once, so the frames are the node ids alone).  A lane runs the searches of the
+// roots it meets in its own stride of ids, block by block.  The graph's lists are read from HBM.
+static constexpr int POA_SORT_LDS = POA_LDS_BYTES / 9;   // 9 bytes per node
+__device__ int poa_sort_lds(const PoaWs& w, const int n_old, const int n, const int m, const int lane)
+{
+    uint32_t* lroot = poa_lds;
+    uint16_t* lsz = (uint16_t*)(lroot + n);
+    uint16_t* lord = lsz + n;
+    uint8_t* lst = (uint8_t*)(lord + n);
+    // lst bit 2: the node is new or its root has been lowered -- its aligned set and its in-edge tails may have to follow
+    for (int v = lane; v < n; v += 64) { lroot[v] = v < n_old ? (uint32_t)w.root[v] : (uint32_t)v; lsz[v] = 0; lst[v] = v < n_old ? 0 : 4; }
+    __syncthreads();
+    {
+        uint32_t smin = 0xffffffffu;
+        for (int i0 = ((m - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
+            const int i = i0 + lane;
+            const int x = i < m ? w.pj[i] : -1;
+            uint32_t val = x >= 0 ? lroot[x] : 0xffffffffu;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_down((int)val, d); if (lane + d < 64) val = o < val ? o : val; }
+            val = val < smin ? val : smin;
+            if (x >= 0 && val < lroot[x]) { lroot[x] = val; lst[x] |= 4; }     // the nodes of a path are distinct
+            smin = (uint32_t)__builtin_amdgcn_readlane((int)val, 0);
+        }
+    }
+    __syncthreads();
+    // relaxation to the fixed point, frontier by frontier: before this sequence every edge and aligned set was consistent (root of
+    // a tail <= root of its head, one root per set) and the path scan keeps the path's own edges so; what can be off is around
+    // the flagged nodes only
+    for (int round = 0; round <= n; ++round) {
+        int nf = 0;
+        for (int v0 = 0; v0 < n; v0 += 64) {
+            const int v = v0 + lane;
+            const bool f = v < n && (lst[v] & 4) != 0;
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(f);
+            if (f) { lst[v] &= (uint8_t)~4; lord[nf + __builtin_popcountll(bm & (((unsigned long long)1 << lane) - 1))] = (uint16_t)v; }
+            nf += __builtin_popcountll(bm);
+        }
+        if (nf == 0) break;
+        __syncthreads();
+        for (int t = lane; t < nf; t += 64) {
+            const int v = lord[t];
+            const int nav = w.na[v], npv = w.np[v];
+            uint32_t rv = lroot[v];
+            int al[POA_MAXA];
+#pragma unroll
+            for (int k = 0; k < POA_MAXA; ++k) { al[k] = k < nav ? w.aligned[v * POA_MAXA + k] : -1; if (al[k] >= 0) { const uint32_t ra = lroot[al[k]]; rv = ra < rv ? ra : rv; } }
+            if (rv < lroot[v]) atomicMin(&lroot[v], rv);
+#pragma unroll
+            for (int k = 0; k < POA_MAXA; ++k) if (al[k] >= 0 && rv < lroot[al[k]]) { atomicMin(&lroot[al[k]], rv); lst[al[k]] |= 4; }
+            for (int k = 0; k < npv; ++k) { const int u = w.pred[v * POA_MAXP + k]; if (rv < lroot[u]) { atomicMin(&lroot[u], rv); lst[u] |= 4; } }
+        }
+        __syncthreads();
+    }
+    for (int v = lane; v < n; v += 64) {
+        const uint32_t rt = lroot[v];
+        w.root[v] = (int32_t)rt;
+        // 16-bit counters, two per LDS word: count through the word that holds the counter
+        atomicAdd((uint32_t*)lsz + (rt >> 1), (rt & 1) ? 0x10000u : 1u);
+    }
+    __syncthreads();
+    int acc = 0, bad = 0;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+        const int r = r0 + lane;
+        const int sz = r < n ? (int)lsz[r] : 0;
+        int inc = sz;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        const int lo = acc + inc - sz;
+        acc += __builtin_amdgcn_readlane(inc, 63);
+        if (sz == 1) lord[lo] = (uint16_t)r;
+        else if (sz > 1) {
+            const int hi = lo + sz;
+            int sp = hi, k = lo;
+            lord[--sp] = (uint16_t)r;
+            while (sp < hi) {
+                const int v = lord[sp];
+                const int stv = lst[v];
+                int cur = stv >> 2;
+                const int npv = w.np[v], nav = w.na[v];
+                const bool ign = (stv & 2) != 0;
+                if (cur == 0 && !ign) for (int t = 0; t < nav; ++t) lst[w.aligned[v * POA_MAXA + t]] |= 2;
+                const int na2 = ign ? 0 : nav, nd = na2 + npv;
+                int nxt = -1;
+                while (cur < nd) {
+                    const int d = cur < na2 ? w.aligned[v * POA_MAXA + na2 - 1 - cur] : w.pred[v * POA_MAXP + npv - 1 - (cur - na2)];
+                    ++cur;
+                    if (lroot[d] == (uint32_t)r && !(lst[d] & 1)) { nxt = d; break; }
+                }
+                if (nxt >= 0) {
+                    lst[v] = (uint8_t)((stv & 3) | (cur << 2));
+                    if (sp - 1 < k) { bad = 1; break; }
+                    lord[--sp] = (uint16_t)nxt;
+                    continue;
+                }
+                lst[v] = (uint8_t)(stv | 1);
+                ++sp;
+                if (!ign) {
+                    if (k + 1 + nav > hi) { bad = 1; break; }
+                    lord[k++] = (uint16_t)v;
+                    for (int t = 0; t < nav; ++t) lord[k++] = (uint16_t)w.aligned[v * POA_MAXA + t];
+                }
+            }
+            bad |= k != hi;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { const int v = lord[i]; w.order[i] = v; w.rank[v] = i + 1; }
+    phase_sync();
+    return __builtin_amdgcn_ballot_w64(bad != 0) || acc != n ? -1 : 0;
+}
+
 // ranks of the first and the last member of the aligned set of node v
 __device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& hi)
 {
@@ -898,9 +1019,26 @@ __device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& 
 //    (r-l, j-l) at once, the length of the run of successes is taken in one step.
 //  * Any other step is evaluated with the in-edges across the lanes (first hit in in-edge order = lowest lane).
 // returns the column the walk ends in (the bases in front of it are not part of the alignment), or -1 (guard: corrupt planes).
-static constexpr int BT_W = 24;                       // columns per band row
-__device__ int poa_backtrack(const PoaWs& w, const PoaScores S, const int N, const int m, const int8_t* seq, const int lane, int r, int j, bool& moved)
+static constexpr int BT_W = POA_LDS_BYTES >= 9216 ? 24 : 20;     // columns per band row (64 rows x 2 planes + the sequence in the LDS block)
+static constexpr int BT_DRIFT = BT_W / 2 - 4;        // how far the walk may leave the band's diagonal before the band is staged again
+// a pointer the compiler cannot see to be wave-uniform, as a scalar-register pair (else it lives in two VGPRs -- and with some
+// thirty workspace pointers alive that is what spills)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, const int m_, const int8_t* seq_, const int lane, int r, int j, bool& moved DBGARG)
 {
+    // the walk is wave-uniform: say so (scalar registers, scalar branches)
+    struct { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; } w;
+    w.pn = uniform_ptr(w_.pn); w.planeH = uniform_ptr(w_.planeH); w.planeD = uniform_ptr(w_.planeD); w.ri = uniform_ptr(w_.ri);
+    w.col0 = uniform_ptr(w_.col0); w.rank = uniform_ptr(w_.rank); w.pred = uniform_ptr(w_.pred); w.order = uniform_ptr(w_.order);
+    const int8_t* seq = uniform_ptr(seq_);
+    const int m = __builtin_amdgcn_readfirstlane(m_);
+    r = __builtin_amdgcn_readfirstlane(r); j = __builtin_amdgcn_readfirstlane(j);
     const bool sw = S.algorithm == 0, nw = S.algorithm == 1;
     const int g = S.g, e = S.e, q = S.q, c = S.c;
     const int gp = poa_pitch(m);
@@ -914,35 +1052,47 @@ __device__ int poa_backtrack(const PoaWs& w, const PoaScores S, const int N, con
     };
     int r0 = -(1 << 20), j0 = 0;
     uint2 rim = make_uint2(0, 0);
-    auto cs_of = [&](int k) -> int { const int x = j0 - k - BT_W / 2; return (x & 1) ? x : x - 1; };    // first column of band row k: odd = a dword boundary of the planes
+    int csk = 0, csk1 = 0, chain = 0;                        // first column of this lane's band row and of the next lane's; the row's first in-edge is the row before
+    auto cs_at = [&](int k) -> int { const int x = j0 - k - BT_W / 2; return (x & 1) ? x : x - 1; };    // first column of band row k: odd = a dword boundary of the planes
+    // Stage the band around (rr0, jj0).  Row 0 (no node) and column 0 are not in the planes: their cells are written into the band
+    // here, so that the walk reads every cell the same way.
     auto reload = [&](int rr0, int jj0) {
         r0 = rr0; j0 = jj0;
         const int rr = r0 - lane;
         rim = make_uint2(0, 0);
+        csk = cs_at(lane); csk1 = cs_at(lane + 1);
+        chain = 0;
         if (rr >= 1) {
             rim = w.ri[rr];
-            const int cs = cs_of(lane);
-            if (cs + BT_W > 1) {
+            chain = (((rim.x >> 8) & 0xf) == 0 ? 0 : (int)(rim.x >> 16)) == rr - 1;
+            if (csk + BT_W > 1) {
                 uint32_t t[BT_W / 2];
-                __builtin_memcpy(t, (const uint32_t*)(w.planeH + (size_t)rr * gp + cs + 7), BT_W * 2);
+                __builtin_memcpy(t, (const uint32_t*)(w.planeH + (size_t)rr * gp + csk + 7), BT_W * 2);
                 __builtin_memcpy(Hb + lane * BT_W, t, BT_W * 2);
-                __builtin_memcpy(t, (const uint32_t*)(w.planeD + (size_t)rr * gp + cs + 7), BT_W * 2);
+                __builtin_memcpy(t, (const uint32_t*)(w.planeD + (size_t)rr * gp + csk + 7), BT_W * 2);
                 __builtin_memcpy(Db + lane * BT_W, t, BT_W * 2);
             }
         }
+        if (r0 < 64) {                                       // the block reaches row 0
+            if (rr == 0) for (int x = 0; x < BT_W; ++x) { Hb[lane * BT_W + x] = (short)(csk + x >= 0 ? row0_h(csk + x) : 0); Db[lane * BT_W + x] = 0; }
+        }
+        if (j0 - BT_W / 2 - 64 <= 0) {                       // some window reaches column 0
+            if (rr >= 1 && csk <= 0 && csk + BT_W > 0) { Hb[lane * BT_W - csk] = (short)(nw ? (int)w.col0[rr] : 0); Db[lane * BT_W - csk] = 0; }
+        }
         __syncthreads();
     };
+    // a cell of the planes: from the band if it is there, else from HBM
     auto Hat = [&](int rr, int jj) -> int {
+        const int k = r0 - rr, x = jj - cs_at(k);
+        if ((unsigned)k < 64u && (unsigned)x < (unsigned)BT_W) return (int)Hb[k * BT_W + x];
         if (rr == 0) return row0_h(jj);
         if (jj == 0) return nw ? (int)w.col0[rr] : 0;
-        const int k = r0 - rr, x = jj - cs_of(k);
-        if ((unsigned)k < 64u && (unsigned)x < (unsigned)BT_W) return (int)Hb[k * BT_W + x];
         return (int)w.planeH[(size_t)rr * gp + jj + 7];
     };
     auto Dat = [&](int rr, int jj) -> int {
-        if (rr == 0 || jj == 0) return 0;
-        const int k = r0 - rr, x = jj - cs_of(k);
+        const int k = r0 - rr, x = jj - cs_at(k);
         if ((unsigned)k < 64u && (unsigned)x < (unsigned)BT_W) return (int)Db[k * BT_W + x];
+        if (rr == 0 || jj == 0) return 0;
         return (int)w.planeD[(size_t)rr * gp + jj + 7];
     };
     // the graph row of rank rr (wave-uniform): from the staged block or from HBM
@@ -964,47 +1114,57 @@ __device__ int poa_backtrack(const PoaWs& w, const PoaScores S, const int N, con
     int guard = 2 * (N + m) + 64;                           // every step lowers r or j: a longer walk means corrupt planes
     while (r > 0 && j > 0) {
         if (--guard < 0) return -1;
+        r = __builtin_amdgcn_readfirstlane(r); j = __builtin_amdgcn_readfirstlane(j);
         int a = r0 - r;
         {
             const int drift = j - (j0 - a);
-            if ((unsigned)a > 48u || drift < -8 || drift > 7) { reload(r, j); a = 0; }
+            if ((unsigned)a > 48u || drift < -BT_DRIFT || drift >= BT_DRIFT) { reload(r, j); a = 0; DBGCNT(18, 1); }
         }
-        {   // a run of diagonal steps through first in-edges that are the row before
-            const int l = lane - a, myr = r0 - lane, myc = j - l;
-            bool ok = l >= 0 && lane < 63 && myr >= 1 && myc >= 1;
-            if (ok) {
-                const int np = (int)((rim.x >> 8) & 0xf);
-                ok = (np == 0 ? 0 : (int)(rim.x >> 16)) == myr - 1;
-                if (ok) {
-                    const int hc = Hat(myr, myc), hd = Hat(myr - 1, myc - 1);
-                    const int sc = (int)(rim.x & 0xff) == (int)lseq[myc - 1] ? S.m : S.n;
-                    ok = hc == hd + sc && !(sw && hc == 0);
-                }
-            }
+        // Everything one step can ask for is read from the band in ONE round: (1) lane a + l: the cells (r - l, j - l) and their diagonal
+        // neighbours -- a run of diagonal steps through first in-edges that are the row before; (2) lane s < in-degree of row r: the
+        // three cells of in-edge s; (3) the left neighbour.  In the band by construction (|drift| is bounded above).
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)rim.x, a), d1 = (uint32_t)__builtin_amdgcn_readlane((int)rim.y, a);
+        const int np = (int)((d0 >> 8) & 0xf), npp = np ? np : 1;
+        const int l = lane - a, myr = r0 - lane, myc = j - l;
+        bool ok = l >= 0 && lane < 63 && chain && myc >= 1;
+        int hc = 0, hd = 0;
+        if (ok) { hc = (int)Hb[lane * BT_W + myc - csk]; hd = (int)Hb[(lane + 1) * BT_W + myc - 1 - csk1]; }
+        const int ps = np == 0 ? 0 : (lane == 0 ? (int)(d0 >> 16) : (lane == 1 ? (int)(d1 & 0xffff) : (int)(d1 >> 16)));
+        const int kp = r0 - ps, xp = j - cs_at(kp);
+        const bool act = lane < npp;
+        const bool inb = (unsigned)kp < 64u && xp >= 1 && xp < BT_W;
+        int hp1 = 0, hp = 0, dp = 0;
+        if (act && inb) { hp1 = (int)Hb[kp * BT_W + xp - 1]; hp = (int)Hb[kp * BT_W + xp]; dp = (int)Db[kp * BT_W + xp]; }
+        const int xl = a * BT_W + j - __builtin_amdgcn_readlane(csk, a);
+        const int h = (int)Hb[xl], hl = (int)Hb[xl - 1], dl = (int)Db[xl - 1];
+        if (ok) {
+            const int sc = (int)(rim.x & 0xff) == (int)lseq[myc - 1] ? S.m : S.n;
+            ok = hc == hd + sc && !(sw && hc == 0);
+        }
+        {
             const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok) >> a;
             const int run = ~okm ? __builtin_ctzll(~okm) : 64;
             if (run > 0) {
+                DBGCNT(16, 1); DBGCNT(17, run);
                 if (l >= 0 && l < run) w.pn[myc - 1] = myr;
                 r -= run; j -= run; moved = true;
                 continue;
             }
         }
         // one step by spoa's full list of tests; lane s looks at in-edge s
-        uint32_t d0, d1;
-        meta(r, d0, d1);
-        const int h = Hat(r, j);
         if (sw && h == 0) break;
         moved = true;
+        DBGCNT(19, 1);
+        int psx = ps;
+        if (np > 3 || __builtin_amdgcn_ballot_w64(act && !inb)) {        // rare: in-edges beyond the third, or a source row outside the band
+            if (act) { psx = pred_of(r, d0, d1, lane); hp1 = Hat(psx, j - 1); hp = Hat(psx, j); dp = Dat(psx, j); }
+        }
         {
-            const int np = (int)((d0 >> 8) & 0xf), npp = np ? np : 1;
-            const bool act = lane < npp;
-            int ps = 0, hp1 = 0, hp = 0, dp = 0;
-            if (act) { ps = pred_of(r, d0, d1, lane); hp1 = Hat(ps, j - 1); hp = Hat(ps, j); dp = Dat(ps, j); }
             const int sc = (int)(d0 & 0xff) == (int)lseq[j - 1] ? S.m : S.n;
             unsigned long long bm = __builtin_amdgcn_ballot_w64(act && h == hp1 + sc);
             if (bm) {
                 if (lane == 0) w.pn[j - 1] = r;
-                r = __builtin_amdgcn_readlane(ps, __builtin_ctzll(bm)); --j;
+                r = __builtin_amdgcn_readlane(psx, __builtin_ctzll(bm)); --j;
                 continue;
             }
             const int fs = hp + (dp & 7) - 1, os = hp + ((dp >> 3) & 31) - 1;
@@ -1013,7 +1173,7 @@ __device__ int poa_backtrack(const PoaWs& w, const PoaScores S, const int N, con
             if (bm) {
                 const int s = __builtin_ctzll(bm);
                 const int kd = __builtin_amdgcn_readlane(kind, s);
-                r = __builtin_amdgcn_readlane(ps, s);
+                r = __builtin_amdgcn_readlane(psx, s);
                 if (kd & 1) {                                 // by F + e or O + c: the run goes on upwards
                     while (r > 0) {
                         if (--guard < 0) return -1;
@@ -1044,7 +1204,6 @@ __device__ int poa_backtrack(const PoaWs& w, const PoaScores S, const int N, con
             }
         }
         {   // to the left
-            const int hl = Hat(r, j - 1), dl = Dat(r, j - 1);
             const int es = hl + ((dl >> 8) & 7) - 1, qs = hl + ((dl >> 11) & 31) - 1;
             int ext;
             if (h == es + g) ext = 1; else if (h == hl + g) ext = 0; else if (h == qs + q) ext = 1; else if (h == hl + q) ext = 0; else return -1;
@@ -1125,6 +1284,10 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
         }
         phase_sync();
         dp_rows(w, S, N, m, seq, lane, bs, br, bc DBGPASS);
+#ifdef POA_EXP_DP2          // timing experiments (tools/dev/k3_ab.py): a phase run twice costs its marginal time once more
+        phase_sync();
+        dp_rows(w, S, N, m, seq, lane, bs, br, bc DBGPASS);
+#endif
         phase_sync();
         if (br < 0) return -4;                               // a cell at the floor of the int16 range: no exact answer from this kernel
 #ifdef CLH_DEBUG_POA
@@ -1146,7 +1309,10 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
         je = j - 1;
         if (br > 0) {
             phase_sync();
-            const int rc = poa_backtrack(w, S, N, m, seq, lane, __builtin_amdgcn_readfirstlane(br), j, moved);
+#ifdef POA_EXP_BT2
+            { bool mv2 = false; (void)poa_backtrack(w, S, N, m, seq, lane, __builtin_amdgcn_readfirstlane(br), j, mv2 DBGPASS); phase_sync(); }
+#endif
+            const int rc = poa_backtrack(w, S, N, m, seq, lane, __builtin_amdgcn_readfirstlane(br), j, moved DBGPASS);
             if (rc < 0) return -3;
             j = rc;
         }
@@ -1220,7 +1386,11 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
     }
     phase_sync();
     TSTAMP(2);
-    if (poa_sort(w, N, n, m, lane) != 0) return -1;
+#ifdef POA_EXP_SORT2
+    if ((n <= POA_SORT_LDS ? poa_sort_lds(w, N, n, m, lane) : poa_sort(w, N, n, m, lane)) != 0) return -1;
+    phase_sync();
+#endif
+    if ((n <= POA_SORT_LDS ? poa_sort_lds(w, N, n, m, lane) : poa_sort(w, N, n, m, lane)) != 0) return -1;
     TSTAMP(3);
     return n;
 }
@@ -1435,7 +1605,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
             }
             PoaWs w = carve(ws, ws_bytes, ncap, mcap);
             phase_sync();
-            unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long tacc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             N = 0; b = 0;
             int si = 0;
             for (int i = 0; i <= ncuts && N >= 0; ++i) {
@@ -1452,6 +1622,10 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
 #ifdef CLH_DEBUG_POA
                 const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef POA_EXP_HB2
+                len = poa_consensus(w, N, mc, p.ccs + off, L, lane);
+                phase_sync();
+#endif
                 len = poa_consensus(w, N, mc, p.ccs + off, L, lane);
 #ifdef CLH_DEBUG_POA
                 tacc[4] += __builtin_amdgcn_s_memtime() - tc0;
@@ -1464,6 +1638,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
 #ifdef CLH_DEBUG_POA
                 if (lane == 0) for (int k = 0; k < 8; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
                 if (lane == 0) for (int k = 8; k < 14; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (41 + k)] = (int)(tacc[k] >> 4);
+                if (lane == 0) for (int k = 16; k < 20; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (26 + k)] = (int)(tacc[k] >> 4);   // back-track counters
 #endif
             }
             break;

@@ -1129,7 +1129,9 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { fail(CLH_E_HIP, "hipMemGetInfo failed"); delete pl; return nullptr; }
     { std::lock_guard<std::mutex> g(ctx->mu); for (auto& kv : ctx->cache) free_b += kv.first; }      // parked blocks are ours to reuse
-    pl->nslots = (int)std::max<long long>(1, std::min<long long>(4096, std::max(n, 1)));
+    int slots_max = 4096;                            // 16 waves per CU x 256 CUs
+    if (const char* e = getenv("CLH_POA_SLOTS")) slots_max = std::max(64, atoi(e));      // tuning experiments
+    pl->nslots = (int)std::max<long long>(1, std::min<long long>(slots_max, std::max(n, 1)));
     unsigned long long budget = std::min<unsigned long long>(40ull << 30, (unsigned long long)(free_b * 0.40));
     if (const char* e = getenv("CLH_POA_BUDGET_MB")) budget = std::max(1ull, strtoull(e, nullptr, 10)) << 20;     // tests: force the second tier
     pl->slot_bytes = std::min<size_t>(need_worst, (size_t)((budget / (unsigned long long)pl->nslots) & ~255ull));

@@ -28,3 +28,5 @@ print('row steps %.4g, register-rows %.4g (mean %.2f per step), cells %.4g' % (x
 y = segs[:, 49:55, 0].astype(np.float64)[ok].sum(0)
 print('row step sections (%% of the DP clock): decode+score %.1f, sources+candidates %.1f, scans %.1f, H/E+horizontal codes %.1f, stores %.1f, end cell+carry %.1f' % tuple(100 * y / y.sum()))
 print('reads with consensus %d, mean total %.1f us' % (ok.sum(), t[ok].sum(1).mean() / 100.0))
+z = segs[:, 42:46, 0].astype(np.float64)[ok].sum(0)
+print('back-track per read: diagonal runs %.1f (mean length %.2f), single steps %.1f, band reloads %.1f' % (z[0] / ok.sum(), z[1] / max(z[0], 1), z[3] / ok.sum(), z[2] / ok.sum()))

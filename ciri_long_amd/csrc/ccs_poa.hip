@@ -490,6 +490,11 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
     const uint32_t NEG2 = dup16(POA_NEG), ONE2 = 0x00010001u;
     const uint32_t floor2 = sw ? 0u : 0x80008000u;           // local mode: a cell is at least 0
+#ifdef POA_NO_BEYOND_FREE
+    const bool beyond_free = false;
+#else
+    const bool beyond_free = sw && S.n < 0 && S.g < 0 && S.q < 0;
+#endif
     // ring row: CP dwords of H per lane, then CP dwords of differences per lane; behind the rows one left-boundary H per row
     uint32_t* ring = poa_lds;
     const int rrow = 128 * poa_ring_cp(m);
@@ -561,22 +566,17 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                     ss[t] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, nz) * __builtin_bit_cast(u16x2, dsn2) + __builtin_bit_cast(u16x2, sm2));
                 }
             }
-            // one source row, packed: H at the lane's columns, the same shifted by one column (register 0), Fs, Os
-            auto source = [&](int qr, uint32_t (&h)[CP], uint32_t& hsh0, uint32_t (&fs)[CP], uint32_t (&os)[CP]) {
+            // one source row that is not the row before, packed: H at the lane's columns, Fs, Os, and the H in front of the pass
+            auto source = [&](int qr, uint32_t (&h)[CP], int& left, uint32_t (&fs)[CP], uint32_t (&os)[CP]) {
                 if (qr == 0) {
 #pragma unroll
                     for (int t = 0; t < CP; ++t) {
                         h[t] = pack16(row0_h(col0 + t + 1), row0_h(col0 + CP + t + 1));
                         fs[t] = pk_adds(h[t], 0xffffffffu); os[t] = fs[t];
                     }
-                    hsh0 = pack16(row0_h(col0), row0_h(col0 + CP));
-                } else if (qr == r - 1) {
-#pragma unroll
-                    for (int t = 0; t < CP; ++t) { h[t] = px[t]; fs[t] = pf[t]; os[t] = po[t]; }
-                    hsh0 = hand_down(px[CP - 1], pcin);
+                    left = row0_h(colbase);
                 } else {
                     uint32_t dd[CP];
-                    int left;
                     if (r - qr < RING) {
                         const uint32_t* rp = ring + (qr & rmask) * rrow + lane * CP;
 #pragma unroll
@@ -590,13 +590,15 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                         // ring path too).  The cells were written by these very lanes earlier in this pass.
 #pragma unroll
                         for (int t = 0; t < CP; ++t) {      // agent-scope loads: served by L2 (a line of the CU's L1 may predate the row next to it)
-                            nh[t] = __hip_atomic_load(sh + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            nd[t] = __hip_atomic_load(sd + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            nh[t] = 0; nd[t] = 0;           // a lane entirely beyond the sequence stores nothing: it reads nothing back
+                            if (stores) {
+                                nh[t] = __hip_atomic_load(sh + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                nd[t] = __hip_atomic_load(sd + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                         left = left_of(qr);
                         to_packed<CP>(nh, h); to_packed<CP>(nd, dd);
                     }
-                    hsh0 = hand_down(h[CP - 1], left);
 #pragma unroll
                     for (int t = 0; t < CP; ++t) {
                         fs[t] = pk_adds(h[t], pk_subu(dd[t] & 0x00070007u, ONE2));
@@ -606,26 +608,36 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             };
             SEC(8);
             uint32_t dg[CP], MF[CP], MO[CP];
-            {
-                uint32_t h[CP], hsh0, fs[CP], os[CP];
-                source(np == 0 ? 0 : p0, h, hsh0, fs, os);
+            if (np <= 1) {
+                // the common shape.  The source's values are used where they are: the registers of the row before, which a source
+                // that is another row overwrites (nothing else reads them in this step) -- no copies on the way to the arithmetic
+                const int q0 = np == 0 ? 0 : p0;
+                if (q0 != r - 1 || q0 == 0) source(q0, px, pcin, pf, po);     // (row 1 of a node without in-edges: row 0 is not in the registers)
+                const uint32_t hsh0 = hand_down(px[CP - 1], pcin);
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
-                    dg[t] = pk_adds(t == 0 ? hsh0 : h[t - 1], ss[t]);
-                    MF[t] = pk_max(h[t], fs[t]); MO[t] = pk_max(h[t], os[t]);
+                    dg[t] = pk_adds(t == 0 ? hsh0 : px[t - 1], ss[t]);
+                    MF[t] = pk_max(px[t], pf[t]); MO[t] = pk_max(px[t], po[t]);
                 }
-            }
-            if (np > 1) {
+            } else {
                 const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
+#pragma unroll
+                for (int t = 0; t < CP; ++t) { dg[t] = NEG2; MF[t] = NEG2; MO[t] = NEG2; }
                 auto add_source = [&](int qr) {
-                    uint32_t h[CP], hsh0, fs[CP], os[CP];
-                    source(qr, h, hsh0, fs, os);
+                    uint32_t h[CP], fs[CP], os[CP];
+                    int left = pcin;
+                    if (qr == r - 1) {
+#pragma unroll
+                        for (int t = 0; t < CP; ++t) { h[t] = px[t]; fs[t] = pf[t]; os[t] = po[t]; }
+                    } else source(qr, h, left, fs, os);
+                    const uint32_t hsh0 = hand_down(h[CP - 1], left);
 #pragma unroll
                     for (int t = 0; t < CP; ++t) {
                         dg[t] = pk_max(dg[t], pk_adds(t == 0 ? hsh0 : h[t - 1], ss[t]));
                         MF[t] = pk_max(MF[t], pk_max(h[t], fs[t])); MO[t] = pk_max(MO[t], pk_max(h[t], os[t]));
                     }
                 };
+                add_source(p0);
                 add_source((int)(d1 & 0xffff));
                 if (np > 2) add_source((int)(d1 >> 16));
                 if (np > 3) {                                    // rare: in-edges beyond the third come from HBM
@@ -693,10 +705,11 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             }
             // ---- end cell: first strict maximum in (rank, column) order --------------------------------------------
             if (sw | (!nw & sink)) {
-                // columns beyond the sequence (letter 0x100: bit 8) do not count
+                // columns beyond the sequence (letter 0x100: bit 8) do not count.  In local mode with a negative mismatch score they cannot
+                // be the end cell anyway: every move into such a cell loses score, so it is below the cell it came from
                 uint32_t hv2[CP];
 #pragma unroll
-                for (int t = 0; t < CP; ++t) hv2[t] = bfi(pk_sra15(sbP[t] << 7), 0x80008000u, Hf[t]);
+                for (int t = 0; t < CP; ++t) hv2[t] = beyond_free ? Hf[t] : bfi(pk_sra15(sbP[t] << 7), 0x80008000u, Hf[t]);
                 uint32_t rm = hv2[0];
 #pragma unroll
                 for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
@@ -1127,20 +1140,18 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
         const int np = (int)((d0 >> 8) & 0xf), npp = np ? np : 1;
         const int l = lane - a, myr = r0 - lane, myc = j - l;
         bool ok = l >= 0 && lane < 63 && chain && myc >= 1;
-        int hc = 0, hd = 0;
-        if (ok) { hc = (int)Hb[lane * BT_W + myc - csk]; hd = (int)Hb[(lane + 1) * BT_W + myc - 1 - csk1]; }
         const int ps = np == 0 ? 0 : (lane == 0 ? (int)(d0 >> 16) : (lane == 1 ? (int)(d1 & 0xffff) : (int)(d1 >> 16)));
         const int kp = r0 - ps, xp = j - cs_at(kp);
         const bool act = lane < npp;
         const bool inb = (unsigned)kp < 64u && xp >= 1 && xp < BT_W;
-        int hp1 = 0, hp = 0, dp = 0;
-        if (act && inb) { hp1 = (int)Hb[kp * BT_W + xp - 1]; hp = (int)Hb[kp * BT_W + xp]; dp = (int)Db[kp * BT_W + xp]; }
+        // no branches around the reads (a lane with nothing to read reads a cell of its own band row): they issue together, one wait
+        const int i_own = ok ? lane * BT_W + myc - csk : lane * BT_W, i_nb = ok ? (lane + 1) * BT_W + myc - 1 - csk1 : lane * BT_W;
+        const int i_p = act && inb ? kp * BT_W + xp : lane * BT_W + 1, i_s = ok ? myc - 1 : 0;
         const int xl = a * BT_W + j - __builtin_amdgcn_readlane(csk, a);
-        const int h = (int)Hb[xl], hl = (int)Hb[xl - 1], dl = (int)Db[xl - 1];
-        if (ok) {
-            const int sc = (int)(rim.x & 0xff) == (int)lseq[myc - 1] ? S.m : S.n;
-            ok = hc == hd + sc && !(sw && hc == 0);
-        }
+        const int hc = (int)Hb[i_own], hd = (int)Hb[i_nb], hp1 = (int)Hb[i_p - 1], hpv = (int)Hb[i_p], dpv = (int)Db[i_p];
+        const int h = (int)Hb[xl], hl = (int)Hb[xl - 1], dl = (int)Db[xl - 1], sb = (int)lseq[i_s];
+        int hp = hpv, dp = dpv, hp1x = hp1;
+        ok = ok && hc == hd + ((int)(rim.x & 0xff) == sb ? S.m : S.n) && !(sw && hc == 0);
         {
             const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok) >> a;
             const int run = ~okm ? __builtin_ctzll(~okm) : 64;
@@ -1157,11 +1168,11 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
         DBGCNT(19, 1);
         int psx = ps;
         if (np > 3 || __builtin_amdgcn_ballot_w64(act && !inb)) {        // rare: in-edges beyond the third, or a source row outside the band
-            if (act) { psx = pred_of(r, d0, d1, lane); hp1 = Hat(psx, j - 1); hp = Hat(psx, j); dp = Dat(psx, j); }
+            if (act) { psx = pred_of(r, d0, d1, lane); hp1x = Hat(psx, j - 1); hp = Hat(psx, j); dp = Dat(psx, j); }
         }
         {
             const int sc = (int)(d0 & 0xff) == (int)lseq[j - 1] ? S.m : S.n;
-            unsigned long long bm = __builtin_amdgcn_ballot_w64(act && h == hp1 + sc);
+            unsigned long long bm = __builtin_amdgcn_ballot_w64(act && h == hp1x + sc);
             if (bm) {
                 if (lane == 0) w.pn[j - 1] = r;
                 r = __builtin_amdgcn_readlane(psx, __builtin_ctzll(bm)); --j;
@@ -1589,6 +1600,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
         const size_t need_min = poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(maxlen + 8, maxlen) + 64;
         bool use_big = need_min > p.slot_bytes;
         int N = 0, len = -1, ncols = 0;
+        unsigned long long dp_cells = 0, dp_rows_n = 0;      // work of this read: DP cells and row steps (the bench's cell-update rate)
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (use_big) {
                 if (p.tier == 0 && p.n_big > 0 && need_min <= p.big_slot_bytes) {
@@ -1612,6 +1624,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
                 if (i == ncuts && !tail) break;
                 const int cut = i < ncuts ? __builtin_amdgcn_readfirstlane(cuts[i]) : L;
                 int sc1 = 0;
+                if (N > 0 && cut > b) { dp_cells += (unsigned long long)N * (unsigned)(cut - b); dp_rows_n += (unsigned long long)N * (unsigned)((cut - b + 128 * POA_MAXCP - 1) / (128 * POA_MAXCP)); }
                 N = poa_add(w, S, N, ncap, seq + b, cut - b, lane, &sc1, p.msa_col ? p.msa_col + off + b : nullptr, tacc);
                 if (p.aln_score && si < CCS_SEG_CAP && lane == 0) p.aln_score[(size_t)rd * CCS_SEG_CAP + si] = sc1;
                 b = cut; ++si;
@@ -1650,7 +1663,13 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
         else if (N < 0) res.status = 2;
         else if (len < 0) res.status = 3;
         else { res.nseg = nseg; res.ccs_len = len; }
-        if (lane == 0) { p.results[rd] = res; if (p.msa_ncols) p.msa_ncols[rd] = ncols; }
+        if (lane == 0) {
+            p.results[rd] = res; if (p.msa_ncols) p.msa_ncols[rd] = ncols;
+            if (p.stats && res.status != 1) {                // a read handed to the second launch is counted there
+                atomicAdd((unsigned long long*)(p.stats + 2), dp_cells); atomicAdd((unsigned long long*)(p.stats + 4), dp_rows_n);
+                if (res.status != 0) atomicAdd(p.stats + 8 + (res.status & 7), 1);      // reads lost to a limit of this kernel, by status
+            }
+        }
         __syncthreads();
         if (big >= 0) {                      // every store into the large slot has landed before another wave may claim it
             __threadfence();

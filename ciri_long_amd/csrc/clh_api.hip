@@ -1208,7 +1208,7 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     P.sc = ccs_scores();
     P.aln_score = (int32_t*)pl->d_score;
     if (!pl->ev[0]) for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipMemsetAsync(pl->d_counter, 0, 8, st));
+    HIPCHK(hipMemsetAsync(pl->d_counter, 0, 256, st));        // the two work counters and every statistic of the run
     const bool trace = getenv("CLH_TRACE") != nullptr;
     HIPCHK(hipEventRecord(pl->ev[0], st));
     P.work_order = (const int32_t*)pl->d_order;
@@ -1263,6 +1263,26 @@ extern "C" int clh_ccs_plan_info(clh_ccs_plan* pl, int64_t* out)
         int st[2] = {0, 0};
         HIPCHK(hipMemcpy(st, (int*)pl->d_counter + 2, sizeof(st), hipMemcpyDeviceToHost));
         out[4] = st[0]; out[5] = st[1];
+    }
+    return 0;
+}
+
+// statistics of the last run: out[16] = {DP cells, DP row steps, 0, reads per status 1..7 (lost to a limit of the kernel: 1
+// workspace, 2 graph limits, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 16-bit range, 7 alignment without a
+// base), 0...}
+extern "C" int clh_ccs_plan_stats(clh_ccs_plan* pl, int64_t* out)
+{
+    if (!pl || !out) return fail(CLH_E_ARG, "clh_ccs_plan_stats: null argument");
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    if (pl->ran && pl->n > 0) {
+        HIPCHK(hipSetDevice(pl->ctx->device));
+        HIPCHK(hipStreamSynchronize(pl->last_stream));
+        int st[64];
+        HIPCHK(hipMemcpy(st, pl->d_counter, sizeof(st), hipMemcpyDeviceToHost));
+        const int* s2 = st + 2;                                  // P.stats
+        out[0] = (int64_t)((unsigned long long)(unsigned)s2[2] | ((unsigned long long)(unsigned)s2[3] << 32));
+        out[1] = (int64_t)((unsigned long long)(unsigned)s2[4] | ((unsigned long long)(unsigned)s2[5] << 32));
+        for (int k = 1; k <= 7; ++k) out[2 + k] = s2[8 + k];
     }
     return 0;
 }
@@ -1362,7 +1382,7 @@ extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, 
         P.results = (clh::CcsResult*)pl->d_res; P.segs = (int32_t*)pl->d_segs; P.ccs = (int8_t*)pl->d_ccs;
         P.sc = sc; P.xcuts = (const int32_t*)d_xcuts; P.xcut_off = (const int64_t*)d_xoff;
         P.msa_col = (int32_t*)d_col; P.msa_ncols = (int32_t*)d_ncols; P.aln_score = (int32_t*)pl->d_score;
-        if (hipMemsetAsync(pl->d_counter, 0, 16, st) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
+        if (hipMemsetAsync(pl->d_counter, 0, 256, st) != hipSuccess) rc = fail(CLH_E_HIP, "memset failed");
         if (!rc) rc = launch_poa_tiers(pl, P, st);
         pl->ran = true; pl->last_stream = st;
     }

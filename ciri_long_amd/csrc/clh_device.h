@@ -81,7 +81,8 @@ struct CcsResult {        // K3 output per read
     int32_t nseg;         // 0 = no consensus
     int32_t ccs_len;
     int32_t period;
-    int32_t status;       // 0 ok, 1 workspace slot too small, 2 graph limits (in-degree, aligned set, 65535 rows), 3 consensus overflow, 4 sequence above 2800 bases
+    int32_t status;       // 0 ok, 1 workspace slot too small, 2 graph limits (in-degree, aligned set, 65000 rows), 3 consensus overflow, 4 sequence above 2800 bases,
+                          // 5 back-track guard, 6 a cell left the 16-bit range, 7 an alignment without a base (spoa throws)
 };
 
 // scores and mode of the partial-order aligner (spoa.poa(seqs, algorithm, genmsa, m, n, g, e, q, c)); affine is passed as
@@ -101,7 +102,8 @@ struct CcsParams {
     int8_t* ccs;               // packed like reads (a consensus is never longer than its read)
     uint8_t* poa_ws;           // nslots * slot_bytes
     int* work_counter;
-    int* stats;                // [0] reads that ran in a claimed large slot, [1] reads run by the second launch
+    int* stats;                // [0] reads that ran in a claimed large slot, [1] reads run by the second launch, [2..3] DP cells and [4..5] DP row
+                               // steps of the run (64 bits each), [8 + s] reads that ended with status s (1..7: lost to a limit of the kernel)
     const int32_t* work_order; // reads, longest first (or nullptr)
     unsigned long long slot_bytes;
     int32_t n;

@@ -221,7 +221,8 @@ extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fast
                     if (g < 0) { if (b.seq_len[(size_t)k] > kMaxRead) stats->too_long += 1; continue; }
                     if (R.rows.empty()) continue;                 // the GPU step failed: only the counters go on
                     const clh_ccs_t& r = R.rows[(size_t)g];
-                    if (r.nseg <= 0 || r.status != 0) continue;
+                    if (r.status != 0) { stats->capacity_dropped += 1; continue; }      // lost to a limit of the kernel: counted, reported by the caller
+                    if (r.nseg <= 0) continue;
                     stats->ro_reads += 1;
                     const char* hdr = b.text.data() + b.hdr_off[(size_t)k];
                     line.assign(">"); line.append(hdr, (size_t)b.hdr_len[(size_t)k]); line.push_back('\t');

@@ -112,6 +112,7 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_results_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_plan_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_ccs_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -323,12 +324,15 @@ class Context(object):
 
     def ccs_file(self, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads=0, first_record=0, max_records=-1):
         """Stage 1 from file to file in native code -> (total_reads, reads_with_consensus, reads_too_long); with
-        first_record / max_records for one rank's contiguous shard of the records"""
-        st = (C.c_int64 * 3)()
+        first_record / max_records for one rank's contiguous shard of the records.  Reads that a limit of the kernel left
+        without a consensus are counted in self.capacity_dropped (and logged by find_ccs_reads)."""
+        st = (C.c_int64 * 4)()
         rc = lib().clh_ccs_file_range(self._h, os.fsencode(in_path), int(bool(is_fastq)), os.fsencode(ccs_fa_path), os.fsencode(raw_fa_path),
                                       int(batch_reads), int(first_record), int(max_records), C.byref(st))
         if rc != 0:
             raise ClhError('clh_ccs_file failed (%d): %s' % (rc, last_error()))
+        self.capacity_dropped = getattr(self, 'capacity_dropped', 0) + int(st[3])
+        self.last_capacity_dropped = int(st[3])
         return int(st[0]), int(st[1]), int(st[2])
 
     def ccs_plan(self, read_off):
@@ -648,6 +652,15 @@ class CcsPlan(object):
         if lib().clh_ccs_plan_info(self._h, out.ctypes.data) != 0:
             raise ClhError('clh_ccs_plan_info: %s' % last_error())
         return dict(zip(('slots', 'slot_bytes', 'big_slots', 'big_slot_bytes', 'ran_in_claimed_big_slot', 'ran_in_second_launch'), (int(x) for x in out)))
+
+    def stats(self):
+        """dict(dp_cells, dp_row_steps, dropped = {status: reads}) of the last run; `dropped` lists the reads a limit of the kernel left
+        without a consensus (status 1 workspace, 2 graph limits, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 16-bit
+        range, 7 alignment without a base)"""
+        out = np.zeros(16, dtype=np.int64)
+        if lib().clh_ccs_plan_stats(self._h, out.ctypes.data) != 0:
+            raise ClhError('clh_ccs_plan_stats: %s' % last_error())
+        return {'dp_cells': int(out[0]), 'dp_row_steps': int(out[1]), 'dropped': {k: int(out[2 + k]) for k in range(1, 8) if out[2 + k]}}
 
     def results_dev(self):
         """device pointers (rows, segs, ccs) of the last run's outputs; ccs is packed at the read offsets"""

@@ -130,8 +130,9 @@ typedef struct {
     int32_t nseg;      /* 0: no tandem repeat / no consensus (find_consensus would return (None, None)) */
     int32_t ccs_len;
     int32_t period;
-    int32_t status;    /* 0 ok; >0 treated as no consensus: 1 workspace, 2 graph limits (12 in-edges, 65000 rows), 3 output, 4 sequence longer than 2800 bases,
-                          5 back-track guard, 6 a DP cell left the 16-bit range (global / overlap modes with costly gaps) */
+    int32_t status;    /* 0 ok; >0 no consensus because of a limit of this kernel (counted, see clh_ccs_plan_stats): 1 workspace, 2 graph limits (12
+                          in-edges, 8 letters in a column, 65000 rows), 3 output, 4 sequence longer than 2800 bases, 5 back-track guard, 6 a DP
+                          cell left the 16-bit range (global / overlap modes with costly gaps), 7 an alignment without a base (spoa throws) */
 } clh_ccs_t;
 typedef struct clh_ccs_plan clh_ccs_plan;
 clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off);
@@ -144,6 +145,9 @@ int clh_ccs_results_dev(const clh_ccs_plan* plan, const void** rows, const void*
 /* Workspace tiers of the plan and how the last run used them: out[6] = {first-tier slots, bytes per slot, large slots,
  * bytes per large slot, reads that ran in a large slot claimed on the fly, reads run by the second launch}. */
 int clh_ccs_plan_info(clh_ccs_plan* plan, int64_t* out);
+/* Work and losses of the last run: out[16] = {DP cells, DP row steps, 0, reads that ended with status 1, 2, ... 7 (no
+ * consensus because of a limit of this kernel -- never silently: callers count and report them), 0 ...}. */
+int clh_ccs_plan_stats(clh_ccs_plan* plan, int64_t* out);
 /* HIP-event durations (ms) of the last run: ms[0] = repeat scan (K2), ms[1] = partial-order consensus (K3). */
 int clh_ccs_plan_timing(clh_ccs_plan* plan, float* ms);
 int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, clh_ccs_t* out, int32_t* segs, int8_t* ccs);
@@ -169,7 +173,8 @@ int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64
  * one sequence line per record; writes tmp/{prefix}.ccs.fa and tmp/{prefix}.raw.fa in the reference's format
  * (find_ccs.py:94-95), reads with a consensus only, input order.  batch_reads <= 0 selects 65536.  too_long counts reads
  * above 16 M bases (not scanned). */
-typedef struct { int64_t total_reads, ro_reads, too_long; } clh_ccs_file_stats;
+typedef struct { int64_t total_reads, ro_reads, too_long, capacity_dropped; } clh_ccs_file_stats;   /* capacity_dropped: reads with a
+                                                                   tandem repeat that a limit of the kernel left without a consensus (status > 0) */
 int clh_ccs_file(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
                  int32_t batch_reads, clh_ccs_file_stats* stats);
 /* The same for the records [first_record, first_record + max_records) of the file (max_records < 0: to the end) -- one

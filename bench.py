@@ -43,6 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 NCHECK = 24                                 # reads of the batch spot-checked against the oracle (by the CPU leg)
 PK_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0       # SIMDs x Hz / 4 cycles: packed-16 ops are half rate (tools/ubench/valu_rate.hip)
+K3_FLOOR_OPS = 22                           # packed operations per cell pair of K3's recurrences, nothing else counted (see FullStep.launches)
 WINDOW = 2000
 B_ASCII = np.frombuffer(b'ACGTN', dtype=np.uint8)
 
@@ -151,7 +152,7 @@ class _DevArray(object):
 
 
 def roofline_of(launches, traffic_file=True):
-    dom = max((x for x in launches if not x.get('host_wall')), key=lambda x: x['ms'])      # kernels timed with HIP events only
+    dom = max((x for x in launches if not x.get('host_wall') and x.get('alg_bytes')), key=lambda x: x['ms'])      # kernels timed with HIP events only
     ach = dom['alg_bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
@@ -195,8 +196,10 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
-        out.append({'kernel': 'ssw_traceback_rows_wide_kernel + ssw_traceback_kernel (handed-over alignments)', 'alignments': None, 'ms': accb[1] / PROF, 'alg_bytes': 0,
-                    'note': 'latency of the few wide-band alignments, one wave or workgroup each'})
+        nwide = int(ssw_plan.traceback_counts()[0])
+        out.append({'kernel': 'ssw_traceback_rows_wide_kernel + ssw_traceback_kernel (handed-over alignments)', 'alignments': nwide, 'ms': accb[1] / PROF,
+                    'alg_bytes': int(b_alg.mean() * nwide) if len(qlen) else 0,
+                    'note': 'latency of the few wide-band alignments, one wave or workgroup each; bytes = their number x the mean B_ssw of the batch'})
     valu = {'bound': 'valu', 'kernel': 'ssw_scan_kernel + ssw_align_kernel (all classes)', 'unit': 'GCUPS',
             'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
             'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,
@@ -306,20 +309,47 @@ class FullStep(object):
             self.ccs_plan.run(self.d_reads.data_ptr(), self.stream)
             a, b = self.ccs_plan.timing()
             k2 += a / PROF; k3 += b / PROF
+        kst = self.ccs_plan.stats()
         L = np.diff(self.ro)
         has, crow = self.has, self.crow
         b_k3 = int(L[has].sum() + crow['ccs_len'][has].sum() + 16 * crow['nseg'][has].sum() + 16 * self.nreads)
         out = [{'kernel': 'ccs_scan_kernel', 'reads': self.nreads, 'ms': k2, 'alg_bytes': int(L.sum() + 272 * self.nreads)},
-               {'kernel': 'poa_consensus_kernel', 'reads': int(len(has)), 'ms': k3, 'alg_bytes': b_k3}]
+               {'kernel': 'poa_consensus_kernel', 'reads': int(len(has)), 'ms': k3, 'alg_bytes': b_k3, 'cells': kst['dp_cells'], 'row_steps': kst['dp_row_steps']}]
+        # K3 against the packed-op issue rate: the five states of a cell pair (two cells per 32-bit lane) cost at least K3_FLOOR_OPS packed
+        # operations in the row-at-a-time formulation -- diagonal add + max, the two vertical states 3 each, their two candidates into the
+        # maximum 2, the two horizontal states as prefix maxima in their gap-free frames 8, H 2, spoa's E from Q 2 -- before any letter
+        # comparison, clamped difference, store, end-cell test or per-row step cost
+        self.k3_valu = {'bound': 'valu', 'kernel': 'poa_consensus_kernel', 'unit': 'GCUPS', 'cells_per_launch': kst['dp_cells'],
+                        'achieved': kst['dp_cells'] / (k3 * 1e-3) / 1e9 if k3 > 0 else None, 'peak': PK_ISSUE_PEAK * 128 / K3_FLOOR_OPS / 1e9,
+                        'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / %d packed ops per cell pair (five-state convex model: '
+                                     'diagonal 2, F 3, O 3, candidates 2, E and Q prefix maxima 8, H 2, E from Q 2)' % K3_FLOOR_OPS,
+                        'dropped_to_kernel_limits': kst['dropped']}
+        self.k3_valu['frac'] = self.k3_valu['achieved'] / self.k3_valu['peak'] if self.k3_valu['achieved'] else None
         d_clips = self.last['clips']
         k1, valu = k1_launches(self.ssw_plan, lambda: self.ssw_plan.run(d_clips.data_ptr(), self.genome.codes_ptr, self.stream),
                                self.co, self.win_len)
         out += k1
         n = max(nsteps, 1)
-        out.append({'kernel': 'genome_count_n_kernel', 'host_wall': True, 'windows': int(len(has)), 'ms': self.t_k5 / n * 1e3, 'alg_bytes': int(24 * len(has)),
-                    'note': 'wall time of the C-ABI call: upload of the spans, kernel, download of the counts'})
-        out.append({'kernel': 'splice_scan_kernel', 'host_wall': True, 'candidates': int(len(has)), 'ms': self.t_k6 / n * 1e3, 'alg_bytes': int(72 * len(has)),
-                    'note': 'wall time of the C-ABI call: upload of the candidates, kernel, download of the rows'})
+        # K5 and K6 once more on an idle GPU: inside the step their calls queue behind the consensus kernel of the next step (its persistent
+        # waves hold every register file), so the in-step wall time says when they got the GPU, not what they cost
+        torch = self.torch
+        rows = self.last['rows']
+        start = self.win_off + rows['ref_begin1'].astype(np.int64); end = self.win_off + rows['ref_end1'].astype(np.int64) + 1
+        cb = np.clip(self.clen - (rows['read_end1'].astype(np.int64) - rows['read_begin1'] + 1), 0, 20).astype(np.int32)
+        cand = {'ctg_off': self.ctg_off, 'ctg_len': self.ctg_len, 'start': start, 'end': end, 'clip_base': cb, 'host_mask': self.zeros32}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(PROF):
+            self.genome.count_n_spans(self.win_off, self.win_len)
+        t1 = time.perf_counter()
+        for _ in range(PROF):
+            self.genome.splice_signals(cand, 10, 3, True)
+        t2 = time.perf_counter()
+        out.append({'kernel': 'genome_count_n_kernel', 'host_wall': True, 'windows': int(len(has)), 'ms': (t1 - t0) / PROF * 1e3, 'ms_in_step': self.t_k5 / n * 1e3,
+                    'alg_bytes': int(24 * len(has)), 'note': 'wall time of the C-ABI call on an idle GPU: upload of the spans, kernel, download of the counts; '
+                    'ms_in_step: the same call inside the timed step, where it waits for the GPU behind the next step\'s consensus kernel'})
+        out.append({'kernel': 'splice_scan_kernel', 'host_wall': True, 'candidates': int(len(has)), 'ms': (t2 - t1) / PROF * 1e3, 'ms_in_step': self.t_k6 / n * 1e3,
+                    'alg_bytes': int(72 * len(has)), 'note': 'wall time of the C-ABI call on an idle GPU: upload of the candidates, kernel, download of the rows'})
         out.append({'kernel': '(K1 wait + D2H of the result rows)', 'host_wall': True, 'rows': int(len(has)), 'ms': self.t_fetch / n * 1e3, 'alg_bytes': int(40 * len(has)),
                     'note': 'host wall time from the K1 launch to the rows on the host: waits for everything queued on the stream (K2, K3, the gather, K1)'})
         return out, valu
@@ -350,12 +380,15 @@ def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmu
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         counters = c.cpu().numpy()
         assert int(counters[0]) == world * nreads, 'junction-count all-reduce: total does not add up'
+        res_exchange = 'int64[7] all_reduce(sum) on RCCL over %d rank(s): total %d' % (world, int(counters[0]))
+    else:
+        res_exchange = None
     launches, valu = fs.launches(steps)
     sig = fs.last['sig']
-    res = {'value': world * nreads * steps / el, 'ms_per_step': el / steps * 1e3, 'launches': launches, 'valu_roofline': valu,
+    res = {'value': world * nreads * steps / el, 'ms_per_step': el / steps * 1e3, 'launches': launches, 'valu_roofline': valu, 'valu_roofline_k3': fs.k3_valu,
            'roofline': roofline_of(launches), 'reads_with_consensus': int(len(fs.has)),
            'counters': dict(zip(['total', 'consensus', 'raw_unmapped', 'ccs_mapped', 'bsj', 'signal', 'partial'], [int(x) for x in counters])),
-           'splice_handed_back': int((sig[:, 0] != 0).sum())}
+           'splice_handed_back': int((sig[:, 0] != 0).sum()), 'counter_exchange': res_exchange}
     fs.genome.close()
     return res
 
@@ -612,12 +645,15 @@ def main():
             'reads_per_gpu': nreads, 'window': WINDOW, 'scoring': '1/1/1/1',
             'parallelism': 'reads sharded x%d, no data-path collective%s' % (world, '; int64[7] counter all-reduce on RCCL after the timed loop' if world > 1 else ''),
             'consensus_parity': 'unpinned (pyccs/spoa absent from the reference tree; clh-poa v2 restates the published spoa algorithm, oracle/poa_oracle.c)' if full else None},
-        'roofline': res['roofline'], 'valu_roofline': res['valu_roofline'], 'launches': res['launches'],
+        'roofline': res['roofline'], 'valu_roofline': res['valu_roofline'],
     }
+    if 'valu_roofline_k3' in res:
+        out['valu_roofline_k3'] = res['valu_roofline_k3']      # the kernel that is most of the step
     if 'reads_with_consensus' in res:
         out['config']['reads_with_consensus'] = res['reads_with_consensus']
         out['counters'] = res['counters']
         out['splice_handed_back'] = res['splice_handed_back']
+        out['counter_exchange'] = res['counter_exchange']
     out['cpu_baseline'] = cpu      # rank 0 at N=1 only; None under a profiler or with --no-cpu
     if world == 1 and not args.no_extra and not profiled and wl == 'c3':
         extra = {}
@@ -633,6 +669,21 @@ def main():
         except Exception as ex:                      # an extra line must not cost the headline
             extra['error'] = repr(ex)
         out['extra'] = extra
+    out['launches'] = res['launches']
+    # LAST, and short: a reader that keeps only the end of this line (the driver's record keeps 2000 characters) still sees every
+    # configuration's number
+    summ = {'c3_or_main_reads_per_s': round(res['value']), 'ms_per_step': round(res['ms_per_step'], 2),
+            'k3_ms': next((round(x['ms'], 2) for x in res['launches'] if x['kernel'] == 'poa_consensus_kernel'), None),
+            'k3_valu_frac': round(res['valu_roofline_k3']['frac'], 4) if res.get('valu_roofline_k3', {}).get('frac') else None,
+            'roofline_frac': res['roofline']['frac']}
+    for k, e in (out.get('extra') or {}).items():
+        if isinstance(e, dict) and 'value' in e:
+            summ[k] = {'value': round(e['value']), 'unit': e.get('unit'), 'ms_per_step': round(e['ms_per_step'], 2) if 'ms_per_step' in e else None,
+                       'roofline_frac': (e.get('roofline') or {}).get('frac'), 'valu_frac': (e.get('valu_roofline') or {}).get('frac'),
+                       'k3_valu_frac': (e.get('valu_roofline_k3') or {}).get('frac')}
+    if out.get('extra', {}).get('error'):
+        summ['extra_error'] = out['extra']['error'][:200]
+    out['summary'] = summ
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

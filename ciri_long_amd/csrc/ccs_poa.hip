@@ -446,6 +446,16 @@ __device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t b) {   
     asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(sh), "v"(b));
     return d;
 }
+// a pointer the compiler cannot see to be wave-uniform, as a scalar-register pair (else it lives in two VGPRs -- and with some
+// thirty workspace pointers alive that is what spills)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    typedef __attribute__((address_space(1))) T* gptr;      // a pointer into HBM: rebuilt as such, or every access through it turns "flat"
+    return (T*)(gptr)(((unsigned long long)hi << 32) | lo);
+}
+
 // lo half = half hx of x, hi half = half hy of y (one v_perm_b32)
 template <int HX, int HY>
 __device__ __forceinline__ uint32_t mix16(uint32_t x, uint32_t y) {
@@ -540,8 +550,11 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     int nbest = -(1 << 30), nrow = 0;                            // global mode: cells (sink row, column m), wave-uniform
     uint32_t lowP = 0x7fff7fffu;                                 // global / overlap: the lowest H of the pass (local cells are >= 0)
     const bool stores = col0 + 1 <= m;
-    short* hrow = w.planeH + col0 + 8;                           // + r * gp per row
-    unsigned short* drow = w.planeD + col0 + 8;
+    // (stores written out as asm with a scalar base and the lane's 32-bit offset saved the 64-bit address arithmetic and cost 2 ms:
+    // the blocks pin the schedule)
+    const char* planeH = (const char*)w.planeH;
+    const char* planeD = (const char*)w.planeD;
+    const uint32_t lane_off = (uint32_t)(col0 + 8) * 2u;
     for (int rb = 1; rb <= N; rb += 64) {
         uint2 nblk; int nH, nE, nQ;
         fetch(rb + 64 + lane, nblk, nH, nE, nQ);
@@ -584,8 +597,8 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                         left = ringL[qr & rmask];
                     } else {
                         uint32_t nh[CP], nd[CP];
-                        const uint32_t* sh = (const uint32_t*)(hrow + (size_t)qr * gp);
-                        const uint32_t* sd = (const uint32_t*)(drow + (size_t)qr * gp);
+                        const uint32_t* sh = (const uint32_t*)(planeH + (size_t)qr * gp * 2 + lane_off);
+                        const uint32_t* sd = (const uint32_t*)(planeD + (size_t)qr * gp * 2 + lane_off);
                         // compiler-visible loads: its own wait counts (an asm block here made it wait for every store in flight on the
                         // ring path too).  The cells were written by these very lanes earlier in this pass.
 #pragma unroll
@@ -675,7 +688,13 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 const uint32_t Hm = pk_subs(Hf[t], ONE2);
                 const uint32_t dF = pk_max(pk_subs(fsn[t], Hm), 0u), dO = pk_max(pk_subs(osn[t], Hm), 0u);
                 const uint32_t dE = pk_max(pk_subs(Es[t], Hm), 0u), dQ = pk_max(pk_subs(Y[t], Hm), 0u);
-                D[t] = lshl_or(lshl_or(dQ, 3, dE), 8, lshl_or(dO, 3, dF));
+                {   // the four fields of both halves: three v_lshl_or_b32 in ONE block (the compiler turns any C form into five operations,
+                    // and pads separate blocks with wait states)
+                    uint32_t dd_, t_;
+                    asm("v_lshl_or_b32 %0, %2, 3, %3\n\tv_lshl_or_b32 %1, %4, 3, %5\n\tv_lshl_or_b32 %0, %0, 8, %1"
+                        : "=&v"(dd_), "=&v"(t_) : "v"(dQ), "v"(dE), "v"(dO), "v"(dF));
+                    D[t] = dd_;
+                }
             }
             SEC(11);
             // ---- what later rows and the back-track read ------------------------------------------------------------------
@@ -685,8 +704,10 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             if (stores) {
                 uint32_t nh[CP], nd[CP];
                 to_natural<CP>(Hf, nh); to_natural<CP>(D, nd);
-                uint32_t* dh = (uint32_t*)(hrow + (size_t)r * gp);
-                uint32_t* dd = (uint32_t*)(drow + (size_t)r * gp);
+                // scalar row base + the lane's 32-bit offset, written out: left to itself the compiler folds the lane's offset into a
+                // 64-bit vector base and pays a 64-bit multiply-add per store
+                uint32_t* dh = (uint32_t*)(w.planeH + (size_t)r * gp + col0 + 8);
+                uint32_t* dd = (uint32_t*)(w.planeD + (size_t)r * gp + col0 + 8);
                 if constexpr (CP == 1) { *dh = nh[0]; *dd = nd[0]; }
                 else if constexpr (CP == 2) { *(uint2*)dh = make_uint2(nh[0], nh[1]); *(uint2*)dd = make_uint2(nd[0], nd[1]); }
                 else if constexpr (CP == 3) { __builtin_memcpy(dh, nh, 12); __builtin_memcpy(dd, nd, 12); }
@@ -1034,15 +1055,6 @@ __device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& 
 // returns the column the walk ends in (the bases in front of it are not part of the alignment), or -1 (guard: corrupt planes).
 static constexpr int BT_W = POA_LDS_BYTES >= 9216 ? 24 : 20;     // columns per band row (64 rows x 2 planes + the sequence in the LDS block)
 static constexpr int BT_DRIFT = BT_W / 2 - 4;        // how far the walk may leave the band's diagonal before the band is staged again
-// a pointer the compiler cannot see to be wave-uniform, as a scalar-register pair (else it lives in two VGPRs -- and with some
-// thirty workspace pointers alive that is what spills)
-template <typename T>
-__device__ __forceinline__ T* uniform_ptr(T* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (T*)(((unsigned long long)hi << 32) | lo);
-}
-
 __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, const int m_, const int8_t* seq_, const int lane, int r, int j, bool& moved DBGARG)
 {
     // the walk is wave-uniform: say so (scalar registers, scalar branches)

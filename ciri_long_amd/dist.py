@@ -72,18 +72,47 @@ def scan_ccs_reads_sharded(ccs_seq, is_canonical=True, chunk_size=250):
     return allreduce_counters(counts), short, gather_records(records)
 
 
-def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_file=None, chunk_size=250):
-    """`CIRI-long call` for one node, one process per GPU (main.py:49-100): stage 1 (consensus of every read) on this
-    rank's contiguous shard of the input records, stage 2 (scan_ccs_chunk) on the reads of that shard, then the reference's
-    two exchanges: the seven counters summed over the ranks (one all-reduce) and the records written in input order by
-    rank 0.  `env` must be initialised (mapper, genome, indices) the way scan_ccs_reads initialises it -- building the
-    minimap2 index is the caller's business, as in main.call.
+def _bcast(obj, src=0):
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def _count_records(in_file, is_fastq):
+    """records of the input as find_ccs_reads' loop counts them: native (host only) when libclh.so loads, else the Python loop"""
+    from . import find_ccs, hip
+    try:
+        return hip.fastx_count(in_file, is_fastq)
+    except (hip.HipUnavailable, OSError):
+        return sum(1 for _ in find_ccs.iter_reads(in_file))
+
+
+def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_file=None, chunk_size=250, stage_setup=None):
+    """`CIRI-long call` for one node, one process per GPU -- every stage of main.py:49-103:
+
+      1    consensus of every read (find_ccs_reads) on this rank's contiguous shard of the input records;
+      2.1  scan_ccs_chunk on the reads of that shard with a consensus;
+      2.2  recover_ccs_chunk on the short reads 2.1 of this rank handed back (the reference runs recover_ccs_reads on all of them);
+      3    scan_raw_chunk on this rank's shard of the input records that are in no candidate record of any rank;
+      then the reference's exchanges: the seven counters summed over the ranks -- ONE all-reduce, after the last stage -- and the
+      records of each stage gathered in rank (= input) order to rank 0, which writes {prefix}.cand_circ.fa (2.1 then 2.2, as the
+      reference appends), {prefix}.low_confidence.fa and {prefix}.json.
+
+    `env` must be initialised for stage 2.1 (mapper, genome, indices) the way scan_ccs_reads initialises it; stage_setup(stage),
+    stage in ('recover', 'raw'), is called before those stages to switch it (bwa for the short reads, find_bsj.py:451-458; the
+    splice-preset mapper again for the raw reads, :655-662) -- building the indices is the caller's business, as in main.call.
+    None: env stays as it is.
 
     Files (identical, byte for byte, to a single-process run): {out_dir}/tmp/{prefix}.ccs.fa, .raw.fa (find_ccs.py:94-95),
-    {out_dir}/{prefix}.cand_circ.fa (find_bsj.py:364-366).  Returns (counters of all ranks, short reads of this rank).
+    {out_dir}/{prefix}.cand_circ.fa (find_bsj.py:364-366, 471-483), {prefix}.low_confidence.fa (:708-710), {prefix}.json
+    (main.py:102-103).  Returns (counters of all ranks, short reads of stage 3 of this rank).
 
     find_consensus_file(in_file, is_fastq, ccs_path, raw_path, first_record, max_records) -> (total, ro, too_long) replaces
     the native stage 1 (`hip.Context.ccs_file`) in CPU tests."""
+    import json
     import os
     import shutil
     from collections import defaultdict
@@ -93,13 +122,14 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
     fq, is_fastq, _gz = find_ccs._open_reads(in_file)
     fq.close()
-    n = hip.fastx_count(in_file, is_fastq)
+    n = _bcast(_count_records(in_file, is_fastq) if rank == 0 else None)      # counted once, not once per rank
     lo, hi = shard_bounds(n, rank, world)
     tmp = os.path.join(out_dir, 'tmp')
     part = os.path.join(tmp, '%s.part%d' % (prefix, rank))
     if find_consensus_file is None:
         def find_consensus_file(path, fastq, ccs_path, raw_path, first, count):
             return hip.default_context().ccs_file(path, fastq, ccs_path, raw_path, 0, first, count)
+    # ---- stage 1 ---------------------------------------------------------------------------------------------------------
     total, ro, _too_long = find_consensus_file(in_file, is_fastq, part + '.ccs.fa', part + '.raw.fa', lo, hi - lo)
     ccs_seq = find_ccs.load_ccs_reads(out_dir, '%s.part%d' % (prefix, rank))
     if dist:
@@ -110,23 +140,56 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
                 for r in range(world):
                     with open(os.path.join(tmp, '%s.part%d.%s' % (prefix, r, kind)), 'rb') as f:
                         shutil.copyfileobj(f, out)
-    counts, short, records = defaultdict(int), [], []
+    counts = defaultdict(int)
     counts['total'] = total
     counts['consensus'] = ro
+
+    def add(cnt):
+        for k, v in cnt.items():
+            counts[k] += v
+    # ---- stage 2.1 -------------------------------------------------------------------------------------------------------
+    short, records = [], []
     for group in grouper(list(ccs_seq), chunk_size * find_bsj.GPU_CHUNKS):
         chunk = [[i, ] + ccs_seq[i] for i in group if i is not None]
         cnt, sh, ret = find_bsj.scan_ccs_chunk(chunk, is_canonical)
-        for k, v in cnt.items():
-            counts[k] += v
+        add(cnt)
         short += sh
         records += ret
-    counts = allreduce_counters(counts)
+    # ---- stage 2.2: the short consensus reads, second mapper ------------------------------------------------------------------
+    if stage_setup is not None:
+        stage_setup('recover')
+    recovered = []
+    for group in grouper(short, chunk_size * find_bsj.GPU_CHUNKS):
+        cnt, ret = find_bsj.recover_ccs_chunk([i for i in group if i is not None], is_canonical)
+        add(cnt)
+        recovered += ret
     records = gather_records(records)
+    recovered = gather_records(recovered)
+    if rank == 0:
+        with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'w') as out:
+            find_bsj._write_records(out, records)
+            find_bsj._write_records(out, recovered)          # the reference appends them (find_bsj.py:471)
+    # ---- stage 3: raw reads that are in no candidate record (find_bsj.py:626-632 reads the ids back from the file) -------------
+    circ_reads = _bcast({rec[0]: 1 for rec in records + recovered} if rank == 0 else None)
+    if stage_setup is not None:
+        stage_setup('raw')
+    partial, short_raw = [], []
+    mine = (rec for k, rec in enumerate(find_ccs.iter_reads(in_file)) if lo <= k < hi)
+    for group in grouper(mine, 1000):
+        cnt, ret, sh = find_bsj.scan_raw_chunk([r for r in group if r is not None], is_canonical, circ_reads)
+        add(cnt)
+        partial += ret
+        short_raw += sh
+    partial = gather_records(partial)
+    # ---- the one exchange of counters: after the last stage --------------------------------------------------------------------
+    counts = allreduce_counters(counts)
     if dist:
         dist.barrier()
     for kind in ('ccs.fa', 'raw.fa'):
         os.remove('%s.%s' % (part, kind))
     if rank == 0:
-        with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'w') as out:
-            find_bsj._write_records(out, records)
-    return counts, short
+        with open('{}/{}.low_confidence.fa'.format(out_dir, prefix), 'w') as out:
+            find_bsj._write_records(out, partial)
+        with open('{}/{}.json'.format(out_dir, prefix), 'w') as f:
+            json.dump(counts, f)
+    return counts, short_raw

@@ -378,7 +378,7 @@ def recover_ccs_reads(short_reads, ref_fasta, ss_index, gtf_index, intron_index,
 # Mapper logic only -- no alignment kernel is involved; kept so that the module offers every stage of the reference's.
 # ---------------------------------------------------------------------------------------------------------------
 def _primary_hits(seq):
-    return sorted([h for h in env.ALIGNER.map(seq) if h.is_primary], key=lambda h: [h.q_st, h.q_en])
+    return sorted([h for h in (env.ALIGNER.map(seq) or ()) if h.is_primary], key=lambda h: [h.q_st, h.q_en])     # (a mapper double may answer None)
 
 
 def _raw_junction(seq, raw_hits):
@@ -408,7 +408,7 @@ def _raw_junction(seq, raw_hits):
 def _raw_layout(seq, circ, junc, raw_hits):
     """(ctg, start, end, strand, clip_base, exons, circ) from the hits of the rotated read (find_bsj.py:543-579)"""
     n = len(seq)
-    circ_hits = sorted([remove_long_insert(h) for h in env.ALIGNER.map(circ) if h.is_primary], key=lambda h: [h.q_st, h.q_en])
+    circ_hits = sorted([remove_long_insert(h) for h in (env.ALIGNER.map(circ) or ()) if h.is_primary], key=lambda h: [h.q_st, h.q_en])
     if len(circ_hits) == 1:
         hit = circ_hits[0]
         if hit.mlen <= max(h.mlen for h in raw_hits) or min(junc, n - junc) < 30:

@@ -110,8 +110,15 @@ def _setup_call_world():
     ssw_wrap.align_pairs = lambda refs, qs, match=2, mismatch=2, gap_open=3, gap_extend=1, **kw: \
         [R(oracle_lib.oracle_align(r, q, match, mismatch, gap_open, gap_extend)) for r, q in zip(refs, qs)]
     w = fm.build_world()
-    env.initializer(fm.FakeMapper(w['genome']), w['genome'].contig_len, w['genome'], w['gtf_index'], None, w['ss_index'])
+    # the first mapper refuses short things (they go to the short-read queue, find_bsj.py:259-263); stage 2.2 maps them with a
+    # second, more permissive mapper -- the roles of minimap2 and bwa in the reference (find_bsj.py:336, 451-458)
+    main = fm.FakeMapper(w['genome'], min_score=170)
+    env.initializer(main, w['genome'].contig_len, w['genome'], w['gtf_index'], None, w['ss_index'])
     find_bsj.THREADS = 3          # the mapper phase of a chunk on a thread pool: same records, same order
+
+    def stage_setup(stage):
+        env.ALIGNER = fm.FakeMapper(w['genome'], min_score=30) if stage == 'recover' else main
+    w['stage_setup'] = stage_setup
     return w
 
 
@@ -121,8 +128,8 @@ def _call_worker(rank, world, port, out_dir, in_file, q):
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from ciri_long_amd import dist as cdist
-    _setup_call_world()
-    counts, short = cdist.call_sharded(in_file, out_dir, 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1)
+    w = _setup_call_world()
+    counts, short = cdist.call_sharded(in_file, out_dir, 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1, stage_setup=w['stage_setup'])
     q.put((rank, dict(counts), len(short)))
     dist.barrier()
     dist.destroy_process_group()
@@ -134,20 +141,36 @@ def test_call_sharded_files_equal_the_single_rank_run(tmp_path):
     from ciri_long_amd import dist as cdist, find_bsj
     w = fm.build_world()
     reads = fm.build_reads(w, 14)
+    rng = w['rng']
+    partial, shorts = [], []
+    for k, (ctg, exons, _strand) in enumerate(w['circs'][:10]):     # one and a half passes over a circle: no consensus, one junction (stage 3)
+        circ = ''.join(w['genome'].genome[ctg][a:b] for a, b in exons)
+        if len(circ) >= 220:
+            unit = circ[len(circ) // 3:] + circ[:len(circ) // 3]
+            partial.append(('part%02d' % k, fm.mutate(unit + unit[:len(unit) // 2], rng, 0.03)))
+    for k in range(6):                                               # consensus below 150 bases: stage 2.2's reads
+        st = 500 + 700 * k
+        shorts.append(('short%02d' % k, fm.mutate(w['genome'].genome['chrA'][st:st + int(rng.integers(70, 120))] * 5, rng, 0.03)))
     in_file = str(tmp_path / 'reads.fa')
     with open(in_file, 'w') as f:
         for rid, _seg, _ccs, raw in reads:
             f.write('>%s some description\n%s\n' % (rid, raw))
+        for rid, raw in partial[:3] + shorts[:3] + partial[3:] + shorts[3:]:
+            f.write('>%s\n%s\n' % (rid, raw))
+    n_in = len(reads) + len(partial) + len(shorts)
     one, two = tmp_path / 'one', tmp_path / 'two'
     for d in (one, two):
         (d / 'tmp').mkdir(parents=True)
     # single process (no process group): the answer
-    _setup_call_world()
+    w1 = _setup_call_world()
     try:
-        counts1, short1 = cdist.call_sharded(in_file, str(one), 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1)
+        counts1, short1 = cdist.call_sharded(in_file, str(one), 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1, stage_setup=w1['stage_setup'])
     finally:
         find_bsj.THREADS = 1
-    assert counts1['total'] == 14 and counts1['consensus'] >= 8 and counts1.get('bsj', 0) >= 3
+    assert counts1['total'] == n_in and counts1['consensus'] >= 12 and counts1.get('bsj', 0) >= 8 and counts1.get('partial', 0) >= 2
+    cand = (one / 'p.cand_circ.fa').read_text()
+    assert cand.count('>short') >= 4 and cand.index('>short') > cand.rindex('>read')      # stage 2.2's records are appended behind stage 2.1's
+    assert (one / 'p.low_confidence.fa').read_text().count('\tpartial\n') == counts1['partial']
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 31500 + os.getpid() % 2000
@@ -163,7 +186,34 @@ def test_call_sharded_files_equal_the_single_rank_run(tmp_path):
         assert p.exitcode == 0
     assert got[0][0] == got[1][0] == dict(counts1)          # the all-reduced counters, on every rank
     assert got[0][1] + got[1][1] == len(short1)
-    for name in ('tmp/p.ccs.fa', 'tmp/p.raw.fa', 'p.cand_circ.fa'):
+    for name in ('tmp/p.ccs.fa', 'tmp/p.raw.fa', 'p.cand_circ.fa', 'p.low_confidence.fa', 'p.json'):
         assert (two / name).read_bytes() == (one / name).read_bytes(), name
     assert (one / 'p.cand_circ.fa').stat().st_size > 0
+    import json
+    assert json.loads((two / 'p.json').read_text()) == dict(counts1)
+    # ... and the single-rank run of the sharded driver writes what the stage drivers of the mirror write one after the other
+    # (find_bsj.scan_ccs_reads -> recover_ccs_reads -> scan_raw_reads, main.py:80-94)
+    w3 = _setup_call_world()
+    try:
+        from ciri_long_amd import env, find_ccs
+        three = tmp_path / 'three'
+        (three / 'tmp').mkdir(parents=True)
+        ccs_seq = find_ccs.load_ccs_reads(str(one), 'p')
+        class _Seqs(object):             # serves sequences like a mapper index: the stage drivers leave it on the host (no GPU here)
+            def __init__(self, g):
+                self.seq, self.contig_len = g.seq, g.contig_len
+        genome, mapper = _Seqs(env.GENOME), env.ALIGNER
+        ss, gtf = env.SS_INDEX, env.GTF_INDEX
+        c1, short = find_bsj.scan_ccs_reads(ccs_seq, None, ss, gtf, None, True, str(three), 'p', 3, aligner=mapper, genome=genome, contig_len=genome.contig_len)
+        c2 = find_bsj.recover_ccs_reads(short, None, ss, gtf, None, True, str(three), 'p', 3, aligner=fm.FakeMapper(w3['genome'], min_score=30), genome=genome)
+        c3, _ = find_bsj.scan_raw_reads(in_file, None, gtf, None, ss, True, str(three), 'p', 3, aligner=mapper, genome=genome, contig_len=genome.contig_len)
+    finally:
+        find_bsj.THREADS = 1
+    for name in ('p.cand_circ.fa', 'p.low_confidence.fa'):
+        assert (three / name).read_bytes() == (one / name).read_bytes(), name
+    merged = {'total': n_in, 'consensus': counts1['consensus']}
+    for c in (c1, c2, c3):
+        for k, v in c.items():
+            merged[k] = merged.get(k, 0) + v
+    assert merged == dict(counts1)
     assert sorted(os.listdir(two / 'tmp')) == ['p.ccs.fa', 'p.raw.fa']       # the per-rank parts are gone

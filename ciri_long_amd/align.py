@@ -142,6 +142,29 @@ class Fasta(object):
         return None if g is None else g[start:end]
 
 
+_FOLD = bytes((c if c in b'ACGT' else (c - 32 if c in b'acgt' else ord('N'))) for c in range(256))
+
+
+class IndexGenome(object):
+    """The genome as a minimap2 index serves it -- `mappy.Aligner.seq`, which is env.GENOME in the reference's main pass
+    (find_bsj.py:340-341: `env.initializer(aligner, contig_len, aligner, ...)`), as opposed to the FASTA text of the short-read
+    pass (:455,462).  The index keeps four bits per base: upper case, anything but ACGT reads as N (soft-masked and IUPAC
+    letters lose their identity); `seq()` answers None for an unknown contig, a start outside [0, length) or an empty range, and
+    clips the end at the contig's (mappy_fetch_seq) -- that None is what find_denovo_signal's `us_seq is None` test is for
+    (align.py:580).  Built from anything with the Fasta contract; `genome` holds the folded text."""
+    index_slices = True
+
+    def __init__(self, fasta):
+        self.genome = {k: v.encode('latin-1').translate(_FOLD).decode('latin-1') for k, v in fasta.genome.items()}
+        self.contig_len = {k: len(v) for k, v in self.genome.items()}
+
+    def seq(self, contig, start=0, end=0x7fffffff):
+        g = self.genome.get(contig)
+        if g is None or start < 0 or start >= len(g) or start >= end:
+            return None
+        return g[start:end]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # CIGAR -> blocks on the reference
 # ---------------------------------------------------------------------------------------------------------------
@@ -154,6 +177,7 @@ class DeviceGenome(object):
     def __init__(self, host, contigs, context=None):
         from . import hip
         self.host = host
+        self.index_slices = bool(getattr(host, 'index_slices', False))     # K6 cuts its windows the way `host.seq` does
         self.contig_len = dict(host.contig_len) if hasattr(host, 'contig_len') else {k: len(v) for k, v in contigs.items()}
         self.device = hip.Genome(context or hip.default_context(), contigs)
 
@@ -442,7 +466,7 @@ def find_signal_batch(cands, is_canonical=True):
             dev.set_splice_sites(env.SS_INDEX)
         rows = dev.splice_signals([(cands[k][0], cands[k][1], cands[k][2], cands[k][3],
                                     (1 if cands[k][4] and '+' in cands[k][4] else 0) | (2 if cands[k][4] and '-' in cands[k][4] else 0))
-                                   for k in on_gpu], 10, 3, is_canonical)
+                                   for k in on_gpu], 10, 3, is_canonical, index_slices=getattr(env.GENOME, 'index_slices', False))
         for k, r in zip(on_gpu, rows.tolist()):
             status, us_free, ds_free, found, strand, i, j, motif = r
             if status != 0:

@@ -527,7 +527,7 @@ extern "C" int clh_splice_signal_batch(clh_genome* g, int32_t n, const int64_t* 
     int rc = 0;
     if (!d_t || !d_o) rc = fail(CLH_E_HIP, "out of device memory");
     if (!rc && (hipMemcpyAsync(d_t, tasks.data(), tb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                clh::launch_splice_scan((const uint8_t*)g->d_codes, (const uint8_t*)g->d_ascii, (const clh::SpliceTask*)d_t, n, search_extra, shift_threshold, is_canonical ? 1 : 0,
+                clh::launch_splice_scan((const uint8_t*)g->d_codes, (const uint8_t*)g->d_ascii, (const clh::SpliceTask*)d_t, n, search_extra, shift_threshold, is_canonical & 3,
                                         sites, (int32_t*)d_o, ctx->stream) != hipSuccess ||
                 hipMemcpyAsync(out, d_o, ob, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess))

@@ -67,7 +67,7 @@ __device__ __forceinline__ unsigned long long site_key(int i, int j, int w, int 
 // ANNO: annotated sites are loaded (the search without them keeps its smaller register file)
 template <bool ANNO>
 __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ ascii, const SpliceTask* __restrict__ tasks, int n,
-                                                          int search_extra, int shift_threshold, int canonical, SpliceSites sites,
+                                                          int search_extra, int shift_threshold, int canonical_flags, SpliceSites sites,
                                                           int32_t* __restrict__ out)
 {
     const int tid = blockIdx.x * 256 + threadIdx.x;
@@ -77,6 +77,8 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
     const uint8_t* ch = ascii + t.ctg_off;               // the characters, for the string comparisons of align.py:477-493
     const long long L = t.ctg_len, S = t.start, E = t.end;
     const int cb = t.clip_base;
+    const bool index_slices = (canonical_flags & 2) != 0;
+    const int canonical = canonical_flags & 1;
     int32_t* o = out + 8 * (size_t)tid;
     const int status = (S < 0 || S >= E || E > L) ? 1 : 0;
     int us_free = 0, ds_free = 0;
@@ -101,6 +103,11 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
     long long ua, nu, da, nd;
     {
         auto pyslice = [&](long long a, long long b, long long& lo, long long& nn) {
+            if (index_slices) {      // mappy's Aligner.seq (the main pass' env.GENOME): no sequence (None) for a start outside the contig or
+                if (a < 0 || a >= L || a >= b) { lo = 0; nn = -1; return; }      // an empty range; the end is clipped
+                lo = a; nn = (b > L ? L : b) - a;
+                return;
+            }
             if (a < 0) { a += L; if (a < 0) a = 0; } else if (a > L) a = L;
             if (b < 0) { b += L; if (b < 0) b = 0; } else if (b > L) b = L;
             lo = a; nn = b > a ? b - a : 0;
@@ -108,7 +115,7 @@ __global__ void __launch_bounds__(256) splice_scan_kernel(const uint8_t* __restr
         pyslice(S - us_len - 2, S + ds_len, ua, nu);
         pyslice(E - us_len, E + ds_len + 2, da, nd);
     }
-    const bool short_seq = nu < ds_len - us_len + 2 || nd < ds_len - us_len + 2;       // align.py:580-583: no search at all
+    const bool short_seq = nu < 0 || nd < 0 || nu < ds_len - us_len + 2 || nd < ds_len - us_len + 2;       // align.py:580-583: no search at all
     // shift i <-> index i + us_len of the upstream slice (str.find from index 1: indices 1 .. n-2); downstream alike
     const long long pu = ua + us_len, pd = da + us_len;   // genome position of shift 0 in each slice (S - 2 and E away from the ends)
     o[1] = us_free; o[2] = ds_free;

@@ -324,10 +324,12 @@ def scan_ccs_reads(ccs_seq, ref_fasta, ss_index, gtf_index, intron_index, is_can
         aligner = mp.Aligner(ref_fasta, n_threads=threads, preset='splice')
     if genome is None:
         # the reference hands the mappy index itself to the workers as GENOME (find_bsj.py:340-341).  Here the FASTA is read
-        # once: it gives the contig lengths AND becomes the genome resident in HBM, so that clip windows are coordinates
-        # (K5/K1) and the splice-signal search runs on the device (K6)
-        from .align import Fasta
-        genome = Fasta(ref_fasta)
+        # once: it gives the contig lengths AND, folded the way the index folds it (upper case, anything but ACGT is N; no
+        # sequence for a start before the contig: align.IndexGenome), becomes the genome resident in HBM, so that clip windows
+        # are coordinates (K5/K1) and the splice-signal search runs on the device (K6) with the main pass' semantics; the
+        # short-read pass keeps the raw text, as the reference does (recover_ccs_reads)
+        from .align import Fasta, IndexGenome
+        genome = IndexGenome(Fasta(ref_fasta))
     if contig_len is None:
         contig_len = genome.contig_len if hasattr(genome, 'contig_len') else None
         if contig_len is None:

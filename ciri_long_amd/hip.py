@@ -486,9 +486,10 @@ class Genome(object):
             raise ClhError('clh_genome_set_splice_sites failed (%d): %s' % (rc, last_error()))
         self._sites_of = ss_index
 
-    def splice_signals(self, cands, search_extra=10, shift_threshold=3, is_canonical=True):
+    def splice_signals(self, cands, search_extra=10, shift_threshold=3, is_canonical=True, index_slices=False):
         """K6: cands = [(contig, start, end, clip_base, host_mask)] (or a dict of columns, see below) -> int32 array [n, 8]:
-        status, us_free, ds_free, found, strand, us_shift, ds_shift, motif (see include/ciri_long_hip.h)"""
+        status, us_free, ds_free, found, strand, us_shift, ds_shift, motif (see include/ciri_long_hip.h).  index_slices: the
+        search windows as a minimap2 index serves them (no sequence for a start before the contig) instead of Python slices"""
         if isinstance(cands, dict):       # columns: ctg_off, ctg_len, start, end (int64), clip_base, host_mask (int32)
             off, ln, st, en = (np.ascontiguousarray(cands[k], dtype=np.int64) for k in ('ctg_off', 'ctg_len', 'start', 'end'))
             cb, hm = (np.ascontiguousarray(cands[k], dtype=np.int32) for k in ('clip_base', 'host_mask'))
@@ -505,7 +506,7 @@ class Genome(object):
         if n == 0:
             return out
         rc = lib().clh_splice_signal_batch(self._h, n, off.ctypes.data, ln.ctypes.data, st.ctypes.data, en.ctypes.data, cb.ctypes.data,
-                                           hm.ctypes.data, search_extra, shift_threshold, 1 if is_canonical else 0, out.ctypes.data)
+                                           hm.ctypes.data, search_extra, shift_threshold, (1 if is_canonical else 0) | (2 if index_slices else 0), out.ctypes.data)
         if rc != 0:
             raise ClhError('clh_splice_signal_batch failed (%d): %s' % (rc, last_error()))
         return out

@@ -211,7 +211,10 @@ int clh_genome_set_splice_sites(clh_genome* genome, const int64_t* pos, const in
  * host_mask: strands of the host gene, bit 0 '+', bit 1 '-'.  out[8k..8k+7] = status (0 done, 1 = outside this kernel's
  * domain: the neighbourhood leaves the contig or holds non-ACGTN characters; run the Python statement), us_free,
  * ds_free, found (0 none, 1 de novo, 2 annotated pair), strand (0 '+', 1 '-'), us_shift, ds_shift, motif (de novo:
- * index into GT-AG, GC-AG, AT-AC, GT-AC, AT-AG). */
+ * index into GT-AG, GC-AG, AT-AC, GT-AC, AT-AG).
+ * is_canonical: bit 0 = search GT-AG only; bit 1 = the two search windows are cut the way a minimap2 index serves sequences
+ * (mappy.Aligner.seq, env.GENOME of the reference's main pass, find_bsj.py:340-341: no sequence for a start outside the contig,
+ * end clipped) instead of the way Python slices a string (align.Fasta.seq, the short-read pass, find_bsj.py:455,462). */
 int clh_splice_signal_batch(clh_genome* genome, int32_t n, const int64_t* ctg_off, const int64_t* ctg_len, const int64_t* start,
                             const int64_t* end, const int32_t* clip_base, const int32_t* host_mask, int32_t search_extra,
                             int32_t shift_threshold, int32_t is_canonical, int32_t* out);

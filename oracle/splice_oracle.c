@@ -97,6 +97,14 @@ static int sort_ss(const list_t* l, int us, int ds, int cb)
     return -1;
 }
 
+/* the same range as a minimap2 index serves it (mappy.Aligner.seq -> mappy_fetch_seq: env.GENOME of the reference's main pass,
+ * find_bsj.py:340-341): no sequence (n = -1, Python's None) for a start outside [0, L) or an empty range; the end is clipped */
+static void idxslice(int64_t L, int64_t a, int64_t b, int64_t* lo, int64_t* n)
+{
+    if (a < 0 || a >= L || a >= b) { *lo = 0; *n = -1; return; }
+    *lo = a; *n = (b > L ? L : b) - a;
+}
+
 /* Python's s[a:b] on a string of length L: first index and length */
 static void pyslice(int64_t L, int64_t a, int64_t b, int64_t* lo, int64_t* n)
 {
@@ -109,12 +117,16 @@ static void pyslice(int64_t L, int64_t a, int64_t b, int64_t* lo, int64_t* n)
  * site_pos / site_cnt: annotated sites of THIS contig as four ascending runs of 1-based positions
  * ('+' starts, '+' ends, '-' starts, '-' ends), all counts zero = no annotation for the contig.
  * out[8] = status (0 done, 1 = invalid coordinates),
- * us_free, ds_free, found (0 none, 1 de novo, 2 annotated pair), strand (0 '+', 1 '-'), us_shift, ds_shift, motif. */
+ * us_free, ds_free, found (0 none, 1 de novo, 2 annotated pair), strand (0 '+', 1 '-'), us_shift, ds_shift, motif.
+ * is_canonical: bit 0 = GT-AG only; bit 1 = the search windows of find_denovo_signal are cut as a minimap2 index serves sequences
+ * (g must then be the text as the index holds it: upper case, anything but ACGT an N) instead of as Python slices a string. */
 int clo_splice_signal(const char* g, int64_t L, int64_t start, int64_t end, int32_t clip_base, int32_t host_mask,
                       int32_t search_extra, int32_t shift_threshold, int32_t is_canonical,
                       const int64_t* site_pos, const int64_t* site_cnt, int32_t* out)
 {
     memset(out, 0, sizeof(int32_t) * 8);
+    const int index_slices = (is_canonical & 2) != 0;
+    is_canonical &= 1;
     if (start < 0 || start >= end || end > L) { out[0] = 1; return 0; }
     const int cb = clip_base, sl = clip_base + search_extra, T = clip_base + shift_threshold;
     /* align.py:477-493 */
@@ -166,11 +178,14 @@ int clo_splice_signal(const char* g, int64_t L, int64_t start, int64_t end, int3
     if (!rc_found) {
         const int us_len = sl + us_free, ds_len = sl + ds_free;
         int64_t ua, nu, da, nd;
-        pyslice(L, start - us_len - 2, start + ds_len, &ua, &nu);       /* genome[start - us_len - 2 : start + ds_len] */
-        pyslice(L, end - us_len, end + ds_len + 2, &da, &nd);           /* genome[end - us_len : end + ds_len + 2]     */
+        if (index_slices) { idxslice(L, start - us_len - 2, start + ds_len, &ua, &nu); idxslice(L, end - us_len, end + ds_len + 2, &da, &nd); }
+        else {
+            pyslice(L, start - us_len - 2, start + ds_len, &ua, &nu);   /* genome[start - us_len - 2 : start + ds_len] */
+            pyslice(L, end - us_len, end + ds_len + 2, &da, &nd);       /* genome[end - us_len : end + ds_len + 2]     */
+        }
         const char* us_seq = g + ua;
         const char* ds_seq = g + da;
-        const int short_seq = nu < ds_len - us_len + 2 || nd < ds_len - us_len + 2;      /* align.py:580-583: no search */
+        const int short_seq = nu < 0 || nd < 0 || nu < ds_len - us_len + 2 || nd < ds_len - us_len + 2;      /* align.py:580-583: None or too short: no search */
         const int OFF = us_len + sl + 2;                                /* shift -> index of the flag arrays */
         const int nflag = OFF + ds_len + sl + 4;
         char* fu = (char*)malloc((size_t)nflag); char* fd = (char*)malloc((size_t)nflag);

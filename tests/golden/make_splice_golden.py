@@ -26,7 +26,25 @@ import make_bsj_golden as mbg  # noqa: E402
 import test_gpu_splice as tgs  # noqa: E402
 
 CONFIGS = [dict(seed=9001, n=1500, canonical=True, annotated=False), dict(seed=9002, n=1500, canonical=False, annotated=False),
-           dict(seed=9003, n=1500, canonical=True, annotated=True), dict(seed=9004, n=1500, canonical=False, annotated=True)]
+           dict(seed=9003, n=1500, canonical=True, annotated=True), dict(seed=9004, n=1500, canonical=False, annotated=True),
+           # env.GENOME as the reference's MAIN pass has it (find_bsj.py:340-341: the mappy index itself).  mappy is not installed
+           # here; IndexDouble below restates mappy.Aligner.seq -> mappy_fetch_seq of minimap2 (python/cmappy.h): the index holds
+           # 4 bits per base (upper case, anything but ACGT reads N), no sequence for a start outside the contig or an empty
+           # range, the end clipped.  The worlds hold soft-masked runs, IUPAC letters and candidates at the contig starts.
+           dict(seed=9005, n=1500, canonical=True, annotated=True, index=True), dict(seed=9006, n=1500, canonical=False, annotated=False, index=True)]
+
+
+class IndexDouble(object):
+    def __init__(self, contigs):
+        fold = bytes((c if c in b'ACGT' else (c - 32 if c in b'acgt' else ord('N'))) for c in range(256))
+        self.genome = {k: v.encode('latin-1').translate(fold).decode('latin-1') for k, v in contigs.items()}
+        self.contig_len = {k: len(v) for k, v in self.genome.items()}
+
+    def seq(self, name, start=0, end=0x7fffffff):
+        g = self.genome.get(name)
+        if g is None or start < 0 or start >= len(g) or start >= end:
+            return None
+        return g[start:min(end, len(g)) if end >= 0 else len(g)]
 
 
 def main():
@@ -35,7 +53,7 @@ def main():
     out = []
     for cfg in CONFIGS:
         contigs, cands = tgs._world(cfg['seed'], cfg['n'])
-        genome = tgs._Genome(contigs)
+        genome = IndexDouble(contigs) if cfg.get('index') else tgs._Genome(contigs)
         ss_index = tgs._annotation(contigs, cands, cfg['seed'] + 1) if cfg['annotated'] else None
         env.initializer(None, genome.contig_len, genome, None, None, ss_index)
         rows = []

@@ -263,7 +263,7 @@ def _rc_upper(s):
     return ''.join(t.get(c, c) for c in reversed(s))
 
 
-def oracle_splice_signal(contig, start, end, clip_base, host, is_canonical=True, site_runs=None):
+def oracle_splice_signal(contig, start, end, clip_base, host, is_canonical=True, site_runs=None, index_slices=False):
     """The splice-signal step for one candidate on the characters of its contig.  host: iterable of '+'/'-' or None;
     site_runs: (positions int64, counts int64[4]) of this contig's annotated sites (1-based, four ascending runs) or None.
     Returns (ss_site | None, us_free, ds_free) like find_annotated_signal + find_denovo_signal, or 'edge' where the
@@ -276,7 +276,8 @@ def oracle_splice_signal(contig, start, end, clip_base, host, is_canonical=True,
     out = np.zeros(8, dtype=np.int32)
     pos, cnt = site_runs if site_runs is not None else (np.zeros(1, dtype=np.int64), np.zeros(4, dtype=np.int64))
     pos = np.ascontiguousarray(pos, dtype=np.int64); cnt = np.ascontiguousarray(cnt, dtype=np.int64)
-    L.clo_splice_signal(raw, len(raw), start, end, clip_base, hm, 10, 3, 1 if is_canonical else 0, pos.ctypes.data, cnt.ctypes.data, out.ctypes.data)
+    L.clo_splice_signal(raw, len(raw), start, end, clip_base, hm, 10, 3, (1 if is_canonical else 0) | (2 if index_slices else 0), pos.ctypes.data,
+                        cnt.ctypes.data, out.ctypes.data)
     status, us_free, ds_free, found, strand, i, j, m = (int(x) for x in out)
     if status:
         return 'edge'

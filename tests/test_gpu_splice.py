@@ -217,3 +217,54 @@ def test_reference_goldens():
     env.GENOME.device.close()
     assert int((rows[:, 0] == 0).sum()) == len(cases)            # every case answered by the kernel, none handed back
     assert n_anno >= 20 and n_denovo >= 20
+
+
+def test_main_pass_genome_as_a_minimap2_index_serves_it():
+    """env.GENOME of the reference's main pass is the mappy index itself (find_bsj.py:340-341): upper case, anything but ACGT an
+    N, no sequence for a start in front of the contig.  With align.IndexGenome resident on the GPU, K6 must give the REFERENCE's
+    answers under that genome (tests/golden/make_splice_golden.py, the two `index` configurations: soft-masked runs, IUPAC letters,
+    candidates at the contig starts), and K1 must complement every base of a minus-strand window (the raw-text route keeps
+    lower-case bases uncomplemented, as the reference's revcomp() does)."""
+    import gzip
+    import numpy as np
+    import oracle_lib
+    from ciri_long_amd import align, env, hip
+    from ciri_long_amd.utils import revcomp
+    with gzip.open(os.path.join(HERE, 'golden', 'splice_golden.json.gz'), 'rt') as f:
+        golden = [c for c in json.load(f) if c.get('index')]
+    assert len(golden) == 2
+    n = n_none_at_start = 0
+    for cfg in golden:
+        contigs, cands = _world(cfg['seed'], cfg['n'])
+        host = align.IndexGenome(_Genome(contigs))
+        ss_index = _annotation(contigs, cands, cfg['seed'] + 1) if cfg['annotated'] else None
+        env.initializer(None, host.contig_len, align.DeviceGenome(host, host.genome), None, None, ss_index)
+        assert env.GENOME.index_slices
+        got = align.find_signal_batch(cands, cfg['canonical'])
+        rows = env.GENOME.device.splice_signals([(c[0], c[1], c[2], c[3], 0) for c in cands], index_slices=True)
+        assert int((rows[:, 0] != 0).sum()) == 0                    # all answered by the kernel
+        for cand, (site, us_free, ds_free), (want_site, wu, wd, tied) in zip(cands, got, cfg['rows']):
+            assert [us_free, ds_free] == [wu, wd] and (site is None) == (want_site is None), cand
+            if not tied:
+                assert (list(site) if site else None) == want_site, (cand, site, want_site)
+            n += 1
+            n_none_at_start += cand[1] - (cand[3] + 10) - wu - 2 < 0 and want_site is None
+        if cfg is golden[0]:
+            # K1 on minus-strand windows of the folded genome, soft-masked stretches included
+            ctg = 'ctg0'
+            text = host.genome[ctg]
+            lows = [k for k, ch in enumerate(contigs[ctg]) if ch.islower()]
+            assert lows
+            wins, reads = [], []
+            for a in (max(0, lows[0] - 150), max(0, lows[len(lows) // 2] - 200)):
+                b = min(len(text), a + 600)
+                wins.append((ctg, a, b))
+                reads.append(revcomp(text[a + 80:a + 80 + 300]))
+            data, off = hip.pack(reads)
+            rows1, _c = env.GENOME.device.ssw_windows(data, off, wins, np.ones(len(wins), dtype=np.uint8), hip.score_matrix(1, 1), 1, 1)
+            for (c2, a, b), q, r in zip(wins, reads, rows1):
+                want = oracle_lib.oracle_align(revcomp(text[a:b]), q, 1, 1, 1, 1)
+                assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1'])) == (want['score'], want['ref_begin'], want['ref_end'])
+                assert int(r['score1']) >= 150          # (an exact substring; N of the folded text score 0)
+        env.GENOME.device.close()
+    assert n == 3000 and n_none_at_start > 20

@@ -80,10 +80,14 @@ def test_reference_answers_on_seeded_worlds():
     from ciri_long_amd import align, env
     with gzip.open(os.path.join(HERE, 'golden', 'splice_golden.json.gz'), 'rt') as f:
         golden = json.load(f)
-    n_c = n_py = n_edge = 0
+    n_c = n_py = n_edge = n_index = n_index_none = 0
     for cfg in golden:
         contigs, cands = tgs._world(cfg['seed'], cfg['n'])
         host = tgs._Genome(contigs)
+        index = bool(cfg.get('index'))
+        if index:        # env.GENOME as the reference's main pass has it: the sequences as a minimap2 index serves them (align.IndexGenome)
+            host = align.IndexGenome(host)
+            contigs = host.genome
         ss_index = tgs._annotation(contigs, cands, cfg['seed'] + 1) if cfg['annotated'] else None
         env.initializer(None, host.contig_len, host, None, None, ss_index)
         runs = {c: _runs(ss_index, c, host.contig_len[c]) for c in contigs}
@@ -95,11 +99,14 @@ def test_reference_answers_on_seeded_worlds():
             if not tied:
                 assert (list(mirror[0]) if mirror[0] else None) == want_site, (cand, mirror, want_site)
                 n_py += 1
-            got = oracle_lib.oracle_splice_signal(contigs[ctg], st, en, cb, hs, cfg['canonical'], runs[ctg])
+            got = oracle_lib.oracle_splice_signal(contigs[ctg], st, en, cb, hs, cfg['canonical'], runs[ctg], index_slices=index)
             assert got != 'edge', cand
             n_edge += st - (cb + 10) - us_free - 2 < 0 or en + (cb + 10) + ds_free + 2 > host.contig_len[ctg]
+            n_index += index
+            n_index_none += index and st - (cb + 10) - us_free - 2 < 0 and want_site is None
             assert [got[1], got[2]] == [us_free, ds_free] and (got[0] is None) == (want_site is None), cand
             if not tied:
                 assert (list(got[0]) if got[0] else None) == want_site, (cand, got, want_site)
                 n_c += 1
-    assert n_c > 5000 and n_py > 5000 and 100 < n_edge < 900
+    assert n_c > 8000 and n_py > 8000 and 100 < n_edge < 1400
+    assert n_index == 3000 and n_index_none > 20        # no sequence in front of a contig: no signal, where Python's slice would wrap around

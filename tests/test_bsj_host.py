@@ -245,7 +245,7 @@ def test_find_signal_batch_host_logic_on_cpu(golden, world):
             self._sites_of = ss_index
             self.uploads += 1
 
-        def splice_signals(self, cands, search_extra, shift_threshold, is_canonical):
+        def splice_signals(self, cands, search_extra, shift_threshold, is_canonical, index_slices=False):
             import numpy as np
             rows = np.zeros((len(cands), 8), dtype=np.int32)
             self.seen += len(cands)

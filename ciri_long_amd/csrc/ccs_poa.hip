@@ -1603,7 +1603,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
             b = cut; ++nseg;
         }
         const int ncap = total + 8, mcap = maxlen + 1;
-        if (maxlen > POA_MAX_COPY) { res.status = 4; if (lane == 0) p.results[rd] = res; continue; }   // cells are int16
+        if (maxlen > POA_MAX_COPY) { res.status = 4; if (lane == 0) { p.results[rd] = res; if (p.stats) atomicAdd(p.stats + 8 + 4, 1); } continue; }   // cells are int16
         // workspace: this wave's slot, or -- a read that needs more -- one of the large slots, claimed for the duration of
         // the read; none free (or none large enough): status 1, the second launch over the large slots takes the read
         uint8_t* ws = slot;

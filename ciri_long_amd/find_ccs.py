@@ -63,11 +63,15 @@ def find_ccs_reads(in_file, out_dir, prefix, threads, debugging):
     prog.update(0)
     fq, is_fastq, _ = _open_reads(in_file)      # suffix check and exit message of find_ccs.py:29-46
     fq.close()
-    total_reads, ro_reads, too_long = hip.default_context().ccs_file(
+    ctx = hip.default_context()
+    total_reads, ro_reads, too_long = ctx.ccs_file(
         in_file, is_fastq, '{}/tmp/{}.ccs.fa'.format(out_dir, prefix), '{}/tmp/{}.raw.fa'.format(out_dir, prefix))
+    import logging
     if too_long:
-        import logging
         logging.getLogger('CIRI-long').warning('%d reads longer than 16 M bases were not scanned for a consensus', too_long)
+    if ctx.last_capacity_dropped:       # counted by the native stage (clh_ccs_file_stats.capacity_dropped): never dropped silently
+        logging.getLogger('CIRI-long').warning('%d reads hold a tandem repeat but got no consensus: a limit of the GPU kernel (workspace, 12 in-edges '
+                                               'at a node, a copy above 2800 bases)', ctx.last_capacity_dropped)
     prog.update(100)
     return total_reads, ro_reads, load_ccs_reads(out_dir, prefix)
 

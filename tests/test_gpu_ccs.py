@@ -355,3 +355,48 @@ def test_native_file_stage_buffer_borders_and_a_trailing_header(tmp_path):
     for name in ('x.ccs.fa', 'x.raw.fa'):
         assert (tmp_path / 'a' / 'tmp' / name).read_bytes() == (tmp_path / 'b' / 'tmp' / name).read_bytes(), name
     assert hip.fastx_count(str(fq), 1) == 6501
+
+
+def test_reads_lost_to_a_kernel_limit_are_counted_and_reported(tmp_path, caplog):
+    """A limit of the kernel never passes for "no repeat".  (1) spoa.poa: thirteen sequences that each skip a different number of
+    letters in front of the same node give that node 14 in-edges, more than the kernel keeps (12; the letters of the stretch are
+    all different, so no deletion can slide): status 2, raised.  (2) find_consensus: a copy above 2800 bases (16-bit cells): status 4
+    in the rows, in the plan's statistics, in pyccs' counter and log line and in the file stage's counter.  The oracle has neither
+    limit."""
+    import logging
+    import random
+    from ciri_long_amd import find_ccs, hip, pyccs, spoa
+    rng = random.Random(3)
+    unit = [rng.choice('ACGT') for _ in range(220)]
+    unit[95:111] = list('bdefhijklmnopqrs')
+    unit = ''.join(unit)
+    copies = [unit] + [unit[:110 - k] + unit[110:] for k in range(1, 14)]
+    assert oracle_lib.oracle_poa(copies, 0, False, 10, -4, -8, -2, -24, -1) is not None
+    with pytest.raises(hip.ClhError, match='status 2'):
+        spoa.poa(copies, 0, False, 10, -4, -8, -2, -24, -1)
+    assert spoa.poa(copies[:11], 0, False, 10, -4, -8, -2, -24, -1)[0] == oracle_lib.oracle_poa(copies[:11], 0, False, 10, -4, -8, -2, -24, -1)   # 12 in-edges: fine
+    long_unit = ''.join(rng.choice('ACGT') for _ in range(3000))
+    read = long_unit * 3
+    short = ''.join(rng.choice('ACGT') for _ in range(220)) * 4
+    ctx = hip.default_context()
+    data, off = hip.pack([read, short])
+    plan = ctx.ccs_plan(off)
+    import torch
+    d = torch.from_numpy(data.view(np.uint8)).cuda()
+    plan.run(d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rows, _segs, _ccs = plan.fetch()
+    assert [int(x) for x in rows['status']] == [4, 0]
+    st = plan.stats()
+    assert st['dropped'] == {4: 1} and st['dp_cells'] > 0 and st['dp_row_steps'] > 0
+    plan.close()
+    before = dict(pyccs.capacity_dropped)
+    with caplog.at_level(logging.WARNING, logger='CIRI-long'):
+        got = pyccs.find_consensus_batch([read, short])
+    assert got[0] == (None, None) and got[1][0] is not None
+    assert pyccs.capacity_dropped.get(4, 0) == before.get(4, 0) + 1
+    assert any('got no consensus' in r.getMessage() for r in caplog.records)
+    (tmp_path / 'tmp').mkdir()
+    fa = tmp_path / 'in.fa'
+    fa.write_text('>lost\n%s\n>kept\n%s\n' % (read, short))
+    total, ro, ccs_seq = find_ccs.find_ccs_reads(str(fa), str(tmp_path), 'p', 1, False)
+    assert (total, ro, list(ccs_seq)) == (2, 1, ['kept']) and ctx.last_capacity_dropped == 1

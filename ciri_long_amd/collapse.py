@@ -16,8 +16,7 @@ import numpy as np
 from . import env
 from .align import find_alignment_pos
 from .ssw_wrap import Aligner, align_pairs
-from .utils import (compress_seq, distance_batch, flatten, get_junc_seq, grouper, pairwise, pairwise_distance, revcomp,
-                    transform_seq)
+from .utils import compress_seq, distance_batch, flatten, get_junc_seq, pairwise, revcomp, transform_seq
 
 LOGGER = logging.getLogger('CIRI-long')
 SCORING = dict(match=10, mismatch=4, gap_open=8, gap_extend=2)
@@ -100,72 +99,132 @@ def refine_to_junction(circ_junc_seq, reads):
     return out
 
 
-def cluster_sequence(hpc_freq, sequence):
-    """collapse.py:458-506.  hpc_freq: [(homopolymer-compressed sequence, [read ids])]; sequence: {read id: sequence}.
-    The distance matrix is one K4 batch, the consensus of every multi-member cluster one K3 batch."""
+# ---------------------------------------------------------------------------------------------------------------
+# isoform clustering of a circRNA's reads (collapse.py:419-506), for MANY circRNAs at once
+# ---------------------------------------------------------------------------------------------------------------
+# The reference clusters one circRNA at a time: a distance matrix (python-Levenshtein per pair), a scipy linkage, one spoa call
+# per cluster with several members; repeated in rounds of 50 sequences until the number of clusters settles.  Here every circRNA
+# of a chunk is a coroutine that asks for "one clustering step of this list" whenever the reference calls cluster_sequence, and
+# `cluster_steps` answers the requests of ALL coroutines of a round together: one K4 launch for every pair of every request, the
+# linkages on the host, one K3 launch for every cluster with several members.  Per circRNA the sequence of steps -- and so the
+# result -- is the reference's.
+def cluster_steps(requests):
+    """[(hpc_freq, sequence)] -> [clustered hpc_freq], each what collapse.py:458-506 returns for that request: hpc_freq =
+    [(homopolymer-compressed sequence, [read ids])], sequence = {read id: sequence}.  All requests share the GPU calls."""
     from scipy.cluster.hierarchy import linkage, leaves_list
     from scipy.spatial.distance import squareform
-    from .spoa import poa
-
-    if len(hpc_freq) == 1:
-        return hpc_freq
-    dist = pairwise_distance([h for h, _ in hpc_freq])
-    if dist.sum() != 0:
-        z = leaves_list(linkage(squareform(dist), "ward", optimal_ordering=True))
-    else:
-        z = list(range(len(hpc_freq)))
-    clusters = [[z[0], ]]
-    for i, j in pairwise(z):
-        d = dist[j][i] if i > j else dist[i][j]
-        if d < 0.3:
-            clusters[-1].append(j)
-        else:
-            clusters.append([j, ])
-    ccs_seq = []
-    for cluster in clusters:
-        if len(cluster) == 1:
-            ccs_seq.append((hpc_freq[cluster[0]]))
+    out = [None] * len(requests)
+    # 1. every pair of every request with more than one entry: one batch of edit distances (K4)
+    xs, ys, spans = [], [], []
+    for k, (hpc_freq, _seq) in enumerate(requests):
+        n = len(hpc_freq)
+        if n == 1:
+            out[k] = hpc_freq
             continue
-        cluster_reads = flatten([hpc_freq[i][1] for i in cluster])
-        ccs, _ = poa([sequence[i] for i in cluster_reads], 2, False, 10, -4, -8, -2, -24, -1)
-        ccs_seq.append((ccs, cluster_reads))
-    return ccs_seq
+        ii, jj = np.triu_indices(n, 1)
+        spans.append((k, n, ii, jj, len(xs)))
+        xs += [hpc_freq[i][0] for i in ii]
+        ys += [hpc_freq[j][0] for j in jj]
+    dists = distance_batch(xs, ys) if xs else []
+    # 2. per request: the matrix, the leaf order of the ward linkage, neighbours in that order closer than 0.3 share a cluster
+    groups, owners = [], []                       # sequences of every cluster with several members; (request, slot in its result)
+    for k, n, ii, jj, at in spans:
+        hpc_freq, sequence = requests[k]
+        dist = np.zeros((n, n))
+        norm = np.array([max(len(hpc_freq[i][0]), len(hpc_freq[j][0])) for i, j in zip(ii, jj)], dtype=np.float64)
+        dist[ii, jj] = np.asarray(dists[at:at + len(ii)], dtype=np.float64) / norm
+        dist = dist + dist.T
+        order = leaves_list(linkage(squareform(dist), "ward", optimal_ordering=True)) if dist.sum() != 0 else list(range(n))
+        clusters = [[order[0]]]
+        for a, b in pairwise(order):
+            if dist[min(a, b)][max(a, b)] < 0.3:
+                clusters[-1].append(b)
+            else:
+                clusters.append([b])
+        res = []
+        for members in clusters:
+            if len(members) == 1:
+                res.append(hpc_freq[members[0]])
+                continue
+            reads = flatten([hpc_freq[i][1] for i in members])
+            owners.append((k, len(res), reads))
+            groups.append([sequence[r] for r in reads])
+            res.append(None)
+        out[k] = res
+    # 3. the consensus of every such cluster: one batch of partial-order alignments (K3), spoa.poa(seqs, 2, False, 10, -4, -8, -2, -24, -1)
+    if groups:
+        for (k, slot, reads), c in zip(owners, consensus_of_groups(groups)):
+            out[k][slot] = (c, reads)
+    return out
 
 
-def iter_cluster_sequence(circ_id, hpc_freq, sequence):
-    """collapse.py:439-455: rounds of at most 50 sequences"""
-    if len(hpc_freq) <= 50:
-        return cluster_sequence(hpc_freq, sequence)
-    res = []
-    for tmp in grouper(hpc_freq, 50):
-        chunk = [i for i in tmp if i is not None]
-        res = cluster_sequence(chunk + res, sequence)
+def consensus_of_groups(groups):
+    """[[sequence]] -> [consensus]: spoa.poa(group, 2, False, 10, -4, -8, -2, -24, -1)[0] (collapse.py:504) for every group, one K3 launch"""
+    from . import hip
+    flat = [s for g in groups for s in g]
+    data, off = hip.pack_raw(flat)
+    goff = np.cumsum([0] + [len(g) for g in groups]).astype(np.int64)
+    return hip.default_context().poa_batch(data, off, goff, algorithm=2, scores=(10, -4, -8, -2, -24, -1), raw=True)
+
+
+def _cluster_job(circ_id, reads):
+    """The steps of collapse.py:419-455 for one circRNA as a coroutine: yields (hpc_freq, sequence) where the reference calls
+    cluster_sequence, receives the clustered list; returns the final list (StopIteration.value)."""
+    sequence = {read_id: seq for read_id, seq in reads}
+    hpc_freq = [(compress_seq(seq), [read_id]) for read_id, seq in reads]
+
+    def settle(res):
+        # until a step leaves the number of clusters as it is, at most 10 steps (collapse.py:428-435, 447-454); the list of the
+        # step BEFORE the unchanged one is kept, as the reference keeps it
         for _ in range(10):
-            n_res = cluster_sequence(res, sequence)
-            if len(n_res) == len(res):
-                break
-            res = n_res
-        else:
-            LOGGER.warning('Sequence not consensus for circRNA: {}'.format(circ_id))
-    return res
+            nxt = yield (res, sequence)
+            if len(nxt) == len(res):
+                return res
+            res = nxt
+        LOGGER.warning('Sequence not consensus for circRNA: {}'.format(circ_id))
+        return res
+
+    if len(hpc_freq) <= 50:
+        res = yield (hpc_freq, sequence)
+    else:
+        res = []
+        for k in range(0, len(hpc_freq), 50):                # rounds of at most 50 new sequences joined with what the last round left
+            res = yield (hpc_freq[k:k + 50] + res, sequence)
+            res = yield from settle(res)
+    return (yield from settle(res))
+
+
+def batch_cluster_sequences(jobs):
+    """[(circ_id, [(read_id, sequence)])] -> [clusters] (collapse.py:419-436 per circRNA), all circRNAs advanced together so that
+    every round is one call of `cluster_steps`."""
+    runs = [_cluster_job(circ_id, reads) for circ_id, reads in jobs]
+    results = [None] * len(runs)
+    waiting = {}
+    for k, g in enumerate(runs):
+        try:
+            waiting[k] = next(g)
+        except StopIteration as done:
+            results[k] = done.value
+    while waiting:
+        ks = list(waiting)
+        answers = cluster_steps([waiting[k] for k in ks])
+        for k, ans in zip(ks, answers):
+            try:
+                waiting[k] = runs[k].send(ans)
+            except StopIteration as done:
+                results[k] = done.value
+                del waiting[k]
+    return results
 
 
 def batch_cluster_sequence(circ_id, x):
-    """collapse.py:419-436.  x: [(read_id, sequence)]"""
-    sequence = {}
-    hpc_freq = []
-    for read_id, read_seq in x:
-        sequence[read_id] = read_seq
-        hpc_freq.append((compress_seq(read_seq), [read_id, ]))
-    res = iter_cluster_sequence(circ_id, hpc_freq, sequence)
-    for _ in range(10):
-        n_res = cluster_sequence(res, sequence)
-        if len(n_res) == len(res):
-            break
-        res = n_res
-    else:
-        LOGGER.warning('Sequence not consensus for circRNA: {}'.format(circ_id))
-    return res
+    """collapse.py:419-436 for one circRNA.  x: [(read_id, sequence)]"""
+    return batch_cluster_sequences([(circ_id, x)])[0]
+
+
+def cluster_sequence(hpc_freq, sequence):
+    """collapse.py:458-506: one clustering step of one list"""
+    return cluster_steps([(hpc_freq, sequence)])[0]
 
 
 def exon_score(circ, aligner, l_exon, n_exon):

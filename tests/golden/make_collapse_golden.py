@@ -110,6 +110,19 @@ def main():
         case.update(hpc=hpc, dist=[[collapse.distance(x, y) / max(len(x), len(y)) for y in hpc] for x in hpc])
         cases.append(case)
 
+    # a circRNA with 120 reads of three isoforms: the rounds of 50 of iter_cluster_sequence (collapse.py:439-455)
+    ctg, exons, strand = world['circs'][7]
+    circ_seq = ''.join(genome.seq(ctg, s, e) for s, e in exons)
+    other = [''.join(genome.seq(c2, s, e) for s, e in ex2) for c2, ex2, _ in world['circs'][8:10]]
+    iso = [circ_seq, circ_seq[:len(circ_seq) // 4] + other[0][:150], other[1][:260]]
+    big_in = []
+    for k in range(120):
+        big_in.append(('b%03d' % k, noisy_rotations(rng, iso[k % 3], 1, 0.02, 0.02, 0.02)[0][:]))
+    # reads of one molecule start at the junction after refinement (collapse.py:373-387): no rotation between them
+    big_in = [(rid, to_str(synth.mutate(oracle_lib.encode(iso[k % 3]), rng, 0.02, 0.02, 0.02))) for k, (rid, _s) in enumerate(big_in)]
+    big_res = collapse.batch_cluster_sequence('big', big_in)
+    big = dict(cluster_input=[list(x) for x in big_in], cluster_res=[[c, list(ids)] for c, ids in big_res])
+
     # exon_score (collapse.py:760-774)
     circ = collapse.CIRC('chrA', 400, 2000, '-')
     aligner = Aligner(genome.seq('chrA', 350, 1500), match=10, mismatch=4, gap_open=8, gap_extend=2)
@@ -117,7 +130,7 @@ def main():
     exon = dict(contig='chrA', start=400, end=2000, strand='-', ref=genome.seq('chrA', 350, 1500), pairs=[list(p) for p in pairs],
                 scores=[int(collapse.exon_score(circ, aligner, l, n)) for l, n in pairs[:3]])
     out = dict(note='distance() = exact DP (python-Levenshtein/edlib absent); poa() = own specification (spoa absent): '
-                    'consensus strings are not reference outputs, everything else is', cases=cases, exon=exon)
+                    'consensus strings are not reference outputs, everything else is', cases=cases, exon=exon, big=big)
     path = os.path.join(HERE, 'collapse_golden.json.gz')
     with gzip.open(path, 'wt') as f:
         json.dump(out, f)

@@ -56,6 +56,7 @@ def cpu_kernels(monkeypatch):
     monkeypatch.setattr(collapse, 'distance_batch', distance_batch)
     monkeypatch.setattr(utils, 'distance_batch', distance_batch)
     monkeypatch.setattr(spoa, 'poa', lambda seqs, algorithm, genmsa, m, n, g, e, q, c: (oracle_lib.oracle_poa(list(seqs), algorithm, False, m, n, g, e, q, c), []))
+    monkeypatch.setattr(collapse, 'consensus_of_groups', lambda groups: [oracle_lib.oracle_poa(list(g), 2, False, 10, -4, -8, -2, -24, -1) for g in groups])
 
 
 def _check_all(golden):
@@ -89,6 +90,15 @@ def _check_all(golden):
         assert utils.pairwise_distance(c['hpc']).tolist() == c['dist']
         res = collapse.batch_cluster_sequence('x', [tuple(x) for x in c['cluster_input']])
         assert [[s, list(ids)] for s, ids in res] == c['cluster_res']
+    # every circRNA of the fixture in ONE lock-step run (one K4 and one K3 launch per round for all of them), the 120-read
+    # circRNA that goes through the reference's rounds of 50 (collapse.py:439-455) among them
+    jobs = [('c%d' % k, [tuple(x) for x in c['cluster_input']]) for k, c in enumerate(golden['cases'])]
+    jobs.insert(2, ('big', [tuple(x) for x in golden['big']['cluster_input']]))
+    res = collapse.batch_cluster_sequences(jobs)
+    want = [c['cluster_res'] for c in golden['cases']]
+    want.insert(2, golden['big']['cluster_res'])
+    assert [[[s, list(ids)] for s, ids in r] for r in res] == want
+    assert len(golden['big']['cluster_input']) > 100 and 2 <= len(golden['big']['cluster_res']) <= 6
     e = golden['exon']
     circ = namedtuple('Circ', 'contig start end strand')(e['contig'], e['start'], e['end'], e['strand'])
     aligner = Aligner(e['ref'], match=10, mismatch=4, gap_open=8, gap_extend=2)

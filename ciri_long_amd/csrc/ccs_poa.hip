@@ -921,27 +921,60 @@ __device__ int poa_sort(const PoaWs& w, const int n_old, const int n, const int 
 // number of nodes per root, the order and the per-node search state (bits 0-1 as st[], bits 2-6 the cursor of the node's frame --
 // a node is on the stack of its search at most once, so the frames are the node ids alone).  A lane runs the searches of the
 // roots it meets in its own stride of ids, block by block.  The graph's lists are read from HBM.
-static constexpr int POA_SORT_LDS = POA_LDS_BYTES / 9;   // 9 bytes per node
-__device__ int poa_sort_lds(const PoaWs& w, const int n_old, const int n, const int m, const int lane)
+static constexpr int POA_SORT_LDS = POA_LDS_BYTES / 10 - 2;   // 9 bytes per node + a list of up to n / 2 roots
+// wave-wide inclusive prefix sum (DPP: row_shr within the 16-lane rows, then the row totals)
+__device__ __forceinline__ int wave_prefix_sum(int v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return v;
+}
+// wave-wide inclusive SUFFIX minimum of unsigned values (lane l: minimum over lanes l..63): the prefix form on the mirrored wave
+__device__ __forceinline__ uint32_t wave_suffix_min(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_down((int)v, d); v = (threadIdx.x & 63) + d < 64 && o < v ? o : v; }
+    return v;
+}
+
+__device__ int poa_sort_lds(const PoaWs& w_, const int n_old, const int n, const int m, const int lane)
 {
-    uint32_t* lroot = poa_lds;
-    uint16_t* lsz = (uint16_t*)(lroot + n);
+    struct { int32_t* root; int32_t* pj; int8_t* na; int8_t* np; int32_t* aligned; int32_t* pred; int32_t* order; int32_t* rank; } w;
+    w.root = uniform_ptr(w_.root); w.pj = uniform_ptr(w_.pj); w.na = uniform_ptr(w_.na); w.np = uniform_ptr(w_.np);
+    w.aligned = uniform_ptr(w_.aligned); w.pred = uniform_ptr(w_.pred); w.order = uniform_ptr(w_.order); w.rank = uniform_ptr(w_.rank);
+    uint32_t* lroot = poa_lds;                         // low 16 bits: the root; bits 16..31 of a root's own entry: its number of nodes (set late)
+    uint16_t* lsz = (uint16_t*)(lroot + n);            // nodes per root, then the root's first position in the order
     uint16_t* lord = lsz + n;
     uint8_t* lst = (uint8_t*)(lord + n);
-    // lst bit 2: the node is new or its root has been lowered -- its aligned set and its in-edge tails may have to follow
-    for (int v = lane; v < n; v += 64) { lroot[v] = v < n_old ? (uint32_t)w.root[v] : (uint32_t)v; lsz[v] = 0; lst[v] = v < n_old ? 0 : 4; }
+    uint16_t* lnt = (uint16_t*)(poa_lds + (POA_LDS_BYTES - n) / 4);      // roots with more than one node: the last n bytes of the block
+    // lst bit 2: the node is new or its root has been lowered -- its aligned set and its in-edge tails may have to follow.
+    // Loads of four strides are issued together (one round trip per 256 nodes instead of four)
+    for (int v0 = 0; v0 < n; v0 += 256) {
+        int32_t old[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int v = v0 + 64 * u + lane; old[u] = v < n_old ? w.root[v] : v; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int v = v0 + 64 * u + lane; if (v < n) { lroot[v] = (uint32_t)old[u]; lsz[v] = 0; lst[v] = v < n_old ? 0 : 4; } }
+    }
     __syncthreads();
     {
         uint32_t smin = 0xffffffffu;
-        for (int i0 = ((m - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
-            const int i = i0 + lane;
-            const int x = i < m ? w.pj[i] : -1;
-            uint32_t val = x >= 0 ? lroot[x] : 0xffffffffu;
+        for (int i1 = ((m - 1) / 64) * 64; i1 >= 0; i1 -= 256) {
+            int x[4];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_down((int)val, d); if (lane + d < 64) val = o < val ? o : val; }
-            val = val < smin ? val : smin;
-            if (x >= 0 && val < lroot[x]) { lroot[x] = val; lst[x] |= 4; }     // the nodes of a path are distinct
-            smin = (uint32_t)__builtin_amdgcn_readlane((int)val, 0);
+            for (int u = 0; u < 4; ++u) { const int i = i1 - 64 * u + lane; x[u] = i >= 0 && i < m ? w.pj[i] : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i1 - 64 * u < 0) break;
+                uint32_t val = wave_suffix_min(x[u] >= 0 ? lroot[x[u]] : 0xffffffffu);
+                val = val < smin ? val : smin;
+                if (x[u] >= 0 && val < lroot[x[u]]) { lroot[x[u]] = val; lst[x[u]] |= 4; }     // the nodes of a path are distinct
+                smin = (uint32_t)__builtin_amdgcn_readlane((int)val, 0);
+            }
         }
     }
     __syncthreads();
@@ -980,50 +1013,56 @@ __device__ int poa_sort_lds(const PoaWs& w, const int n_old, const int n, const 
         atomicAdd((uint32_t*)lsz + (rt >> 1), (rt & 1) ? 0x10000u : 1u);
     }
     __syncthreads();
-    int acc = 0, bad = 0;
+    // positions: a root's nodes go behind the nodes of all smaller roots.  One pass gives every root its first position, writes the
+    // roots that are alone and collects the others; their searches then run ALL AT ONCE, one per lane
+    int acc = 0, nnt = 0, bad = 0;
     for (int r0 = 0; r0 < n; r0 += 64) {
         const int r = r0 + lane;
         const int sz = r < n ? (int)lsz[r] : 0;
-        int inc = sz;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        const int inc = wave_prefix_sum(sz);
         const int lo = acc + inc - sz;
         acc += __builtin_amdgcn_readlane(inc, 63);
         if (sz == 1) lord[lo] = (uint16_t)r;
-        else if (sz > 1) {
-            const int hi = lo + sz;
-            int sp = hi, k = lo;
-            lord[--sp] = (uint16_t)r;
-            while (sp < hi) {
-                const int v = lord[sp];
-                const int stv = lst[v];
-                int cur = stv >> 2;
-                const int npv = w.np[v], nav = w.na[v];
-                const bool ign = (stv & 2) != 0;
-                if (cur == 0 && !ign) for (int t = 0; t < nav; ++t) lst[w.aligned[v * POA_MAXA + t]] |= 2;
-                const int na2 = ign ? 0 : nav, nd = na2 + npv;
-                int nxt = -1;
-                while (cur < nd) {
-                    const int d = cur < na2 ? w.aligned[v * POA_MAXA + na2 - 1 - cur] : w.pred[v * POA_MAXP + npv - 1 - (cur - na2)];
-                    ++cur;
-                    if (lroot[d] == (uint32_t)r && !(lst[d] & 1)) { nxt = d; break; }
-                }
-                if (nxt >= 0) {
-                    lst[v] = (uint8_t)((stv & 3) | (cur << 2));
-                    if (sp - 1 < k) { bad = 1; break; }
-                    lord[--sp] = (uint16_t)nxt;
-                    continue;
-                }
-                lst[v] = (uint8_t)(stv | 1);
-                ++sp;
-                if (!ign) {
-                    if (k + 1 + nav > hi) { bad = 1; break; }
-                    lord[k++] = (uint16_t)v;
-                    for (int t = 0; t < nav; ++t) lord[k++] = (uint16_t)w.aligned[v * POA_MAXA + t];
-                }
+        const bool nt = sz > 1;
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(nt);
+        if (nt) { lsz[r] = (uint16_t)lo; lroot[r] |= (uint32_t)sz << 16; lnt[nnt + __builtin_popcountll(bm & (((unsigned long long)1 << lane) - 1))] = (uint16_t)r; }
+        nnt += __builtin_popcountll(bm);
+    }
+    __syncthreads();
+    for (int t = lane; t < nnt; t += 64) {
+        const int r = lnt[t];
+        const int lo = lsz[r], hi = lo + (int)(lroot[r] >> 16);
+        int sp = hi, k = lo;
+        lord[--sp] = (uint16_t)r;
+        while (sp < hi) {
+            const int v = lord[sp];
+            const int stv = lst[v];
+            int cur = stv >> 2;
+            const int npv = w.np[v], nav = w.na[v];
+            const bool ign = (stv & 2) != 0;
+            if (cur == 0 && !ign) for (int u = 0; u < nav; ++u) lst[w.aligned[v * POA_MAXA + u]] |= 2;
+            const int na2 = ign ? 0 : nav, nd = na2 + npv;
+            int nxt = -1;
+            while (cur < nd) {
+                const int d = cur < na2 ? w.aligned[v * POA_MAXA + na2 - 1 - cur] : w.pred[v * POA_MAXP + npv - 1 - (cur - na2)];
+                ++cur;
+                if ((lroot[d] & 0xffffu) == (uint32_t)r && !(lst[d] & 1)) { nxt = d; break; }
             }
-            bad |= k != hi;
+            if (nxt >= 0) {
+                lst[v] = (uint8_t)((stv & 3) | (cur << 2));
+                if (sp - 1 < k) { bad = 1; break; }
+                lord[--sp] = (uint16_t)nxt;
+                continue;
+            }
+            lst[v] = (uint8_t)(stv | 1);
+            ++sp;
+            if (!ign) {
+                if (k + 1 + nav > hi) { bad = 1; break; }
+                lord[k++] = (uint16_t)v;
+                for (int u = 0; u < nav; ++u) lord[k++] = (uint16_t)w.aligned[v * POA_MAXA + u];
+            }
         }
+        bad |= k != hi;
     }
     __syncthreads();
     for (int i = lane; i < n; i += 64) { const int v = lord[i]; w.order[i] = v; w.rank[v] = i + 1; }

@@ -486,15 +486,24 @@ __device__ __forceinline__ void to_packed(const uint32_t (&nat)[CP], uint32_t (&
 // against the five-matrix oracle on the CPU).  Per cell pair: the maxima only -- no strictly-greater updates, no code selection.
 // A source row that is not the row before comes from the LDS ring (raw packed registers) or, older, from the planes.
 static constexpr int D_F = 0x0007, D_O_SHIFT = 3, D_E_SHIFT = 8, D_Q_SHIFT = 11;
+// The planes are what the kernel writes most of, and writing them is what bounds the pass (measured: the pass run twice costs 18 ms with
+// its stores, 9 ms without).  The back-track only ever reads cells next to the path, and the path of a copy against the graph of
+// its siblings stays near the straight line from (1, 1) to (N, m).  So a row leaves its cells only within POA_BAND columns of
+// column r * m / N -- rows that an older successor reads back as a source ("full", 0x8000 in the graph row) leave all of them --
+// and the back-track, which knows the same rule, answers "miss" when it is about to use a cell that was not left: the pass is
+// then run once more with every cell stored.  Results never depend on the band.
+static constexpr int POA_BAND = 64;
+static constexpr int POA_H_NONE = -32768;            // a cell of the staged band that the planes do not hold (H is never below POA_NEG)
+static constexpr int BT_MISS = -2;
 
 template <int CP>
 __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int pass, const int colbase,
-                           const bool more, const int RING, int& bs_io, int& br_io, int& bc_io DBGARG)
+                           const bool more, const int RING, const int slope16, int& bs_io, int& br_io, int& bc_io DBGARG)
 {
     constexpr int C = 2 * CP;
     const int gp = poa_pitch(m);
     const int rmask = RING - 1;
-    const bool sw = S.algorithm == 0, nw = S.algorithm == 1;
+    const bool sw = (S.algorithm & 0xff) == 0, nw = (S.algorithm & 0xff) == 1;
     const int g = S.g, e = S.e, q = S.q, c = S.c;
     const uint32_t g2 = dup16(g), e2 = dup16(e), q2 = dup16(q), c2 = dup16(c), sm2 = dup16(S.m), dsn2 = dup16(S.n - S.m);
     const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
@@ -549,7 +558,11 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     uint32_t bsP = sw ? 0u : 0x80008000u, brP = 0, bcP = 0;
     int nbest = -(1 << 30), nrow = 0;                            // global mode: cells (sink row, column m), wave-uniform
     uint32_t lowP = 0x7fff7fffu;                                 // global / overlap: the lowest H of the pass (local cells are >= 0)
+#ifdef POA_EXP_DP2_NOSTORE     // timing experiment: the second of two runs of the pass writes no planes
+    const bool stores = col0 + 1 <= m && !(S.algorithm & 0x100);
+#else
     const bool stores = col0 + 1 <= m;
+#endif
     // (stores written out as asm with a scalar base and the lane's 32-bit offset saved the 64-bit address arithmetic and cost 2 ms:
     // the blocks pin the schedule)
     const char* planeH = (const char*)w.planeH;
@@ -701,7 +714,12 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
             for (int t = 0; t < CP; ++t) { px[t] = Hf[t]; pf[t] = fsn[t]; po[t] = osn[t]; }
             pcin = cinH;
-            if (stores) {
+            bool st_row = stores;
+            if (slope16 && !(d0 & 0x8000u)) {            // only the lanes whose columns lie within POA_BAND of the row's centre column
+                const int cen = (int)(((unsigned)r * (unsigned)slope16) >> 16);
+                st_row = stores && (unsigned)(col0 + C - (cen - POA_BAND)) <= (unsigned)(2 * POA_BAND + C - 1);
+            }
+            if (st_row) {
                 uint32_t nh[CP], nd[CP];
                 to_natural<CP>(Hf, nh); to_natural<CP>(D, nd);
                 // scalar row base + the lane's 32-bit offset, written out: left to itself the compiler folds the lane's offset into a
@@ -790,21 +808,21 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 
 // DP rows of one sequence: passes of 128 * POA_MAXCP columns; the last pass takes 2, 4 or 6 columns per lane by its width (a
 // row step costs a fixed part plus a part per register)
-__device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, int& bs_out, int& br_out, int& bc_out DBGARG)
+__device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int slope16, int& bs_out, int& br_out, int& bc_out DBGARG)
 {
     constexpr int WMAX = 128 * POA_MAXCP;
     const int RING = poa_ring(m);
-    int bs = S.algorithm == 0 ? 0 : -(1 << 30), br = 0, bc = 0;
+    int bs = (S.algorithm & 0xff) == 0 ? 0 : -(1 << 30), br = 0, bc = 0;
     int pass = 0;
     for (int colbase = 0; colbase < m; colbase += WMAX, ++pass) {
         const int rem = m - colbase;
         const bool more = rem > WMAX;
         const int cp = more ? POA_MAXCP : poa_cols(rem);
         switch (cp) {
-            case 1: dp_pass_lz<1>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
-            case 2: dp_pass_lz<2>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
-            case 3: dp_pass_lz<3>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
-            default: dp_pass_lz<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, bs, br, bc DBGPASS); break;
+            case 1: dp_pass_lz<1>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;
+            case 2: dp_pass_lz<2>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;
+            case 3: dp_pass_lz<3>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;
+            default: dp_pass_lz<4>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;
         }
         if (br < 0) break;                               // a cell left the int16 range
     }
@@ -1094,18 +1112,28 @@ __device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& 
 // returns the column the walk ends in (the bases in front of it are not part of the alignment), or -1 (guard: corrupt planes).
 static constexpr int BT_W = POA_LDS_BYTES >= 9216 ? 24 : 20;     // columns per band row (64 rows x 2 planes + the sequence in the LDS block)
 static constexpr int BT_DRIFT = BT_W / 2 - 4;        // how far the walk may leave the band's diagonal before the band is staged again
-__device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, const int m_, const int8_t* seq_, const int lane, int r, int j, bool& moved DBGARG)
+// A function of its own, NOT inlined: inside the kernel's one big body the register allocator spilled a value of this loop and
+// reloaded it every iteration -- and the wait for that reload is a wait for every store in flight, i.e. for the walk's own result
+// stores to reach memory: 2 us per step.  With its own frame the loop keeps its registers.
+struct BtArgs { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; const int8_t* seq; int N, m, r, j, slope16; };
+// returns 2 * (column the walk ends in) + (1 if the alignment holds a step), -1 (guard) or BT_MISS (a cell outside the band the planes hold)
+__device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const PoaScores S DBGARG)
 {
     // the walk is wave-uniform: say so (scalar registers, scalar branches)
     struct { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; } w;
-    w.pn = uniform_ptr(w_.pn); w.planeH = uniform_ptr(w_.planeH); w.planeD = uniform_ptr(w_.planeD); w.ri = uniform_ptr(w_.ri);
-    w.col0 = uniform_ptr(w_.col0); w.rank = uniform_ptr(w_.rank); w.pred = uniform_ptr(w_.pred); w.order = uniform_ptr(w_.order);
-    const int8_t* seq = uniform_ptr(seq_);
-    const int m = __builtin_amdgcn_readfirstlane(m_);
-    r = __builtin_amdgcn_readfirstlane(r); j = __builtin_amdgcn_readfirstlane(j);
+    w.pn = uniform_ptr(A.pn); w.planeH = uniform_ptr(A.planeH); w.planeD = uniform_ptr(A.planeD); w.ri = uniform_ptr(A.ri);
+    w.col0 = uniform_ptr(A.col0); w.rank = uniform_ptr(A.rank); w.pred = uniform_ptr(A.pred); w.order = uniform_ptr(A.order);
+    const int8_t* seq = uniform_ptr(A.seq);
+    const int lane = threadIdx.x & 63;
+    const int N = __builtin_amdgcn_readfirstlane(A.N), m = __builtin_amdgcn_readfirstlane(A.m), slope16 = __builtin_amdgcn_readfirstlane(A.slope16);
+    int r = __builtin_amdgcn_readfirstlane(A.r), j = __builtin_amdgcn_readfirstlane(A.j);
+    bool moved = false;
     const bool sw = S.algorithm == 0, nw = S.algorithm == 1;
     const int g = S.g, e = S.e, q = S.q, c = S.c;
     const int gp = poa_pitch(m);
+#ifdef CLH_DEBUG_POA
+    const unsigned long long t_bt0 = __builtin_amdgcn_s_memtime();
+#endif
     short* Hb = (short*)poa_lds;
     unsigned short* Db = (unsigned short*)poa_lds + 64 * BT_W;
     uint8_t* lseq = (uint8_t*)poa_lds + 4 * 64 * BT_W;
@@ -1135,6 +1163,12 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
                 __builtin_memcpy(Hb + lane * BT_W, t, BT_W * 2);
                 __builtin_memcpy(t, (const uint32_t*)(w.planeD + (size_t)rr * gp + csk + 7), BT_W * 2);
                 __builtin_memcpy(Db + lane * BT_W, t, BT_W * 2);
+                if (slope16 && !(rim.x & 0x8000u)) {        // cells of this row that the planes do not hold (POA_BAND): marked, so that using one is seen
+                    const int cen = (int)(((unsigned)rr * (unsigned)slope16) >> 16);
+                    const int xlo = cen - POA_BAND - csk, xhi = cen + POA_BAND - csk;      // band row indices of the first and last cell held
+                    for (int x = 0; x < xlo && x < BT_W; ++x) Hb[lane * BT_W + x] = (short)POA_H_NONE;
+                    for (int x = xhi + 1 > 0 ? xhi + 1 : 0; x < BT_W; ++x) Hb[lane * BT_W + x] = (short)POA_H_NONE;
+                }
             }
         }
         if (r0 < 64) {                                       // the block reaches row 0
@@ -1151,6 +1185,10 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
         if ((unsigned)k < 64u && (unsigned)x < (unsigned)BT_W) return (int)Hb[k * BT_W + x];
         if (rr == 0) return row0_h(jj);
         if (jj == 0) return nw ? (int)w.col0[rr] : 0;
+        if (slope16) {                                       // outside the staged band: is the cell in the planes at all?
+            const int cen = (int)(((unsigned)rr * (unsigned)slope16) >> 16);
+            if ((jj < cen - POA_BAND || jj > cen + POA_BAND) && !(w.ri[rr].x & 0x8000u)) return POA_H_NONE;
+        }
         return (int)w.planeH[(size_t)rr * gp + jj + 7];
     };
     auto Dat = [&](int rr, int jj) -> int {
@@ -1175,6 +1213,9 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
         return w.rank[w.pred[w.order[rr - 1] * POA_MAXP + s]];
     };
     __syncthreads();
+#ifdef CLH_DEBUG_POA
+    tacc[15] += __builtin_amdgcn_s_memtime() - t_bt0;
+#endif
     int guard = 2 * (N + m) + 64;                           // every step lowers r or j: a longer walk means corrupt planes
     while (r > 0 && j > 0) {
         if (--guard < 0) return -1;
@@ -1182,7 +1223,7 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
         int a = r0 - r;
         {
             const int drift = j - (j0 - a);
-            if ((unsigned)a > 48u || drift < -BT_DRIFT || drift >= BT_DRIFT) { reload(r, j); a = 0; DBGCNT(18, 1); }
+            if ((unsigned)a > 48u || drift < -BT_DRIFT || drift >= BT_DRIFT) { SEC0(); reload(r, j); a = 0; DBGCNT(18, 1); SEC(14); }
         }
         // Everything one step can ask for is read from the band in ONE round: (1) lane a + l: the cells (r - l, j - l) and their diagonal
         // neighbours -- a run of diagonal steps through first in-edges that are the row before; (2) lane s < in-degree of row r: the
@@ -1202,7 +1243,7 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
         const int hc = (int)Hb[i_own], hd = (int)Hb[i_nb], hp1 = (int)Hb[i_p - 1], hpv = (int)Hb[i_p], dpv = (int)Db[i_p];
         const int h = (int)Hb[xl], hl = (int)Hb[xl - 1], dl = (int)Db[xl - 1], sb = (int)lseq[i_s];
         int hp = hpv, dp = dpv, hp1x = hp1;
-        ok = ok && hc == hd + ((int)(rim.x & 0xff) == sb ? S.m : S.n) && !(sw && hc == 0);
+        ok = ok && hc != POA_H_NONE && hd != POA_H_NONE && hc == hd + ((int)(rim.x & 0xff) == sb ? S.m : S.n) && !(sw && hc == 0);
         {
             const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok) >> a;
             const int run = ~okm ? __builtin_ctzll(~okm) : 64;
@@ -1215,12 +1256,13 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
         }
         // one step by spoa's full list of tests; lane s looks at in-edge s
         if (sw && h == 0) break;
-        moved = true;
         DBGCNT(19, 1);
         int psx = ps;
         if (np > 3 || __builtin_amdgcn_ballot_w64(act && !inb)) {        // rare: in-edges beyond the third, or a source row outside the band
             if (act) { psx = pred_of(r, d0, d1, lane); hp1x = Hat(psx, j - 1); hp = Hat(psx, j); dp = Dat(psx, j); }
         }
+        if (h == POA_H_NONE || hl == POA_H_NONE || __builtin_amdgcn_ballot_w64(act && (hp1x == POA_H_NONE || hp == POA_H_NONE))) return BT_MISS;
+        moved = true;
         {
             const int sc = (int)(d0 & 0xff) == (int)lseq[j - 1] ? S.m : S.n;
             unsigned long long bm = __builtin_amdgcn_ballot_w64(act && h == hp1x + sc);
@@ -1243,13 +1285,15 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
                         meta(r, e0, e1);
                         const int np2 = (int)((e0 >> 8) & 0xf), npp2 = np2 ? np2 : 1;
                         const bool act2 = lane < npp2;
-                        int ps2 = 0, xf = -(1 << 30), xo = -(1 << 30), hp2 = 0, fs2 = 0, os2 = 0;
+                        int ps2 = 0, xf = -(1 << 30), xo = -(1 << 30), hp2 = 0, fs2 = 0, os2 = 0, miss = 0;
                         if (act2) {
                             ps2 = pred_of(r, e0, e1, lane); hp2 = Hat(ps2, j);
+                            if (hp2 == POA_H_NONE) miss = 1;
                             const int dp2 = Dat(ps2, j);
                             fs2 = hp2 + (dp2 & 7) - 1; os2 = hp2 + ((dp2 >> 3) & 31) - 1;
                             xf = hp2 > fs2 ? hp2 : fs2; xo = hp2 > os2 ? hp2 : os2;
                         }
+                        if (__builtin_amdgcn_ballot_w64(miss != 0)) return BT_MISS;
 #pragma unroll
                         for (int d = 1; d < 16; d <<= 1) { const int f2 = __shfl_xor(xf, d), o2 = __shfl_xor(xo, d); xf = f2 > xf ? f2 : xf; xo = o2 > xo ? o2 : xo; }
                         const int mf = __builtin_amdgcn_readlane(xf, 0), mo = __builtin_amdgcn_readlane(xo, 0);
@@ -1273,18 +1317,19 @@ __device__ int poa_backtrack(const PoaWs& w_, const PoaScores S, const int N, co
             if (ext) for (;;) {                               // by E + e or Q + c: the run goes on to the left
                 if (--guard < 0) return -1;
                 --j;
+                if (Hat(r, j) == POA_H_NONE) return BT_MISS;
                 const int dj = Dat(r, j);
                 if (!(dj >> 8)) break;                        // neither E nor Q of this column feeds the next
             }
         }
     }
-    return j;
+    return 2 * j + (moved ? 1 : 0);
 }
 
 // returns the new node count; -1 graph limits, -2 workspace, -3 back-track guard, -4 a cell at the floor of the int16 range
 // (global / overlap modes with costly gaps).  *score_out = end-cell score.
 // path_out (may be null): node of every base (for the MSA)
-__device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8_t* seq, int m_, int lane, int* score_out, int32_t* path_out, unsigned long long* tacc)
+__device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8_t* seq, int m_, int lane, int* score_out, int32_t* path_out, unsigned long long* tacc, int* band_misses, const int mref)
 {
     // wave-uniform by construction; say so, or every quantity derived from them lives in VGPRs behind exec-mask branches
     const int N = __builtin_amdgcn_readfirstlane(N_), m = __builtin_amdgcn_readfirstlane(m_);
@@ -1294,7 +1339,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
 #endif
     *score_out = 0;
     if (m == 0) return N;
-    int bs = 0, br = 0, bc = 0;
+    int bs = 0, br = 0, bc = 0, slope16 = 0;
     if (N > 0) {
         if (N > POA_MAX_ROWS || (S.algorithm == 1 && N > 25000)) return -1;
         // ---- graph rows in rank space (w.ri: base, in-degree, sink, ranks of the first three sources) ---------------------
@@ -1316,7 +1361,7 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
             const uint2 d = w.ri[r];
             const int np = (int)((d.x >> 8) & 0xf);
             const int p0 = (int)(d.x >> 16), p1 = (int)(d.y & 0xffff), p2 = (int)(d.y >> 16);
-            auto mark = [&](int q) { if (q != 0 && r - q >= 2 && r - q < RING) atomicOr(&ri32[q * 2], 0x4000u); };
+            auto mark = [&](int q) { if (q != 0 && r - q >= 2) atomicOr(&ri32[q * 2], r - q < RING ? 0x4000u : 0x8000u); };     // ring copy / every cell to the planes
             if (np > 0) mark(p0);
             if (np > 1) mark(p1);
             if (np > 2) mark(p2);
@@ -1345,10 +1390,20 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
             }
         }
         phase_sync();
-        dp_rows(w, S, N, m, seq, lane, bs, br, bc DBGPASS);
+        // the planes keep a band around the straight line through the matrix (see POA_BAND) unless the sequence is short anyway
+        // (the line's end: the longest sequence so far, not this one -- a partial last copy runs along the same line and stops early)
+        slope16 = m > 2 * POA_BAND + 64 ? (int)(((unsigned)(mref > m ? mref : m) << 16) / (unsigned)N) : 0;
+#ifdef POA_NO_BAND
+        slope16 = 0;
+#endif
+        dp_rows(w, S, N, m, seq, lane, slope16, bs, br, bc DBGPASS);
 #ifdef POA_EXP_DP2          // timing experiments (tools/dev/k3_ab.py): a phase run twice costs its marginal time once more
         phase_sync();
-        dp_rows(w, S, N, m, seq, lane, bs, br, bc DBGPASS);
+#ifdef POA_EXP_DP2_NOSTORE
+        { PoaScores S2 = S; S2.algorithm |= 0x100; int b1 = 0, b2 = 0, b3 = 0; dp_rows(w, S2, N, m, seq, lane, slope16, b1, b2, b3 DBGPASS); }
+#else
+        dp_rows(w, S, N, m, seq, lane, slope16, bs, br, bc DBGPASS);
+#endif
 #endif
         phase_sync();
         if (br < 0) return -4;                               // a cell at the floor of the int16 range: no exact answer from this kernel
@@ -1371,12 +1426,25 @@ __device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8
         je = j - 1;
         if (br > 0) {
             phase_sync();
+            BtArgs A = {w.pn, w.planeH, w.planeD, w.ri, w.col0, w.rank, w.pred, w.order, seq, N, m, __builtin_amdgcn_readfirstlane(br), j, slope16};
 #ifdef POA_EXP_BT2
-            { bool mv2 = false; (void)poa_backtrack(w, S, N, m, seq, lane, __builtin_amdgcn_readfirstlane(br), j, mv2 DBGPASS); phase_sync(); }
+            { (void)poa_backtrack(A, S DBGPASS); phase_sync(); }
 #endif
-            const int rc = poa_backtrack(w, S, N, m, seq, lane, __builtin_amdgcn_readfirstlane(br), j, moved DBGPASS);
+            int rc = poa_backtrack(A, S DBGPASS);
+            if (rc == BT_MISS) {
+                // the walk left the band of cells the planes hold: the pass once more, every cell stored (the end cell is the same), and
+                // the walk again.  Rare; counted (clh_ccs_plan_stats) so that it is seen if it ever is not
+                if (band_misses) *band_misses += 1;
+                phase_sync();
+                int b1 = S.algorithm == 0 ? 0 : -(1 << 30), b2 = 0, b3 = 0;
+                dp_rows(w, S, N, m, seq, lane, 0, b1, b2, b3 DBGPASS);
+                for (int t = lane; t < m; t += 64) w.pn[t] = 0;
+                phase_sync();
+                A.slope16 = 0;
+                rc = poa_backtrack(A, S DBGPASS);
+            }
             if (rc < 0) return -3;
-            j = rc;
+            j = rc >> 1; moved = (rc & 1) != 0;
         }
         jb = S.algorithm == 1 ? 0 : j;                           // global mode: spoa walks on along the border to (0, 0)
     }
@@ -1652,6 +1720,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
         bool use_big = need_min > p.slot_bytes;
         int N = 0, len = -1, ncols = 0;
         unsigned long long dp_cells = 0, dp_rows_n = 0;      // work of this read: DP cells and row steps (the bench's cell-update rate)
+        int band_miss_n = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (use_big) {
                 if (p.tier == 0 && p.n_big > 0 && need_min <= p.big_slot_bytes) {
@@ -1670,13 +1739,14 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
             phase_sync();
             unsigned long long tacc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             N = 0; b = 0;
-            int si = 0;
+            int si = 0, mref = 0;
             for (int i = 0; i <= ncuts && N >= 0; ++i) {
                 if (i == ncuts && !tail) break;
                 const int cut = i < ncuts ? __builtin_amdgcn_readfirstlane(cuts[i]) : L;
                 int sc1 = 0;
                 if (N > 0 && cut > b) { dp_cells += (unsigned long long)N * (unsigned)(cut - b); dp_rows_n += (unsigned long long)N * (unsigned)((cut - b + 128 * POA_MAXCP - 1) / (128 * POA_MAXCP)); }
-                N = poa_add(w, S, N, ncap, seq + b, cut - b, lane, &sc1, p.msa_col ? p.msa_col + off + b : nullptr, tacc);
+                N = poa_add(w, S, N, ncap, seq + b, cut - b, lane, &sc1, p.msa_col ? p.msa_col + off + b : nullptr, tacc, &band_miss_n, mref);
+                mref = cut - b > mref ? cut - b : mref;
                 if (p.aln_score && si < CCS_SEG_CAP && lane == 0) p.aln_score[(size_t)rd * CCS_SEG_CAP + si] = sc1;
                 b = cut; ++si;
             }
@@ -1703,6 +1773,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
                 if (lane == 0) for (int k = 0; k < 8; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (55 + k)] = (int)(tacc[k] >> 4);
                 if (lane == 0) for (int k = 8; k < 14; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (41 + k)] = (int)(tacc[k] >> 4);
                 if (lane == 0) for (int k = 16; k < 20; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (26 + k)] = (int)(tacc[k] >> 4);   // back-track counters
+                if (lane == 0) for (int k = 14; k < 16; ++k) p.segs[(size_t)rd * 2 * CCS_SEG_CAP + 2 * (26 + k)] = (int)(tacc[k] >> 4);   // back-track clocks: band staging, set-up
 #endif
             }
             break;
@@ -1718,6 +1789,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
             p.results[rd] = res; if (p.msa_ncols) p.msa_ncols[rd] = ncols;
             if (p.stats && res.status != 1) {                // a read handed to the second launch is counted there
                 atomicAdd((unsigned long long*)(p.stats + 2), dp_cells); atomicAdd((unsigned long long*)(p.stats + 4), dp_rows_n);
+                if (band_miss_n) atomicAdd(p.stats + 6, band_miss_n);
                 if (res.status != 0) atomicAdd(p.stats + 8 + (res.status & 7), 1);      // reads lost to a limit of this kernel, by status
             }
         }

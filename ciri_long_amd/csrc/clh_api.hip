@@ -1267,7 +1267,7 @@ extern "C" int clh_ccs_plan_info(clh_ccs_plan* pl, int64_t* out)
     return 0;
 }
 
-// statistics of the last run: out[16] = {DP cells, DP row steps, 0, reads per status 1..7 (lost to a limit of the kernel: 1
+// statistics of the last run: out[16] = {DP cells, DP row steps, alignments run a second time with every cell stored, reads per status 1..7 (lost to a limit of the kernel: 1
 // workspace, 2 graph limits, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 16-bit range, 7 alignment without a
 // base), 0...}
 extern "C" int clh_ccs_plan_stats(clh_ccs_plan* pl, int64_t* out)
@@ -1282,6 +1282,7 @@ extern "C" int clh_ccs_plan_stats(clh_ccs_plan* pl, int64_t* out)
         const int* s2 = st + 2;                                  // P.stats
         out[0] = (int64_t)((unsigned long long)(unsigned)s2[2] | ((unsigned long long)(unsigned)s2[3] << 32));
         out[1] = (int64_t)((unsigned long long)(unsigned)s2[4] | ((unsigned long long)(unsigned)s2[5] << 32));
+        out[2] = s2[6];                                          // alignments whose walk left the band of stored cells (pass run again, everything stored)
         for (int k = 1; k <= 7; ++k) out[2 + k] = s2[8 + k];
     }
     return 0;

@@ -661,7 +661,7 @@ class CcsPlan(object):
         out = np.zeros(16, dtype=np.int64)
         if lib().clh_ccs_plan_stats(self._h, out.ctypes.data) != 0:
             raise ClhError('clh_ccs_plan_stats: %s' % last_error())
-        return {'dp_cells': int(out[0]), 'dp_row_steps': int(out[1]), 'dropped': {k: int(out[2 + k]) for k in range(1, 8) if out[2 + k]}}
+        return {'dp_cells': int(out[0]), 'dp_row_steps': int(out[1]), 'band_misses': int(out[2]), 'dropped': {k: int(out[2 + k]) for k in range(1, 8) if out[2 + k]}}
 
     def results_dev(self):
         """device pointers (rows, segs, ccs) of the last run's outputs; ccs is packed at the read offsets"""

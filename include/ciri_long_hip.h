@@ -145,7 +145,8 @@ int clh_ccs_results_dev(const clh_ccs_plan* plan, const void** rows, const void*
 /* Workspace tiers of the plan and how the last run used them: out[6] = {first-tier slots, bytes per slot, large slots,
  * bytes per large slot, reads that ran in a large slot claimed on the fly, reads run by the second launch}. */
 int clh_ccs_plan_info(clh_ccs_plan* plan, int64_t* out);
-/* Work and losses of the last run: out[16] = {DP cells, DP row steps, 0, reads that ended with status 1, 2, ... 7 (no
+/* Work and losses of the last run: out[16] = {DP cells, DP row steps, alignments whose back-track left the band of cells the forward
+ * pass had stored (run again with all cells: cost, never a different answer), reads that ended with status 1, 2, ... 7 (no
  * consensus because of a limit of this kernel -- never silently: callers count and report them), 0 ...}. */
 int clh_ccs_plan_stats(clh_ccs_plan* plan, int64_t* out);
 /* HIP-event durations (ms) of the last run: ms[0] = repeat scan (K2), ms[1] = partial-order consensus (K3). */

@@ -29,7 +29,11 @@ for k in range(7):
         best = min(best, k3)
 rows, segs, ccs = plan.fetch()
 import zlib
-print('%%-10s K3 %%.2f ms  (K2 %%.2f)  consensus %%d  status!=0 %%d  crc %%08x' %% (name, best, k2, int((rows['nseg'] > 0).sum()), int((rows['status'] != 0).sum()), zlib.crc32(ccs.tobytes()) & 0xffffffff))
+try:
+    bm = plan.stats()['band_misses']
+except Exception:
+    bm = -1
+print('%%-10s K3 %%.2f ms  (K2 %%.2f)  consensus %%d  status!=0 %%d  crc %%08x  band misses %%d' %% (name, best, k2, int((rows['nseg'] > 0).sum()), int((rows['status'] != 0).sum()), zlib.crc32(ccs.tobytes()) & 0xffffffff, bm))
 ''' % HERE
 
 args = sys.argv[1:]

@@ -30,3 +30,5 @@ print('row step sections (%% of the DP clock): decode+score %.1f, sources+candid
 print('reads with consensus %d, mean total %.1f us' % (ok.sum(), t[ok].sum(1).mean() / 100.0))
 z = segs[:, 42:46, 0].astype(np.float64)[ok].sum(0)
 print('back-track per read: diagonal runs %.1f (mean length %.2f), single steps %.1f, band reloads %.1f' % (z[0] / ok.sum(), z[1] / max(z[0], 1), z[3] / ok.sum(), z[2] / ok.sum()))
+zz = segs[:, 40:42, 0].astype(np.float64)[ok].sum(0) * 16
+print('back-track clock: band staging %.1f %%, set-up (sequence to LDS) %.1f %% of the walk-back time' % (100 * zz[0] / t[ok, 1].sum(), 100 * zz[1] / t[ok, 1].sum()))

@@ -43,6 +43,7 @@ struct clh_ctx {
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     std::mutex mu;
     std::vector<std::pair<size_t, void*>> cache;
+    int64_t last_poa_stats[16] = {0};                  // clh_ccs_plan_stats of the last clh_poa_batch (its plan lives only inside the call)
 
     void* alloc(size_t bytes)
     {
@@ -1315,6 +1316,13 @@ extern "C" int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const
     return rc;
 }
 
+extern "C" int clh_poa_last_stats(clh_ctx* ctx, int64_t* out)
+{
+    if (!ctx || !out) return fail(CLH_E_ARG, "clh_poa_last_stats: null argument");
+    for (int k = 0; k < 16; ++k) out[k] = ctx->last_poa_stats[k];
+    return 0;
+}
+
 // spoa's AlignmentEngine::Create rules + what the kernel's 16-bit cells can hold
 static int poa_check_opts(const clh_poa_opts* o, clh::PoaScores* s)
 {
@@ -1397,6 +1405,7 @@ extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, 
         if (!rc && aln_score && hipMemcpy(aln_score, pl->d_score, sizeof(int32_t) * clh::CCS_SEG_CAP * (size_t)ngroups, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(CLH_E_HIP, "D2H failed");
     } else (void)hipStreamSynchronize(st);
+    if (!rc) (void)clh_ccs_plan_stats(pl, ctx->last_poa_stats);
     ctx->release(d_xcuts); ctx->release(d_xoff); ctx->release(d_col); ctx->release(d_ncols);
     clh_ccs_plan_destroy(pl);
     return rc;

@@ -113,6 +113,7 @@ def lib():
         L.clh_ccs_results_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_ccs_plan_info.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_ccs_plan_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_poa_last_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -300,6 +301,13 @@ class Context(object):
                 item = item + ([int(x) for x in asc[k, :min(CCS_SEG_CAP, int(group_off[k + 1] - group_off[k]))]],)
             res.append(item)
         return res
+
+    def poa_last_stats(self):
+        """statistics of the last poa_batch (see CcsPlan.stats)"""
+        out = np.zeros(16, dtype=np.int64)
+        if lib().clh_poa_last_stats(self._h, out.ctypes.data) != 0:
+            raise ClhError('clh_poa_last_stats: %s' % last_error())
+        return {'dp_cells': int(out[0]), 'dp_row_steps': int(out[1]), 'band_misses': int(out[2]), 'dropped': {k: int(out[2 + k]) for k in range(1, 8) if out[2 + k]}}
 
     def edit_distance_batch(self, xs, ys):
         """Unit-cost edit distance of the pairs (xs[k], ys[k]) (str or bytes) -> int32 array.  K4 through the C ABI."""

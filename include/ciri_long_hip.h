@@ -166,6 +166,8 @@ int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* r
  * row[msa_col[b]] = base b for the bases b of sequence i.  aln_score (may be NULL; int32[ngroups][65]) receives the
  * end-cell score of the alignment of each of the first 65 sequences of a group. */
 typedef struct { int32_t algorithm, m, n, g, e, q, c, min_coverage; } clh_poa_opts;
+/* clh_ccs_plan_stats of the last clh_poa_batch of this context (out[16], same layout) */
+int clh_poa_last_stats(clh_ctx* ctx, int64_t* out);
 int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, const int64_t* seq_off, const int64_t* group_off,
                   const clh_poa_opts* opts, int32_t* out_len, int8_t* out_ccs, int32_t* msa_col, int32_t* msa_ncols, int32_t* aln_score);
 

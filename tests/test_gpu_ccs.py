@@ -400,3 +400,28 @@ def test_reads_lost_to_a_kernel_limit_are_counted_and_reported(tmp_path, caplog)
     fa.write_text('>lost\n%s\n>kept\n%s\n' % (read, short))
     total, ro, ccs_seq = find_ccs.find_ccs_reads(str(fa), str(tmp_path), 'p', 1, False)
     assert (total, ro, list(ccs_seq)) == (2, 1, ['kept']) and ctx.last_capacity_dropped == 1
+
+
+def test_walks_that_leave_the_band_of_stored_cells_fall_back_to_the_full_planes():
+    """The forward pass leaves its cells only near the straight line through the matrix (POA_BAND); a sequence that joins the
+    graph far from that line -- here: sequences that start in the middle of the first one -- makes the back-track ask for a cell
+    that is not there: the pass runs again with every cell stored and the answer is the oracle's, in all three modes.  The misses
+    are counted."""
+    import random
+    from ciri_long_amd import hip, spoa
+    rng = random.Random(77)
+    ctx = hip.default_context()
+    total = 0
+    for it in range(12):
+        x = ''.join(rng.choice('ACGT') for _ in range(rng.choice([420, 700, 1100])))
+        seqs = [x]
+        for k in range(4):
+            a = rng.randrange(120, len(x) // 2)
+            y = x[a:] + ''.join(rng.choice('ACGT') for _ in range(rng.choice([0, 150, 260])))
+            seqs.append(''.join(rng.choice('ACGT') if rng.random() < 0.05 else ch for ch in y))
+        seqs.append(x[:len(x) // 2])
+        algorithm = it % 3
+        want = oracle_lib.oracle_poa(seqs, algorithm, True, 10, -4, -8, -2, -24, -1)
+        assert spoa.poa(seqs, algorithm, True, 10, -4, -8, -2, -24, -1) == tuple(want), it
+        total += ctx.poa_last_stats()['band_misses']
+    assert total >= 12

@@ -492,7 +492,10 @@ static constexpr int D_F = 0x0007, D_O_SHIFT = 3, D_E_SHIFT = 8, D_Q_SHIFT = 11;
 // column r * m / N -- rows that an older successor reads back as a source ("full", 0x8000 in the graph row) leave all of them --
 // and the back-track, which knows the same rule, answers "miss" when it is about to use a cell that was not left: the pass is
 // then run once more with every cell stored.  Results never depend on the band.
-static constexpr int POA_BAND = 64;
+#ifndef POA_BAND_W
+#define POA_BAND_W 64
+#endif
+static constexpr int POA_BAND = POA_BAND_W;
 static constexpr int POA_H_NONE = -32768;            // a cell of the staged band that the planes do not hold (H is never below POA_NEG)
 static constexpr int BT_MISS = -2;
 

@@ -441,6 +441,14 @@ __device__ __forceinline__ void scan_left_pk2(const uint32_t (&a)[CP], int leftA
     for (int t = 0; t < CP; ++t) { pa[t] = pk_max(runA[t], exA); pb[t] = pk_max(runB[t], exB); }
 }
 
+// (x == 0 ? lo : lo + d) per half from x = letter ^ node letter: min and multiply-add written out -- left to itself the compiler
+// "simplifies" min(x, 1) * d into per-half compares and selects (eight operations and their wait states instead of two)
+__device__ __forceinline__ uint32_t pk_nz_select(uint32_t x, uint32_t d, uint32_t lo) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_mad_u16 %0, %0, %2, %3" : "=&v"(r) : "v"(x), "v"(d), "v"(lo));
+    return r;
+}
+__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }      // a value the compiler shall not re-derive
 __device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t b) {   // (a << sh) | b as ONE instruction (the compiler reassociates a tree of them into shifts and ors)
     uint32_t d;
     asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(sh), "v"(b));
@@ -507,6 +515,15 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     const int gp = poa_pitch(m);
     const int rmask = RING - 1;
     const bool sw = (S.algorithm & 0xff) == 0, nw = (S.algorithm & 0xff) == 1;
+    // The workspace record lives in memory (this is a function of its own): every pointer of it that the row loop uses is taken out
+    // here, once, as a scalar pair.  Left inside the loop the compiler reloads it per row -- and the wait for that load is a wait for
+    // every store in flight (loads and stores share one counter), i.e. for the row's own plane stores to reach memory.
+    char* const gH = (char*)uniform_ptr(w.planeH);
+    char* const gD = (char*)uniform_ptr(w.planeD);
+    const uint2* const gri = uniform_ptr(w.ri);
+    const short* const gcol0 = uniform_ptr(w.col0);
+    const int cpitch = __builtin_amdgcn_readfirstlane(w.cpitch);
+    const int32_t* const gorder = uniform_ptr(w.order); const int32_t* const grank = uniform_ptr(w.rank); const int32_t* const gpred = uniform_ptr(w.pred);
     const int g = S.g, e = S.e, q = S.q, c = S.c;
     const uint32_t g2 = dup16(g), e2 = dup16(e), q2 = dup16(q), c2 = dup16(c), sm2 = dup16(S.m), dsn2 = dup16(S.n - S.m);
     const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
@@ -538,21 +555,31 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
         const int l1 = g + (j - 1) * e, l2 = q + (j - 1) * c;
         return (sw || j == 0) ? 0 : (l1 > l2 ? l1 : l2);
     };
-    const short* cprev = w.carry + (size_t)(pass & 1) * 3 * w.cpitch;
-    short* cnext = w.carry + (size_t)((pass + 1) & 1) * 3 * w.cpitch;
+    short* const gcarry = uniform_ptr(w.carry);
+    const short* cprev = gcarry + (size_t)(pass & 1) * 3 * cpitch;
+    short* cnext = gcarry + (size_t)((pass + 1) & 1) * 3 * cpitch;
     const bool carried = pass > 0;
     uint2 blk = make_uint2(0, 0); int cH = 0, cE = POA_NEG, cQ = POA_NEG;
-    auto fetch = [&](int rr, uint2& b, int& h, int& ee, int& qq) {
-        b = make_uint2(0, 0); h = 0; ee = POA_NEG; qq = POA_NEG;
-        if (rr <= N) {
-            b = w.ri[rr];
-            if (carried) { h = (int)cprev[rr]; ee = (int)cprev[w.cpitch + rr]; qq = (int)cprev[2 * w.cpitch + rr]; }
-            else if (nw) h = (int)w.col0[rr];
-        }
+    struct RowIn { uint2 b; int h, e, q; };
+    // Every load unconditional, from a clamped index, the unwanted values dropped afterwards: around conditional loads the compiler
+    // builds "load through a pointer that is either the array or a stack slot holding the default", and the row loop then starts
+    // with a load from the stack -- whose wait is a wait for every plane store in flight
+    auto fetch1 = [&](int rr) -> RowIn {
+        const bool in = rr <= N;
+        const int rc = in ? rr : N;
+        const uint2 b = gri[rc];
+        const int hc = (int)cprev[rc], ec = (int)cprev[cpitch + rc], qc = (int)cprev[2 * cpitch + rc], h0 = (int)gcol0[rc];
+        RowIn x;
+        x.b = in ? b : make_uint2(0, 0);
+        x.h = !in ? 0 : (carried ? hc : (nw ? h0 : 0));
+        x.e = in && carried ? ec : POA_NEG; x.q = in && carried ? qc : POA_NEG;
+        return x;
     };
+    auto fetch = [&](int rr, uint2& b, int& h, int& ee, int& qq) { const RowIn x = fetch1(rr); b = x.b; h = x.h; ee = x.e; qq = x.q; };
     // H of the column in front of the pass for a row that is not the row before
-    auto left_of = [&](int qr) -> int { return carried ? (int)cprev[qr] : (nw ? (int)w.col0[qr] : 0); };
+    auto left_of = [&](int qr) -> int { return carried ? (int)cprev[qr] : (nw ? (int)gcol0[qr] : 0); };
     fetch(1 + lane, blk, cH, cE, cQ);
+    asm volatile("" :: "v"(blk.x), "v"(blk.y), "v"(cH), "v"(cE), "v"(cQ));      // (arrived: see the end of the block loop)
     uint32_t px[CP], pf[CP], po[CP];                             // the previous row, still in registers (packed)
     int pcin = 0;
 #pragma unroll
@@ -568,9 +595,11 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #endif
     // (stores written out as asm with a scalar base and the lane's 32-bit offset saved the 64-bit address arithmetic and cost 2 ms:
     // the blocks pin the schedule)
-    const char* planeH = (const char*)w.planeH;
-    const char* planeD = (const char*)w.planeD;
     const uint32_t lane_off = (uint32_t)(col0 + 8) * 2u;
+    // columns beyond the sequence, as masks (0xFFFF in those halves): for the lowest-cell watch, and for the end cell
+    uint32_t beyondP[CP], endP[CP];
+#pragma unroll
+    for (int t = 0; t < CP; ++t) { beyondP[t] = opaque(pk_sra15(sbP[t] << 7)); endP[t] = opaque(beyond_free ? 0u : beyondP[t]); }
     for (int rb = 1; rb <= N; rb += 64) {
         uint2 nblk; int nH, nE, nQ;
         fetch(rb + 64 + lane, nblk, nH, nE, nQ);
@@ -591,8 +620,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 const uint32_t vb2 = dup16(vb);
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
-                    const uint32_t nz = pk_minu(sbP[t] ^ vb2, ONE2);                 // 0 where the letter equals the node's
-                    ss[t] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, nz) * __builtin_bit_cast(u16x2, dsn2) + __builtin_bit_cast(u16x2, sm2));
+                    ss[t] = pk_nz_select(sbP[t] ^ vb2, dsn2, sm2);                   // S.m where the letter equals the node's, else S.n
                 }
             }
             // one source row that is not the row before, packed: H at the lane's columns, Fs, Os, and the H in front of the pass
@@ -613,8 +641,8 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                         left = ringL[qr & rmask];
                     } else {
                         uint32_t nh[CP], nd[CP];
-                        const uint32_t* sh = (const uint32_t*)(planeH + (size_t)qr * gp * 2 + lane_off);
-                        const uint32_t* sd = (const uint32_t*)(planeD + (size_t)qr * gp * 2 + lane_off);
+                        const uint32_t* sh = (const uint32_t*)(gH + (size_t)qr * gp * 2 + lane_off);
+                        const uint32_t* sd = (const uint32_t*)(gD + (size_t)qr * gp * 2 + lane_off);
                         // compiler-visible loads: its own wait counts (an asm block here made it wait for every store in flight on the
                         // ring path too).  The cells were written by these very lanes earlier in this pass.
 #pragma unroll
@@ -670,8 +698,8 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 add_source((int)(d1 & 0xffff));
                 if (np > 2) add_source((int)(d1 >> 16));
                 if (np > 3) {                                    // rare: in-edges beyond the third come from HBM
-                    const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
-                    for (int s2 = 3; s2 < np; ++s2) add_source(__builtin_amdgcn_readfirstlane(w.rank[w.pred[vnode * POA_MAXP + s2]]));
+                    const int vnode = __builtin_amdgcn_readfirstlane(gorder[r - 1]);
+                    for (int s2 = 3; s2 < np; ++s2) add_source(__builtin_amdgcn_readfirstlane(grank[gpred[vnode * POA_MAXP + s2]]));
                 }
             }
             SEC(9);
@@ -727,8 +755,8 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 to_natural<CP>(Hf, nh); to_natural<CP>(D, nd);
                 // scalar row base + the lane's 32-bit offset, written out: left to itself the compiler folds the lane's offset into a
                 // 64-bit vector base and pays a 64-bit multiply-add per store
-                uint32_t* dh = (uint32_t*)(w.planeH + (size_t)r * gp + col0 + 8);
-                uint32_t* dd = (uint32_t*)(w.planeD + (size_t)r * gp + col0 + 8);
+                uint32_t* dh = (uint32_t*)(gH + (size_t)r * gp * 2 + lane_off);
+                uint32_t* dd = (uint32_t*)(gD + (size_t)r * gp * 2 + lane_off);
                 if constexpr (CP == 1) { *dh = nh[0]; *dd = nd[0]; }
                 else if constexpr (CP == 2) { *(uint2*)dh = make_uint2(nh[0], nh[1]); *(uint2*)dd = make_uint2(nd[0], nd[1]); }
                 else if constexpr (CP == 3) { __builtin_memcpy(dh, nh, 12); __builtin_memcpy(dd, nd, 12); }
@@ -743,7 +771,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             SEC(12);
             if (!sw) {
 #pragma unroll
-                for (int t = 0; t < CP; ++t) lowP = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, lowP), __builtin_bit_cast(s16x2, bfi(pk_sra15(sbP[t] << 7), 0x7fff7fffu, Hf[t]))));
+                for (int t = 0; t < CP; ++t) lowP = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, lowP), __builtin_bit_cast(s16x2, bfi(beyondP[t], 0x7fff7fffu, Hf[t]))));
             }
             // ---- end cell: first strict maximum in (rank, column) order --------------------------------------------
             if (sw | (!nw & sink)) {
@@ -751,7 +779,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 // be the end cell anyway: every move into such a cell loses score, so it is below the cell it came from
                 uint32_t hv2[CP];
 #pragma unroll
-                for (int t = 0; t < CP; ++t) hv2[t] = beyond_free ? Hf[t] : bfi(pk_sra15(sbP[t] << 7), 0x80008000u, Hf[t]);
+                for (int t = 0; t < CP; ++t) hv2[t] = bfi(endP[t], 0x80008000u, Hf[t]);
                 uint32_t rm = hv2[0];
 #pragma unroll
                 for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
@@ -781,8 +809,11 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             SEC(13);
             asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder
         }
-        if (more && lane < cnt) { cnext[rb + lane] = (short)cobH; cnext[w.cpitch + rb + lane] = (short)cobE; cnext[2 * w.cpitch + rb + lane] = (short)cobQ; }
+        if (more && lane < cnt) { cnext[rb + lane] = (short)cobH; cnext[cpitch + rb + lane] = (short)cobE; cnext[2 * cpitch + rb + lane] = (short)cobQ; }
         blk = nblk; cH = nH; cE = nE; cQ = nQ;
+        // the next block's rows have arrived HERE: first used inside the row loop, the wait for them would sit there, and a wait for a
+        // load is a wait for every store before it
+        asm volatile("" :: "v"(blk.x), "v"(blk.y), "v"(cH), "v"(cE), "v"(cQ));
     }
     if (more) phase_sync();
     {   // a cell at the floor of the int16 range may have been cut off there: the caller reports it (status 6)
@@ -811,9 +842,17 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 
 // DP rows of one sequence: passes of 128 * POA_MAXCP columns; the last pass takes 2, 4 or 6 columns per lane by its width (a
 // row step costs a fixed part plus a part per register)
-__device__ void dp_rows(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int slope16, int& bs_out, int& br_out, int& bc_out DBGARG)
+__device__ __attribute__((noinline)) void dp_rows(const PoaWs& w, const PoaScores S_, int N, int m, const int8_t* seq_, int lane, const int slope16_, int& bs_out, int& br_out, int& bc_out DBGARG)
 {
+    PoaScores S;
+    S.algorithm = __builtin_amdgcn_readfirstlane(S_.algorithm); S.m = __builtin_amdgcn_readfirstlane(S_.m); S.n = __builtin_amdgcn_readfirstlane(S_.n);
+    S.g = __builtin_amdgcn_readfirstlane(S_.g); S.e = __builtin_amdgcn_readfirstlane(S_.e); S.q = __builtin_amdgcn_readfirstlane(S_.q);
+    S.c = __builtin_amdgcn_readfirstlane(S_.c); S.min_cov = 0;
+    const int slope16 = __builtin_amdgcn_readfirstlane(slope16_);
+    const int8_t* seq = uniform_ptr(seq_);
     constexpr int WMAX = 128 * POA_MAXCP;
+    // wave-uniform, all of them: say so (arguments of a function arrive in vector registers)
+    N = __builtin_amdgcn_readfirstlane(N); m = __builtin_amdgcn_readfirstlane(m);
     const int RING = poa_ring(m);
     int bs = (S.algorithm & 0xff) == 0 ? 0 : -(1 << 30), br = 0, bc = 0;
     int pass = 0;
@@ -875,7 +914,7 @@ __device__ void poa_dfs_root(const PoaWs& w, const int r, const int lo, const in
 
 // sort the graph after a sequence of m bases (nodes w.pj[0..m)) has been fused; nodes [n_old, n) are new.  returns 0, or -1 if
 // the order violates an edge (cannot happen; checked because everything downstream relies on it)
-__device__ int poa_sort(const PoaWs& w, const int n_old, const int n, const int m, const int lane)
+__device__ __forceinline__ int poa_sort(const PoaWs& w, const int n_old, const int n, const int m, const int lane)
 {
     for (int v = n_old + lane; v < n; v += 64) w.root[v] = v;
     for (int v = lane; v < n; v += 64) { w.rsz[v] = 0; w.st[v] = 0; }
@@ -962,7 +1001,7 @@ __device__ __forceinline__ uint32_t wave_suffix_min(uint32_t v) {
     return v;
 }
 
-__device__ int poa_sort_lds(const PoaWs& w_, const int n_old, const int n, const int m, const int lane)
+__device__ __forceinline__ int poa_sort_lds(const PoaWs& w_, const int n_old, const int n, const int m, const int lane)
 {
     struct { int32_t* root; int32_t* pj; int8_t* na; int8_t* np; int32_t* aligned; int32_t* pred; int32_t* order; int32_t* rank; } w;
     w.root = uniform_ptr(w_.root); w.pj = uniform_ptr(w_.pj); w.na = uniform_ptr(w_.na); w.np = uniform_ptr(w_.np);
@@ -1332,7 +1371,7 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
 // returns the new node count; -1 graph limits, -2 workspace, -3 back-track guard, -4 a cell at the floor of the int16 range
 // (global / overlap modes with costly gaps).  *score_out = end-cell score.
 // path_out (may be null): node of every base (for the MSA)
-__device__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8_t* seq, int m_, int lane, int* score_out, int32_t* path_out, unsigned long long* tacc, int* band_misses, const int mref)
+__device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8_t* seq, int m_, int lane, int* score_out, int32_t* path_out, unsigned long long* tacc, int* band_misses, const int mref)
 {
     // wave-uniform by construction; say so, or every quantity derived from them lives in VGPRs behind exec-mask branches
     const int N = __builtin_amdgcn_readfirstlane(N_), m = __builtin_amdgcn_readfirstlane(m_);

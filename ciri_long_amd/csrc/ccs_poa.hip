@@ -425,17 +425,16 @@ __device__ __forceinline__ void scan_left_pk(const uint32_t (&a)[CP], int left, 
 template <int CP>
 __device__ __forceinline__ void scan_left_pk2(const uint32_t (&a)[CP], int leftA, uint32_t (&pa)[CP], const uint32_t (&b)[CP], int leftB, uint32_t (&pb)[CP])
 {
-    constexpr int NEGB = -(1 << 30);
     uint32_t runA[CP], runB[CP];
     runA[0] = 0x80008000u; runB[0] = 0x80008000u;
 #pragma unroll
     for (int t = 1; t < CP; ++t) { runA[t] = pk_max(runA[t - 1], a[t - 1]); runB[t] = pk_max(runB[t - 1], b[t - 1]); }
     const uint32_t totA = pk_max(runA[CP - 1], a[CP - 1]), totB = pk_max(runB[CP - 1], b[CP - 1]);
     const int loA = (int)(short)(totA & 0xffffu), hiA = (int)totA >> 16, loB = (int)(short)(totB & 0xffffu), hiB = (int)totB >> 16;
-    int incA = loA > hiA ? loA : hiA, incB = loB > hiB ? loB : hiB;
-    wave_prefix_max2(incA, incB);
-    int excA = dpp_shr1(NEGB, incA), excB = dpp_shr1(NEGB, incB);
-    excA = leftA > excA ? leftA : excA; excB = leftB > excB ? leftB : excB;
+    // the lane totals move one lane up first (lane 0 takes the value entering the pass): the inclusive scan of that is the
+    // exclusive prefix, the entering value included
+    int excA = dpp_shr1(leftA, loA > hiA ? loA : hiA), excB = dpp_shr1(leftB, loB > hiB ? loB : hiB);
+    wave_prefix_max2(excA, excB);
     const uint32_t exA = pack16(excA, excA > loA ? excA : loA), exB = pack16(excB, excB > loB ? excB : loB);
 #pragma unroll
     for (int t = 0; t < CP; ++t) { pa[t] = pk_max(runA[t], exA); pb[t] = pk_max(runB[t], exB); }
@@ -525,7 +524,8 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     const int cpitch = __builtin_amdgcn_readfirstlane(w.cpitch);
     const int32_t* const gorder = uniform_ptr(w.order); const int32_t* const grank = uniform_ptr(w.rank); const int32_t* const gpred = uniform_ptr(w.pred);
     const int g = S.g, e = S.e, q = S.q, c = S.c;
-    const uint32_t g2 = dup16(g), e2 = dup16(e), q2 = dup16(q), c2 = dup16(c), sm2 = dup16(S.m), dsn2 = dup16(S.n - S.m);
+    const uint32_t g2 = dup16(g), e2 = dup16(e), q2 = dup16(q), c2 = dup16(c);
+    const uint32_t sm2 = opaque(dup16(S.m)), dsn2 = opaque(dup16(S.n - S.m));          // (operands of an asm block: kept in vector registers, not copied there per row)
     const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
     const uint32_t NEG2 = dup16(POA_NEG), ONE2 = 0x00010001u;
     const uint32_t floor2 = sw ? 0u : 0x80008000u;           // local mode: a cell is at least 0
@@ -753,14 +753,26 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             if (st_row) {
                 uint32_t nh[CP], nd[CP];
                 to_natural<CP>(Hf, nh); to_natural<CP>(D, nd);
-                // scalar row base + the lane's 32-bit offset, written out: left to itself the compiler folds the lane's offset into a
-                // 64-bit vector base and pays a 64-bit multiply-add per store
-                uint32_t* dh = (uint32_t*)(gH + (size_t)r * gp * 2 + lane_off);
-                uint32_t* dd = (uint32_t*)(gD + (size_t)r * gp * 2 + lane_off);
+                // scalar row base + the lane's 32-bit offset: the row base is made opaque, or the compiler folds the lane's offset
+                // into a 64-bit vector base and pays two 64-bit multiply-adds (quarter rate) per row
+                const unsigned long long roff = (unsigned long long)((unsigned)r * (unsigned)gp) * 2ull;
+                typedef __attribute__((address_space(1))) char* gchar;
+                typedef __attribute__((address_space(1))) uint32_t* gu32;
+                gchar rowH = (gchar)gH + roff, rowD = (gchar)gD + roff;
+                asm("" : "+s"(rowH), "+s"(rowD));
+                gu32 dh = (gu32)(rowH + lane_off), dd = (gu32)(rowD + lane_off);
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 if constexpr (CP == 1) { *dh = nh[0]; *dd = nd[0]; }
-                else if constexpr (CP == 2) { *(uint2*)dh = make_uint2(nh[0], nh[1]); *(uint2*)dd = make_uint2(nd[0], nd[1]); }
-                else if constexpr (CP == 3) { __builtin_memcpy(dh, nh, 12); __builtin_memcpy(dd, nd, 12); }
-                else { *(uint4*)dh = make_uint4(nh[0], nh[1], nh[2], nh[3]); *(uint4*)dd = make_uint4(nd[0], nd[1], nd[2], nd[3]); }
+                else if constexpr (CP == 2) {
+                    *(__attribute__((address_space(1))) u32x2*)dh = u32x2{nh[0], nh[1]}; *(__attribute__((address_space(1))) u32x2*)dd = u32x2{nd[0], nd[1]};
+                } else if constexpr (CP == 3) {
+                    typedef u32x3 __attribute__((aligned(4))) u32x3u;
+                    *(__attribute__((address_space(1))) u32x3u*)dh = u32x3{nh[0], nh[1], nh[2]}; *(__attribute__((address_space(1))) u32x3u*)dd = u32x3{nd[0], nd[1], nd[2]};
+                } else {
+                    *(__attribute__((address_space(1))) u32x4*)dh = u32x4{nh[0], nh[1], nh[2], nh[3]}; *(__attribute__((address_space(1))) u32x4*)dd = u32x4{nd[0], nd[1], nd[2], nd[3]};
+                }
             }
             if (tolds) {
                 uint32_t* rp = ring + (r & rmask) * rrow + lane * CP;

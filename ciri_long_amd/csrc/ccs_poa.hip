@@ -1165,14 +1165,20 @@ __device__ __forceinline__ void group_span(const PoaWs& w, int v, int& lo, int& 
 //  * Any other step is evaluated with the in-edges across the lanes (first hit in in-edge order = lowest lane).
 // returns the column the walk ends in (the bases in front of it are not part of the alignment), or -1 (guard: corrupt planes).
 static constexpr int BT_W = POA_LDS_BYTES >= 9216 ? 24 : 20;     // columns per band row (64 rows x 2 planes + the sequence in the LDS block)
+static constexpr int BT_SQ = 128, BT_RING = 1024;    // letters staged with the band; entries of the result ring
 static constexpr int BT_DRIFT = BT_W / 2 - 4;        // how far the walk may leave the band's diagonal before the band is staged again
+static_assert(4 * 64 * BT_W + BT_SQ + 2 * BT_RING <= POA_LDS_BYTES, "back-track LDS");
 // A function of its own, NOT inlined: inside the kernel's one big body the register allocator spilled a value of this loop and
 // reloaded it every iteration -- and the wait for that reload is a wait for every store in flight, i.e. for the walk's own result
 // stores to reach memory: 2 us per step.  With its own frame the loop keeps its registers.
 struct BtArgs { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; const int8_t* seq; int N, m, r, j, slope16; };
 // returns 2 * (column the walk ends in) + (1 if the alignment holds a step), -1 (guard) or BT_MISS (a cell outside the band the planes hold)
-__device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const PoaScores S DBGARG)
+__device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const PoaScores S_ DBGARG)
 {
+    PoaScores S;                                             // (arguments arrive in vector registers; a test on one is a divergent branch)
+    S.algorithm = __builtin_amdgcn_readfirstlane(S_.algorithm); S.m = __builtin_amdgcn_readfirstlane(S_.m); S.n = __builtin_amdgcn_readfirstlane(S_.n);
+    S.g = __builtin_amdgcn_readfirstlane(S_.g); S.e = __builtin_amdgcn_readfirstlane(S_.e); S.q = __builtin_amdgcn_readfirstlane(S_.q);
+    S.c = __builtin_amdgcn_readfirstlane(S_.c); S.min_cov = 0;
     // the walk is wave-uniform: say so (scalar registers, scalar branches)
     struct { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; } w;
     w.pn = uniform_ptr(A.pn); w.planeH = uniform_ptr(A.planeH); w.planeD = uniform_ptr(A.planeD); w.ri = uniform_ptr(A.ri);
@@ -1188,10 +1194,23 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
 #ifdef CLH_DEBUG_POA
     const unsigned long long t_bt0 = __builtin_amdgcn_s_memtime();
 #endif
-    short* Hb = (short*)poa_lds;
-    unsigned short* Db = (unsigned short*)poa_lds + 64 * BT_W;
-    uint8_t* lseq = (uint8_t*)poa_lds + 4 * 64 * BT_W;
-    for (int i = lane; i < m; i += 64) lseq[i] = (uint8_t)seq[i];
+    // (In a function that is not a kernel the address of the dynamic LDS array is a table look-up in memory, which the compiler repeats
+    // where it is used.  Handing the address in as an argument removes the look-ups and measured 2.6 ms SLOWER on C3: through a pointer
+    // made from an integer the compiler no longer tells the band, the letters and the ring apart and serialises their accesses.)
+    uint32_t* const lds = poa_lds;
+    short* Hb = (short*)lds;
+    unsigned short* Db = (unsigned short*)lds + 64 * BT_W;
+    // The walk's results (pn[column] = rank) go to a ring in LDS and from there to HBM in blocks: a store to HBM inside the loop stays in
+    // flight for a microsecond, and any wait the compiler places in the loop for whatever reason (a register about to be reused by a
+    // rare path's load is enough) then waits for it -- once per step.  The sequence's letters around the band are staged with it.
+    uint8_t* lsq = (uint8_t*)lds + 4 * 64 * BT_W;                   // letters of columns sb0 + 1 .. sb0 + BT_SQ
+    unsigned short* lpn = (unsigned short*)(lsq + BT_SQ);           // ring: entry t & (BT_RING - 1) = pn[t]; 0 = none
+    for (int i = lane; i < BT_RING / 2; i += 64) ((uint32_t*)lpn)[i] = 0;
+    int jflush = j, sb0 = 0;                                        // pn[t] for t in [j, jflush) is in the ring
+    auto flush = [&](int jlo) {
+        for (int t = jlo + lane; t < jflush; t += 64) { w.pn[t] = (int32_t)lpn[t & (BT_RING - 1)]; lpn[t & (BT_RING - 1)] = 0; }
+        jflush = jlo;
+    };
     auto row0_h = [&](int jj) -> int {
         const int l1 = g + (jj - 1) * e, l2 = q + (jj - 1) * c;
         return (sw || jj == 0) ? 0 : (l1 > l2 ? l1 : l2);
@@ -1204,6 +1223,13 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
     // here, so that the walk reads every cell the same way.
     auto reload = [&](int rr0, int jj0) {
         r0 = rr0; j0 = jj0;
+        if (jflush - jj0 >= BT_RING / 2) flush(jj0);
+        sb0 = jj0 - BT_SQ + 28;
+        {
+            const int i = sb0 + 2 * lane;
+            const int b0 = i >= 0 && i < m ? (int)(uint8_t)seq[i] : 0, b1 = i + 1 >= 0 && i + 1 < m ? (int)(uint8_t)seq[i + 1] : 0;
+            ((unsigned short*)lsq)[lane] = (unsigned short)(b0 | (b1 << 8));
+        }
         const int rr = r0 - lane;
         rim = make_uint2(0, 0);
         csk = cs_at(lane); csk1 = cs_at(lane + 1);
@@ -1271,9 +1297,12 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
     tacc[15] += __builtin_amdgcn_s_memtime() - t_bt0;
 #endif
     int guard = 2 * (N + m) + 64;                           // every step lowers r or j: a longer walk means corrupt planes
-    while (r > 0 && j > 0) {
+    for (;;) {
+        // (the loop's own test on values the compiler can see to be uniform: else the whole walk is built as a divergent loop, every
+        // branch an exec-mask update)
+        r = __builtin_amdgcn_readfirstlane(r); j = __builtin_amdgcn_readfirstlane(j); guard = __builtin_amdgcn_readfirstlane(guard);
+        if (!(r > 0 && j > 0)) break;
         if (--guard < 0) return -1;
-        r = __builtin_amdgcn_readfirstlane(r); j = __builtin_amdgcn_readfirstlane(j);
         int a = r0 - r;
         {
             const int drift = j - (j0 - a);
@@ -1292,10 +1321,10 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
         const bool inb = (unsigned)kp < 64u && xp >= 1 && xp < BT_W;
         // no branches around the reads (a lane with nothing to read reads a cell of its own band row): they issue together, one wait
         const int i_own = ok ? lane * BT_W + myc - csk : lane * BT_W, i_nb = ok ? (lane + 1) * BT_W + myc - 1 - csk1 : lane * BT_W;
-        const int i_p = act && inb ? kp * BT_W + xp : lane * BT_W + 1, i_s = ok ? myc - 1 : 0;
+        const int i_p = act && inb ? kp * BT_W + xp : lane * BT_W + 1, i_s = ok ? myc - 1 : j - 1;
         const int xl = a * BT_W + j - __builtin_amdgcn_readlane(csk, a);
         const int hc = (int)Hb[i_own], hd = (int)Hb[i_nb], hp1 = (int)Hb[i_p - 1], hpv = (int)Hb[i_p], dpv = (int)Db[i_p];
-        const int h = (int)Hb[xl], hl = (int)Hb[xl - 1], dl = (int)Db[xl - 1], sb = (int)lseq[i_s];
+        const int h = (int)Hb[xl], hl = (int)Hb[xl - 1], dl = (int)Db[xl - 1], sb = (int)lsq[i_s - sb0];
         int hp = hpv, dp = dpv, hp1x = hp1;
         ok = ok && hc != POA_H_NONE && hd != POA_H_NONE && hc == hd + ((int)(rim.x & 0xff) == sb ? S.m : S.n) && !(sw && hc == 0);
         {
@@ -1303,7 +1332,7 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
             const int run = ~okm ? __builtin_ctzll(~okm) : 64;
             if (run > 0) {
                 DBGCNT(16, 1); DBGCNT(17, run);
-                if (l >= 0 && l < run) w.pn[myc - 1] = myr;
+                if (l >= 0 && l < run) lpn[(myc - 1) & (BT_RING - 1)] = (unsigned short)myr;
                 r -= run; j -= run; moved = true;
                 continue;
             }
@@ -1318,10 +1347,10 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
         if (h == POA_H_NONE || hl == POA_H_NONE || __builtin_amdgcn_ballot_w64(act && (hp1x == POA_H_NONE || hp == POA_H_NONE))) return BT_MISS;
         moved = true;
         {
-            const int sc = (int)(d0 & 0xff) == (int)lseq[j - 1] ? S.m : S.n;
+            const int sc = (int)(d0 & 0xff) == (int)lsq[j - 1 - sb0] ? S.m : S.n;
             unsigned long long bm = __builtin_amdgcn_ballot_w64(act && h == hp1x + sc);
             if (bm) {
-                if (lane == 0) w.pn[j - 1] = r;
+                if (lane == 0) lpn[(j - 1) & (BT_RING - 1)] = (unsigned short)r;
                 r = __builtin_amdgcn_readlane(psx, __builtin_ctzll(bm)); --j;
                 continue;
             }
@@ -1377,6 +1406,7 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
             }
         }
     }
+    flush(j);
     return 2 * j + (moved ? 1 : 0);
 }
 

@@ -187,20 +187,28 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         cls[scan] = 0
         if not os.environ.get('CLH_NO_SLICES'):                  # class -1 = K1s with the forward pass cut into window slices
             cls[scan & (np.asarray(wlen) >= 32768)] = -1
+        if not os.environ.get('CLH_NO_SCANW'):                   # class -3 = K1w, the row-scan kernel for long reads / large scores (scanw_class_ok)
+            cls[~scan & (qlen <= 4096) & (np.asarray(wlen) < 32768) & (max_match * qlen < 32000)] = -3
     out, cells_total, k1ms = [], 0, 0.0
+    merged = []                                  # (a large K1w class runs as several launches: one line for the class)
     for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
+        if merged and merged[-1][0] == rv:
+            merged[-1] = (rv, merged[-1][1] + cnt, merged[-1][2] + k1)
+        else:
+            merged.append((rv, cnt, k1))
+    for rv, cnt, k1 in merged:
         sel = cls == rv
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         nwide = int(ssw_plan.traceback_counts()[0])
         out.append({'kernel': 'ssw_traceback_rows_wide_kernel + ssw_traceback_kernel (handed-over alignments)', 'alignments': nwide, 'ms': accb[1] / PROF,
                     'alg_bytes': int(b_alg.mean() * nwide) if len(qlen) else 0,
                     'note': 'latency of the few wide-band alignments, one wave or workgroup each; bytes = their number x the mean B_ssw of the batch'})
-    valu = {'bound': 'valu', 'kernel': 'ssw_scan_kernel + ssw_align_kernel (all classes)', 'unit': 'GCUPS',
+    valu = {'bound': 'valu', 'kernel': 'ssw_scan_kernel + ssw_scanw_kernel + ssw_align_kernel (all classes)', 'unit': 'GCUPS',
             'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
             'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,
             'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / 6 packed ops per cell pair (gapO == gapE path)'}

@@ -152,6 +152,7 @@ struct clh_plan {
     hipEvent_t done_ev = nullptr;           // recorded behind the run's last launch: fetch waits for the RUN, not for what the caller queued later
     bool ran = false;
     bool profiling = false;
+    std::vector<hipEvent_t> chain_ev;   // between the parts of a split K1w class
     std::vector<hipEvent_t> ev;     // per segment: K1 start, K1 stop; then K1b small-window start/stop, large-window start/stop
 };
 
@@ -165,6 +166,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
                     pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base};
     for (void* b : bufs) c->release(b);
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pl->chain_ev) (void)hipEventDestroy(e);
     if (pl->done_ev) (void)hipEventDestroy(pl->done_ev);
     delete pl;
 }
@@ -186,6 +188,14 @@ static bool scan_class_ok(int64_t L, const clh_ssw_opts* o, int max_match, int b
 {
     static const bool off = getenv("CLH_NO_SCAN") != nullptr;
     return !off && L <= 254 && o->score_size != 1 && (int64_t)max_match * L + bias < 255 && o->gap_extend >= 0 && o->gap_extend <= 16 && o->gap_open <= 255;
+}
+
+// K1w (ssw_scan_wide.hip): the same walk for what K1s leaves -- reads up to 4096 bases, any score below the 16-bit ceiling -- on
+// windows that are not cut into slices.  CLH_NO_SCANW=1 switches it off (A/B measurements): the anti-diagonal classes take over.
+static bool scanw_class_ok(int64_t L, int64_t R, const clh_ssw_opts* o, int max_match)
+{
+    const bool off = getenv("CLH_NO_SCAN") != nullptr || getenv("CLH_NO_SCANW") != nullptr;      // (read per plan: the tests switch it)
+    return !off && L <= 4096 && R < 32768 && (int64_t)max_match * L < 32000 && o->gap_extend >= 0 && o->gap_extend <= 16 && o->gap_open <= 255;
 }
 
 // K1s on long windows: the forward pass runs as slices of >= 8192 owned columns (at most 64 per alignment), each started
@@ -242,7 +252,8 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         if (L < 1 || R < 0 || L > 0x7fffffff || R > 0x7fffffff) { fail(CLH_E_ARG, "empty read or negative length in batch"); delete pl; return nullptr; }
         const int rc = (!ref_off && win_rc && win_rc[a]) ? 1 : 0;
         const int rows = (int)((L + 15) / 16) * 16;
-        const int rv = scan_class_ok(L, o, mx, -mn) ? (scan_sliced(R, o) ? clh::kRvScanSliced : clh::kRvScan) : rv_class_for(rows);
+        const int rv = scan_class_ok(L, o, mx, -mn) ? (scan_sliced(R, o) ? clh::kRvScanSliced : clh::kRvScan)
+                                                    : (scanw_class_ok(L, R, o, mx) ? clh::kRvScanWide : rv_class_for(rows));
         cls[a] = rv;
         clh::SswTask& t = pl->tasks[a];
         t.read_off = read_off[a]; t.ref_off = ref_off ? ref_off[a] : (rc ? win_off[a] + R - 1 : win_off[a]);
@@ -257,6 +268,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
             t.dir_off = (int64_t)pl->strip_bytes;
             pl->strip_bytes += 2 * (size_t)((R + 63) & ~63ll) * 8 + 256;
         }
+        if (rv == clh::kRvScanWide) { t.dir_off = (int64_t)pl->strip_bytes; pl->strip_bytes += clh::scanw_task_bytes((int)L); }
         if (pl->do_cigar) {
             t.cigar_cap = (int32_t)(2 * L + 2);
             if (cig + (size_t)t.cigar_cap > 0x7fffffffull) { fail(CLH_E_CAPACITY, "batch too large for 32-bit CIGAR offsets; split it"); delete pl; return nullptr; }
@@ -318,7 +330,13 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
     for (int k = 0; k < n_all;) {
         int e = k;
         while (e < n_all && cls[order[e]] == cls[order[k]]) ++e;
-        pl->segs.push_back({cls[order[k]], k, e - k});
+        // a large K1w class with CIGARs goes as up to four launches: the traceback of one runs under the score kernel of the next
+        // (clh_ssw_run) instead of all of it behind the one score kernel
+        const int parts = (cls[order[k]] == clh::kRvScanWide && pl->do_cigar && e - k >= 16384 && getenv("CLH_SCANW_PARTS")) ? 4 : 1;   // (measured on C2, 10 000 alignments: 4 parts of 2 500 are each less than one round of the GPU's wave slots -- 28 -> 35 ms; kept for batches far above that, off by default)
+        for (int q = 0; q < parts; ++q) {
+            const int b = k + (int)((int64_t)(e - k) * q / parts), b2 = k + (int)((int64_t)(e - k) * (q + 1) / parts);
+            pl->segs.push_back({cls[order[k]], b, b2 - b});
+        }
         k = e;
     }
     pl->tasks.swap(sorted);
@@ -571,7 +589,8 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     std::vector<size_t> ord(pl->segs.size());
     for (size_t k = 0; k < ord.size(); ++k) ord[k] = k;
     std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
-        const int rx = pl->segs[x].rv == clh::kRvStrips ? 1000 : pl->segs[x].rv, ry = pl->segs[y].rv == clh::kRvStrips ? 1000 : pl->segs[y].rv;
+        auto weight = [](int rv) { return rv == clh::kRvStrips ? 1000 : (rv == clh::kRvScanWide ? 900 : rv); };      // (K1w: whole long reads, one wave each)
+        const int rx = weight(pl->segs[x].rv), ry = weight(pl->segs[y].rv);
         return rx > ry;
     });
     clh::SswParams PG = P;                                  // the traceback launches index the whole task table
@@ -595,19 +614,32 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     P.slice_base = (const int32_t*)pl->d_slice_base; PG.slice_base = P.slice_base;
     int rv_all = 4;                                              // longest read class of the plan (the combined alignments have any length)
     for (const auto& s : pl->segs) rv_all = std::max(rv_all, s.rv == clh::kRvStrips ? 32 : s.rv);
+    int n_wide = 0, i_wide = 0;
+    for (const auto& s : pl->segs) n_wide += s.rv == clh::kRvScanWide;
     for (size_t q = 0; q < ord.size(); ++q) {
         const size_t k = ord[q];
         const auto& s = pl->segs[k];
         if (s.rv == clh::kRvCombine) continue;                   // after the join below: it reads the other classes' rows
         hipStream_t ls = (fan && (q & 3)) ? c->side[(q & 3) - 1] : st;
+        // the parts of a K1w class: score kernels one after the other on the main stream, the traceback of each part on a side
+        // stream behind an event (the last part's stays on the main stream)
+        const bool chained = fan && tb && s.rv == clh::kRvScanWide && n_wide > 1;
+        if (chained) ls = st;
         P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], ls));
         if (s.rv == clh::kRvScanSliced) {
             P.slices = (const clh::ScanSlice*)pl->d_slices; P.parts = (clh::ScanPart*)pl->d_parts;
             HIPCHK(clh::launch_ssw_scan_sliced(pl->quirk, P, s.count, (int)pl->slices.size(), ls));
         } else if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
+        else if (s.rv == clh::kRvScanWide) HIPCHK(clh::launch_ssw_scanw(pl->quirk, P, s.count, ls));
         else HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], ls));
+        if (chained && ++i_wide < n_wide) {
+            if (pl->chain_ev.size() < (size_t)i_wide) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); pl->chain_ev.push_back(e); }
+            HIPCHK(hipEventRecord(pl->chain_ev[i_wide - 1], st));
+            ls = c->side[(i_wide - 1) % 3];
+            HIPCHK(hipStreamWaitEvent(ls, pl->chain_ev[i_wide - 1], 0));
+        }
         if (tb && !pl->profiling) { if (int rc = traceback(s.begin, s.count, (int)(k % clh::kTbMaxSeg), s.rv, ls)) return rc; }
     }
     if (fan)

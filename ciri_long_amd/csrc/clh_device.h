@@ -173,6 +173,10 @@ static constexpr int kRvCombine = -2;    // pseudo class: alignments whose score
 hipError_t launch_ssw_combine(const SswParams& p, int ntasks, hipStream_t stream);
 static constexpr int kRvScanSliced = -1; // pseudo class: K1s with the forward pass cut into window slices (task.dir_off = first part, task.pad = slices)
 hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int nslices, hipStream_t stream);
+static constexpr int kRvScanWide = -3;   // pseudo class: K1w, the row-scan kernel for reads of 255..4096 bases / scores above 254 (ssw_scan_wide.hip);
+                                         // task.dir_off = its workspace inside `dirs` (scanw_task_bytes)
+hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, hipStream_t stream);
+size_t scanw_task_bytes(int read_len);
 // K1b launches.  All take the plan's WHOLE task table in p.tasks and work on the tasks [task_base, task_base + ntasks) of launch
 // class `seg` (every class has its own hand-over counters and list regions, so the classes' launch chains run on different
 // streams at once).  Words behind the pool's bump pointer: [4 + seg] alignments the row kernel handed to its wide form,

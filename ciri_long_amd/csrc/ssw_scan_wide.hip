@@ -1,0 +1,454 @@
+// ssw_scan_wide.hip -- K1w: the row-scan form of K1s (ssw_scan.hip) for the alignments that kernel does not take: reads of
+// 255..4096 bases and every alignment whose score can pass 254 (10/4/8/2 scoring of collapse), windows below 32768 columns.
+//
+// Same answers as ssw_wavefront.hip (reference: libs/striped_smith_waterman/ssw.c:123-345 sw_sse2_byte, :371-546 sw_sse2_word,
+// and the forward + reverse orchestration of ssw_align, ssw.c:779-849; row-major statement: oracle/rowmajor_spec.c).
+// The lanes own reference columns, the loop runs over the read's rows (see ssw_scan.hip for the layout of a chunk, the prefix
+// maximum that carries the gap along a row, and the hand-over between chunks).  What is different here:
+//   * two regimes, chosen per alignment as ssw_align does (ssw.c:804-822): the 16-bit pass when the 8-bit pass would overflow
+//     (the byte-regime pass runs first, as in the reference, and hands over when it overflows);
+//   * the byte regime in 16-bit arithmetic: the exact recurrence, rows padded to 16, abandoned as soon as a column maximum +
+//     bias reaches 255 (ssw.c:285; checked once per 64 rows -- what the abandoned pass computed is never used);
+//   * the word regime: rows padded to 8; with gap_open == gap_extend the fix-up loop of ssw.c:462-481 touches only the first
+//     position of every stripe (rowmajor_spec.c: "16 bit, gapO <= gapE"): in the rows r = S, 2S, .., 7S (S = ceil(readLen/8)) the
+//     gap from the row above does not enter the main value Hm, only the final value Hf = max(Hm, that gap); the column maximum
+//     and the gap along the row follow Hm, the next row's diagonal and the end-row search follow Hf.  Those seven rows leave
+//     both values in HBM (per chunk, read back by the lanes that wrote them); every other row keeps, per column, the running
+//     maximum and the first row that holds it in two packed registers;
+//   * the hand-over between chunks (one H and one E per row) goes through HBM, not LDS: up to 4112 rows.
+// 11 packed operations per cell pair (gap_open == gap_extend) or 15, plus ~45 per row step of 1024 columns.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "clh_device.h"
+
+namespace clh {
+
+namespace {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_subus(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pk_sra15(uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) >> (short)15); }
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
+__device__ __forceinline__ uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
+__device__ __forceinline__ uint32_t hand_down(uint32_t v, int lane0_lo) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp((int)((uint32_t)lane0_lo << 16), (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __builtin_amdgcn_alignbit(v, x, 16);
+}
+__device__ __forceinline__ int dpp_shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_prefix_max(int v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
+    return v;
+}
+
+#ifndef SCANW_WAVES
+#define SCANW_WAVES 3      // measured on C2: 2 -> 12.6 ms, 3 -> 12.2 ms, 4 -> 15.1 ms (at 3 the spills stay outside the row loop)
+#endif
+static constexpr int W_CPR_MAX = 8;
+static constexpr int W_PROF_WORDS = 6 * W_CPR_MAX * 64;      // uint32 per wave: [query code 0..5][register][lane]
+static constexpr int W_NB = 7;                               // stripe boundaries of a word pass
+static constexpr int W_INF = 0x7fffffff;
+
+struct WIn {
+    const int8_t* read;   // first row's base
+    int rstep;            // +1 / -1
+    int L;                // rows of the read
+    int rows;             // rows processed (L padded with wildcard rows)
+    int S;                // word regime with gap_open == gap_extend: the stripe length (rows S, 2S, .. 7S are boundary rows); else 0
+    const int8_t* ref;    // first column's base
+    int cstep;            // +1 / -1
+    int comp;
+    int ncols;
+    int terminate;        // column maximum that ends the pass (ssw.c:296, 489); 1 << 30 = never
+    int overflow_at;      // byte regime: a column maximum >= this abandons the pass (255 - bias); 1 << 30 = never
+    uint16_t* colmax;     // per-column maxima (indexed by column), or nullptr
+};
+struct WOut { int max, col, row, overflow; };
+
+struct WMem {
+    uint32_t* prof;       // LDS: W_PROF_WORDS
+    const int* mat;       // LDS: [6 reference codes][8 query codes]
+    uint32_t* bnd;        // HBM: boundary rows of the chunk, [W_NB][2 (Hm, Hf)][CPR][64 lanes] packed registers
+    short* cH;            // HBM: [2][rows_cap]: final H of the chunk's last column per row (parity of the chunk)
+    short* cE;            // HBM: [2][rows_cap]: E entering the next chunk's first column per row
+    int rows_cap;
+};
+
+// one chunk of 128*CPR columns starting at column c0
+template <int CPR, bool GEQ, bool WORD>
+__device__ bool scanw_chunk(const WIn& in, const WMem& mem, const int c0, const int parity, const bool first, const bool more,
+                            const int gapO, const int gapE, int& best_score, int& best_col, int& best_row, int& tcol)
+{
+    constexpr int VEC = CPR < 4 ? CPR : 4;       // registers per LDS read
+    constexpr int NCH = CPR / VEC;
+    constexpr bool QUIRK = WORD && GEQ;
+    const int lane = threadIdx.x & 63;
+    const int K = CPR * gapE;                    // what a gap loses across one virtual lane
+    const int kLo = 2 * lane * K;
+    const uint32_t gO2 = dup16(gapO), gE2 = dup16(gapE);
+    uint32_t tgE[CPR];                           // what the gap entering a virtual lane has lost at its t-th column
+#pragma unroll
+    for (int t = 0; t < CPR; ++t) tgE[t] = dup16(t * gapE);
+
+    // ---- profile of the chunk's columns: prof[q][c][lane][VEC], entry = scores of the row base q against the two columns
+    {
+        int rlo[CPR], rhi[CPR];
+#pragma unroll
+        for (int t = 0; t < CPR; ++t) {
+            const int jlo = c0 + 2 * CPR * lane + t, jhi = jlo + CPR;
+            const int blo = jlo < in.ncols ? (int)in.ref[(int64_t)jlo * in.cstep] : 0, bhi = jhi < in.ncols ? (int)in.ref[(int64_t)jhi * in.cstep] : 0;
+            rlo[t] = jlo < in.ncols ? ref_code(blo, in.comp) : 5;
+            rhi[t] = jhi < in.ncols ? ref_code(bhi, in.comp) : 5;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int t = 0; t < CPR; ++t) {
+                const int slo = mem.mat[rlo[t] * 8 + q], shi = mem.mat[rhi[t] * 8 + q];
+                mem.prof[((q * NCH + t / VEC) * 64 + lane) * VEC + (t % VEC)] = (uint32_t)(slo & 0xffff) | ((uint32_t)shi << 16);
+            }
+    }
+    const short* cHin = mem.cH + (parity ^ 1) * mem.rows_cap;
+    const short* cEin = mem.cE + (parity ^ 1) * mem.rows_cap;
+    short* cHout = mem.cH + parity * mem.rows_cap;
+    short* cEout = mem.cE + parity * mem.rows_cap;
+    __syncthreads();
+
+    uint32_t Hp[CPR], Hd[QUIRK ? CPR : 1], Fst[GEQ ? 1 : CPR], cmv[CPR], cmr[CPR];
+#pragma unroll
+    for (int t = 0; t < CPR; ++t) { Hp[t] = 0; cmv[t] = 0; cmr[t] = 0; if constexpr (!GEQ) Fst[t] = 0; if constexpr (QUIRK) Hd[t] = 0; }
+    int prev_hb = 0;                             // final H[row - 1][c0 - 1]
+    int next_b = QUIRK && in.S > 0 ? in.S : W_INF, nb_seen = 0;
+    bool diag_d = false;                         // the row before was a boundary row: its final values are in Hd
+    bool overflow = false;
+    for (int rb = 0; rb < in.rows && !overflow; rb += 64) {
+        const int row = rb + lane;
+        int qv = 5;
+        if (row < in.L) { const int c = (int)in.read[(int64_t)row * in.rstep] & 7; qv = c > 5 ? 5 : c; }
+        int hbv = 0, ebv = 0;
+        if (!first && row < in.rows) { hbv = cHin[row]; ebv = cEin[row]; }
+        const int cnt = in.rows - rb < 64 ? in.rows - rb : 64;
+        int cobH = 0, cobE = 0;
+        // one row.  SLOW (the word regime with gap_open == gap_extend only): the rows around a stripe boundary -- `bnd`: a boundary
+        // row, `dd`: the row before was one and the diagonal comes from its final values Hd.  At most 14 rows of a pass take it.
+        auto step = [&](const int i, auto slow_c, const bool bnd, const bool dd) {
+            constexpr bool SLOW = decltype(slow_c)::value;
+            const int q = __builtin_amdgcn_readlane(qv, i), hb = __builtin_amdgcn_readlane(hbv, i), eb = __builtin_amdgcn_readlane(ebv, i);
+            uint32_t P[CPR];
+            {
+                const uint32_t* pp = mem.prof + (q * NCH * 64 + lane) * VEC;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if constexpr (VEC == 4) { const uint4 v = *(const uint4*)(pp + c * 64 * VEC); P[4 * c] = v.x; P[4 * c + 1] = v.y; P[4 * c + 2] = v.z; P[4 * c + 3] = v.w; }
+                    else { const uint2 v = *(const uint2*)(pp + c * 64 * VEC); P[0] = v.x; P[1] = v.y; }
+                }
+            }
+            uint32_t dsrc[CPR];
+#pragma unroll
+            for (int t = 0; t < CPR; ++t) { dsrc[t] = Hp[t]; if constexpr (SLOW) dsrc[t] = dd ? Hd[t] : Hp[t]; }
+            const uint32_t d0 = hand_down(dsrc[CPR - 1], prev_hb);
+            uint32_t R[CPR];
+            uint32_t e = 0, U;
+#pragma unroll
+            for (int t = 0; t < CPR; ++t) {
+                const uint32_t tt = pk_adds(t == 0 ? d0 : dsrc[t - 1], P[t]);
+                uint32_t X;
+                if constexpr (GEQ) {
+                    uint32_t Fv = pk_subus(Hp[t], gO2);
+                    if constexpr (SLOW) Fv = bnd ? 0u : Fv;                           // a boundary row: the gap from the row above stays out of the main value
+                    X = pk_max(tt, Fv);
+                } else { const uint32_t Fv = pk_max(pk_subus(Fst[t], gE2), pk_subus(Hp[t], gO2)); Fst[t] = Fv; X = pk_max(tt, Fv); }
+                if (t == 0) R[0] = X;
+                else if constexpr (GEQ) R[t] = pk_max(X, pk_subus(R[t - 1], gO2));
+                else { e = pk_max(pk_subus(e, gE2), pk_subus(R[t - 1], gO2)); R[t] = pk_max(X, e); }
+            }
+            if (GEQ) U = pk_subus(R[CPR - 1], gO2);
+            else U = pk_max(pk_subus(e, gE2), pk_subus(R[CPR - 1], gO2));
+            const int Blo = (int)(U & 0xffffu) + kLo, Bhi = (int)(U >> 16) + kLo + K;
+            const int inc = wave_prefix_max(Blo > Bhi ? Blo : Bhi);
+            const int fill = eb - K;
+            int exc = dpp_shr1(fill, inc);
+            exc = exc > fill ? exc : fill;
+            const int einLo = exc - kLo + K;
+            const int m2 = exc > Blo ? exc : Blo;
+            const int einHi = m2 - kLo;
+            const uint32_t Ein = ((uint32_t)einLo & 0xffffu) | ((uint32_t)einHi << 16);
+            const uint32_t rowc = dup16(rb + i);
+            uint32_t last = 0;
+#pragma unroll
+            for (int t = 0; t < CPR; ++t) {
+                const uint32_t h = pk_max(R[t], pk_subs(Ein, tgE[t]));
+                bool keyed = true;
+                if constexpr (SLOW) {
+                    if (bnd) {
+                        Hd[t] = pk_max(h, pk_subus(Hp[t], gO2));
+                        uint32_t* o = mem.bnd + ((nb_seen * 2) * CPR + t) * 64 + lane;
+                        o[0] = h; o[CPR * 64] = Hd[t];
+                        keyed = false;
+                    }
+                }
+                if (keyed) {
+                    const uint32_t m = pk_sra15(pk_subs(cmv[t], h));                 // halves where h is a new maximum (strictly)
+                    cmv[t] = pk_max(cmv[t], h);
+                    cmr[t] = bfi(m, rowc, cmr[t]);
+                }
+                Hp[t] = h;
+                if (t == CPR - 1) { last = h; if constexpr (SLOW) last = bnd ? Hd[t] : h; }
+            }
+            prev_hb = hb;
+            if (more) {   // the chunk's last column: final H, and the E that enters the next chunk's first column
+                const int outH = (int)((uint32_t)__builtin_amdgcn_readlane((int)last, 63) >> 16);
+                int outE = __builtin_amdgcn_readlane(inc, 63);
+                outE = (outE > fill ? outE : fill) - 127 * K;
+                outE = outE < 0 ? 0 : outE;
+                cobH = lane == i ? outH : cobH; cobE = lane == i ? outE : cobE;
+            }
+        };
+        int i = 0;
+        while (i < cnt) {
+            int stop = cnt;
+            if constexpr (QUIRK) { const int tb = next_b - rb; stop = diag_d ? i : (tb < cnt ? tb : cnt); }
+            for (; i < stop; ++i) step(i, std::false_type{}, false, false);
+            if constexpr (QUIRK) {
+                if (i < cnt) {
+                    const bool isb = rb + i == next_b;
+                    step(i, std::true_type{}, isb, diag_d);
+                    if (isb) { ++nb_seen; next_b = nb_seen < W_NB ? next_b + in.S : W_INF; }
+                    diag_d = isb;
+                    ++i;
+                }
+            }
+        }
+        if (more && lane < cnt) { cHout[rb + lane] = (short)cobH; cEout[rb + lane] = (short)cobE; }
+        if constexpr (!WORD) {   // byte regime: a column maximum at 255 - bias abandons the pass
+            uint32_t mx = cmv[0];
+#pragma unroll
+            for (int t = 1; t < CPR; ++t) mx = pk_max(mx, cmv[t]);
+            const int hi = (int)(mx >> 16), lo = (int)(mx & 0xffffu);
+            if (__builtin_amdgcn_ballot_w64((hi > lo ? hi : lo) >= in.overflow_at)) overflow = true;
+        }
+    }
+    // the boundary rows and the hand-over arrays were written through the CU's L1 without updating lines it may hold: complete
+    // the stores and drop the L1 before anything is read back
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    if (overflow) return true;
+
+    // ---- the chunk's columns: maxima, terminate column, best cell (first column wins), its end row ----
+    int tmin = W_INF;
+    int colM[2 * CPR], colR[2 * CPR];
+#pragma unroll
+    for (int t = 0; t < CPR; ++t)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            int M = hf ? (int)(cmv[t] >> 16) : (int)(cmv[t] & 0xffffu);
+            const int rA = hf ? (int)(cmr[t] >> 16) : (int)(cmr[t] & 0xffffu);
+            int hmB[W_NB], hfB[W_NB];
+            if constexpr (QUIRK) {
+                for (int k = 0; k < W_NB; ++k) {
+                    hmB[k] = 0; hfB[k] = -1;
+                    if (k < nb_seen) {
+                        const uint32_t a = mem.bnd[((k * 2) * CPR + t) * 64 + lane], b = mem.bnd[((k * 2 + 1) * CPR + t) * 64 + lane];
+                        hmB[k] = hf ? (int)(a >> 16) : (int)(a & 0xffffu); hfB[k] = hf ? (int)(b >> 16) : (int)(b & 0xffffu);
+                    }
+                }
+            }
+            const int mA = M;
+            if constexpr (QUIRK) for (int k = 0; k < W_NB; ++k) M = hmB[k] > M ? hmB[k] : M;
+            // smallest row whose FINAL value equals the column maximum (ssw.c:502-511): a non-boundary row holding the maximum, or a
+            // boundary row whose final value is the maximum
+            int rw = mA == M ? rA : W_INF;
+            if constexpr (QUIRK) for (int k = W_NB - 1; k >= 0; --k) if (hfB[k] == M) { const int rk = (k + 1) * in.S; rw = rk < rw ? rk : rw; }
+            colM[2 * t + hf] = M; colR[2 * t + hf] = rw;
+            const int j = c0 + 2 * CPR * lane + hf * CPR + t;
+            if (j < in.ncols) {
+                if (in.colmax) in.colmax[j] = (uint16_t)M;
+                if (M == in.terminate) tmin = j < tmin ? j : tmin;
+            }
+        }
+    tmin = wave_min(tmin);
+    int b32 = -1, brow = 0;
+#pragma unroll
+    for (int t = 0; t < CPR; ++t)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int jc = 2 * CPR * lane + hf * CPR + t, j = c0 + jc;
+            const int v = (colM[2 * t + hf] << 11) | (0x7ff - jc);
+            if (j < in.ncols && j <= tmin && v > b32) { b32 = v; brow = colR[2 * t + hf]; }
+        }
+    const int bw = wave_max(b32);
+    // the lane that owns the best column says its end row
+    const unsigned long long own = __builtin_amdgcn_ballot_w64(b32 == bw);
+    const int wrow = __builtin_amdgcn_readlane(brow, own ? __builtin_ctzll(own) : 0);
+    const int sc = bw < 0 ? 0 : bw >> 11;
+    if (sc > best_score) { best_score = sc; best_col = c0 + (0x7ff - (bw & 0x7ff)); best_row = wrow; }
+    tcol = tmin;
+    return false;
+}
+
+template <bool GEQ, bool WORD>
+__device__ WOut scanw_pass(const WIn& in, const WMem& mem, const int gapO, const int gapE)
+{
+    int best_score = 0, best_col = -1, best_row = 0;
+    const bool ends = in.terminate < (1 << 30);  // reverse pass: stops at the first column whose maximum is the forward score
+    int parity = 0;
+    WOut o; o.overflow = 0;
+    for (int c0 = 0; c0 < in.ncols; parity ^= 1) {
+        const int rem = in.ncols - c0;
+        int tcol = W_INF;
+        const bool first = c0 == 0;
+        bool ov;
+        // a pass that ends at a column (the reverse pass) is expected to end about one read length in: its first chunks are sized for
+        // that, not for the window (columns behind the end column are wasted work, narrow chunks pay the row step's fixed part more often)
+        const int want = ends ? (c0 == 0 ? in.L + in.L / 8 + 16 : 256) : rem;
+        const int width = want < rem ? want : rem;
+        if (width <= 256) { ov = scanw_chunk<2, GEQ, WORD>(in, mem, c0, parity, first, rem > 256, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 256; }
+        else if (width <= 512) { ov = scanw_chunk<4, GEQ, WORD>(in, mem, c0, parity, first, rem > 512, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 512; }
+        else { ov = scanw_chunk<8, GEQ, WORD>(in, mem, c0, parity, first, rem > 1024, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 1024; }
+        if (ov) { o.overflow = 1; o.max = 255; o.col = -1; o.row = 0; return o; }
+        if (tcol != W_INF) break;
+    }
+    o.max = best_score;
+    if (best_score == 0) { o.col = -1; o.row = 0; return o; }
+    o.col = best_col;
+    o.row = best_row < in.L - 1 ? best_row : in.L - 1;
+    return o;
+}
+
+// masked second-best column maximum, ssw.c:325-340 (8 bit) / 528-541 (16 bit); wave-parallel
+__device__ void second_best_w(const uint16_t* colmax, int refLen, int end_ref, int maskLen, int word, int& score2, int& ref_end2)
+{
+    const int lane = threadIdx.x & 63;
+    int e1 = end_ref - maskLen; if (e1 < 0) e1 = 0;
+    int e2 = end_ref + maskLen; if (e2 > refLen) e2 = refLen;
+    e2 += word ? 0 : 1;
+    int bv = 0, bp = W_INF;
+    for (int i = lane; i < refLen; i += 64) {
+        if (i < e1 || i >= e2) {
+            const int v = colmax[i];
+            if (v > bv) { bv = v; bp = i; }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v2 = __shfl_xor(bv, d), p2 = __shfl_xor(bp, d);
+        const bool take = v2 > bv || (v2 == bv && p2 < bp);
+        bv = take ? v2 : bv; bp = take ? p2 : bp;
+    }
+    score2 = bv;
+    ref_end2 = bv > 0 ? bp : 0;
+}
+
+}  // namespace
+
+// bytes of HBM workspace of one K1w task (SswTask.dir_off into SswParams.dirs): boundary rows of a chunk + the two hand-over arrays
+size_t scanw_task_bytes(int read_len) {
+    const size_t rows_cap = ((size_t)read_len + 16 + 63) & ~(size_t)63;
+    return (size_t)W_NB * 2 * W_CPR_MAX * 64 * 4 + 2 * 2 * rows_cap * 2 + 256;
+}
+
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_prof[W_PROF_WORDS];
+    __shared__ int s_mat[48];
+    const int lane = threadIdx.x & 63;
+    if (lane < 48) { const int b = lane >> 3, q = lane & 7; s_mat[lane] = (b < p.n && q < p.n) ? (int)p.mat[b * p.n + q] : 0; }
+    __syncthreads();
+    const SswTask task = p.tasks[blockIdx.x];
+    const int8_t* read = p.reads + task.read_off;
+    const int8_t* ref = p.refs + task.ref_off;
+    const int L = task.read_len, refLen = task.ref_len;
+    uint16_t* colmax = p.colmax ? p.colmax + task.colmax_off : nullptr;
+    const int bias = p.bias, gO = p.gapO, gE = p.gapE;
+    WMem mem;
+    mem.prof = s_prof; mem.mat = s_mat;
+    mem.rows_cap = (int)((((size_t)L + 16 + 63) & ~(size_t)63));
+    mem.bnd = (uint32_t*)(p.dirs + task.dir_off);
+    mem.cH = (short*)(mem.bnd + W_NB * 2 * W_CPR_MAX * 64);
+    mem.cE = mem.cH + 2 * mem.rows_cap;
+    SswResult res;
+    res.score1 = 0; res.score2 = 0; res.ref_begin1 = -1; res.ref_end1 = -1; res.read_begin1 = -1; res.read_end1 = 0;
+    res.ref_end2 = 0; res.status = 0;
+
+    // ---- forward: which regime?  (ssw.c:804-822; the order of ssw_wavefront.hip's kernel) -----------------------------------
+    const int rdir = task.ref_rc ? -1 : 1;
+    WIn in;
+    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = task.ref_rc; in.ncols = refLen; in.terminate = 1 << 30;
+    in.colmax = colmax;
+    auto word_rows = [&](WIn& x) { x.S = GEQ ? (x.L + 7) / 8 : 0; x.rows = ((x.L + 7) / 8) * 8; x.overflow_at = 1 << 30; };
+    auto byte_rows = [&](WIn& x) { x.S = 0; x.rows = ((x.L + 15) / 16) * 16; x.overflow_at = 255 - bias; };
+    int regime = -1;
+    WOut fw;
+    bool byte_overflowed = false;
+    // The reference's own order: the byte regime first (ssw.c:804).  It is abandoned within 64 rows of the first cell at 255 - bias, so an
+    // alignment that does overflow pays a fraction of a pass for it, and one that does not (half of a mixed batch) needs no second pass
+    // -- the anti-diagonal kernel's "word first when the bound allows an overflow" pays a whole pass there.
+    int job_word = p.score_size == 1 ? 1 : 0;
+    while (regime < 0) {
+        if (job_word) {
+            word_rows(in);
+            const WOut r = scanw_pass<GEQ, true>(in, mem, gO, gE);
+            if (p.score_size == 1 || byte_overflowed || r.max + bias >= 255) { fw = r; regime = 1; }
+            else job_word = 0;
+        } else {
+            byte_rows(in);
+            const WOut r = scanw_pass<GEQ, false>(in, mem, gO, gE);
+            if (!r.overflow) { fw = r; regime = 0; }
+            else if (p.score_size == 0) { res.status = CLH_STATUS_OVERFLOW8; if (lane == 0) p.results[task.out_index] = res; return; }
+            else { byte_overflowed = true; job_word = 1; }
+        }
+    }
+    res.status = regime ? CLH_STATUS_WORD : 0;
+    res.score1 = fw.max;
+    if (fw.max == 0) { res.ref_end1 = regime ? 0 : -1; res.read_end1 = 0; }
+    else { res.ref_end1 = fw.col; res.read_end1 = fw.row; }
+    if (task.mask_len >= 15 && colmax) { __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); second_best_w(colmax, refLen, res.ref_end1, task.mask_len, regime, res.score2, res.ref_end2); }
+    else { res.score2 = 0; res.ref_end2 = task.mask_len >= 15 ? 0 : -1; }
+
+    // ---- reverse: begin coordinates (ssw.c:834-849) ---------------------------------------------------------------
+    const bool want_begin = !(p.flag == 0 || (p.flag == 2 && res.score1 < p.filters));
+    if (want_begin) {
+        WIn rv;
+        rv.L = res.read_end1 + 1; rv.read = read + res.read_end1; rv.rstep = -1;
+        rv.ncols = res.ref_end1 + 1; rv.ref = ref + (int64_t)res.ref_end1 * rdir; rv.cstep = -rdir; rv.comp = task.ref_rc;
+        rv.terminate = res.score1; rv.colmax = nullptr;
+        WOut r;
+        if (regime) { word_rows(rv); r = scanw_pass<GEQ, true>(rv, mem, gO, gE); }
+        else { byte_rows(rv); rv.overflow_at = 1 << 30; r = scanw_pass<GEQ, false>(rv, mem, gO, gE); }
+        if (r.max == 0) { res.ref_begin1 = regime ? 0 : -1; res.read_begin1 = res.read_end1; }
+        else { res.ref_begin1 = res.ref_end1 - r.col; res.read_begin1 = res.read_end1 - r.row; }
+    }
+    if (lane == 0) p.results[task.out_index] = res;
+}
+
+hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, hipStream_t stream)
+{
+    if (geq) hipLaunchKernelGGL((ssw_scanw_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL((ssw_scanw_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace clh

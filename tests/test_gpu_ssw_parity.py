@@ -66,8 +66,11 @@ def _mut(s, rng, p):
     return ''.join(out)
 
 
+@pytest.mark.parametrize('wide', [True, False])
 @pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (10, 4, 8, 2), (2, 2, 3, 1), (3, 5, 7, 7)])
-def test_random_batch_vs_oracle(ctx, scheme):
+def test_random_batch_vs_oracle(ctx, scheme, wide, monkeypatch):
+    if not wide:                                 # the anti-diagonal classes instead of K1w
+        monkeypatch.setenv('CLH_NO_SCANW', '1')
     rng = np.random.default_rng(sum(scheme) * 13 + 1)
     refs, qs = [], []
     for _ in range(300):
@@ -170,11 +173,15 @@ def test_reference_test_ssw_orientation_430kb_query(ctx, testfa):
     assert [int(x) for x in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar']
 
 
+@pytest.mark.parametrize('wide', [True, False])
 @pytest.mark.parametrize('score2', [True, False])
-def test_every_row_class_up_to_4096_vs_oracle(ctx, score2):
+def test_every_row_class_up_to_4096_vs_oracle(ctx, score2, wide, monkeypatch):
     """read lengths that land in each launch class (rows per lane 1..32), with and without the column maxima
-    (want_score2 off selects the lean forward pass)"""
+    (want_score2 off selects the lean forward pass).  wide: through K1w, the row-scan kernel for long reads (ssw_scan_wide.hip:
+    both regimes, the stripe-boundary rule of the word pass, reads of 255..4096 rows); else through the anti-diagonal classes"""
     from ciri_long_amd import hip
+    if not wide:
+        monkeypatch.setenv('CLH_NO_SCANW', '1')
     rng = np.random.default_rng(31)
     reads, refs = [], []
     for L in (60, 200, 330, 470, 600, 730, 860, 1000, 1200, 1500, 1900, 2400, 3000, 3500, 4090):
@@ -540,3 +547,34 @@ def test_row_scan_and_row_traceback_unusual_gap_costs(ctx, scheme):
                 assert span > 12000 and e == 0, (nmat, k, span)
                 continue
             assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (nmat, k, int(r['status']))
+
+
+def test_launch_classes_of_a_mixed_batch(ctx, monkeypatch):
+    """which kernel takes what (clh_api.hip: scan_class_ok, scanw_class_ok): short reads whose scores fit 8 bits -> K1s (class 0),
+    reads up to 4096 bases on windows below 32768 columns -> K1w (class -3), longer reads and K1w switched off -> the anti-diagonal
+    classes; and the word regime's stripe-boundary rows in reads of every residue modulo 8 (S = ceil(L / 8))"""
+    from ciri_long_amd import hip
+    rng = np.random.default_rng(77)
+    reads, refs = [], []
+    for L in [30, 200, 254, 255, 256, 257, 258, 259, 260, 261, 262, 263, 500, 1001, 4096, 4200]:
+        ref = rng.integers(0, 4, 1500, dtype=np.int8)
+        core = ref[100:100 + min(L, 1300)]
+        read = np.concatenate([core, rng.integers(0, 4, L - len(core), dtype=np.int8)]).astype(np.int8)
+        flip = rng.random(L) < 0.1
+        reads.append(np.where(flip, rng.integers(0, 4, L, dtype=np.int8), read).astype(np.int8)); refs.append(ref)
+    rd, ro = hip.pack(reads); fd, fo = hip.pack(refs)
+    for no_wide in (False, True):
+        if no_wide:
+            monkeypatch.setenv('CLH_NO_SCANW', '1')
+        plan = ctx.plan(ro, fo, hip.score_matrix(1, 1), 1, 1, want_score2=True, want_cigar=True)
+        classes = {rv: cnt for rv, cnt, _a, _b in plan.segments()}
+        if no_wide:
+            assert -3 not in classes and classes[0] == 2 and sum(v for k, v in classes.items() if k > 0) == 14
+        else:
+            assert classes[0] == 2 and classes[-3] == 13 and sum(v for k, v in classes.items() if k > 0) == 1      # (254 bases: 254 + bias reaches 255)
+        rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(1, 1), 1, 1, want_score2=True, want_cigar=True)
+        for k in range(len(reads)):
+            want = oracle_align(refs[k], reads[k], 1, 1, 1, 1)
+            assert _row_tuple(rows[k]) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
+                                           want['query_end'], want['ref_end2']), (k, len(reads[k]), no_wide)
+            assert [int(x) for x in cig[rows[k]['cigar_off']:rows[k]['cigar_off'] + rows[k]['cigar_len']]] == want['cigar']

@@ -39,7 +39,12 @@ static constexpr int POA_MAX_COPY = 2800;            // longest sequence: cells 
 // handful of times per copy, never per row).
 __device__ __forceinline__ void phase_sync() {
     __syncthreads();
+#ifdef POA_EXP_NOINV        // timing experiment only (results may be stale): the stores completed, the CU's L1 kept
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+#else
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
 }
 
 // inclusive prefix maximum over the 64 lanes: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 and 31 carry

@@ -594,7 +594,7 @@ def main():
     full = wl != 'c2'            # c3 / c4: the whole device part of `call`; c2: Smith-Waterman only
     nreads = args.reads or {'c3': 100000, 'c2': 10000, 'c4': 125000}[wl]
 
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if (args.gpus > 1 or os.environ.get('CLH_BENCH_SPAWN')) and 'WORLD_SIZE' not in os.environ:      # (CLH_BENCH_SPAWN: the launcher path on a one-GPU box)
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts the N ranks as CHILD
         # processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) before anything here has touched the GPU,
         # never execs, relays rank 0's JSON line and exits with the children's code.

@@ -4,20 +4,24 @@
 // What they replace: pyccs.find_consensus (called at CIRI_long/find_ccs.py:14) and the spoa engine inside it.  Those are
 // external packages that exist neither in the reference tree nor in this environment: PARITY UNPINNED.  Both kernels
 // implement, bit for bit, what oracle/ccs_oracle.c ("clh-ccs v1": period and copy boundaries, this project's own
-// specification) and oracle/poa_oracle.c ("clh-poa v2": a restatement of the published spoa algorithm -- two-piece gap
-// cost, local/global/overlap alignment, heaviest bundle) state; read those headers for every rule and tie-break.
+// specification) and oracle/poa_oracle.c ("clh-poa v3": a restatement of the published spoa algorithm -- two-piece gap
+// cost, local/global/overlap alignment, Graph::TopologicalSort's depth-first order, AddAlignment's node ids, raw-byte letters,
+// heaviest bundle; no departures) state; read those headers for every rule and tie-break.
 // One read per wavefront, one wavefront per workgroup.
 //
 // K2: 8-mer codes of the read sit in LDS.  Matches per offset are counted per PAIR of equal 8-mers (positions chained per
 //     hash bucket with LDS atomics, each pair visited once: O(L * copies) instead of O(L^2/4) comparisons); the smoothed
 //     maximum, the harmonic test and the per-copy boundary search (same chains, a histogram over the candidate offsets)
 //     are lane-parallel with shuffle reductions.
-// K3: persistent waves pull reads from an atomic counter; each owns a workspace slot in HBM (graph arrays, one byte per
-//     DP cell for the back-track, the few rows a far successor reads; slots are sized for the common case, the few reads
-//     that need more claim one of a handful of large slots).  A DP row (one graph node) is computed by the 64 lanes over
-//     the sequence positions: the diagonal and the two vertical gap states over the node's in-edges are independent per
-//     position, the two horizontal gap states are max-plus prefix scans (DPP).  The back-track and the heaviest-bundle
-//     pass are sequential by nature and run wave-uniformly on data staged in registers; the graph update is data-parallel.
+// K3: persistent waves pull reads from an atomic counter; each owns a workspace slot in HBM (graph arrays, the two 16-bit
+//     planes of one sequence's pass; slots are sized for the common case, the few reads that need more claim one of a
+//     handful of large slots).  A DP row (one graph node) is computed by the 64 lanes over the sequence positions, two
+//     cells per lane-operation: the diagonal and the two vertical gap states over the node's in-edges are independent per
+//     position, the two horizontal gap states are max-plus prefix scans (DPP).  The pass leaves H and one word of clamped
+//     state differences per cell (a band around the matrix diagonal); spoa's value-comparing back-track is replayed from those
+//     on the cells of the path only, staged in LDS.  The graph update is data-parallel; the topological sort reproduces the
+//     order of spoa's sequential depth-first search from independent pieces (one small search per lane); the heaviest bundle
+//     runs wave-uniformly on data staged in LDS.  DESIGN.md section 3 (K3) has the measurements.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "clh_device.h"

@@ -1910,6 +1910,51 @@ hipError_t launch_ccs_scan(const CcsParams& p, int count, bool with_long, hipStr
     return hipGetLastError();
 }
 
+// K3's work list by what a read will COST, heaviest first -- an experiment (clh_api.hip: CLH_POA_ORDER_BY_COST), not the default:
+// it balances the end of the launch (7 % of the wave-slot time is idle there) and loses more than that in the middle, see
+// clh_ccs_run.  Cost of a read after K2: its alignments x period^2.  One workgroup: a counting sort over 1024 buckets of
+// log2(cost) with 5 fractional bits; the order inside a bucket is whatever the atomics give -- results do not depend on it.
+__global__ void __launch_bounds__(1024) ccs_work_order_kernel(const CcsScan* scan, const int n, int32_t* order)
+{
+    __shared__ int hist[1024];
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    auto bucket = [&](int r) -> int {
+        const CcsScan& sc = scan[r];
+        const unsigned long long cost = sc.period > 0 && sc.ncuts > 0 ? (unsigned long long)sc.ncuts * (unsigned long long)sc.period * (unsigned long long)sc.period : 0ull;
+        if (cost < 32) return 1023 - (int)cost;
+        const int lg = 63 - __builtin_clzll(cost);                   // >= 5
+        const int frac = (int)((cost >> (lg - 5)) & 31);
+        int key = (lg - 4) * 32 + frac;                              // 32.. : monotone in cost
+        key = key > 1023 ? 1023 : key;
+        return 1023 - key;                                           // heaviest first
+    };
+    for (int r = tid; r < n; r += 1024) atomicAdd(&hist[bucket(r)], 1);
+    __syncthreads();
+    // exclusive prefix sum of the 1024 counts (one per thread)
+    const int mine = hist[tid];
+    int inc = mine;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    __shared__ int wsum[16];
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; ++k) base += wsum[k];
+    __syncthreads();
+    hist[tid] = base + inc - mine;
+    __syncthreads();
+    for (int r = tid; r < n; r += 1024) order[atomicAdd(&hist[bucket(r)], 1)] = r;
+}
+
+hipError_t launch_ccs_work_order(const CcsScan* scan, int n, int32_t* order, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ccs_work_order_kernel, dim3(1), dim3(1024), 0, stream, scan, n, order);
+    return hipGetLastError();
+}
+
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream)
 {
     hipLaunchKernelGGL(poa_consensus_kernel, dim3(nslots), dim3(64), (size_t)POA_LDS_BYTES, stream, p);

@@ -1101,7 +1101,7 @@ struct clh_ccs_plan {
     int64_t total = 0;
     size_t slot_bytes = 0, slot_bytes_big = 0;      // second tier: a few slots sized for the worst case of the batch
     void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr, *d_ws_big = nullptr,
-         *d_counter = nullptr, *d_order = nullptr, *d_reads = nullptr, *d_score = nullptr;
+         *d_counter = nullptr, *d_order = nullptr, *d_order3 = nullptr, *d_reads = nullptr, *d_score = nullptr;
     hipStream_t last_stream = nullptr;
     bool ran = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // K2 start, K2 stop = K3 start, K3 stop
@@ -1112,7 +1112,7 @@ extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
-    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_reads, pl->d_long, pl->d_k2ws, pl->d_busy, pl->d_score};
+    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_order3, pl->d_reads, pl->d_long, pl->d_k2ws, pl->d_busy, pl->d_score};
     for (void* b : bufs) pl->ctx->release(b);
     for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
     delete pl;
@@ -1197,7 +1197,8 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     }
     pl->d_counter = ctx->alloc(256);
     pl->d_order = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
-    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || (pl->nslots_big && (!pl->d_ws_big || !pl->d_busy)) || !pl->d_counter || !pl->d_order) {
+    pl->d_order3 = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));     // K3's work list by cost (clh_ccs_run)
+    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || (pl->nslots_big && (!pl->d_ws_big || !pl->d_busy)) || !pl->d_counter || !pl->d_order || !pl->d_order3) {
         fail(CLH_E_HIP, "out of device memory while building the consensus plan");
         clh_ccs_plan_destroy(pl); return nullptr;
     }
@@ -1211,9 +1212,10 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
 }
 
 // the K3 launches of a plan: first tier over every read, second tier over what found no slot large enough
-static int launch_poa_tiers(clh_ccs_plan* pl, clh::CcsParams& P, hipStream_t st)
+static int launch_poa_tiers(clh_ccs_plan* pl, clh::CcsParams& P, hipStream_t st, bool by_cost = false)
 {
-    P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.stats = (int*)pl->d_counter + 2; P.work_order = (const int32_t*)pl->d_order;
+    P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.stats = (int*)pl->d_counter + 2;
+    P.work_order = (const int32_t*)(by_cost ? pl->d_order3 : pl->d_order);
     P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap; P.tier = 0;
     if (pl->nslots_big) { P.big_ws = (uint8_t*)pl->d_ws_big; P.big_slot_bytes = pl->slot_bytes_big; P.big_busy = (int*)pl->d_busy; P.n_big = pl->nslots_big; }
     HIPCHK(clh::launch_poa(P, pl->nslots, st));
@@ -1252,7 +1254,12 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     P.lcap = pl->lcap;
     if (trace) { fprintf(stderr, "[clh] K2 launched (n=%d lcap=%d)\n", pl->n, pl->lcap); HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[clh] K2 done\n"); }
     HIPCHK(hipEventRecord(pl->ev[1], st));
-    if (int rc = launch_poa_tiers(pl, P, st)) return rc;
+    // K3's work list: by read length (the plan's order).  By estimated cost after K2, heaviest first (CLH_POA_ORDER_BY_COST=1), measured
+    // SLOWER: 19.3 -> 20.8 ms on C3, 76.5 -> 85.3 on C4 -- with the heavy reads all at the start every wave of a SIMD is in its pass
+    // at once and nothing is left to fill the latency of the others' walks; the mixed order overlaps better than the balanced one
+    static const bool by_len = getenv("CLH_POA_ORDER_BY_COST") == nullptr;
+    if (!by_len) HIPCHK(clh::launch_ccs_work_order((const clh::CcsScan*)pl->d_scan, pl->n, (int32_t*)pl->d_order3, st));
+    if (int rc = launch_poa_tiers(pl, P, st, !by_len)) return rc;
     if (trace) { fprintf(stderr, "[clh] K3 launched (slots %d x %zu, big %d x %zu)\n", pl->nslots, pl->slot_bytes, pl->nslots_big, pl->slot_bytes_big); HIPCHK(hipStreamSynchronize(st)); fprintf(stderr, "[clh] K3 done\n"); }
     HIPCHK(hipEventRecord(pl->ev[2], st));
     pl->last_stream = st; pl->ran = true;

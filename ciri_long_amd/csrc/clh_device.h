@@ -130,6 +130,7 @@ struct CcsParams {
 
 hipError_t launch_ccs_scan(const CcsParams& p, int count, bool with_long, hipStream_t stream);
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream);
+hipError_t launch_ccs_work_order(const CcsScan* scan, int n, int32_t* order, hipStream_t stream);   // K3's work list by cost after K2
 size_t poa_slot_bytes_host(int ncap, int mcap);
 size_t poa_slot_min_bytes_host(int ncap, int mcap);
 static constexpr int kK2LdsMax = 16000;

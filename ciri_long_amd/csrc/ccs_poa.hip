@@ -34,7 +34,9 @@ static constexpr int CCS_MIN_SUPPORT = 12;
 static constexpr int CCS_SMOOTH = 3;
 static constexpr int CCS_MAX_CUTS = 64;
 static constexpr int CCS_MIN_TAIL = 20;
-static constexpr int POA_MAXP = 12;                  // in-edges a node can hold (implementation limit)
+static constexpr int POA_MAXP = 12;                  // in-edges a node holds in place; further ones go to the graph's overflow table
+static constexpr int POA_MAXP_ALL = 48;              // in-edges of a node, overflow included (the sort's per-node cursor has 6 bits for in-edges + aligned nodes)
+static constexpr int POA_OVF_CAP = 2048;             // entries of the overflow table of one graph
 static constexpr int POA_MAXA = 7;                   // other members of an aligned set: 8 different letters in one column (implementation limit)
 static constexpr int POA_MAX_COPY = 2800;            // longest sequence: cells are int16 (match score <= 11)
 
@@ -264,7 +266,19 @@ struct PoaWs {            // views into one wave's workspace slot
     short* carry; int cpitch;
     uint8_t* dp; size_t dp_bytes;                                            // the rest of the slot: DP planes of the current sequence
     short* planeH; unsigned short* planeD;                                   // set per sequence (poa_add): H and the clamped differences
+    int32_t* ovn; int32_t* ovp; int32_t* ovw; int32_t* ovc;                  // in-edges beyond POA_MAXP: node, source, weight per entry (in the order they were made); ovc[0] = entries
 };
+
+// the s-th in-edge of node v (spoa's order = the order the edges were made): in place, or the (s - POA_MAXP)-th entry of v in the
+// overflow table (a linear search: a node with more than 12 in-edges is rare, the table short)
+__device__ __forceinline__ int poa_ovf_slot(const PoaWs& w, int v, int k)
+{
+    const int n = w.ovc[0];
+    for (int i = 0; i < n; ++i) if (w.ovn[i] == v) { if (k == 0) return i; --k; }
+    return 0;                                                                // cannot happen (k < np[v] - POA_MAXP)
+}
+__device__ __forceinline__ int poa_pred_at(const PoaWs& w, int v, int s) { return s < POA_MAXP ? w.pred[v * POA_MAXP + s] : w.ovp[poa_ovf_slot(w, v, s - POA_MAXP)]; }
+__device__ __forceinline__ int poa_pw_at(const PoaWs& w, int v, int s) { return s < POA_MAXP ? w.pw[v * POA_MAXP + s] : w.ovw[poa_ovf_slot(w, v, s - POA_MAXP)]; }
 
 // row pitch (elements) of the DP planes for a sequence of m bases: column j sits at element j+7,
 // so the 2..8 columns a lane owns start at an aligned element, and the pitch is a multiple of 16
@@ -285,6 +299,7 @@ __host__ __device__ inline size_t poa_fixed_bytes(int ncap, int mcap, int* cpitc
     if (cpitch_out) *cpitch_out = cp;
     add(sizeof(short) * 6 * (size_t)cp);                                                                    // carries: 2 x (H, E, Q)
     add(ncap); add(ncap); add(ncap);                                                                       // base np na
+    add(sizeof(int32_t) * POA_OVF_CAP); add(sizeof(int32_t) * POA_OVF_CAP); add(sizeof(int32_t) * POA_OVF_CAP); add(16);   // overflow in-edges: node, source, weight, count
     return o;
 }
 // DP planes of one sequence against N rows: H (int16) and the clamped differences (16 bits), one row more than the graph has
@@ -323,6 +338,8 @@ __device__ PoaWs carve(uint8_t* slot, size_t slot_bytes, int ncap, int mcap)
     w.base = (int8_t*)take(ncap);
     w.np = (int8_t*)take(ncap);
     w.na = (int8_t*)take(ncap);
+    w.ovn = (int32_t*)take(sizeof(int32_t) * POA_OVF_CAP); w.ovp = (int32_t*)take(sizeof(int32_t) * POA_OVF_CAP); w.ovw = (int32_t*)take(sizeof(int32_t) * POA_OVF_CAP);
+    w.ovc = (int32_t*)take(16);
     w.dp = slot + o;
     w.dp_bytes = slot_bytes > o ? slot_bytes - o : 0;
     w.planeH = nullptr; w.planeD = nullptr;
@@ -708,7 +725,8 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 if (np > 2) add_source((int)(d1 >> 16));
                 if (np > 3) {                                    // rare: in-edges beyond the third come from HBM
                     const int vnode = __builtin_amdgcn_readfirstlane(gorder[r - 1]);
-                    for (int s2 = 3; s2 < np; ++s2) add_source(__builtin_amdgcn_readfirstlane(grank[gpred[vnode * POA_MAXP + s2]]));
+                    const int npt = np < 15 ? np : __builtin_amdgcn_readfirstlane((int)w.np[vnode]);      // (the graph row's field holds up to 15)
+                    for (int s2 = 3; s2 < npt; ++s2) add_source(__builtin_amdgcn_readfirstlane(grank[poa_pred_at(w, vnode, s2)]));
                 }
             }
             SEC(9);
@@ -919,7 +937,7 @@ __device__ void poa_dfs_root(const PoaWs& w, const int r, const int lo, const in
         const int na2 = ign ? 0 : nav, nd = na2 + npv;
         int nxt = -1;
         while (cur < nd) {
-            const int d = cur < na2 ? w.aligned[v * POA_MAXA + na2 - 1 - cur] : w.pred[v * POA_MAXP + npv - 1 - (cur - na2)];
+            const int d = cur < na2 ? w.aligned[v * POA_MAXA + na2 - 1 - cur] : poa_pred_at(w, v, npv - 1 - (cur - na2));
             ++cur;
             if (w.root[d] == r && !(w.st[d] & 1)) { nxt = d; break; }
         }
@@ -962,7 +980,7 @@ __device__ __forceinline__ int poa_sort(const PoaWs& w, const int n_old, const i
             const int nav = w.na[v], npv = w.np[v];
             for (int t = 0; t < nav; ++t) { const int ra = w.root[w.aligned[v * POA_MAXA + t]]; rv = ra < rv ? ra : rv; }
             if (rv < r0) { atomicMin(&w.root[v], rv); changed = 1; }
-            for (int t = 0; t < npv; ++t) { const int u = w.pred[v * POA_MAXP + t]; if (rv < w.root[u]) { atomicMin(&w.root[u], rv); changed = 1; } }
+            for (int t = 0; t < npv; ++t) { const int u = poa_pred_at(w, v, t); if (rv < w.root[u]) { atomicMin(&w.root[u], rv); changed = 1; } }
         }
         phase_sync();
         if (!__builtin_amdgcn_ballot_w64(changed != 0)) break;
@@ -993,7 +1011,7 @@ __device__ __forceinline__ int poa_sort(const PoaWs& w, const int n_old, const i
     for (int v = lane; v < n; v += 64) {
         const int r = w.rank[v];
         const int np = w.np[v];
-        for (int s2 = 0; s2 < np; ++s2) bad |= (w.rank[w.pred[v * POA_MAXP + s2]] >= r);
+        for (int s2 = 0; s2 < np; ++s2) bad |= (w.rank[poa_pred_at(w, v, s2)] >= r);
     }
     return __builtin_amdgcn_ballot_w64(bad != 0) ? -1 : 0;
 }
@@ -1083,7 +1101,7 @@ __device__ __forceinline__ int poa_sort_lds(const PoaWs& w_, const int n_old, co
             if (rv < lroot[v]) atomicMin(&lroot[v], rv);
 #pragma unroll
             for (int k = 0; k < POA_MAXA; ++k) if (al[k] >= 0 && rv < lroot[al[k]]) { atomicMin(&lroot[al[k]], rv); lst[al[k]] |= 4; }
-            for (int k = 0; k < npv; ++k) { const int u = w.pred[v * POA_MAXP + k]; if (rv < lroot[u]) { atomicMin(&lroot[u], rv); lst[u] |= 4; } }
+            for (int k = 0; k < npv; ++k) { const int u = poa_pred_at(w_, v, k); if (rv < lroot[u]) { atomicMin(&lroot[u], rv); lst[u] |= 4; } }
         }
         __syncthreads();
     }
@@ -1125,7 +1143,7 @@ __device__ __forceinline__ int poa_sort_lds(const PoaWs& w_, const int n_old, co
             const int na2 = ign ? 0 : nav, nd = na2 + npv;
             int nxt = -1;
             while (cur < nd) {
-                const int d = cur < na2 ? w.aligned[v * POA_MAXA + na2 - 1 - cur] : w.pred[v * POA_MAXP + npv - 1 - (cur - na2)];
+                const int d = cur < na2 ? w.aligned[v * POA_MAXA + na2 - 1 - cur] : poa_pred_at(w_, v, npv - 1 - (cur - na2));
                 ++cur;
                 if ((lroot[d] & 0xffffu) == (uint32_t)r && !(lst[d] & 1)) { nxt = d; break; }
             }
@@ -1180,7 +1198,7 @@ static_assert(4 * 64 * BT_W + BT_SQ + 2 * BT_RING <= POA_LDS_BYTES, "back-track 
 // A function of its own, NOT inlined: inside the kernel's one big body the register allocator spilled a value of this loop and
 // reloaded it every iteration -- and the wait for that reload is a wait for every store in flight, i.e. for the walk's own result
 // stores to reach memory: 2 us per step.  With its own frame the loop keeps its registers.
-struct BtArgs { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; const int8_t* seq; int N, m, r, j, slope16; };
+struct BtArgs { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; const int8_t* seq; int N, m, r, j, slope16; const int32_t* ovn; const int32_t* ovp; const int32_t* ovc; const int8_t* np; };
 // returns 2 * (column the walk ends in) + (1 if the alignment holds a step), -1 (guard) or BT_MISS (a cell outside the band the planes hold)
 __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const PoaScores S_ DBGARG)
 {
@@ -1299,7 +1317,12 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
         if (s == 0) return (int)(d0 >> 16);
         if (s == 1) return (int)(d1 & 0xffff);
         if (s == 2) return (int)(d1 >> 16);
-        return w.rank[w.pred[w.order[rr - 1] * POA_MAXP + s]];
+        const int v = w.order[rr - 1];
+        if (s < POA_MAXP) return w.rank[w.pred[v * POA_MAXP + s]];
+        int k = s - POA_MAXP, hit = 0;                        // the (s - POA_MAXP)-th entry of v in the overflow table (poa_pred_at)
+        const int no = A.ovc[0];
+        for (int i = 0; i < no; ++i) if (A.ovn[i] == v) { if (k == 0) { hit = i; break; } --k; }
+        return w.rank[A.ovp[hit]];
     };
     __syncthreads();
 #ifdef CLH_DEBUG_POA
@@ -1321,7 +1344,9 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
         // neighbours -- a run of diagonal steps through first in-edges that are the row before; (2) lane s < in-degree of row r: the
         // three cells of in-edge s; (3) the left neighbour.  In the band by construction (|drift| is bounded above).
         const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)rim.x, a), d1 = (uint32_t)__builtin_amdgcn_readlane((int)rim.y, a);
-        const int np = (int)((d0 >> 8) & 0xf), npp = np ? np : 1;
+        int np = (int)((d0 >> 8) & 0xf);
+        if (np == 15) np = __builtin_amdgcn_readfirstlane((int)A.np[w.order[r - 1]]);       // (the graph row's field holds up to 15)
+        const int npp = np ? np : 1;
         const int l = lane - a, myr = r0 - lane, myc = j - l;
         bool ok = l >= 0 && lane < 63 && chain && myc >= 1;
         const int ps = np == 0 ? 0 : (lane == 0 ? (int)(d0 >> 16) : (lane == 1 ? (int)(d1 & 0xffff) : (int)(d1 >> 16)));
@@ -1375,7 +1400,9 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
                         if (--guard < 0) return -1;
                         uint32_t e0, e1;
                         meta(r, e0, e1);
-                        const int np2 = (int)((e0 >> 8) & 0xf), npp2 = np2 ? np2 : 1;
+                        int np2 = (int)((e0 >> 8) & 0xf);
+                        if (np2 == 15) np2 = __builtin_amdgcn_readfirstlane((int)A.np[w.order[r - 1]]);
+                        const int npp2 = np2 ? np2 : 1;
                         const bool act2 = lane < npp2;
                         int ps2 = 0, xf = -(1 << 30), xo = -(1 << 30), hp2 = 0, fs2 = 0, os2 = 0, miss = 0;
                         if (act2) {
@@ -1445,7 +1472,7 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
             const int np = w.np[v];
             uint32_t pr[3] = {0, 0, 0};
             for (int s2 = 0; s2 < 3; ++s2) if (s2 < np) pr[s2] = (uint32_t)w.rank[w.pred[v * POA_MAXP + s2]];
-            w.ri[r] = make_uint2((uint32_t)(w.base[v] & 0xff) | ((uint32_t)np << 8) | (w.nout[v] == 0 ? 0x1000u : 0u) | (pr[0] << 16), pr[1] | (pr[2] << 16));
+            w.ri[r] = make_uint2((uint32_t)(w.base[v] & 0xff) | ((uint32_t)(np < 15 ? np : 15) << 8) | (w.nout[v] == 0 ? 0x1000u : 0u) | (pr[0] << 16), pr[1] | (pr[2] << 16));
         }
         phase_sync();
         // where will row r read source p from?  the row before it: registers; another recent row: the LDS ring (0x4000 on
@@ -1458,7 +1485,7 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
             if (np > 0) mark(p0);
             if (np > 1) mark(p1);
             if (np > 2) mark(p2);
-            if (np > 3) { const int v = w.order[r - 1]; for (int s2 = 3; s2 < np; ++s2) mark(w.rank[w.pred[v * POA_MAXP + s2]]); }
+            if (np > 3) { const int v = w.order[r - 1]; const int npt = w.np[v]; for (int s2 = 3; s2 < npt; ++s2) mark(w.rank[poa_pred_at(w, v, s2)]); }
         }
         if (poa_dp_bytes(N, m) > w.dp_bytes) return -2;
         w.planeH = (short*)w.dp;
@@ -1471,7 +1498,7 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
                 const int np = w.np[v];
                 int f = np ? -(1 << 28) : S.g - S.e, o = np ? -(1 << 28) : S.q - S.c;
                 for (int s2 = 0; s2 < np; ++s2) {
-                    const int pr = w.rank[w.pred[v * POA_MAXP + s2]];
+                    const int pr = w.rank[poa_pred_at(w, v, s2)];
                     f = w.score[pr] > f ? w.score[pr] : f; o = w.bp[pr] > o ? w.bp[pr] : o;
                 }
                 f += S.e; o += S.c;
@@ -1519,7 +1546,7 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
         je = j - 1;
         if (br > 0) {
             phase_sync();
-            BtArgs A = {w.pn, w.planeH, w.planeD, w.ri, w.col0, w.rank, w.pred, w.order, seq, N, m, __builtin_amdgcn_readfirstlane(br), j, slope16};
+            BtArgs A = {w.pn, w.planeH, w.planeD, w.ri, w.col0, w.rank, w.pred, w.order, seq, N, m, __builtin_amdgcn_readfirstlane(br), j, slope16, w.ovn, w.ovp, w.ovc, w.np};
 #ifdef POA_EXP_BT2
             { (void)poa_backtrack(A, S DBGPASS); phase_sync(); }
 #endif
@@ -1549,6 +1576,7 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
     // front of the alignment [0, jb), the bases behind it (je, m), then the new nodes among the bases [jb, je] it holds.
     int n = N, fail = 0;
     {
+        if (N == 0 && lane == 0) { w.ovc[0] = 0; w.ovc[1] = 0; }       // a new graph: its overflow table is empty
         if (!moved) { jb = m; je = m - 1; }                // empty alignment: the whole sequence is a chain of new nodes
         else if (jb > je) return -5;                       // steps but no base (overlap mode, vertical steps only): spoa throws
         const int nlead = jb, ntrail = m - 1 - je;
@@ -1600,12 +1628,21 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
             const int u = w.pj[i - 1];
             const int cnt = w.np[x];
             int found = -1;
-            for (int s2 = 0; s2 < cnt; ++s2) if (w.pred[x * POA_MAXP + s2] == u) { found = s2; break; }
-            if (found >= 0) w.pw[x * POA_MAXP + found] += 2;
-            else if (cnt >= POA_MAXP) fail = 1;
-            else { w.pred[x * POA_MAXP + cnt] = u; w.pw[x * POA_MAXP + cnt] = 2; w.np[x] = (int8_t)(cnt + 1); w.nout[u] += 1; }
+            for (int s2 = 0; s2 < cnt; ++s2) if (poa_pred_at(w, x, s2) == u) { found = s2; break; }
+            if (found >= 0) {
+                if (found < POA_MAXP) w.pw[x * POA_MAXP + found] += 2; else w.ovw[poa_ovf_slot(w, x, found - POA_MAXP)] += 2;
+            } else if (cnt >= POA_MAXP_ALL) fail = 1;
+            else if (cnt >= POA_MAXP) {                     // the node's in-place slots are full: the graph's overflow table (a node gains at most one in-edge per sequence, so the entries of a node keep their order)
+                const int slot = atomicAdd(&w.ovc[1], 1);
+                if (slot >= POA_OVF_CAP) fail = 1;
+                else { w.ovn[slot] = x; w.ovp[slot] = u; w.ovw[slot] = 2; w.np[x] = (int8_t)(cnt + 1); w.nout[u] += 1; }
+            } else { w.pred[x * POA_MAXP + cnt] = u; w.pw[x * POA_MAXP + cnt] = 2; w.np[x] = (int8_t)(cnt + 1); w.nout[u] += 1; }
         }
         if (__builtin_amdgcn_ballot_w64(fail != 0)) return -1;
+        // entries appended during this sequence become visible to the searches only now (ovc[1] counts ahead of ovc[0]): a search
+        // that ran beside the appends never saw a half-written entry
+        phase_sync();
+        if (lane == 0) w.ovc[0] = w.ovc[1] < POA_OVF_CAP ? w.ovc[1] : POA_OVF_CAP;
     }
     phase_sync();
     TSTAMP(2);
@@ -1669,7 +1706,7 @@ __device__ int poa_consensus(const PoaWs& w, int N_, int min_cov, int8_t* out, i
                     const int v = w.order[r - 1];
                     const int cn = w.np[v];
                     for (int s2 = 0; s2 < cn; ++s2)
-                        relax(__builtin_amdgcn_readfirstlane(w.rank[w.pred[v * POA_MAXP + s2]]), __builtin_amdgcn_readfirstlane(w.pw[v * POA_MAXP + s2]));
+                        relax(__builtin_amdgcn_readfirstlane(w.rank[poa_pred_at(w, v, s2)]), __builtin_amdgcn_readfirstlane(poa_pw_at(w, v, s2)));
                 } else {
                     if (np > 0) relax((int)(t0 >> 16), (int)(t2 & 0xff));
                     if (np > 1) relax((int)(t1 & 0xffff), (int)((t2 >> 8) & 0xff));
@@ -1698,8 +1735,8 @@ __device__ int poa_consensus(const PoaWs& w, int N_, int min_cov, int8_t* out, i
             const int v = w.order[r - 1];
             const int np = w.np[v];
             bool succ = false;
-            for (int s2 = 0; s2 < np; ++s2) succ |= w.rank[w.pred[v * POA_MAXP + s2]] == top;
-            if (succ) for (int s2 = 0; s2 < np; ++s2) { const int u = w.rank[w.pred[v * POA_MAXP + s2]]; if (u != top) score[u] = -1; }
+            for (int s2 = 0; s2 < np; ++s2) succ |= w.rank[poa_pred_at(w, v, s2)] == top;
+            if (succ) for (int s2 = 0; s2 < np; ++s2) { const int u = w.rank[poa_pred_at(w, v, s2)]; if (u != top) score[u] = -1; }
         }
         phase_sync();
         const int t2 = pass(top, true);

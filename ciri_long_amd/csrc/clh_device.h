@@ -81,7 +81,7 @@ struct CcsResult {        // K3 output per read
     int32_t nseg;         // 0 = no consensus
     int32_t ccs_len;
     int32_t period;
-    int32_t status;       // 0 ok, 1 workspace slot too small, 2 graph limits (in-degree, aligned set, 65000 rows), 3 consensus overflow, 4 sequence above 2800 bases,
+    int32_t status;       // 0 ok, 1 workspace slot too small, 2 graph limits (in-degree above 48, aligned set above 8 letters, 65000 rows), 3 consensus overflow, 4 sequence above 2800 bases,
                           // 5 back-track guard, 6 a cell left the 16-bit range, 7 an alignment without a base (spoa throws)
 };
 

@@ -259,7 +259,7 @@ class Context(object):
         """spoa.poa per group of sequences: -> list of consensus str, or list of (consensus, msa rows[, end-cell scores of
         the first 65 sequences]) with genmsa / with_scores.  The letters of `seqs` are bytes compared for equality only;
         raw=False reads them as the codes 0..4 of `encode` and writes ACGTN, raw=True hands them through as characters
-        (`pack_raw`).  Raises ClhError when a group has no consensus (a sequence above 2800 bases, a node with more than 12
+        (`pack_raw`).  Raises ClhError when a group has no consensus (a sequence above 2800 bases, a node with more than 48
         in-edges, more than 8 different letters in a column) or the scores are outside what the kernel honours."""
         seqs = np.ascontiguousarray(seqs, dtype=np.int8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
@@ -280,7 +280,7 @@ class Context(object):
         res = []
         for k in range(ng):
             if lens[k] < 0:
-                raise ClhError('poa: no consensus for group %d (status %d: 1 workspace, 2 graph limits -- more than 12 in-edges, more than 8 '
+                raise ClhError('poa: no consensus for group %d (status %d: 1 workspace, 2 graph limits -- more than 48 in-edges, more than 8 '
                                'letters in a column or 65000 nodes, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 a cell left the '
                                '16-bit score range, 7 an alignment without a base: spoa throws)' % (k, -1 - int(lens[k])))
             o = int(seq_off[group_off[k]])

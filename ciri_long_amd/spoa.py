@@ -9,7 +9,7 @@ max(g + (k-1) e, q + (k-1) c), with spoa's rule for falling back to the one-piec
 depth-first after every sequence as spoa sorts it; heaviest-bundle consensus; ``genmsa`` returns one row per non-empty
 sequence.  Nothing is accepted and ignored: what the kernel does not honour raises -- the linear model (g >= e), scores
 outside its 16-bit cells (match 1..11, e - g <= 6, c - q <= 30), a sequence above 2800 bases, a graph node with more than
-12 in-edges, more than 8 different letters in one column (``hip.ClhError``).
+48 in-edges (12 in place, the rest in an overflow table of 2048 entries per graph), more than 8 different letters in one column (``hip.ClhError``).
 """
 import numpy as np
 

@@ -130,7 +130,7 @@ typedef struct {
     int32_t nseg;      /* 0: no tandem repeat / no consensus (find_consensus would return (None, None)) */
     int32_t ccs_len;
     int32_t period;
-    int32_t status;    /* 0 ok; >0 no consensus because of a limit of this kernel (counted, see clh_ccs_plan_stats): 1 workspace, 2 graph limits (12
+    int32_t status;    /* 0 ok; >0 no consensus because of a limit of this kernel (counted, see clh_ccs_plan_stats): 1 workspace, 2 graph limits (48
                           in-edges, 8 letters in a column, 65000 rows), 3 output, 4 sequence longer than 2800 bases, 5 back-track guard, 6 a DP
                           cell left the 16-bit range (global / overlap modes with costly gaps), 7 an alignment without a base (spoa throws) */
 } clh_ccs_t;

@@ -358,23 +358,34 @@ def test_native_file_stage_buffer_borders_and_a_trailing_header(tmp_path):
 
 
 def test_reads_lost_to_a_kernel_limit_are_counted_and_reported(tmp_path, caplog):
-    """A limit of the kernel never passes for "no repeat".  (1) spoa.poa: thirteen sequences that each skip a different number of
-    letters in front of the same node give that node 14 in-edges, more than the kernel keeps (12; the letters of the stretch are
-    all different, so no deletion can slide): status 2, raised.  (2) find_consensus: a copy above 2800 bases (16-bit cells): status 4
-    in the rows, in the plan's statistics, in pyccs' counter and log line and in the file stage's counter.  The oracle has neither
-    limit."""
+    """A limit of the kernel never passes for "no repeat".  (1) spoa.poa: sequences that each skip a different number of letters in
+    front of the same node give that node one in-edge each (the letters of the stretch are all different, so no deletion can slide):
+    14 and 31 in-edges -- more than the 12 a node holds in place -- go through the graph's overflow table and equal the oracle; 51 are
+    more than the kernel keeps (48): status 2, raised; so are 9 different letters in one column.  (2) find_consensus: a copy above
+    2800 bases (16-bit cells): status 4 in the rows, in the plan's statistics, in pyccs' counter and log line and in the file stage's
+    counter.  The oracle has none of these limits."""
     import logging
     import random
     from ciri_long_amd import find_ccs, hip, pyccs, spoa
     rng = random.Random(3)
-    unit = [rng.choice('ACGT') for _ in range(220)]
-    unit[95:111] = list('bdefhijklmnopqrs')
+    unit = [rng.choice('ACGT') for _ in range(260)]
+    unit[95:155] = [chr(0x80 + k) for k in range(60)]      # 60 letters that occur nowhere else (raw bytes: the alphabet is whatever comes in)
     unit = ''.join(unit)
-    copies = [unit] + [unit[:110 - k] + unit[110:] for k in range(1, 14)]
-    assert oracle_lib.oracle_poa(copies, 0, False, 10, -4, -8, -2, -24, -1) is not None
+    copies = [unit] + [unit[:154 - k] + unit[154:] for k in range(1, 56)]
+    args = (10, -4, -8, -2, -24, -1)
+    for n_seq in (11, 13, 30):                             # 12, 14, 31 in-edges at the node behind the stretch
+        for mode in (0, 1, 2):
+            got = spoa.poa(copies[:n_seq], mode, True, *args)
+            want = oracle_lib.oracle_poa(copies[:n_seq], mode, True, *args)
+            assert got[0] == want[0] and list(got[1]) == list(want[1]), (n_seq, mode)
+    assert oracle_lib.oracle_poa(copies[:50], 0, False, *args) is not None
     with pytest.raises(hip.ClhError, match='status 2'):
-        spoa.poa(copies, 0, False, 10, -4, -8, -2, -24, -1)
-    assert spoa.poa(copies[:11], 0, False, 10, -4, -8, -2, -24, -1)[0] == oracle_lib.oracle_poa(copies[:11], 0, False, 10, -4, -8, -2, -24, -1)   # 12 in-edges: fine
+        spoa.poa(copies[:50], 0, False, *args)                # 51 in-edges
+    nine = [unit[:40] + chr(0x61 + k) + unit[41:] for k in range(9)]
+    assert oracle_lib.oracle_poa(nine, 0, False, *args) is not None
+    with pytest.raises(hip.ClhError, match='status 2'):
+        spoa.poa(nine, 0, False, *args)                       # 9 letters in one column
+    assert spoa.poa(nine[:8], 0, False, *args)[0] == oracle_lib.oracle_poa(nine[:8], 0, False, *args)
     long_unit = ''.join(rng.choice('ACGT') for _ in range(3000))
     read = long_unit * 3
     short = ''.join(rng.choice('ACGT') for _ in range(220)) * 4

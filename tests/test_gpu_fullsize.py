@@ -162,3 +162,38 @@ def test_c4_mixed_lengths_batch_invariance_both_workspace_tiers_and_sample(monke
         r = srow[pos[int(i)]]
         assert [int(r[f]) for f in fields] == [w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']], i
     assert n_cons >= 35
+
+
+def test_c4_full_per_gpu_share_125000_reads_order_and_split_invariance():
+    """BASELINE config 4 at its full per-GPU size (125 000 reads of 500-4000 bases, the batch `bench.py --workload c4` runs):
+    consensus through K2/K3, no read lost to a kernel limit, and the per-read results (copy count, consensus length, period,
+    checksum of the consensus) do not depend on the order of the batch or on splitting it in two."""
+    import torch
+    torch.cuda.init()
+    from ciri_long_amd import hip, synth
+    n = 125000
+    reads, _w = synth.c4_batch(n, seed=synth.SEEDS['C4'])
+    ctx = hip.default_context()
+
+    def consensus(idx):
+        data, off = hip.pack([reads[i] for i in idx])
+        d = torch.from_numpy(data.view(np.uint8)).cuda()
+        plan = ctx.ccs_plan(off)
+        plan.run(d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        rows, _segs, ccs = plan.fetch()
+        stats = plan.stats()
+        plan.close()
+        sums = np.array([zlib.crc32(ccs[off[k]:off[k] + int(rows['ccs_len'][k])].tobytes()) for k in range(len(idx))], dtype=np.int64)
+        return rows, sums, stats
+
+    order = np.arange(n)
+    rows_a, sums_a, st_a = consensus(order)
+    assert int((rows_a['status'] != 0).sum()) == 0 and st_a['dropped'] == {}
+    assert 0.3 * n < int((rows_a['nseg'] > 0).sum()) < 0.55 * n
+    rows_b, sums_b, _s = consensus(order[::-1])
+    for f in ('nseg', 'ccs_len', 'period'):
+        assert np.array_equal(rows_a[f], rows_b[f][::-1]), f
+    assert np.array_equal(sums_a, sums_b[::-1])
+    for part in (order[:n // 2], order[n // 2:]):
+        rows_c, sums_c, _s = consensus(part)
+        assert np.array_equal(rows_a['ccs_len'][part], rows_c['ccs_len']) and np.array_equal(sums_a[part], sums_c)

@@ -521,12 +521,12 @@ __device__ __forceinline__ void to_packed(const uint32_t (&nat)[CP], uint32_t (&
 static constexpr int D_F = 0x0007, D_O_SHIFT = 3, D_E_SHIFT = 8, D_Q_SHIFT = 11;
 // The planes are what the kernel writes most of, and writing them is what bounds the pass (measured: the pass run twice costs 18 ms with
 // its stores, 9 ms without).  The back-track only ever reads cells next to the path, and the path of a copy against the graph of
-// its siblings stays near the straight line from (1, 1) to (N, m).  So a row leaves its cells only within POA_BAND columns of
+// its siblings stays near the straight line from (1, 1) to (N, m).  So a row leaves its cells only within POA_BAND (32) columns of
 // column r * m / N -- rows that an older successor reads back as a source ("full", 0x8000 in the graph row) leave all of them --
 // and the back-track, which knows the same rule, answers "miss" when it is about to use a cell that was not left: the pass is
 // then run once more with every cell stored.  Results never depend on the band.
 #ifndef POA_BAND_W
-#define POA_BAND_W 64
+#define POA_BAND_W 32      // measured, C3 / C4 ms per launch (walks that left the band and ran their pass again): 64 -> 19.90 (0) / 78.3 (27), 48 -> 19.65 (0) / 77.9 (78), 32 -> 19.30 (22 of 85 000) / 77.3 (353 of 250 000)
 #endif
 static constexpr int POA_BAND = POA_BAND_W;
 static constexpr int POA_H_NONE = -32768;            // a cell of the staged band that the planes do not hold (H is never below POA_NEG)

@@ -1050,6 +1050,8 @@ __device__ __forceinline__ int poa_sort_lds(const PoaWs& w_, const int n_old, co
     uint16_t* lord = lsz + n;
     uint8_t* lst = (uint8_t*)(lord + n);
     uint16_t* lnt = (uint16_t*)(poa_lds + (POA_LDS_BYTES - n) / 4);      // roots with more than one node: the last n bytes of the block
+    // (Tried: the one dependency of a node with one in-edge and no aligned node kept in LDS, so that the relaxation rounds and the
+    // searches touch HBM only for the other nodes -- no gain on C3, +0.6 ms on C4: dropped.)
     // lst bit 2: the node is new or its root has been lowered -- its aligned set and its in-edge tails may have to follow.
     // Loads of four strides are issued together (one round trip per 256 nodes instead of four)
     for (int v0 = 0; v0 < n; v0 += 256) {
@@ -1692,7 +1694,31 @@ __device__ int poa_consensus(const PoaWs& w, int N_, int min_cov, int8_t* out, i
             if (nr <= N) { n0 = w.tab[nr * 3]; n1 = w.tab[nr * 3 + 1]; n2 = w.tab[nr * 3 + 2]; }
             const int cnt = N - rb + 1 < 64 ? N - rb + 1 : 64;
             int bpb = 0;
+            // Most ranks are links of a chain: one in-edge, from the rank before.  Along such a run the score is the running sum of the
+            // edge weights on top of the score in front of the run (weights are >= 2: the scores rise strictly, so only the run's
+            // last rank can become the best one), and all of it is taken at once: one prefix sum of the weights per 64 ranks.
+            const bool chain_l = in_lds && lane < cnt && (b0 & 0x7f) == 1 && (int)(b0 >> 16) == rb + lane - 1;
+            const int psum = wave_prefix_sum(chain_l ? (int)(b2 & 0xff) : 0);
+            const unsigned long long chain_m = __builtin_amdgcn_ballot_w64(chain_l);
             for (int i = 0; i < cnt; ++i) {
+                {
+                    const unsigned long long rest = ~(chain_m >> i);
+                    int run = rest ? __builtin_ctzll(rest) : 64;
+                    run = run < cnt - i ? run : cnt - i;
+                    if (run >= 3) {
+                        const int before = i > 0 ? __builtin_amdgcn_readlane(psum, i - 1) : 0;
+                        const bool dead = barred && prev == -1;                   // a barred tail: nothing reaches these ranks
+                        const int scl = dead ? -1 : prev + (psum - before);
+                        if (lane >= i && lane < i + run) { score[rb + lane] = scl; bpb = dead ? 0 : rb + lane - 1; }
+                        const int lastsc = __builtin_amdgcn_readlane(scl, i + run - 1);
+                        if (dead) { if (-1 > tops) { tops = -1; top = rb + i; } }
+                        else if (lastsc > tops) { tops = lastsc; top = rb + i + run - 1; }
+                        prev = lastsc;
+                        asm volatile("" ::: "memory");
+                        i += run - 1;
+                        continue;
+                    }
+                }
                 const int r = rb + i;
                 const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, i), t1 = (uint32_t)__builtin_amdgcn_readlane((int)b1, i), t2 = (uint32_t)__builtin_amdgcn_readlane((int)b2, i);
                 const int np = (int)(t0 & 0x7f);

@@ -636,8 +636,8 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             SEC0();
             const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)blk.x, i);
             int cinH = 0, cinE = POA_NEG, cinQ = POA_NEG;
-            if (carried | nw) cinH = __builtin_amdgcn_readlane(cH, i);
-            if (carried) { cinE = __builtin_amdgcn_readlane(cE, i); cinQ = __builtin_amdgcn_readlane(cQ, i); }
+            if (__builtin_expect(carried | nw, 0)) cinH = __builtin_amdgcn_readlane(cH, i);
+            if (__builtin_expect(carried, 0)) { cinE = __builtin_amdgcn_readlane(cE, i); cinQ = __builtin_amdgcn_readlane(cQ, i); }
             const int vb = (int)(d0 & 0xff), np = (int)((d0 >> 8) & 0xf);
             const bool sink = (d0 & 0x1000u) != 0, tolds = (d0 & 0x4000u) != 0;
             const int p0 = (int)(d0 >> 16);
@@ -691,11 +691,11 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             };
             SEC(8);
             uint32_t dg[CP], MF[CP], MO[CP];
-            if (np <= 1) {
+            if (__builtin_expect(np <= 1, 1)) {
                 // the common shape.  The source's values are used where they are: the registers of the row before, which a source
                 // that is another row overwrites (nothing else reads them in this step) -- no copies on the way to the arithmetic
                 const int q0 = np == 0 ? 0 : p0;
-                if (q0 != r - 1 || q0 == 0) source(q0, px, pcin, pf, po);     // (row 1 of a node without in-edges: row 0 is not in the registers)
+                if (__builtin_expect(q0 != r - 1 || q0 == 0, 0)) source(q0, px, pcin, pf, po);     // (row 1 of a node without in-edges: row 0 is not in the registers)
                 const uint32_t hsh0 = hand_down(px[CP - 1], pcin);
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
@@ -777,7 +777,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 const int cen = (int)(((unsigned)r * (unsigned)slope16) >> 16);
                 st_row = stores && (unsigned)(col0 + C - (cen - POA_BAND)) <= (unsigned)(2 * POA_BAND + C - 1);
             }
-            if (st_row) {
+            if (__builtin_expect(st_row, 1)) {
                 uint32_t nh[CP], nd[CP];
                 to_natural<CP>(Hf, nh); to_natural<CP>(D, nd);
                 // scalar row base + the lane's 32-bit offset: the row base is made opaque, or the compiler folds the lane's offset
@@ -801,19 +801,19 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                     *(__attribute__((address_space(1))) u32x4*)dh = u32x4{nh[0], nh[1], nh[2], nh[3]}; *(__attribute__((address_space(1))) u32x4*)dd = u32x4{nd[0], nd[1], nd[2], nd[3]};
                 }
             }
-            if (tolds) {
+            if (__builtin_expect(tolds, 0)) {
                 uint32_t* rp = ring + (r & rmask) * rrow + lane * CP;
 #pragma unroll
                 for (int t = 0; t < CP; ++t) { rp[t] = Hf[t]; rp[64 * CP + t] = D[t]; }
                 if (lane == 0) ringL[r & rmask] = cinH;
             }
             SEC(12);
-            if (!sw) {
+            if (__builtin_expect(!sw, 0)) {
 #pragma unroll
                 for (int t = 0; t < CP; ++t) lowP = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, lowP), __builtin_bit_cast(s16x2, bfi(beyondP[t], 0x7fff7fffu, Hf[t]))));
             }
             // ---- end cell: first strict maximum in (rank, column) order --------------------------------------------
-            if (sw | (!nw & sink)) {
+            if (__builtin_expect(sw | (!nw & sink), 1)) {
                 // columns beyond the sequence (letter 0x100: bit 8) do not count.  In local mode with a negative mismatch score they cannot
                 // be the end cell anyway: every move into such a cell loses score, so it is below the cell it came from
                 uint32_t hv2[CP];
@@ -823,7 +823,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
                 for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
                 const uint32_t imp = pk_sra15(pk_subs(bsP, rm));                  // halves whose best is exceeded (strictly: the first row stays)
-                if (__builtin_amdgcn_ballot_w64(imp != 0u)) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(imp != 0u) != 0, 0)) {
                     uint32_t colP = 0;
 #pragma unroll
                     for (int t = CP - 1; t >= 0; --t) {
@@ -839,7 +839,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 const int val = hm ? (int)pick >> 16 : (int)(short)(pick & 0xffffu);
                 if (val > nbest) { nbest = val; nrow = r; }
             }
-            if (more) {
+            if (__builtin_expect(more, 0)) {
                 const int rH = (int)__builtin_amdgcn_readlane((int)Hf[CP - 1], 63) >> 16, rEs = (int)__builtin_amdgcn_readlane((int)Es[CP - 1], 63) >> 16,
                           rQ = (int)__builtin_amdgcn_readlane((int)qhat[CP - 1], 63) >> 16;
                 const int rE = rEs - (e - g);

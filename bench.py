@@ -652,7 +652,7 @@ def main():
                          'CIGAR) vs own 2 kb window, rows and CIGARs to the host in every step' % nreads),
             'reads_per_gpu': nreads, 'window': WINDOW, 'scoring': '1/1/1/1',
             'parallelism': 'reads sharded x%d, no data-path collective%s' % (world, '; int64[7] counter all-reduce on RCCL after the timed loop' if world > 1 else ''),
-            'consensus_parity': 'unpinned (pyccs/spoa absent from the reference tree; clh-poa v2 restates the published spoa algorithm, oracle/poa_oracle.c)' if full else None},
+            'consensus_parity': 'unpinned (pyccs/spoa absent from the reference tree; clh-poa v3 restates the published spoa algorithm, no departures, oracle/poa_oracle.c)' if full else None},
         'roofline': res['roofline'], 'valu_roofline': res['valu_roofline'],
     }
     if 'valu_roofline_k3' in res:

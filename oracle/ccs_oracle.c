@@ -34,7 +34,7 @@
  *
  * Step 3 is spoa.poa(copies, 0, ., 10, -4, -8, -2, -24, -1) -- local alignment, two-piece gap cost, the call of the
  * reference's tests/test_poa.py:30, whose assertion (:32) equates the length of that consensus with the length of
- * find_consensus' -- as stated in poa_oracle.c ("clh-poa v2": a restatement of the published spoa algorithm).
+ * find_consensus' -- as stated in poa_oracle.c ("clh-poa v3": a restatement of the published spoa algorithm).
  */
 #include <stdint.h>
 #include <stdlib.h>

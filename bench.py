@@ -680,7 +680,7 @@ def main():
     if world == 1 and not args.no_extra and not profiled and wl == 'c3':
         extra = {}
         try:
-            s = run_c2(torch, dist, hip, synth, ctx, 10000, 0, 1, 3, 1, None)
+            s = run_c2(torch, dist, hip, synth, ctx, 10000, 0, 1, 10, 2, None)
             extra['c2'] = dict(s, unit='reads/s', workload='C2: 10000 ~1 kb reads vs own 2 kb window, complete s_align incl. CIGAR, rows to the host; two batches in flight')
             s = run_full(torch, dist, hip, synth, ctx, 'c4', 125000, 0, 1, 2, 1, None)
             extra['c4'] = dict(s, unit='reads/s', workload='C4 per-GPU share: 125000 reads of 500-4000 bases through the C3 step')

@@ -566,6 +566,12 @@ def extra_stage1(hip, synth, ctx, n=100000):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def under_profiler():
+    """rocprofv3 (or another HSA tool library) is preloaded into this process: the GPU is initialised already"""
+    return any('rocprof' in os.environ.get(k, '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB')) \
+        or any(k.startswith('ROCPROF') for k in os.environ)
+
+
 def launch_ranks(n):
     """`bench.py --gpus N` started without a launcher: run the N ranks as children of this process, one per GPU, through
     torch.distributed.run on 127.0.0.1.  This process has not touched the GPU (no HIP call, no torch.cuda call) and does
@@ -607,7 +613,12 @@ def main():
     full = wl != 'c2'            # c3 / c4: the whole device part of `call`; c2: Smith-Waterman only
     nreads = args.reads or {'c3': 100000, 'c2': 10000, 'c4': 125000}[wl]
 
+    # under rocprofv3 the preloaded tool library has initialised the GPU before Python started: this process must then neither
+    # spawn nor exec anything (launcher, CPU leg)
+    profiled = under_profiler()
     if (args.gpus > 1 or os.environ.get('CLH_BENCH_SPAWN')) and 'WORLD_SIZE' not in os.environ:      # (CLH_BENCH_SPAWN: the launcher path on a one-GPU box)
+        if profiled:
+            raise SystemExit('bench.py: --gpus N under a profiler: profile a single rank (--gpus 1), or start the ranks with a launcher outside the profiler')
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts the N ranks as CHILD
         # processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) before anything here has touched the GPU,
         # never execs, relays rank 0's JSON line and exits with the children's code.
@@ -622,8 +633,6 @@ def main():
     # The CPU leg spawns one process per host core.  It runs BEFORE this process touches the GPU (a child of a process
     # that has initialised the GPU must not exec), and not at all under rocprofv3, whose preloaded library initialises
     # the GPU before Python starts (and again in every child).
-    profiled = any('rocprof' in os.environ.get(k, '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB')) \
-        or any(k.startswith('ROCPROF') for k in os.environ)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and not profiled:
         cpu = cpu_baseline(args.cpu_seconds, wl)

@@ -38,6 +38,7 @@ extern "C" int clh_device_count(void)
 // ------------------------------------------------------------------------------------------------------------
 struct clh_ctx {
     int device;
+    int n_cu = 256;                                      // compute units (persistent launches are sized by it)
     hipStream_t stream;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the read-length classes of a batch are launched on 4 streams so their tails overlap
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
@@ -98,6 +99,7 @@ extern "C" clh_ctx* clh_create(int device)
     if ((e = hipSetDevice(device)) != hipSuccess) { fail(CLH_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); return nullptr; }
     clh_ctx* c = new clh_ctx();
     c->device = device;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(CLH_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         delete c;
@@ -139,6 +141,10 @@ struct clh_plan {
     struct Seg { int rv, begin, count; };
     std::vector<clh::ScanSlice> slices;      // window slices of the sliced scan class (one segment at most)
     void *d_slices = nullptr, *d_parts = nullptr;
+    // prefilter of the sliced scan class (ssw_prefilter.hip): block minima of the edit-distance bound, slices made on the device
+    bool pf_on = false;
+    int pf_nwork = 0, pf_bpl = 0, pf_cap = 0, pf_ntasks = 0;
+    void *d_pf_tasks = nullptr, *d_pf_work = nullptr, *d_pf_dmin = nullptr, *d_pf_slices = nullptr, *d_pf_out = nullptr, *d_pf_ctl = nullptr;
     std::vector<int32_t> slice_base;         // task-level slices of the anti-diagonal classes: first window column of scratch row k
     void* d_slice_base = nullptr;
     int n_all = 0;                           // tasks incl. those slices (their result rows sit behind the n real ones)
@@ -163,7 +169,8 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     (void)hipSetDevice(c->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
-                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base};
+                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base,
+                    pl->d_pf_tasks, pl->d_pf_work, pl->d_pf_dmin, pl->d_pf_slices, pl->d_pf_out, pl->d_pf_ctl};
     for (void* b : bufs) c->release(b);
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : pl->chain_ev) (void)hipEventDestroy(e);
@@ -206,6 +213,14 @@ static bool scan_sliced(int64_t R, const clh_ssw_opts* o)
 {
     static const bool off = getenv("CLH_NO_SLICES") != nullptr;
     return !off && R >= kSliceMinWindow && o->gap_extend >= 1;
+}
+
+// The sliced class behind the exact prefilter (ssw_prefilter.hip): needs the bound's constant c = min(max_match, gap_extend) >= 1
+// and no second-best score (the column maxima of the columns it skips would be missing).  CLH_NO_PREFILTER=1 switches it off
+// (A/B measurements, and the parity tests run both ways).
+static bool prefilter_ok(const clh_ssw_opts* o, int max_match)
+{
+    return getenv("CLH_NO_PREFILTER") == nullptr && !o->want_score2 && max_match >= 1 && o->gap_extend >= 1;
 }
 
 // ref_off != nullptr: packed references, alignment a against [ref_off[a], ref_off[a+1]).  Otherwise windows of a resident
@@ -340,8 +355,35 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         k = e;
     }
     pl->tasks.swap(sorted);
+    std::vector<clh::PfTask> pf_tasks;
+    std::vector<clh::PfWork> pf_work;
     for (const auto& sg : pl->segs) {
-        if (sg.rv != clh::kRvScanSliced) continue;
+        if (sg.rv != clh::kRvScanSliced || !prefilter_ok(o, mx)) continue;
+        // per task: the 256-byte blocks of the refs buffer its window touches, in processing order (minus-strand windows run down
+        // the addresses); a lane of the prefilter owns pf_bpl of them
+        pl->pf_on = true; pl->pf_ntasks = sg.count;
+        int64_t total = 0, cap = 0;
+        pf_tasks.resize(sg.count);
+        for (int k = 0; k < sg.count; ++k) {
+            const clh::SswTask& t = pl->tasks[sg.begin + k];
+            clh::PfTask& pt = pf_tasks[k];
+            const int64_t R = t.ref_len;
+            if (t.ref_rc) { const int64_t hi = t.ref_off, lo = hi - R + 1; pt.mem_block0 = (int32_t)(hi >> 8); pt.phase = (int32_t)(255 - (hi & 255)); pt.nsub = (int32_t)((hi >> 8) - (lo >> 8) + 1); }
+            else { const int64_t lo = t.ref_off, hi = lo + R - 1; pt.mem_block0 = (int32_t)(lo >> 8); pt.phase = (int32_t)(lo & 255); pt.nsub = (int32_t)((hi >> 8) - (lo >> 8) + 1); }
+            pt.sub_off = (int32_t)total;
+            total += pt.nsub;
+            cap += std::max<int64_t>(64, pt.nsub / 8 + 1);
+            if (total > 0x7fffffffll || cap > 0x7fffffffll) { fail(CLH_E_CAPACITY, "batch too large for the prefilter's 32-bit block offsets; split it"); delete pl; return nullptr; }
+        }
+        int bpl = (int)std::min<int64_t>(16, std::max<int64_t>(4, total / (64 * 12288)));
+        if (const char* e = getenv("CLH_PF_BPL")) bpl = std::max(1, atoi(e));
+        pl->pf_bpl = bpl; pl->pf_cap = (int)cap;
+        for (int k = 0; k < sg.count; ++k)
+            for (int fb = 0; fb < pf_tasks[k].nsub; fb += 64 * bpl) pf_work.push_back({k, fb});
+        pl->pf_nwork = (int)pf_work.size();
+    }
+    for (const auto& sg : pl->segs) {
+        if (sg.rv != clh::kRvScanSliced || pl->pf_on) continue;
         for (int k = 0; k < sg.count; ++k) {
             clh::SswTask& t = pl->tasks[sg.begin + k];
             const int64_t R = t.ref_len, L = t.read_len;
@@ -381,6 +423,22 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         pl->d_slices = ctx->alloc(sizeof(clh::ScanSlice) * pl->slices.size());
         pl->d_parts = ctx->alloc(sizeof(clh::ScanPart) * pl->slices.size());
         if (!pl->d_slices || !pl->d_parts || hipMemcpy(pl->d_slices, pl->slices.data(), sizeof(clh::ScanSlice) * pl->slices.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            fail(CLH_E_HIP, "out of device memory while building the plan");
+            clh_plan_destroy(pl); return nullptr;
+        }
+    }
+    if (pl->pf_on) {
+        pl->d_pf_tasks = ctx->alloc(sizeof(clh::PfTask) * pf_tasks.size());
+        pl->d_pf_work = ctx->alloc(sizeof(clh::PfWork) * std::max<size_t>(pf_work.size(), 1));
+        pl->d_pf_dmin = ctx->alloc((size_t)pf_tasks.back().sub_off + (size_t)pf_tasks.back().nsub + 64);
+        pl->d_pf_slices = ctx->alloc(sizeof(clh::ScanSlice) * (size_t)pl->pf_cap);
+        pl->d_parts = ctx->alloc(sizeof(clh::ScanPart) * (size_t)pl->pf_cap);
+        pl->d_pf_out = ctx->alloc(sizeof(clh::PfOut) * pf_tasks.size());
+        pl->d_pf_ctl = ctx->alloc(sizeof(clh::PfCtl));
+        if (!pl->d_pf_tasks || !pl->d_pf_work || !pl->d_pf_dmin || !pl->d_pf_slices || !pl->d_parts || !pl->d_pf_out || !pl->d_pf_ctl ||
+            hipMemcpy(pl->d_pf_tasks, pf_tasks.data(), sizeof(clh::PfTask) * pf_tasks.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            (!pf_work.empty() && hipMemcpy(pl->d_pf_work, pf_work.data(), sizeof(clh::PfWork) * pf_work.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+            hipMemset(pl->d_pf_ctl, 0, sizeof(clh::PfCtl)) != hipSuccess) {
             fail(CLH_E_HIP, "out of device memory while building the plan");
             clh_plan_destroy(pl); return nullptr;
         }
@@ -627,7 +685,18 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         if (chained) ls = st;
         P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], ls));
-        if (s.rv == clh::kRvScanSliced) {
+        if (s.rv == clh::kRvScanSliced && pl->pf_on) {
+            // block minima of the bound, then seed + candidate slices, the slices, the finish -- one chain on the class's stream.
+            // The prefilter reads the window text in address-aligned 256-byte blocks of the refs buffer: a buffer that is not
+            // aligned so keeps the static slices (the pick kernel writes them)
+            P.pf_tasks = (const clh::PfTask*)pl->d_pf_tasks; P.pf_work = (const clh::PfWork*)pl->d_pf_work;
+            P.pf_slices = (clh::ScanSlice*)pl->d_pf_slices; P.pf_out = (clh::PfOut*)pl->d_pf_out; P.pf_ctl = (clh::PfCtl*)pl->d_pf_ctl;
+            P.parts = (clh::ScanPart*)pl->d_parts; P.pf_bpl = pl->pf_bpl; P.pf_cap = pl->pf_cap;
+            P.pf_dmin = ((uintptr_t)d_refs & 255) == 0 ? (uint8_t*)pl->d_pf_dmin : nullptr;
+            HIPCHK(hipMemsetAsync(pl->d_pf_ctl, 0, sizeof(clh::PfCtl), ls));
+            if (P.pf_dmin) HIPCHK(clh::launch_ssw_prefilter(P, pl->pf_nwork, ls));
+            HIPCHK(clh::launch_ssw_scan_filtered(pl->quirk, P, s.count, std::min(pl->pf_cap, c->n_cu * 12), ls));
+        } else if (s.rv == clh::kRvScanSliced) {
             P.slices = (const clh::ScanSlice*)pl->d_slices; P.parts = (clh::ScanPart*)pl->d_parts;
             HIPCHK(clh::launch_ssw_scan_sliced(pl->quirk, P, s.count, (int)pl->slices.size(), ls));
         } else if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
@@ -723,6 +792,22 @@ extern "C" int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts)
     int32_t w[64];
     HIPCHK(hipMemcpy(w, (const char*)pl->d_pool_head + 16, sizeof(w), hipMemcpyDeviceToHost));
     for (int k = 0; k < 32; ++k) { counts[0] += w[k]; counts[1] += w[32 + k]; }
+    return 0;
+}
+
+// what the prefilter of the sliced scan class did in the last run: out[0] alignments of the class, [1] of them with candidate
+// slices instead of the static ones, [2] slices run, [3] window columns those slices computed, [4] window columns of the class;
+// all zero when the plan has no such class or the filter is off; waits for the run
+extern "C" int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out)
+{
+    if (!pl || !out) return fail(CLH_E_ARG, "clh_plan_prefilter_stats: null argument");
+    for (int k = 0; k < 5; ++k) out[k] = 0;
+    if (!pl->pf_on || !pl->ran) return 0;
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    clh::PfCtl c;
+    HIPCHK(hipMemcpy(&c, pl->d_pf_ctl, sizeof(c), hipMemcpyDeviceToHost));
+    out[0] = pl->pf_ntasks; out[1] = c.n_pruned; out[2] = c.qcount; out[3] = (int64_t)c.cols_scanned; out[4] = (int64_t)c.cols_window;
     return 0;
 }
 

@@ -48,6 +48,26 @@ struct SswResult {        // 32 bytes; the s_align fields of ssw.h:42-52 minus t
 struct ScanSlice { int32_t task, c_begin, own_begin, c_end, part, pad0, pad1, pad2; };   // columns [c_begin, c_end) computed, [own_begin, c_end) counted
 struct ScanPart { int32_t max, col, row, pad; };                                        // best cell of one slice
 
+// Exact prefilter of the sliced scan class (ssw_prefilter.hip; tools/prefilter_model.py): per block of 256 bytes of window text
+// the minimum of d(j), the edit distance of the whole read to a window substring ending at column j; H(j) <= M L - c d(j).
+static constexpr int kPfBlock = 256;
+struct PfTask {           // host-built, one per task of the class
+    int32_t sub_off;      // first entry of the task's block minima
+    int32_t nsub;         // blocks the window touches
+    int32_t phase;        // column 0 sits `phase` bytes into the first block (in processing order)
+    int32_t mem_block0;   // forward windows: refs block of processing block 0; reverse-complemented: refs block of processing block 0 (the highest)
+};
+struct PfWork {           // one workgroup of the prefilter: 64 lanes x `bpl` blocks of one task
+    int32_t task, first_block;
+};
+struct PfOut {            // device-filled per task: its slices in the queue, what the filter saw
+    int32_t first, count, s0, pruned;
+};
+struct PfCtl {            // device control block of one run (zeroed before it)
+    int32_t qcount, qnext, n_pruned, pad;
+    unsigned long long cols_scanned, cols_window;
+};
+
 struct SswParams {
     const int8_t* reads;
     const int8_t* refs;
@@ -65,6 +85,14 @@ struct SswParams {
     int32_t n_real;            // result rows of real alignments; tasks with out_index >= n_real are window slices of the
                                // anti-diagonal classes (scratch rows, no CIGAR), see clh_api.hip and ssw_combine_kernel
     const int32_t* slice_base; // first window column of scratch row k (index out_index - n_real)
+    // sliced scan class with the prefilter: the slices are made on the device (ssw_scan.hip: ssw_scan_pick_kernel)
+    const PfTask* pf_tasks;    // nullptr: static slices from `slices`
+    const PfWork* pf_work;
+    uint8_t* pf_dmin;          // block minima (nullptr at run time: the filter is off for this run, the pick kernel writes the static slices)
+    ScanSlice* pf_slices;      // the queue
+    PfOut* pf_out;
+    PfCtl* pf_ctl;
+    int32_t pf_bpl, pf_cap;    // blocks per lane of the prefilter; capacity of the queue
 };
 
 // ---- cyclic consensus (K2/K3, csrc/ccs_poa.hip) ----------------------------------------------------------------
@@ -174,6 +202,10 @@ static constexpr int kRvCombine = -2;    // pseudo class: alignments whose score
 hipError_t launch_ssw_combine(const SswParams& p, int ntasks, hipStream_t stream);
 static constexpr int kRvScanSliced = -1; // pseudo class: K1s with the forward pass cut into window slices (task.dir_off = first part, task.pad = slices)
 hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int nslices, hipStream_t stream);
+// the same class behind the prefilter: block minima (ssw_prefilter.hip), then seed + candidate slices, the slices by persistent
+// workgroups, the finish (ssw_scan.hip)
+hipError_t launch_ssw_prefilter(const SswParams& p, int nwork, hipStream_t stream);
+hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, hipStream_t stream);
 static constexpr int kRvScanWide = -3;   // pseudo class: K1w, the row-scan kernel for reads of 255..4096 bases / scores above 254 (ssw_scan_wide.hip);
                                          // task.dir_off = its workspace inside `dirs` (scanw_task_bytes)
 hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, hipStream_t stream);

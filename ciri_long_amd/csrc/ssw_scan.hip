@@ -389,6 +389,156 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_finish_kernel(const S
     scan_finish<GEQ>(p, task, fw, lds);
 }
 
+// ---- the sliced class behind the prefilter (ssw_prefilter.hip; tools/prefilter_model.py) --------------------------------------
+// One wave per task: (1) the block with the smallest minimum of d; a forward pass around it ATTAINS a score S0; (2) every
+// block whose minimum is at most (M L - S0) / c is a candidate -- no other block can hold the maximum or tie it; runs of
+// candidate blocks (cut at groups of 64) become slices in the queue, each started `overlap` columns early like a static slice;
+// (3) when the runs outnumber the task's share of the queue or cover about as much as the window, the static slices of
+// clh_api.hip are written instead.  p.pf_dmin == nullptr (filter off for this run): static slices at once.
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const SswParams p)
+{
+    SCAN_LDS_SETUP
+    const int lane = threadIdx.x & 63;
+    const SswTask task = p.tasks[blockIdx.x];
+    const PfTask pt = p.pf_tasks[blockIdx.x];
+    const int R = task.ref_len, L = task.read_len;
+    const int overlap = L + (L * p.max_match + p.gapE - 1) / p.gapE + 32;
+    const uint8_t* dmin = p.pf_dmin ? p.pf_dmin + pt.sub_off : nullptr;
+    int own = (R + 63) / 64; own = own < 8192 ? 8192 : own;
+    const int nstatic = (R + own - 1) / own;
+    int S0 = 0, nrun = 0, pruned = 0, thr = 0;
+    if (dmin) {
+        int key = 0x7fffffff;
+        for (int k = lane; k < pt.nsub; k += 64) { const int v = ((int)dmin[k] << 20) | k; key = v < key ? v : key; }
+        key = wave_min(key);
+        const int kb = key & 0xfffff;
+        int c0 = kb * kPfBlock - pt.phase, c1 = c0 + kPfBlock;
+        c0 = c0 < 0 ? 0 : c0; c1 = c1 > R ? R : c1;
+        const int cb = c0 - overlap < 0 ? 0 : c0 - overlap;
+        const ScanOut fw = scan_forward<GEQ>(p, task, lds, cb, c0, c1);
+        S0 = fw.max;
+        if (S0 > 0) {
+            const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
+            thr = (p.max_match * L - S0) / cc;
+            long long cost = 0;
+            for (int g = 0; g < pt.nsub; g += 64) {
+                const int k = g + lane;
+                const unsigned long long m = __ballot(k < pt.nsub && (int)dmin[k] <= thr);
+                nrun += __popcll(m & ~(m << 1));
+                cost += (long long)__popcll(m) * kPfBlock;
+            }
+            cost += (long long)nrun * overlap;
+            const int cap = pt.nsub / 8 + 1 > 64 ? pt.nsub / 8 + 1 : 64;
+            pruned = nrun <= cap && cost < (long long)R + (long long)nstatic * overlap;
+        }
+    }
+    const int count = pruned ? nrun : nstatic;
+    int first = 0;
+    if (lane == 0) {
+        first = atomicAdd(&p.pf_ctl->qcount, count);
+        if (pruned) atomicAdd(&p.pf_ctl->n_pruned, 1);
+        atomicAdd(&p.pf_ctl->cols_window, (unsigned long long)R);
+    }
+    first = __builtin_amdgcn_readfirstlane(first);
+    unsigned long long cols = 0;
+    if (pruned) {
+        int done = 0;
+        for (int g = 0; g < pt.nsub; g += 64) {
+            const int k = g + lane;
+            const unsigned long long m = __ballot(k < pt.nsub && (int)dmin[k] <= thr);
+            const unsigned long long starts = m & ~(m << 1);
+            if ((starts >> lane) & 1ull) {
+                const unsigned long long rest = ~(m >> lane);              // bit 0 is clear: this lane's block is a candidate
+                const int len = rest ? __builtin_ctzll(rest) : 64 - lane;
+                const int rank = __popcll(starts & ((1ull << lane) - 1ull));
+                int b0 = k * kPfBlock - pt.phase, b1 = (k + len) * kPfBlock - pt.phase;
+                b0 = b0 < 0 ? 0 : b0; b1 = b1 > R ? R : b1;
+                ScanSlice sl;
+                sl.task = blockIdx.x; sl.own_begin = b0; sl.c_begin = b0 - overlap < 0 ? 0 : b0 - overlap; sl.c_end = b1;
+                sl.part = first + done + rank; sl.pad0 = sl.pad1 = sl.pad2 = 0;
+                p.pf_slices[sl.part] = sl;
+                cols += (unsigned long long)(b1 - sl.c_begin);
+            }
+            done += __popcll(starts);
+        }
+    } else {
+        for (int s = lane; s < nstatic; s += 64) {
+            const long long b = (long long)s * own;
+            ScanSlice sl;
+            sl.task = blockIdx.x; sl.own_begin = (int)b; sl.c_begin = (int)(b - overlap < 0 ? 0 : b - overlap); sl.c_end = (int)(b + own > R ? R : b + own);
+            sl.part = first + s; sl.pad0 = sl.pad1 = sl.pad2 = 0;
+            p.pf_slices[sl.part] = sl;
+            cols += (unsigned long long)(sl.c_end - sl.c_begin);
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) cols += __shfl_xor(cols, d);
+    if (lane == 0) {
+        atomicAdd(&p.pf_ctl->cols_scanned, cols);
+        PfOut o; o.first = first; o.count = count; o.s0 = S0; o.pruned = pruned;
+        p.pf_out[blockIdx.x] = o;
+    }
+}
+
+// the queue's slices by persistent workgroups (the number of slices is only known on the device)
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_queue_kernel(const SswParams p)
+{
+    SCAN_LDS_SETUP
+    const int lane = threadIdx.x & 63;
+    const int total = p.pf_ctl->qcount;
+    for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(&p.pf_ctl->qnext, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= total) break;
+        const ScanSlice sl = p.pf_slices[idx];
+        const SswTask task = p.tasks[sl.task];
+        const ScanOut fw = scan_forward<GEQ>(p, task, lds, sl.c_begin, sl.own_begin, sl.c_end);
+        if (lane == 0) { ScanPart pt; pt.max = fw.max; pt.col = fw.col; pt.row = fw.row; pt.pad = 0; p.parts[sl.part] = pt; }
+        __syncthreads();
+    }
+}
+
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_finish_queue_kernel(const SswParams p)
+{
+    SCAN_LDS_SETUP
+    const int lane = threadIdx.x & 63;
+    const SswTask task = p.tasks[blockIdx.x];
+    const PfOut po = p.pf_out[blockIdx.x];
+    int v = 0, c = 0x7fffffff, r = 0;
+    for (int k = lane; k < po.count; k += 64) {
+        const ScanPart pt = p.parts[po.first + k];
+        const int c2 = pt.max > 0 ? pt.col : 0x7fffffff;
+        const bool take = pt.max > v || (pt.max == v && c2 < c);
+        v = take ? pt.max : v; c = take ? c2 : c; r = take ? pt.row : r;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v2 = __shfl_xor(v, d), c2 = __shfl_xor(c, d), r2 = __shfl_xor(r, d);
+        const bool take = v2 > v || (v2 == v && c2 < c);
+        v = take ? v2 : v; c = take ? c2 : c; r = take ? r2 : r;
+    }
+    ScanOut fw; fw.max = v; fw.col = v > 0 ? c : -1; fw.row = v > 0 ? r : 0;
+    scan_finish<GEQ>(p, task, fw, lds);
+}
+
+hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, hipStream_t stream)
+{
+    if (geq) {
+        hipLaunchKernelGGL((ssw_scan_pick_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((ssw_scan_queue_kernel<true>), dim3(nworkgroups), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((ssw_scan_finish_queue_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((ssw_scan_pick_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((ssw_scan_queue_kernel<false>), dim3(nworkgroups), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((ssw_scan_finish_queue_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_ssw_scan(bool geq, const SswParams& p, int ntasks, hipStream_t stream)
 {
     if (geq) hipLaunchKernelGGL((ssw_scan_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);

@@ -118,6 +118,7 @@ def lib():
         L.clh_plan_segments.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.clh_plan_traceback_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_plan_prefilter_stats.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -606,6 +607,14 @@ class Plan(object):
         if lib().clh_plan_traceback_counts(self._h, c.ctypes.data) != 0:
             raise ClhError('clh_plan_traceback_counts: %s' % last_error())
         return int(c[0]), int(c[1])
+
+    def prefilter_stats(self):
+        """what the exact column prefilter (csrc/ssw_prefilter.hip) did in the last run: alignments of the sliced scan class, of
+        them with candidate slices, slices run, window columns computed, window columns of the class"""
+        c = np.zeros(5, dtype=np.int64)
+        if lib().clh_plan_prefilter_stats(self._h, c.ctypes.data) != 0:
+            raise ClhError('clh_plan_prefilter_stats: %s' % last_error())
+        return dict(zip(('alignments', 'pruned', 'slices', 'cols_computed', 'cols_window'), (int(x) for x in c)))
 
     def timing(self):
         """([K1 ms per segment], (K1b small-window ms, K1b large-window ms)) for the last run"""

@@ -90,6 +90,13 @@ void clh_plan_destroy(clh_plan* plan);
  * where banded_sw, ssw.c:636-696, reads direction bytes of earlier band iterations; bands above 2048 cells).  Waits for the run. */
 int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts);
 
+/* Diagnostics of the exact column prefilter (csrc/ssw_prefilter.hip) in front of the score pass of short reads on long windows --
+ * the shape of find_bsj.py:196-216, a 20..254-base clip against hit +- 200 kb: a bit-vector edit-distance bound finds the blocks
+ * of the window that can hold the maximum of sw_sse2_byte (ssw.c:123-345) and only those are computed; results are identical with
+ * and without it.  out[0] = alignments of that class in the last run, out[1] = of them with candidate slices instead of the
+ * whole window, out[2] = slices run, out[3] = window columns computed, out[4] = window columns of the class.  Waits for the run. */
+int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out);
+
 /* Launch the batch on packed code arrays that already live in HBM (device pointers).  Asynchronous on `stream`
  * (a hipStream_t).  NULL selects the context's own, private, non-blocking stream -- NOT the legacy default stream: work
  * a caller has queued on the default stream (or on any other stream) is then unordered with these kernels.  A caller

@@ -578,3 +578,102 @@ def test_launch_classes_of_a_mixed_batch(ctx, monkeypatch):
             assert _row_tuple(rows[k]) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
                                            want['query_end'], want['ref_end2']), (k, len(reads[k]), no_wide)
             assert [int(x) for x in cig[rows[k]['cigar_off']:rows[k]['cigar_off'] + rows[k]['cigar_len']]] == want['cigar']
+
+
+def _clip_cases(rng, m, R, n):
+    """(window, clip) pairs for the call-path shape: a short clip somewhere in a long window -- planted with 0..15 % errors, across
+    256-column block borders, at the window's ends, twice (first end column wins, ssw.c:283), next to N runs, and absent"""
+    refs, qs = [], []
+    for case in range(n):
+        L = int(rng.integers(20, min(250, 250 // m)))
+        ref = _rnd(rng, R)
+        kind = case % 8
+        pos = int(rng.integers(0, R - L))
+        if kind == 1:
+            pos = 256 * int(rng.integers(1, R // 256 - 1)) - L // 2          # across a block border
+        if kind == 2:
+            pos = 0
+        if kind == 3:
+            pos = R - L
+        q = _mut(ref[pos:pos + L], rng, float(rng.choice([0.0, 0.04, 0.15])))[:L] or 'A'
+        if kind == 4 and pos > 3 * L:                                       # an exact copy earlier: the tie goes to the first column
+            ref = (ref[:pos - 2 * L] + ref[pos:pos + L] + ref[pos - L:])[:R]
+        if kind == 5:
+            q = _rnd(rng, L)                                                # absent: nothing to prune with
+        if kind == 6:
+            ref = ref[:pos + L // 2] + 'N' * 9 + ref[pos + L // 2 + 9:]
+            q = q[:L // 3] + 'N' + q[L // 3 + 1:]
+        if kind == 7 and pos > 40000:                                       # a weaker copy far away must not win, a stronger one must
+            far = pos - 30000
+            ref = ref[:far] + _mut(ref[pos:pos + L], rng, 0.3)[:L].ljust(L, 'A') + ref[far + L:]
+            ref = ref[:R]
+        refs.append(ref); qs.append(q)
+    return refs, qs
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (2, 2, 3, 1), (1, 3, 5, 2), (3, 1, 2, 2)])
+def test_prefilter_on_long_windows_vs_oracle(ctx, scheme, monkeypatch):
+    """The exact column prefilter in front of K1s on windows of 32 kb and more (csrc/ssw_prefilter.hip, find_bsj.py:196-216's
+    shape): block minima of the edit-distance bound, a seed pass, K1s on the candidate blocks only.  Rows equal the oracle's with
+    the filter and equal the static slices' without it (CLH_NO_PREFILTER); the filter must actually prune the planted clips."""
+    import torch
+    from ciri_long_amd import hip, utils
+    m, x, o, e = scheme
+    rng = np.random.default_rng(1700 + sum(scheme))
+    refs, qs = [], []
+    for R in [32768, 33000, 90000, 200000]:
+        a, b = _clip_cases(rng, m, R, 8)
+        refs += a; qs += b
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    d_r = torch.from_numpy(rd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
+    want = [oracle_align(ref, q, *scheme) for ref, q in zip(refs, qs)]
+    got_rows = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('CLH_NO_PREFILTER', '1')
+        plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=False)
+        assert sum(c for rv, c, _a, _b in plan.segments() if rv == -1) == len(qs)
+        plan.run(d_r.data_ptr(), d_f.data_ptr())
+        rows, _ = plan.fetch()
+        st = plan.prefilter_stats()
+        plan.close()
+        got_rows[off] = rows
+        for k, (w, r) in enumerate(zip(want, rows)):
+            got = (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1']))
+            assert got == (w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']), (off, k, len(qs[k]), len(refs[k]), got)
+        if off:
+            assert st['alignments'] == 0 and st['pruned'] == 0
+        else:
+            assert st['alignments'] == len(qs) and st['pruned'] >= len(qs) // 2 and st['cols_computed'] < st['cols_window'] // 3, st
+    monkeypatch.delenv('CLH_NO_PREFILTER')
+    assert (got_rows[False] == got_rows[True]).all()
+    # a refs buffer that is not 256-byte aligned: the filter is off for the run, the static slices run, same rows
+    d_f2 = torch.zeros(len(fd) + 256, dtype=torch.uint8, device='cuda')
+    d_f2[3:3 + len(fd)] = d_f
+    plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=False)
+    plan.run(d_r.data_ptr(), d_f2.data_ptr() + 3)
+    rows, _ = plan.fetch()
+    assert plan.prefilter_stats()['pruned'] == 0 and (rows == got_rows[True]).all()
+    plan.close()
+    # windows of a resident genome, both strands (minus-strand windows run down the addresses)
+    text = _rnd(rng, 260000)
+    text = text[:5000] + text[5000:5600].lower() + text[5600:]
+    g = hip.Genome(ctx, {'chr1': text})
+    wins, minus, queries, strings = [], [], [], []
+    for k in range(16):
+        s = int(rng.integers(0, 30000)); e2 = s + int(rng.integers(40000, 220000))
+        w = text[s:e2]
+        mstrand = k % 2 == 1
+        wstr = utils.revcomp(w) if mstrand else w
+        L = int(rng.integers(20, min(250, 250 // m)))
+        p0 = [int(rng.integers(0, len(wstr) - L)), 0, len(wstr) - L, 256 * 7 - (s & 255) - 5][k // 4 % 4] if k < 14 else int(rng.integers(0, len(wstr) - L))
+        p0 = max(0, p0)
+        queries.append((_mut(wstr[p0:p0 + L].upper(), rng, 0.08)[:L] or 'A') if k != 13 else _rnd(rng, L)); strings.append(wstr)
+        wins.append(('chr1', s, e2)); minus.append(mstrand)
+    qd, qo = hip.pack(queries)
+    rows, _ = g.ssw_windows(qd, qo, wins, minus, hip.score_matrix(m, x), o, e, want_score2=False, want_cigar=False)
+    for k, (wstr, q, r) in enumerate(zip(strings, queries, rows)):
+        w = oracle_align(wstr, q, *scheme)
+        got = (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1']))
+        assert got == (w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']), ('window', k, minus[k], got)
+    g.close()

@@ -1,0 +1,112 @@
+"""tools/prefilter_model.py: the edit-distance bound in front of K1s on long windows (csrc/ssw_prefilter.hip) -- the
+bit-vector recurrence against the plain dynamic programme, the bound H(j) <= M L - c d(j) against the exact column maxima
+of the 8-bit pass (ssw.c:123-345 as tools/scan_model.py states it, itself held to the oracle by test_scan_model.py), and the
+filtered forward pass against the whole-window pass: same maximum, same first column, same smallest row."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+from oracle_lib import make_mat  # noqa: E402
+from prefilter_model import (PF_B, block_minima, bound_consts, candidate_runs, myers_semiglobal, prefilter_forward,  # noqa: E402
+                             semiglobal_dp)
+from scan_model import scan_pass  # noqa: E402
+
+SCORINGS = [(1, 1, 1, 1), (2, 2, 3, 1), (1, 3, 5, 2), (3, 1, 2, 2)]
+
+
+def _mut(s, rng, p):
+    out = []
+    for c in s:
+        u = rng.random()
+        if u < p / 3:
+            continue
+        if u < 2 * p / 3:
+            out.append(int(rng.integers(0, 4))); continue
+        out.append(int(c))
+        if u < p:
+            out.extend(int(x) for x in rng.integers(0, 4, int(rng.integers(1, 3))))
+    return np.array(out or [0], dtype=np.int8)
+
+
+def _case(rng, R, L, p, nrich=False, plant=True):
+    ref = rng.integers(0, 4, R).astype(np.int8)
+    if nrich:
+        for _ in range(3):
+            a = int(rng.integers(0, max(1, R - 10))); ref[a:a + int(rng.integers(1, 40))] = 4
+    if plant:
+        st = int(rng.integers(0, max(1, R - L)))
+        read = _mut(ref[st:st + L], rng, p)[:L]
+    else:
+        read = rng.integers(0, 4, L).astype(np.int8)
+    if nrich and len(read) > 4:
+        read[int(rng.integers(0, len(read)))] = 4
+    return ref, read
+
+
+@pytest.mark.parametrize('sc', SCORINGS)
+def test_bit_vector_recurrence_equals_the_plain_programme(sc):
+    m, x, go, ge = sc
+    mat = make_mat(m, x)
+    rng = np.random.Generator(np.random.PCG64(11 + m))
+    for _ in range(12):
+        L = int(rng.integers(1, 70))
+        ref, read = _case(rng, int(rng.integers(1, 300)), L, 0.2, nrich=True)
+        assert (myers_semiglobal(ref, read, mat, 5, ge) == semiglobal_dp(ref, read, mat, 5, ge)).all()
+
+
+@pytest.mark.parametrize('sc', SCORINGS)
+def test_the_bound_holds_in_every_column(sc):
+    m, x, go, ge = sc
+    mat = make_mat(m, x)
+    M, c = bound_consts(mat, 5, ge)
+    rng = np.random.Generator(np.random.PCG64(23 + m))
+    tight = 0
+    for k in range(40):
+        L = int(rng.integers(1, min(250 // m, 120)))
+        ref, read = _case(rng, int(rng.integers(1, 900)), L, float(rng.choice([0.0, 0.1, 0.3])), nrich=k % 3 == 0, plant=k % 4 != 3)
+        L = len(read)
+        colmax = scan_pass(ref, read, mat, 5, go, ge, L)[3]
+        d = myers_semiglobal(ref, read, mat, 5, ge)
+        assert (colmax <= M * L - c * d).all()
+        tight += int((colmax == M * L - c * d).any())
+    assert tight > 0          # an exact copy attains it
+
+
+@pytest.mark.parametrize('sc', SCORINGS)
+def test_filtered_forward_pass_equals_the_whole_window_pass(sc):
+    m, x, go, ge = sc
+    mat = make_mat(m, x)
+    rng = np.random.Generator(np.random.PCG64(37 + m))
+    pruned = 0
+    for k in range(14):
+        L = int(rng.integers(8, min(250 // m, 90)))
+        R = int(rng.choice([700, 2049, 5000]))
+        ref, read = _case(rng, R, L, float(rng.choice([0.0, 0.08, 0.2])), nrich=k % 4 == 1, plant=k % 5 != 4)
+        if k % 3 == 0:                                   # the clip twice: the first column must win the tie
+            a = int(rng.integers(0, R - 2 * len(read) - 300))
+            ref[a:a + len(read)] = read; ref[a + len(read) + 200:a + 2 * len(read) + 200] = read
+        L = len(read)
+        phase = int(rng.integers(0, PF_B))
+        want = scan_pass(ref, read, mat, 5, go, ge, L)[:3]
+        for cap in (None, 1):                            # cap 1: the static slices unless one run suffices
+            got = prefilter_forward(ref, read, mat, 5, go, ge, phase=phase, cap=cap)
+            assert got[:3] == want, (k, phase, cap, got, want)
+            pruned += int(got[3]['pruned'])
+    assert pruned > 4
+
+
+def test_candidate_runs_cover_exactly_the_blocks_under_the_threshold():
+    rng = np.random.Generator(np.random.PCG64(5))
+    for _ in range(50):
+        dm = rng.integers(0, 6, int(rng.integers(1, 200)))
+        thr = int(rng.integers(0, 6))
+        cover = np.zeros(len(dm), dtype=bool)
+        for b, e in candidate_runs(dm, thr):
+            assert not cover[b:e].any() and e - b <= 64
+            cover[b:e] = True
+        assert (cover == (dm <= thr)).all()
+    d = np.arange(1000)
+    assert list(block_minima(d, 0)) == [0, 256, 512, 768] and list(block_minima(d, 100)) == [0, 156, 412, 668, 924]

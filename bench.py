@@ -202,7 +202,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         nwide = int(ssw_plan.traceback_counts()[0])
@@ -461,21 +461,30 @@ def run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, steps, warmup, exp
 
 
 # ---- the further lines of `extra` (N = 1 only) -------------------------------------------------------------------------
-def extra_production_shape(torch, hip, synth, ctx, n=4000):
-    """20-300 nt clips against hit +- 200 kb windows of a resident 20 Mb genome (find_bsj.py:191-216), K5 + K1"""
+def extra_production_shape(torch, hip, synth, ctx, n=4000, r03_strands=False):
+    """20-300 nt clips against hit +- 200 kb windows of a resident 20 Mb genome (find_bsj.py:191-216), K5 + K1.  Every clip is
+    a mutated copy of a stretch of ITS window, in the window's orientation: for a minus-strand hit the reference aligns the
+    clip against revcomp(window) (find_bsj.py:214), so the clip is drawn from the reverse complement.  r03_strands=True is the
+    line as rounds 2-3 printed it -- clips always drawn from the plus strand, i.e. half of them (the minus-strand windows) have
+    no locus in their window and nothing can be pruned for them."""
     rng = np.random.Generator(np.random.PCG64(synth.SEEDS['C3'] + 1))
     G = 20_000_000
     codes = rng.integers(0, 4, G).astype(np.int8)
     genome = hip.Genome(ctx, [('chr1', B_ASCII[codes].tobytes().decode())])
-    woff = np.zeros(n, dtype=np.int64); wlen = np.zeros(n, dtype=np.int64); clips = []
+    woff = np.zeros(n, dtype=np.int64); wlen = np.zeros(n, dtype=np.int64); clips = []; src = []
     for k in range(n):
         c = int(rng.integers(300000, G - 300000))
         s, e = c - 200000, c + 200000 + int(rng.integers(100, 1500))
         L = int(rng.integers(20, 301))
         p = int(rng.integers(s, e - L))
         clips.append(synth.mutate(codes[p:p + L], rng))
+        src.append((p, L))
         woff[k], wlen[k] = s, e - s
     minus = rng.integers(0, 2, n).astype(np.uint8)
+    if not r03_strands:
+        for k in np.nonzero(minus)[0]:
+            p, L = src[k]
+            clips[k] = synth.mutate((3 - codes[p:p + L][::-1]).astype(np.int8), rng)
     cd, co = hip.pack(clips)
     d_clips = torch.from_numpy(cd.view(np.uint8)).cuda()
     tstream = torch.cuda.Stream()
@@ -487,16 +496,21 @@ def extra_production_shape(torch, hip, synth, ctx, n=4000):
         genome.count_n_spans(woff, wlen)
         plan.run(d_clips.data_ptr(), genome.codes_ptr, stream)
         return plan.fetch()
-    step()
-    K = 3
+    rows, _ = step()
+    K = 5
     t0 = time.perf_counter()
     for _ in range(K):
         step()
     el = (time.perf_counter() - t0) / K
+    pf = plan.prefilter_stats()
     launches, valu = k1_launches(plan, lambda: plan.run(d_clips.data_ptr(), genome.codes_ptr, stream), co, wlen)
     genome.close()
-    return {'workload': 'production shape: %d clips of 20-300 nt vs hit +- 200 kb windows of a resident 20 Mb genome, both strands (K5 count_n + K1, rows to the host)' % n,
-            'value': n / el, 'unit': 'clips/s', 'ms_per_step': el * 1e3, 'launches': launches, 'valu_roofline': valu, 'roofline': roofline_of(launches, False)}
+    return {'workload': 'production shape: %d clips of 20-300 nt (raw-read error rates) vs hit +- 200 kb windows of a resident 20 Mb genome, both strands (K5 count_n + K1, rows to the host); %s'
+                        % (n, 'clips drawn from the plus strand only: the minus-strand half has no locus in its window (the line of rounds 2-3)' if r03_strands else
+                           'every clip drawn from its window in the window\'s orientation (find_bsj.py:214: minus-strand hits align against revcomp(window))'),
+            'value': n / el, 'unit': 'clips/s', 'ms_per_step': el * 1e3, 'launches': launches, 'valu_roofline': valu, 'roofline': roofline_of(launches, True),
+            'prefilter': pf, 'mean_score_over_len': float(np.mean(rows['score1'] / np.diff(co))),
+            'valu_note': 'cells = read x window of every alignment: with the prefilter most of them are never computed, so GCUPS here is an EFFECTIVE rate, not an issue rate'}
 
 
 def extra_collapse(torch, hip, synth, ctx, ncl=200):
@@ -694,6 +708,7 @@ def main():
             s = run_full(torch, dist, hip, synth, ctx, 'c4', 125000, 0, 1, 2, 1, None)
             extra['c4'] = dict(s, unit='reads/s', workload='C4 per-GPU share: 125000 reads of 500-4000 bases through the C3 step')
             extra['production_shape'] = extra_production_shape(torch, hip, synth, ctx)
+            extra['production_shape_r03'] = extra_production_shape(torch, hip, synth, ctx, r03_strands=True)
             extra['collapse_c5'] = extra_collapse(torch, hip, synth, ctx)
             extra['stage1_files'] = extra_stage1(hip, synth, ctx)
             out['e2e_stage1_reads_per_s'] = extra['stage1_files']['e2e_stage1_reads_per_s']

@@ -644,7 +644,8 @@ def test_prefilter_on_long_windows_vs_oracle(ctx, scheme, monkeypatch):
         if off:
             assert st['alignments'] == 0 and st['pruned'] == 0
         else:
-            assert st['alignments'] == len(qs) and st['pruned'] >= len(qs) // 2 and st['cols_computed'] < st['cols_window'] // 3, st
+            # (1/1/1/1: the bound is tight; with larger match scores a substitution still counts c = min(M, gap_extend) only)
+            assert st['alignments'] == len(qs) and st['pruned'] >= len(qs) // 2 and st['cols_computed'] < st['cols_window'] // (3 if m == 1 else 1), st
     monkeypatch.delenv('CLH_NO_PREFILTER')
     assert (got_rows[False] == got_rows[True]).all()
     # a refs buffer that is not 256-byte aligned: the filter is off for the run, the static slices run, same rows

@@ -110,3 +110,31 @@ def test_candidate_runs_cover_exactly_the_blocks_under_the_threshold():
         assert (cover == (dm <= thr)).all()
     d = np.arange(1000)
     assert list(block_minima(d, 0)) == [0, 256, 512, 768] and list(block_minima(d, 100)) == [0, 156, 412, 668, 924]
+
+
+@pytest.mark.parametrize('sc', SCORINGS)
+def test_the_bound_of_a_read_in_pieces_holds_in_every_block(sc):
+    """reads above 254 bases go through the bit-vector pass in pieces (csrc/ssw_scan_wide.hip): M L - c D(block) bounds every
+    column maximum of the block.  Small pieces on short reads here, so that the exact 8-bit pass is the checker."""
+    from prefilter_model import piece_rows, piecewise_block_bound
+    m, x, go, ge = sc
+    mat = make_mat(m, x)
+    M, c = bound_consts(mat, 5, ge)
+    rng = np.random.Generator(np.random.PCG64(51 + m))
+    assert piece_rows(300) == [(0, 150), (150, 150)] and piece_rows(254) == [(0, 254)] and sum(r for _, r in piece_rows(1000)) == 1000
+    tight = 0
+    for k in range(24):
+        L = int(rng.integers(20, min(250 // m, 110)))
+        R = int(rng.choice([300, 1500, 2600]))
+        ref, read = _case(rng, R, L, float(rng.choice([0.0, 0.1, 0.25])), nrich=k % 3 == 0, plant=k % 4 != 3)
+        L = len(read)
+        phase = int(rng.integers(0, PF_B))
+        colmax = scan_pass(ref, read, mat, 5, go, ge, L)[3]
+        for max_rows in (7, 16, 33):
+            D, sb = piecewise_block_bound(ref, read, mat, 5, ge, phase=phase, max_rows=max_rows)
+            for b in range(len(D)):
+                lo, hi = max(0, b * PF_B - phase), min(R, (b + 1) * PF_B - phase)
+                if hi > lo:
+                    assert colmax[lo:hi].max() <= M * L - c * D[b], (k, max_rows, b)
+                    tight += int(colmax[lo:hi].max() == M * L - c * D[b])
+    assert tight > 0

@@ -171,3 +171,38 @@ def prefilter_forward(ref, read, mat, n, gapO, gapE, phase=0, cap=None, chunk=25
     if best[0] == 0:
         return 0, -1, 0, info
     return best[0], best[1], best[2], info
+
+
+# ---- reads above the bit-vector's 8 registers: the read in PIECES ------------------------------------------------------------
+# Cut a local alignment that ends at column j at the piece borders of the read.  The part inside piece k (rows L_k) ends at
+# some column j_k of [j - span, j] (span = L + L M / gapE: what a local alignment can cover) and, charging every gap base to the
+# piece it falls in (a gap of n bases costs at least n gapE; one that straddles a border is charged by bases), scores at most
+# M L_k - c d_k(j_k), where d_k is the semi-global distance of piece k alone; a piece the alignment does not touch contributes
+# 0 <= M L_k - c d_k(anything).  Hence
+#        H(j) <= sum over k of ( M L_k - c min over j' in [j - span, j] of d_k(j') )  =  M L - c D(j),
+# and per block of columns D(block b) >= sum over k of the minimum of piece k's block minima over blocks b - sb .. b,
+# sb = ceil(span / 256).  csrc/ssw_scan_wide.hip (ssw_scanw_seed_kernel / ssw_scanw_pick_kernel) uses exactly this sum.
+def piece_rows(L, max_rows=254):
+    """row ranges [(row0, rows)] of the pieces: as few as fit max_rows, equal sizes"""
+    K = (L + max_rows - 1) // max_rows
+    base, extra = divmod(L, K)
+    out, r = [], 0
+    for k in range(K):
+        n = base + (1 if k < extra else 0)
+        out.append((r, n)); r += n
+    return out
+
+
+def piecewise_block_bound(ref, read, mat, n, gapE, phase=0, max_rows=254):
+    """D per block (the sum of the pieces' windowed block minima) and the number of blocks the window of a piece reaches back"""
+    ref = np.asarray(ref); read = np.asarray(read)
+    L = len(read)
+    M, c = bound_consts(mat, n, gapE)
+    span = L + (L * M + gapE - 1) // gapE
+    sb = (span + PF_B - 1) // PF_B
+    D = None
+    for r0, rows in piece_rows(L, max_rows):
+        dm = block_minima(myers_semiglobal(ref, read[r0:r0 + rows], mat, n, gapE), phase)
+        wm = np.array([dm[max(0, b - sb):b + 1].min() for b in range(len(dm))], dtype=np.int64)
+        D = wm if D is None else D + wm
+    return D, sb

@@ -190,6 +190,8 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
             cls[scan & (np.asarray(wlen) >= 32768)] = -1
         if not os.environ.get('CLH_NO_SCANW'):                   # class -3 = K1w, the row-scan kernel for long reads / large scores (scanw_class_ok)
             cls[~scan & (qlen <= 4096) & (np.asarray(wlen) < 32768) & (max_match * qlen < 32000)] = -3
+            if not os.environ.get('CLH_NO_SLICES') and not os.environ.get('CLH_NO_PREFILTER'):      # class -4 = K1w tasks on long windows behind the prefilter (scanw_sliced_ok)
+                cls[~scan & (qlen <= 4096) & (np.asarray(wlen) >= 32768) & (np.asarray(wlen) < 1500000) & (max_match * qlen < 32000)] = -4
     out, cells_total, k1ms = [], 0, 0.0
     merged = []                                  # (a large K1w class runs as several launches: one line for the class)
     for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
@@ -202,7 +204,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel', -4: 'ssw_prefilter_kernel + ssw_scanw_seed/pick/queue/combine kernels (K1w tasks on long windows)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         nwide = int(ssw_plan.traceback_counts()[0])

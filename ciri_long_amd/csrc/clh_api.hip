@@ -141,10 +141,16 @@ struct clh_plan {
     struct Seg { int rv, begin, count; };
     std::vector<clh::ScanSlice> slices;      // window slices of the sliced scan class (one segment at most)
     void *d_slices = nullptr, *d_parts = nullptr;
-    // prefilter of the sliced scan class (ssw_prefilter.hip): block minima of the edit-distance bound, slices made on the device
-    bool pf_on = false;
-    int pf_nwork = 0, pf_bpl = 0, pf_cap = 0, pf_ntasks = 0;
-    void *d_pf_tasks = nullptr, *d_pf_work = nullptr, *d_pf_dmin = nullptr, *d_pf_slices = nullptr, *d_pf_out = nullptr, *d_pf_ctl = nullptr;
+    // the long-window classes behind the prefilter (ssw_prefilter.hip): [0] K1s (kRvScanSliced), [1] K1w (kRvScanWideSliced)
+    struct PfClass {
+        bool on = false;
+        int ntasks = 0, nwork = 0, bpl = 0, cap = 0;
+        void *d_win = nullptr, *d_pieces = nullptr, *d_work = nullptr, *d_dmin = nullptr, *d_queue = nullptr, *d_out = nullptr, *d_ctl = nullptr,
+             *d_bound = nullptr, *d_parts = nullptr;
+        int ws_row0 = 0, ws_slot = 0, ws_wgs = 0;
+        int64_t ws_dirs_off = 0;
+    } pf[2];
+    int n_rows = 0;                          // result rows: n_all + the scratch rows of the K1w long-window class
     std::vector<int32_t> slice_base;         // task-level slices of the anti-diagonal classes: first window column of scratch row k
     void* d_slice_base = nullptr;
     int n_all = 0;                           // tasks incl. those slices (their result rows sit behind the n real ones)
@@ -169,9 +175,9 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     (void)hipSetDevice(c->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
-                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base,
-                    pl->d_pf_tasks, pl->d_pf_work, pl->d_pf_dmin, pl->d_pf_slices, pl->d_pf_out, pl->d_pf_ctl};
+                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base};
     for (void* b : bufs) c->release(b);
+    for (auto& f : pl->pf) { void* pb[] = {f.d_win, f.d_pieces, f.d_work, f.d_dmin, f.d_queue, f.d_out, f.d_ctl, f.d_bound, f.d_parts}; for (void* b : pb) c->release(b); }
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : pl->chain_ev) (void)hipEventDestroy(e);
     if (pl->done_ev) (void)hipEventDestroy(pl->done_ev);
@@ -223,6 +229,19 @@ static bool prefilter_ok(const clh_ssw_opts* o, int max_match)
     return getenv("CLH_NO_PREFILTER") == nullptr && !o->want_score2 && max_match >= 1 && o->gap_extend >= 1;
 }
 
+// K1w on long windows (ssw_scan_wide.hip, class kRvScanWideSliced): what K1s's 8-bit class does not take, on windows of 32 kb and
+// more with call-path options -- the prefilter in pieces of the read, a seed, candidate regions as K1w tasks.  Windows up to 1.5 Mb
+// (a static slice + its overlap must stay inside K1w's 32 767 columns).  Without the prefilter (CLH_NO_PREFILTER) these alignments
+// run as window-slice tasks of the anti-diagonal classes, as in rounds 2-3.
+static bool scanw_sliced_ok(int64_t L, int64_t R, const clh_ssw_opts* o, int max_match)
+{
+    const bool off = getenv("CLH_NO_SCAN") != nullptr || getenv("CLH_NO_SCANW") != nullptr || getenv("CLH_NO_SLICES") != nullptr;
+    if (off || !prefilter_ok(o, max_match)) return false;
+    const int64_t overlap = L + (L * max_match + o->gap_extend - 1) / o->gap_extend + 32;
+    const int64_t own = std::max<int64_t>(std::max<int64_t>(8192, 2 * overlap), (R + 63) / 64);
+    return L <= 4096 && R >= kSliceMinWindow && own + overlap < 32768 && (int64_t)max_match * L < 32000 && o->gap_extend <= 16 && o->gap_open <= 255;
+}
+
 // ref_off != nullptr: packed references, alignment a against [ref_off[a], ref_off[a+1]).  Otherwise windows of a resident
 // genome: win_off[a], win_len[a], win_rc[a] (1 = read backwards and complemented).
 static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
@@ -268,7 +287,8 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         const int rc = (!ref_off && win_rc && win_rc[a]) ? 1 : 0;
         const int rows = (int)((L + 15) / 16) * 16;
         const int rv = scan_class_ok(L, o, mx, -mn) ? (scan_sliced(R, o) ? clh::kRvScanSliced : clh::kRvScan)
-                                                    : (scanw_class_ok(L, R, o, mx) ? clh::kRvScanWide : rv_class_for(rows));
+                                                    : (scanw_class_ok(L, R, o, mx) ? clh::kRvScanWide
+                                                       : (scanw_sliced_ok(L, R, o, mx) ? clh::kRvScanWideSliced : rv_class_for(rows)));
         cls[a] = rv;
         clh::SswTask& t = pl->tasks[a];
         t.read_off = read_off[a]; t.ref_off = ref_off ? ref_off[a] : (rc ? win_off[a] + R - 1 : win_off[a]);
@@ -355,35 +375,77 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         k = e;
     }
     pl->tasks.swap(sorted);
-    std::vector<clh::PfTask> pf_tasks;
-    std::vector<clh::PfWork> pf_work;
+    pl->n_rows = n_all;
     for (const auto& sg : pl->segs) {
-        if (sg.rv != clh::kRvScanSliced || !prefilter_ok(o, mx)) continue;
-        // per task: the 256-byte blocks of the refs buffer its window touches, in processing order (minus-strand windows run down
-        // the addresses); a lane of the prefilter owns pf_bpl of them
-        pl->pf_on = true; pl->pf_ntasks = sg.count;
-        int64_t total = 0, cap = 0;
-        pf_tasks.resize(sg.count);
+        const int ci = sg.rv == clh::kRvScanSliced ? 0 : (sg.rv == clh::kRvScanWideSliced ? 1 : -1);
+        if (ci < 0 || !prefilter_ok(o, mx)) continue;
+        // per alignment: the 256-byte blocks of the refs buffer its window touches, in processing order (minus-strand windows run
+        // down the addresses); per piece of its read (<= 254 rows) one run of block minima; a lane of the prefilter owns bpl blocks
+        clh_plan::PfClass& f = pl->pf[ci];
+        std::vector<clh::PfWin> wins(sg.count);
+        std::vector<clh::PfTask> pieces;
+        std::vector<clh::PfWork> work;
+        int64_t total = 0, cap = 0, dtot = 0;
+        int lmax = 1;
         for (int k = 0; k < sg.count; ++k) {
             const clh::SswTask& t = pl->tasks[sg.begin + k];
-            clh::PfTask& pt = pf_tasks[k];
+            clh::PfWin& w = wins[k];
+            memset(&w, 0, sizeof(w));
             const int64_t R = t.ref_len;
-            if (t.ref_rc) { const int64_t hi = t.ref_off, lo = hi - R + 1; pt.mem_block0 = (int32_t)(hi >> 8); pt.phase = (int32_t)(255 - (hi & 255)); pt.nsub = (int32_t)((hi >> 8) - (lo >> 8) + 1); }
-            else { const int64_t lo = t.ref_off, hi = lo + R - 1; pt.mem_block0 = (int32_t)(lo >> 8); pt.phase = (int32_t)(lo & 255); pt.nsub = (int32_t)((hi >> 8) - (lo >> 8) + 1); }
-            pt.sub_off = (int32_t)total;
-            total += pt.nsub;
-            cap += std::max<int64_t>(64, pt.nsub / 8 + 1);
-            if (total > 0x7fffffffll || cap > 0x7fffffffll) { fail(CLH_E_CAPACITY, "batch too large for the prefilter's 32-bit block offsets; split it"); delete pl; return nullptr; }
+            if (t.ref_rc) { const int64_t hi = t.ref_off, lo = hi - R + 1; w.mem_block0 = (int32_t)(hi >> 8); w.phase = (int32_t)(255 - (hi & 255)); w.nsub = (int32_t)((hi >> 8) - (lo >> 8) + 1); }
+            else { const int64_t lo = t.ref_off, hi = lo + R - 1; w.mem_block0 = (int32_t)(lo >> 8); w.phase = (int32_t)(lo & 255); w.nsub = (int32_t)((hi >> 8) - (lo >> 8) + 1); }
+            const int L = t.read_len, K = (L + 253) / 254;
+            w.piece_first = (int32_t)pieces.size(); w.piece_count = K; w.d_off = (int32_t)dtot;
+            dtot += w.nsub;
+            for (int q = 0, r0 = 0; q < K; ++q) {
+                const int rows = L / K + (q < L % K ? 1 : 0);
+                pieces.push_back({k, r0, rows, (int32_t)total});
+                r0 += rows; total += w.nsub;
+            }
+            cap += ci == 0 ? std::max<int64_t>(64, w.nsub / 8 + 1) : 2 * 64;
+            lmax = std::max(lmax, L);
+            if (total > 0x7fffffffll || cap > 0x3fffffffll) { fail(CLH_E_CAPACITY, "batch too large for the prefilter's 32-bit block offsets; split it"); delete pl; return nullptr; }
         }
         int bpl = (int)std::min<int64_t>(16, std::max<int64_t>(4, total / (64 * 12288)));
         if (const char* e = getenv("CLH_PF_BPL")) bpl = std::max(1, atoi(e));
-        pl->pf_bpl = bpl; pl->pf_cap = (int)cap;
-        for (int k = 0; k < sg.count; ++k)
-            for (int fb = 0; fb < pf_tasks[k].nsub; fb += 64 * bpl) pf_work.push_back({k, fb});
-        pl->pf_nwork = (int)pf_work.size();
+        for (int q = 0; q < (int)pieces.size(); ++q)
+            for (int fb = 0; fb < wins[pieces[q].task].nsub; fb += 64 * bpl) work.push_back({q, fb});
+        f.on = true; f.ntasks = sg.count; f.bpl = bpl; f.cap = (int)cap; f.nwork = (int)work.size();
+        f.d_win = ctx->alloc(sizeof(clh::PfWin) * wins.size());
+        f.d_pieces = ctx->alloc(sizeof(clh::PfTask) * pieces.size());
+        f.d_work = ctx->alloc(sizeof(clh::PfWork) * std::max<size_t>(work.size(), 1));
+        f.d_dmin = ctx->alloc((size_t)total + 64);
+        f.d_out = ctx->alloc(sizeof(clh::PfOut) * wins.size());
+        f.d_ctl = ctx->alloc(sizeof(clh::PfCtl));
+        bool ok = f.d_win && f.d_pieces && f.d_work && f.d_dmin && f.d_out && f.d_ctl;
+        if (ci == 0) {
+            f.d_queue = ctx->alloc(sizeof(clh::ScanSlice) * (size_t)cap);
+            f.d_parts = ctx->alloc(sizeof(clh::ScanPart) * (size_t)cap);
+            ok = ok && f.d_queue && f.d_parts;
+        } else {
+            // 2 seed tasks per alignment in fixed places, then the candidate queue; 130 scratch result rows per alignment behind every other
+            // row; the K1w workspaces belong to the persistent workgroups, not to the tasks
+            f.d_queue = ctx->alloc(sizeof(clh::WsTask) * ((size_t)2 * sg.count + (size_t)cap));
+            f.d_bound = ctx->alloc(sizeof(uint16_t) * (size_t)(dtot + 64));
+            ok = ok && f.d_queue && f.d_bound;
+            f.ws_row0 = pl->n_rows;
+            pl->n_rows += clh::kWsRows * sg.count;
+            f.ws_slot = (int)((clh::scanw_task_bytes(lmax) + 255) & ~(size_t)255);
+            f.ws_wgs = (int)std::min<int64_t>((int64_t)2 * sg.count + cap, (int64_t)ctx->n_cu * 12);
+            pl->strip_bytes = (pl->strip_bytes + 255) & ~(size_t)255;
+            f.ws_dirs_off = (int64_t)pl->strip_bytes;
+            pl->strip_bytes += (size_t)f.ws_slot * (size_t)f.ws_wgs;
+        }
+        if (!ok || hipMemcpy(f.d_win, wins.data(), sizeof(clh::PfWin) * wins.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(f.d_pieces, pieces.data(), sizeof(clh::PfTask) * pieces.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            (!work.empty() && hipMemcpy(f.d_work, work.data(), sizeof(clh::PfWork) * work.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+            hipMemset(f.d_ctl, 0, sizeof(clh::PfCtl)) != hipSuccess) {
+            fail(CLH_E_HIP, "out of device memory while building the plan");
+            clh_plan_destroy(pl); return nullptr;
+        }
     }
     for (const auto& sg : pl->segs) {
-        if (sg.rv != clh::kRvScanSliced || pl->pf_on) continue;
+        if (sg.rv != clh::kRvScanSliced || pl->pf[0].on) continue;
         for (int k = 0; k < sg.count; ++k) {
             clh::SswTask& t = pl->tasks[sg.begin + k];
             const int64_t R = t.ref_len, L = t.read_len;
@@ -403,7 +465,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
     }
 
     pl->d_tasks = ctx->alloc(sizeof(clh::SswTask) * (size_t)std::max(n_all, 1));
-    pl->d_results = ctx->alloc(sizeof(clh::SswResult) * (size_t)std::max(n_all, 1));
+    pl->d_results = ctx->alloc(sizeof(clh::SswResult) * (size_t)std::max(pl->n_rows, 1));
     pl->d_cigar_len = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n_all, 1));
     if (!pl->slice_base.empty()) {
         pl->d_slice_base = ctx->alloc(sizeof(int32_t) * pl->slice_base.size());
@@ -423,22 +485,6 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         pl->d_slices = ctx->alloc(sizeof(clh::ScanSlice) * pl->slices.size());
         pl->d_parts = ctx->alloc(sizeof(clh::ScanPart) * pl->slices.size());
         if (!pl->d_slices || !pl->d_parts || hipMemcpy(pl->d_slices, pl->slices.data(), sizeof(clh::ScanSlice) * pl->slices.size(), hipMemcpyHostToDevice) != hipSuccess) {
-            fail(CLH_E_HIP, "out of device memory while building the plan");
-            clh_plan_destroy(pl); return nullptr;
-        }
-    }
-    if (pl->pf_on) {
-        pl->d_pf_tasks = ctx->alloc(sizeof(clh::PfTask) * pf_tasks.size());
-        pl->d_pf_work = ctx->alloc(sizeof(clh::PfWork) * std::max<size_t>(pf_work.size(), 1));
-        pl->d_pf_dmin = ctx->alloc((size_t)pf_tasks.back().sub_off + (size_t)pf_tasks.back().nsub + 64);
-        pl->d_pf_slices = ctx->alloc(sizeof(clh::ScanSlice) * (size_t)pl->pf_cap);
-        pl->d_parts = ctx->alloc(sizeof(clh::ScanPart) * (size_t)pl->pf_cap);
-        pl->d_pf_out = ctx->alloc(sizeof(clh::PfOut) * pf_tasks.size());
-        pl->d_pf_ctl = ctx->alloc(sizeof(clh::PfCtl));
-        if (!pl->d_pf_tasks || !pl->d_pf_work || !pl->d_pf_dmin || !pl->d_pf_slices || !pl->d_parts || !pl->d_pf_out || !pl->d_pf_ctl ||
-            hipMemcpy(pl->d_pf_tasks, pf_tasks.data(), sizeof(clh::PfTask) * pf_tasks.size(), hipMemcpyHostToDevice) != hipSuccess ||
-            (!pf_work.empty() && hipMemcpy(pl->d_pf_work, pf_work.data(), sizeof(clh::PfWork) * pf_work.size(), hipMemcpyHostToDevice) != hipSuccess) ||
-            hipMemset(pl->d_pf_ctl, 0, sizeof(clh::PfCtl)) != hipSuccess) {
             fail(CLH_E_HIP, "out of device memory while building the plan");
             clh_plan_destroy(pl); return nullptr;
         }
@@ -647,7 +693,7 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     std::vector<size_t> ord(pl->segs.size());
     for (size_t k = 0; k < ord.size(); ++k) ord[k] = k;
     std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
-        auto weight = [](int rv) { return rv == clh::kRvStrips ? 1000 : (rv == clh::kRvScanWide ? 900 : rv); };      // (K1w: whole long reads, one wave each)
+        auto weight = [](int rv) { return rv == clh::kRvStrips ? 1000 : (rv == clh::kRvScanWide ? 900 : (rv == clh::kRvScanWideSliced ? 800 : rv)); };      // (K1w: whole long reads, one wave each)
         const int rx = weight(pl->segs[x].rv), ry = weight(pl->segs[y].rv);
         return rx > ry;
     });
@@ -685,17 +731,24 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         if (chained) ls = st;
         P.tasks = (const clh::SswTask*)pl->d_tasks + s.begin;
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 0], ls));
-        if (s.rv == clh::kRvScanSliced && pl->pf_on) {
-            // block minima of the bound, then seed + candidate slices, the slices, the finish -- one chain on the class's stream.
+        if ((s.rv == clh::kRvScanSliced && pl->pf[0].on) || s.rv == clh::kRvScanWideSliced) {
+            // block minima of the bound, then seed + candidate slices (tasks), the slices, the finish -- one chain on the class's stream.
             // The prefilter reads the window text in address-aligned 256-byte blocks of the refs buffer: a buffer that is not
-            // aligned so keeps the static slices (the pick kernel writes them)
-            P.pf_tasks = (const clh::PfTask*)pl->d_pf_tasks; P.pf_work = (const clh::PfWork*)pl->d_pf_work;
-            P.pf_slices = (clh::ScanSlice*)pl->d_pf_slices; P.pf_out = (clh::PfOut*)pl->d_pf_out; P.pf_ctl = (clh::PfCtl*)pl->d_pf_ctl;
-            P.parts = (clh::ScanPart*)pl->d_parts; P.pf_bpl = pl->pf_bpl; P.pf_cap = pl->pf_cap;
-            P.pf_dmin = ((uintptr_t)d_refs & 255) == 0 ? (uint8_t*)pl->d_pf_dmin : nullptr;
-            HIPCHK(hipMemsetAsync(pl->d_pf_ctl, 0, sizeof(clh::PfCtl), ls));
-            if (P.pf_dmin) HIPCHK(clh::launch_ssw_prefilter(P, pl->pf_nwork, ls));
-            HIPCHK(clh::launch_ssw_scan_filtered(pl->quirk, P, s.count, std::min(pl->pf_cap, c->n_cu * 12), ls));
+            // aligned so keeps the static slices (the pick kernels write them)
+            const clh_plan::PfClass& f = pl->pf[s.rv == clh::kRvScanSliced ? 0 : 1];
+            P.pf_win = (const clh::PfWin*)f.d_win; P.pf_tasks = (const clh::PfTask*)f.d_pieces; P.pf_work = (const clh::PfWork*)f.d_work;
+            P.pf_out = (clh::PfOut*)f.d_out; P.pf_ctl = (clh::PfCtl*)f.d_ctl; P.pf_bpl = f.bpl; P.pf_cap = f.cap;
+            P.pf_dmin = ((uintptr_t)d_refs & 255) == 0 ? (uint8_t*)f.d_dmin : nullptr;
+            HIPCHK(hipMemsetAsync(f.d_ctl, 0, sizeof(clh::PfCtl), ls));
+            if (s.rv == clh::kRvScanSliced) {
+                P.pf_slices = (clh::ScanSlice*)f.d_queue; P.parts = (clh::ScanPart*)f.d_parts;
+                if (P.pf_dmin) HIPCHK(clh::launch_ssw_prefilter(P, f.nwork, ls));
+                HIPCHK(clh::launch_ssw_scan_filtered(pl->quirk, P, s.count, std::min(f.cap, c->n_cu * 12), ls));
+            } else {
+                P.ws_tasks = (clh::WsTask*)f.d_queue; P.ws_bound = (uint16_t*)f.d_bound; P.ws_row0 = f.ws_row0; P.ws_slot_bytes = f.ws_slot;
+                P.ws_dirs_off = f.ws_dirs_off;
+                HIPCHK(clh::launch_ssw_scanw_filtered(pl->quirk, P, s.count, f.ws_wgs, P.pf_dmin != nullptr, f.nwork, ls));
+            }
         } else if (s.rv == clh::kRvScanSliced) {
             P.slices = (const clh::ScanSlice*)pl->d_slices; P.parts = (clh::ScanPart*)pl->d_parts;
             HIPCHK(clh::launch_ssw_scan_sliced(pl->quirk, P, s.count, (int)pl->slices.size(), ls));
@@ -802,12 +855,15 @@ extern "C" int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out)
 {
     if (!pl || !out) return fail(CLH_E_ARG, "clh_plan_prefilter_stats: null argument");
     for (int k = 0; k < 5; ++k) out[k] = 0;
-    if (!pl->pf_on || !pl->ran) return 0;
+    if (!pl->ran) return 0;
     HIPCHK(hipSetDevice(pl->ctx->device));
     HIPCHK(hipStreamSynchronize(pl->last_stream));
-    clh::PfCtl c;
-    HIPCHK(hipMemcpy(&c, pl->d_pf_ctl, sizeof(c), hipMemcpyDeviceToHost));
-    out[0] = pl->pf_ntasks; out[1] = c.n_pruned; out[2] = c.qcount; out[3] = (int64_t)c.cols_scanned; out[4] = (int64_t)c.cols_window;
+    for (const auto& f : pl->pf) {
+        if (!f.on) continue;
+        clh::PfCtl c;
+        HIPCHK(hipMemcpy(&c, f.d_ctl, sizeof(c), hipMemcpyDeviceToHost));
+        out[0] += f.ntasks; out[1] += c.n_pruned; out[2] += c.qcount; out[3] += (int64_t)c.cols_scanned; out[4] += (int64_t)c.cols_window;
+    }
     return 0;
 }
 

@@ -51,21 +51,38 @@ struct ScanPart { int32_t max, col, row, pad; };                                
 // Exact prefilter of the sliced scan class (ssw_prefilter.hip; tools/prefilter_model.py): per block of 256 bytes of window text
 // the minimum of d(j), the edit distance of the whole read to a window substring ending at column j; H(j) <= M L - c d(j).
 static constexpr int kPfBlock = 256;
-struct PfTask {           // host-built, one per task of the class
-    int32_t sub_off;      // first entry of the task's block minima
-    int32_t nsub;         // blocks the window touches
+struct PfWin {            // host-built, one per alignment (task of the class): the blocks its window touches
+    int32_t nsub;         // blocks
     int32_t phase;        // column 0 sits `phase` bytes into the first block (in processing order)
-    int32_t mem_block0;   // forward windows: refs block of processing block 0; reverse-complemented: refs block of processing block 0 (the highest)
+    int32_t mem_block0;   // refs block of processing block 0 (minus-strand windows run down the addresses: the highest block)
+    int32_t piece_first;  // the alignment's pieces in the piece table
+    int32_t piece_count;  // 1 for reads up to 254 bases; longer reads go through the bit-vector pass in pieces of <= 254 rows
+    int32_t d_off;        // K1w class: first entry of the alignment's summed block bound (uint16 per block)
+    int32_t pad0, pad1;
 };
-struct PfWork {           // one workgroup of the prefilter: 64 lanes x `bpl` blocks of one task
-    int32_t task, first_block;
+struct PfTask {           // host-built, one per PIECE of a read
+    int32_t task;         // alignment (index into the class's tasks and PfWin table)
+    int32_t row0, rows;   // the piece's rows of the read
+    int32_t sub_off;      // first entry of the piece's block minima
 };
-struct PfOut {            // device-filled per task: its slices in the queue, what the filter saw
+struct PfWork {           // one workgroup of the prefilter: 64 lanes x `bpl` blocks of one piece
+    int32_t piece, first_block;
+};
+struct PfOut {            // device-filled per alignment: its slices / tasks in the queue, what the filter saw
     int32_t first, count, s0, pruned;
 };
 struct PfCtl {            // device control block of one run (zeroed before it)
-    int32_t qcount, qnext, n_pruned, pad;
+    int32_t qcount, qnext, n_pruned, seed_next;
     unsigned long long cols_scanned, cols_window;
+};
+// K1w on long windows (ssw_scan_wide.hip): per alignment 2 seed rows + 2 x 64 candidate rows behind the real result rows
+static constexpr int kWsRows = 130;       // scratch rows per alignment: [0] seed, [1] seed in the word regime, [2 + 2 k] / [3 + 2 k] candidate k as-is / word regime
+struct WsTask {           // a device-made K1w task: the read against columns [c_begin, c_end) of its alignment's window
+    int32_t task;         // alignment (index into the class's tasks)
+    int32_t c_begin, c_end;
+    int32_t row;          // scratch row of the alignment (0 .. kWsRows - 1)
+    int32_t force_word;   // 1: the word regime whatever the byte pass would say (ssw.c:806-809 with the decision made elsewhere)
+    int32_t pad0, pad1, pad2;
 };
 
 struct SswParams {
@@ -85,14 +102,21 @@ struct SswParams {
     int32_t n_real;            // result rows of real alignments; tasks with out_index >= n_real are window slices of the
                                // anti-diagonal classes (scratch rows, no CIGAR), see clh_api.hip and ssw_combine_kernel
     const int32_t* slice_base; // first window column of scratch row k (index out_index - n_real)
-    // sliced scan class with the prefilter: the slices are made on the device (ssw_scan.hip: ssw_scan_pick_kernel)
-    const PfTask* pf_tasks;    // nullptr: static slices from `slices`
+    // the long-window classes behind the prefilter: slices / tasks are made on the device (ssw_scan.hip: ssw_scan_pick_kernel;
+    // ssw_scan_wide.hip: ssw_scanw_seed_kernel, ssw_scanw_pick_kernel)
+    const PfWin* pf_win;       // nullptr: static slices from `slices`
+    const PfTask* pf_tasks;    // pieces
     const PfWork* pf_work;
-    uint8_t* pf_dmin;          // block minima (nullptr at run time: the filter is off for this run, the pick kernel writes the static slices)
-    ScanSlice* pf_slices;      // the queue
+    uint8_t* pf_dmin;          // block minima per piece (nullptr at run time: the filter is off for this run, the pick kernels write the static slices)
+    ScanSlice* pf_slices;      // K1s class: the queue
     PfOut* pf_out;
     PfCtl* pf_ctl;
     int32_t pf_bpl, pf_cap;    // blocks per lane of the prefilter; capacity of the queue
+    uint16_t* ws_bound;        // K1w class: summed block bound D per alignment (PfWin.d_off)
+    WsTask* ws_tasks;          // K1w class: [0, 2 n) seed tasks (fixed places), then the candidate queue
+    int32_t ws_row0;           // first scratch result row of the class (alignment a: ws_row0 + a * kWsRows)
+    int32_t ws_slot_bytes;     // K1w workspace of one persistent workgroup inside `dirs`
+    int64_t ws_dirs_off;       // where those workspaces start inside `dirs`
 };
 
 // ---- cyclic consensus (K2/K3, csrc/ccs_poa.hip) ----------------------------------------------------------------
@@ -206,6 +230,8 @@ hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int 
 // workgroups, the finish (ssw_scan.hip)
 hipError_t launch_ssw_prefilter(const SswParams& p, int nwork, hipStream_t stream);
 hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, hipStream_t stream);
+static constexpr int kRvScanWideSliced = -4;   // pseudo class: K1w on windows of 32 kb and more: prefilter in pieces, seed, candidate tasks, best row
+hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, bool with_prefilter, int nwork, hipStream_t stream);
 static constexpr int kRvScanWide = -3;   // pseudo class: K1w, the row-scan kernel for reads of 255..4096 bases / scores above 254 (ssw_scan_wide.hip);
                                          // task.dir_off = its workspace inside `dirs` (scanw_task_bytes)
 hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, hipStream_t stream);

@@ -11,7 +11,8 @@
 // when too many pass it writes the static slices instead -- the answer never depends on this kernel.
 //
 // Scheme: Myers' bit-vector recurrence, semi-global (free start in the window: the horizontal delta entering row 0 is 0).  The
-// read's rows are the bits of W = ceil(L / 32) registers (L <= 254: W <= 8); ONE LANE walks a stretch of the window column by
+// read's rows are the bits of W = ceil(L / 32) registers (L <= 254: W <= 8; a longer read goes through in PIECES of <= 254 rows, each
+// a task of its own here: tools/prefilter_model.py, "the read in pieces"); ONE LANE walks a stretch of the window column by
 // column -- 13 W + 8 integer instructions per column, no cross-lane traffic -- so a wave covers 64 stretches of one task's
 // window at once.  A lane owns `bpl` blocks and starts 2 L columns early with the fresh state (an alignment that costs at most
 // L spans at most 2 L columns, so from its first owned column on its d(j) is the whole-window d(j)).  Window text is read 16
@@ -78,11 +79,11 @@ __device__ __forceinline__ void pf_column(uint32_t (&Pv)[W], uint32_t (&Mv)[W], 
 }
 
 template <int W>
-__device__ void pf_walk(const SswParams& p, const PfTask& pt, const PfWork& wk, const SswTask& task, const uint32_t* s_eq)
+__device__ void pf_walk(const SswParams& p, const PfTask& pc, const PfWin& pt, const PfWork& wk, const SswTask& task, const uint32_t* s_eq)
 {
     constexpr int P = PfRow<W>::P;
     const int lane = threadIdx.x & 63;
-    const int L = task.read_len;
+    const int L = pc.rows;                                   // the piece's rows (the whole read when it has one piece)
     const int lastbit = (L - 1) & 31;
     const int bpl = p.pf_bpl;
     const int ovch = (2 * L + 15) >> 4;                      // chunks of 16 columns a lane starts early
@@ -93,7 +94,7 @@ __device__ void pf_walk(const SswParams& p, const PfTask& pt, const PfWork& wk, 
     const int n_iter = ovch + bpl * 16;
     const bool rc = task.ref_rc != 0;
     const int8_t* base = p.refs;
-    uint8_t* dmin = p.pf_dmin + pt.sub_off;
+    uint8_t* dmin = p.pf_dmin + pc.sub_off;
 
     auto chunk_ptr = [&](int g) -> const uint4* {
         const int64_t blk = rc ? (int64_t)pt.mem_block0 - (g >> 4) : (int64_t)pt.mem_block0 + (g >> 4);
@@ -148,16 +149,17 @@ __global__ void __launch_bounds__(64, 6) ssw_prefilter_kernel(const SswParams p)
     __shared__ int s_mat[48];
     const int lane = threadIdx.x & 63;
     const PfWork wk = p.pf_work[blockIdx.x];
-    const SswTask task = p.tasks[wk.task];
-    const PfTask pt = p.pf_tasks[wk.task];
-    const int L = task.read_len;
+    const PfTask pc = p.pf_tasks[wk.piece];
+    const SswTask task = p.tasks[pc.task];
+    const PfWin pt = p.pf_win[pc.task];
+    const int L = pc.rows;
     const int W = (L + 31) >> 5;
     if (lane < 48) { const int b_ = lane >> 3, q_ = lane & 7; s_mat[lane] = (b_ < p.n && q_ < p.n) ? (int)p.mat[b_ * p.n + q_] : 0; }
     __syncthreads();
     // match vectors of the five window codes: bit i = read base i and the code are "equal" (mat[code][q] > M - c)
     const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
     const int eq_above = p.max_match - cc;
-    const int8_t* read = p.reads + task.read_off;
+    const int8_t* read = p.reads + task.read_off + pc.row0;
     for (int half = 0; half < (W + 1) / 2; ++half) {
         const int row = 64 * half + lane;
         int q = 5;
@@ -175,14 +177,14 @@ __global__ void __launch_bounds__(64, 6) ssw_prefilter_kernel(const SswParams p)
     }
     __syncthreads();
     switch (W) {
-        case 1: pf_walk<1>(p, pt, wk, task, s_eq); break;
-        case 2: pf_walk<2>(p, pt, wk, task, s_eq); break;
-        case 3: pf_walk<3>(p, pt, wk, task, s_eq); break;
-        case 4: pf_walk<4>(p, pt, wk, task, s_eq); break;
-        case 5: pf_walk<5>(p, pt, wk, task, s_eq); break;
-        case 6: pf_walk<6>(p, pt, wk, task, s_eq); break;
-        case 7: pf_walk<7>(p, pt, wk, task, s_eq); break;
-        default: pf_walk<8>(p, pt, wk, task, s_eq); break;
+        case 1: pf_walk<1>(p, pc, pt, wk, task, s_eq); break;
+        case 2: pf_walk<2>(p, pc, pt, wk, task, s_eq); break;
+        case 3: pf_walk<3>(p, pc, pt, wk, task, s_eq); break;
+        case 4: pf_walk<4>(p, pc, pt, wk, task, s_eq); break;
+        case 5: pf_walk<5>(p, pc, pt, wk, task, s_eq); break;
+        case 6: pf_walk<6>(p, pc, pt, wk, task, s_eq); break;
+        case 7: pf_walk<7>(p, pc, pt, wk, task, s_eq); break;
+        default: pf_walk<8>(p, pc, pt, wk, task, s_eq); break;
     }
 }
 

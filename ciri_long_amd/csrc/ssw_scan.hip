@@ -401,10 +401,10 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
     SCAN_LDS_SETUP
     const int lane = threadIdx.x & 63;
     const SswTask task = p.tasks[blockIdx.x];
-    const PfTask pt = p.pf_tasks[blockIdx.x];
+    const PfWin pt = p.pf_win[blockIdx.x];
     const int R = task.ref_len, L = task.read_len;
     const int overlap = L + (L * p.max_match + p.gapE - 1) / p.gapE + 32;
-    const uint8_t* dmin = p.pf_dmin ? p.pf_dmin + pt.sub_off : nullptr;
+    const uint8_t* dmin = p.pf_dmin ? p.pf_dmin + p.pf_tasks[pt.piece_first].sub_off : nullptr;     // (one piece: reads of this class have <= 254 bases)
     int own = (R + 63) / 64; own = own < 8192 ? 8192 : own;
     const int nstatic = (R + own - 1) / own;
     int S0 = 0, nrun = 0, pruned = 0, thr = 0;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <algorithm>
 #include "clh_device.h"
 
 namespace clh {
@@ -369,44 +370,31 @@ size_t scanw_task_bytes(int read_len) {
     return (size_t)W_NB * 2 * W_CPR_MAX * 64 * 4 + 2 * 2 * rows_cap * 2 + 256;
 }
 
+// one alignment, start to finish: the read against refLen columns from `ref` on (read backwards and complemented when ref_rc).
+// force_word: the word regime without asking the byte pass (the decision was made for the whole window, see ssw_scanw_pick_kernel).
+// Returns false when the reference would have returned NULL (score_size 0 and an 8-bit overflow): res.status says so.
 template <bool GEQ>
-__global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswParams p)
+__device__ bool scanw_align(const SswParams& p, const int8_t* read, const int8_t* ref, const int L, const int refLen, const int ref_rc, const int mask_len,
+                            uint16_t* colmax, const WMem& mem, const bool force_word, SswResult& res)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_prof[W_PROF_WORDS];
-    __shared__ int s_mat[48];
-    const int lane = threadIdx.x & 63;
-    if (lane < 48) { const int b = lane >> 3, q = lane & 7; s_mat[lane] = (b < p.n && q < p.n) ? (int)p.mat[b * p.n + q] : 0; }
-    __syncthreads();
-    const SswTask task = p.tasks[blockIdx.x];
-    const int8_t* read = p.reads + task.read_off;
-    const int8_t* ref = p.refs + task.ref_off;
-    const int L = task.read_len, refLen = task.ref_len;
-    uint16_t* colmax = p.colmax ? p.colmax + task.colmax_off : nullptr;
     const int bias = p.bias, gO = p.gapO, gE = p.gapE;
-    WMem mem;
-    mem.prof = s_prof; mem.mat = s_mat;
-    mem.rows_cap = (int)((((size_t)L + 16 + 63) & ~(size_t)63));
-    mem.bnd = (uint32_t*)(p.dirs + task.dir_off);
-    mem.cH = (short*)(mem.bnd + W_NB * 2 * W_CPR_MAX * 64);
-    mem.cE = mem.cH + 2 * mem.rows_cap;
-    SswResult res;
     res.score1 = 0; res.score2 = 0; res.ref_begin1 = -1; res.ref_end1 = -1; res.read_begin1 = -1; res.read_end1 = 0;
     res.ref_end2 = 0; res.status = 0;
 
     // ---- forward: which regime?  (ssw.c:804-822; the order of ssw_wavefront.hip's kernel) -----------------------------------
-    const int rdir = task.ref_rc ? -1 : 1;
+    const int rdir = ref_rc ? -1 : 1;
     WIn in;
-    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = task.ref_rc; in.ncols = refLen; in.terminate = 1 << 30;
+    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = ref_rc; in.ncols = refLen; in.terminate = 1 << 30;
     in.colmax = colmax;
     auto word_rows = [&](WIn& x) { x.S = GEQ ? (x.L + 7) / 8 : 0; x.rows = ((x.L + 7) / 8) * 8; x.overflow_at = 1 << 30; };
     auto byte_rows = [&](WIn& x) { x.S = 0; x.rows = ((x.L + 15) / 16) * 16; x.overflow_at = 255 - bias; };
     int regime = -1;
     WOut fw;
-    bool byte_overflowed = false;
+    bool byte_overflowed = force_word;
     // The reference's own order: the byte regime first (ssw.c:804).  It is abandoned within 64 rows of the first cell at 255 - bias, so an
     // alignment that does overflow pays a fraction of a pass for it, and one that does not (half of a mixed batch) needs no second pass
     // -- the anti-diagonal kernel's "word first when the bound allows an overflow" pays a whole pass there.
-    int job_word = p.score_size == 1 ? 1 : 0;
+    int job_word = (p.score_size == 1 || force_word) ? 1 : 0;
     while (regime < 0) {
         if (job_word) {
             word_rows(in);
@@ -417,7 +405,7 @@ __global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswPar
             byte_rows(in);
             const WOut r = scanw_pass<GEQ, false>(in, mem, gO, gE);
             if (!r.overflow) { fw = r; regime = 0; }
-            else if (p.score_size == 0) { res.status = CLH_STATUS_OVERFLOW8; if (lane == 0) p.results[task.out_index] = res; return; }
+            else if (p.score_size == 0) { res.status = CLH_STATUS_OVERFLOW8; return false; }
             else { byte_overflowed = true; job_word = 1; }
         }
     }
@@ -425,15 +413,15 @@ __global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswPar
     res.score1 = fw.max;
     if (fw.max == 0) { res.ref_end1 = regime ? 0 : -1; res.read_end1 = 0; }
     else { res.ref_end1 = fw.col; res.read_end1 = fw.row; }
-    if (task.mask_len >= 15 && colmax) { __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); second_best_w(colmax, refLen, res.ref_end1, task.mask_len, regime, res.score2, res.ref_end2); }
-    else { res.score2 = 0; res.ref_end2 = task.mask_len >= 15 ? 0 : -1; }
+    if (mask_len >= 15 && colmax) { __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); second_best_w(colmax, refLen, res.ref_end1, mask_len, regime, res.score2, res.ref_end2); }
+    else { res.score2 = 0; res.ref_end2 = mask_len >= 15 ? 0 : -1; }
 
     // ---- reverse: begin coordinates (ssw.c:834-849) ---------------------------------------------------------------
     const bool want_begin = !(p.flag == 0 || (p.flag == 2 && res.score1 < p.filters));
     if (want_begin) {
         WIn rv;
         rv.L = res.read_end1 + 1; rv.read = read + res.read_end1; rv.rstep = -1;
-        rv.ncols = res.ref_end1 + 1; rv.ref = ref + (int64_t)res.ref_end1 * rdir; rv.cstep = -rdir; rv.comp = task.ref_rc;
+        rv.ncols = res.ref_end1 + 1; rv.ref = ref + (int64_t)res.ref_end1 * rdir; rv.cstep = -rdir; rv.comp = ref_rc;
         rv.terminate = res.score1; rv.colmax = nullptr;
         WOut r;
         if (regime) { word_rows(rv); r = scanw_pass<GEQ, true>(rv, mem, gO, gE); }
@@ -441,7 +429,276 @@ __global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswPar
         if (r.max == 0) { res.ref_begin1 = regime ? 0 : -1; res.read_begin1 = res.read_end1; }
         else { res.ref_begin1 = res.ref_end1 - r.col; res.read_begin1 = res.read_end1 - r.row; }
     }
+    return true;
+}
+
+__device__ __forceinline__ void scanw_mem_at(WMem& mem, uint8_t* ws, int L)
+{
+    mem.rows_cap = (int)((((size_t)L + 16 + 63) & ~(size_t)63));
+    mem.bnd = (uint32_t*)ws;
+    mem.cH = (short*)(mem.bnd + W_NB * 2 * W_CPR_MAX * 64);
+    mem.cE = mem.cH + 2 * mem.rows_cap;
+}
+
+#define SCANW_LDS_SETUP \
+    __shared__ __attribute__((aligned(16))) uint32_t s_prof[W_PROF_WORDS]; \
+    __shared__ int s_mat[48]; \
+    const int lane = threadIdx.x & 63; \
+    if (lane < 48) { const int b = lane >> 3, q = lane & 7; s_mat[lane] = (b < p.n && q < p.n) ? (int)p.mat[b * p.n + q] : 0; } \
+    __syncthreads(); \
+    WMem mem; \
+    mem.prof = s_prof; mem.mat = s_mat;
+
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswParams p)
+{
+    SCANW_LDS_SETUP
+    const SswTask task = p.tasks[blockIdx.x];
+    scanw_mem_at(mem, p.dirs + task.dir_off, task.read_len);
+    SswResult res;
+    scanw_align<GEQ>(p, p.reads + task.read_off, p.refs + task.ref_off, task.read_len, task.ref_len, task.ref_rc, task.mask_len,
+                     p.colmax ? p.colmax + task.colmax_off : nullptr, mem, false, res);
     if (lane == 0) p.results[task.out_index] = res;
+}
+
+// ---- K1w on windows of 32 kb and more (class kRvScanWideSliced), behind the prefilter -------------------------------------------
+// The alignments the 8-bit class of ssw_scan.hip does not take (reads of 255..4096 bases, scores that can pass 254), call-path
+// options (no second best).  The bit-vector pass (ssw_prefilter.hip) has left block minima of d for every PIECE of the read
+// (<= 254 rows each); a local alignment that ends in block b scores at most  M L - c D(b),  D(b) = sum over the pieces of the
+// smallest minimum in blocks b - sb .. b  (tools/prefilter_model.py, "the read in pieces"; the word regime only lowers scores).
+//   ssw_scanw_seed_kernel   D per block, its smallest value, the seed region around that block as one or two tasks;
+//   ssw_scanw_queue_kernel  persistent workgroups run tasks (a task = the whole alignment of the read against a stretch of the window);
+//   ssw_scanw_pick_kernel   S0 from the seed rows; blocks with D <= (M L - S0) / c in runs -> tasks (or the static slices);
+//   ssw_scanw_combine_kernel the alignment's row: largest score, then smallest end column, then the earlier task.
+// Which regime (ssw.c:804-809 decides it on the WHOLE window: any column at 255 - bias in the byte pass):
+//   * M L - c min D + bias < 255: no cell of the window can overflow -- byte regime, tasks as they come;
+//   * the seed task overflowed: word regime for the window -- every task runs the word pass only, S0 is the seed's word score;
+//   * else undecided: the seed also runs in the word regime and S0 is THAT score (it is attained in either regime and not
+//     above the byte score), every candidate region runs both ways.  The byte rows give the exact byte-regime maximum (the
+//     candidates of a smaller S0 include those of a larger one); if none overflowed they are the answer, else the word rows are:
+//     every column that holds the word-regime maximum Q >= S0 is a candidate, because word H <= byte H <= the bound.
+// A refs buffer that is not 256-byte aligned has no minima: every static slice then runs both ways.
+template <bool GEQ>
+__global__ void __launch_bounds__(64) ssw_scanw_seed_kernel(const SswParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int a = blockIdx.x;
+    const SswTask task = p.tasks[a];
+    const PfWin pt = p.pf_win[a];
+    WsTask t0, t1;
+    t0.task = -1; t0.c_begin = t0.c_end = 0; t0.row = 0; t0.force_word = 0; t0.pad0 = t0.pad1 = t0.pad2 = 0;
+    t1 = t0; t1.row = 1; t1.force_word = 1;
+    int ub = 1 << 30;
+    if (p.pf_dmin) {
+        const int R = task.ref_len, L = task.read_len;
+        const int span = L + (L * p.max_match + p.gapE - 1) / p.gapE;
+        const int overlap = span + 32;
+        const int sb = (span + kPfBlock - 1) / kPfBlock;
+        const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
+        uint16_t* D = p.ws_bound + pt.d_off;
+        int key = 0x7fffffff;
+        for (int b = lane; b < pt.nsub; b += 64) {
+            int sum = 0;
+            for (int k = 0; k < pt.piece_count; ++k) {
+                const uint8_t* dm = p.pf_dmin + p.pf_tasks[pt.piece_first + k].sub_off;
+                int mn = 255;
+                for (int q = b - sb < 0 ? 0 : b - sb; q <= b; ++q) { const int v = dm[q]; mn = v < mn ? v : mn; }
+                sum += mn;
+            }
+            D[b] = (uint16_t)sum;
+            const int v = (sum << 16) | (b & 0xffff);
+            key = v < key ? v : key;
+        }
+        // (blocks above 65535 -- windows above 16 Mb -- are not a case: the class rule keeps windows below 1.5 Mb)
+        key = wave_min(key);
+        const int kb = key & 0xffff, dmin = key >> 16;
+        ub = p.max_match * L - cc * dmin;
+        int c0 = kb * kPfBlock - pt.phase, c1 = c0 + kPfBlock;
+        c0 = c0 < 0 ? 0 : c0; c1 = c1 > R ? R : c1;
+        t0.task = a; t0.c_begin = c0 - overlap < 0 ? 0 : c0 - overlap; t0.c_end = c1;
+        if (ub + p.bias >= 255 && p.score_size != 1) { t1.task = a; t1.c_begin = t0.c_begin; t1.c_end = t0.c_end; }
+    }
+    if (lane == 0) {
+        p.ws_tasks[2 * a] = t0; p.ws_tasks[2 * a + 1] = t1;
+        PfOut o; o.first = 0; o.count = 0; o.s0 = ub; o.pruned = 0;
+        p.pf_out[a] = o;
+    }
+}
+
+// tasks [first, first + count) of the table by persistent workgroups; count < 0: the candidate queue (its length is on the device)
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_queue_kernel(const SswParams p, const int first, const int count_arg)
+{
+    SCANW_LDS_SETUP
+    const int total = count_arg >= 0 ? count_arg : p.pf_ctl->qcount;
+    int* const next = count_arg >= 0 ? &p.pf_ctl->seed_next : &p.pf_ctl->qnext;
+    uint8_t* const ws = p.dirs + p.ws_dirs_off + (int64_t)blockIdx.x * p.ws_slot_bytes;
+    for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(next, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= total) break;
+        const WsTask wt = p.ws_tasks[first + idx];
+        if (wt.task < 0) continue;
+        const SswTask task = p.tasks[wt.task];
+        scanw_mem_at(mem, ws, task.read_len);
+        const int rdir = task.ref_rc ? -1 : 1;
+        SswResult res;
+        scanw_align<GEQ>(p, p.reads + task.read_off, p.refs + task.ref_off + (int64_t)wt.c_begin * rdir, task.read_len, wt.c_end - wt.c_begin, task.ref_rc, 0,
+                         nullptr, mem, wt.force_word != 0, res);
+        res.ref_end2 = wt.c_begin;               // (no second best in this class: the field carries the task's first window column)
+        if (lane == 0) p.results[p.ws_row0 + wt.task * kWsRows + wt.row] = res;
+        __syncthreads();
+    }
+}
+
+template <bool GEQ>
+__global__ void __launch_bounds__(64) ssw_scanw_pick_kernel(const SswParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int a = blockIdx.x;
+    const SswTask task = p.tasks[a];
+    const PfWin pt = p.pf_win[a];
+    const int R = task.ref_len, L = task.read_len;
+    const int span = L + (L * p.max_match + p.gapE - 1) / p.gapE;
+    const int overlap = span + 32;
+    int own = (R + 63) / 64; own = own < 8192 ? 8192 : own; own = own < 2 * overlap ? 2 * overlap : own;
+    const int nstatic = (R + own - 1) / own;
+    const SswResult* rows = p.results + p.ws_row0 + a * kWsRows;
+    const int ub = p.pf_out[a].s0;
+    // mode 1: tasks as they come (byte first); 2: word regime only; 3: both
+    int mode = 3, S0 = 0, thr = 0, nrun = 0, pruned = 0;
+    const uint16_t* D = p.ws_bound ? p.ws_bound + pt.d_off : nullptr;
+    if (p.score_size == 1) mode = 1;             // the caller asked for the word pass alone: one regime by construction
+    if (p.pf_dmin) {
+        const SswResult r0 = rows[0];
+        if (p.score_size == 1 || ub + p.bias < 255) { mode = 1; S0 = r0.score1; }
+        else if (r0.status & CLH_STATUS_WORD) { mode = 2; S0 = r0.score1; }
+        else { mode = 3; S0 = rows[1].score1; }
+        if (r0.status & CLH_STATUS_OVERFLOW8) S0 = 0;      // score_size 0 and an overflow: the whole window decides (static slices)
+        if (S0 > 0) {
+            const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
+            thr = (p.max_match * L - S0) / cc;
+            long long cost = 0;
+            for (int g = 0; g < pt.nsub; g += 64) {
+                const int k = g + lane;
+                const unsigned long long m = __ballot(k < pt.nsub && (int)D[k] <= thr);
+                nrun += __popcll(m & ~(m << 1));
+                cost += (long long)__popcll(m) * kPfBlock;
+            }
+            cost += (long long)nrun * overlap;
+            pruned = nrun <= 64 && cost < (long long)R + (long long)nstatic * overlap;
+        }
+    }
+    const int count = pruned ? nrun : nstatic;
+    const int per = mode == 3 ? 2 : 1;
+    int first = 0;
+    if (lane == 0) {
+        first = atomicAdd(&p.pf_ctl->qcount, count * per);
+        if (pruned) atomicAdd(&p.pf_ctl->n_pruned, 1);
+        atomicAdd(&p.pf_ctl->cols_window, (unsigned long long)R);
+    }
+    first = __builtin_amdgcn_readfirstlane(first);
+    WsTask* q = p.ws_tasks + 2 * gridDim.x + first;
+    unsigned long long cols = 0;
+    auto emit = [&](int k, int b0, int b1) {
+        WsTask t;
+        t.task = a; t.c_begin = b0 - overlap < 0 ? 0 : b0 - overlap; t.c_end = b1; t.pad0 = t.pad1 = t.pad2 = 0;
+        if (mode != 2) { t.row = 2 + 2 * k; t.force_word = 0; q[per * k] = t; }
+        if (mode != 1) { t.row = 3 + 2 * k; t.force_word = 1; q[per * k + per - 1] = t; }
+        cols += (unsigned long long)(t.c_end - t.c_begin) * per;
+    };
+    if (pruned) {
+        int done = 0;
+        for (int g = 0; g < pt.nsub; g += 64) {
+            const int k = g + lane;
+            const unsigned long long m = __ballot(k < pt.nsub && (int)D[k] <= thr);
+            const unsigned long long starts = m & ~(m << 1);
+            if ((starts >> lane) & 1ull) {
+                const unsigned long long rest = ~(m >> lane);
+                const int len = rest ? __builtin_ctzll(rest) : 64 - lane;
+                const int rank = done + __popcll(starts & ((1ull << lane) - 1ull));
+                int b0 = k * kPfBlock - pt.phase, b1 = (k + len) * kPfBlock - pt.phase;
+                b0 = b0 < 0 ? 0 : b0; b1 = b1 > R ? R : b1;
+                emit(rank, b0, b1);
+            }
+            done += __popcll(starts);
+        }
+    } else {
+        for (int sidx = lane; sidx < nstatic; sidx += 64) {
+            const long long b = (long long)sidx * own;
+            emit(sidx, (int)b, (int)(b + own > R ? R : b + own));
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) cols += __shfl_xor(cols, d);
+    if (lane == 0) {
+        atomicAdd(&p.pf_ctl->cols_scanned, cols);
+        PfOut o; o.first = mode; o.count = count; o.s0 = S0; o.pruned = pruned;
+        p.pf_out[a] = o;
+    }
+}
+
+__global__ void __launch_bounds__(64) ssw_scanw_combine_kernel(const SswParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int a = blockIdx.x;
+    const SswTask task = p.tasks[a];
+    const PfOut po = p.pf_out[a];
+    const SswResult* rows = p.results + p.ws_row0 + a * kWsRows;
+    const int mode = po.first;
+    bool use_word = mode == 2;
+    if (mode == 3) {
+        bool ov = false;
+        if (lane < po.count) ov = (rows[2 + 2 * lane].status & (CLH_STATUS_WORD | CLH_STATUS_OVERFLOW8)) != 0;
+        use_word = __ballot(ov) != 0ull;
+    }
+    int v = -1, c = 0x7fffffff, k = 0x7fffffff;
+    if (lane < po.count) {
+        const SswResult r = rows[2 + 2 * lane + (use_word ? 1 : 0)];
+        v = r.score1; k = lane;
+        c = r.score1 > 0 ? r.ref_end1 + r.ref_end2 : 0x7fffffff;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v2 = __shfl_xor(v, d), c2 = __shfl_xor(c, d), k2 = __shfl_xor(k, d);
+        const bool take = v2 > v || (v2 == v && (c2 < c || (c2 == c && k2 < k)));
+        v = take ? v2 : v; c = take ? c2 : c; k = take ? k2 : k;
+    }
+    if (lane == 0) {
+        SswResult r = rows[2 + 2 * k + (use_word ? 1 : 0)];
+        const int base = r.ref_end2;
+        if (r.score1 > 0) {
+            r.ref_end1 += base;
+            if (r.ref_begin1 >= 0) r.ref_begin1 += base;
+        }
+        r.ref_end2 = task.mask_len >= 15 ? 0 : -1;
+        // score_size 0 and an overflow somewhere in the window: the reference returns NULL (ssw.c:810-813)
+        if (p.score_size == 0) {
+            bool any = false;
+            for (int q = 0; q < po.count; ++q) any = any || (rows[2 + 2 * q].status & CLH_STATUS_OVERFLOW8);
+            if (any) { r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = -1; r.read_begin1 = -1; r.read_end1 = 0; r.status = CLH_STATUS_OVERFLOW8; }
+        }
+        p.results[task.out_index] = r;
+    }
+}
+
+hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, bool with_prefilter, int nwork, hipStream_t stream)
+{
+    if (with_prefilter) { const hipError_t e = launch_ssw_prefilter(p, nwork, stream); if (e != hipSuccess) return e; }
+    if (geq) {
+        hipLaunchKernelGGL((ssw_scanw_seed_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+        if (with_prefilter) hipLaunchKernelGGL((ssw_scanw_queue_kernel<true>), dim3(std::min(nworkgroups, 2 * ntasks)), dim3(64), 0, stream, p, 0, 2 * ntasks);
+        hipLaunchKernelGGL((ssw_scanw_pick_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((ssw_scanw_queue_kernel<true>), dim3(nworkgroups), dim3(64), 0, stream, p, 2 * ntasks, -1);
+    } else {
+        hipLaunchKernelGGL((ssw_scanw_seed_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+        if (with_prefilter) hipLaunchKernelGGL((ssw_scanw_queue_kernel<false>), dim3(std::min(nworkgroups, 2 * ntasks)), dim3(64), 0, stream, p, 0, 2 * ntasks);
+        hipLaunchKernelGGL((ssw_scanw_pick_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((ssw_scanw_queue_kernel<false>), dim3(nworkgroups), dim3(64), 0, stream, p, 2 * ntasks, -1);
+    }
+    hipLaunchKernelGGL(ssw_scanw_combine_kernel, dim3(ntasks), dim3(64), 0, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, hipStream_t stream)

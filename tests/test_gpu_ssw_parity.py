@@ -441,13 +441,16 @@ def test_stale_walk_goldens(ctx):
         assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar']
 
 
+@pytest.mark.parametrize('filtered', [True, False])
 @pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (10, 4, 8, 2), (2, 2, 3, 1)])
-def test_long_windows_of_the_anti_diagonal_classes_in_slices_vs_oracle(ctx, scheme):
+def test_long_windows_of_the_anti_diagonal_classes_in_slices_vs_oracle(ctx, scheme, filtered, monkeypatch):
     """Reads outside K1s's 8-bit class against windows of 32 kb and more, call-path options (no second best): the alignment
     runs as window-slice tasks of its anti-diagonal class and `ssw_combine_kernel` takes the best slice (clh_api.hip).  The
     read placed across slice borders, inside overlaps, twice (first end column wins), absent; forward windows as packed
     references and minus-strand windows of a resident genome.  Scores, coordinates and CIGARs equal the oracle's."""
     from ciri_long_amd import hip, utils
+    if not filtered:                             # without the prefilter: window-slice tasks of the anti-diagonal classes (rounds 2-3)
+        monkeypatch.setenv('CLH_NO_PREFILTER', '1')
     m, x, o, e = scheme
     rng = np.random.default_rng(1500 + sum(scheme))
     refs, qs = [], []
@@ -468,7 +471,8 @@ def test_long_windows_of_the_anti_diagonal_classes_in_slices_vs_oracle(ctx, sche
             refs.append(ref); qs.append(q[:4000])
     rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
     plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=True)
-    assert sum(c for rv, c, _a, _b in plan.segments() if rv == -2) >= len(qs) - 6      # nearly all: reads outside the 8-bit class
+    # nearly all: reads outside the 8-bit class -- K1w tasks behind the prefilter (-4), or window-slice tasks + combine (-2)
+    assert sum(c for rv, c, _a, _b in plan.segments() if rv == (-4 if filtered else -2)) >= len(qs) - 6
     plan.close()
     rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(m, x), o, e, want_score2=False, want_cigar=True)
     for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
@@ -678,3 +682,63 @@ def test_prefilter_on_long_windows_vs_oracle(ctx, scheme, monkeypatch):
         got = (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1']))
         assert got == (w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']), ('window', k, minus[k], got)
     g.close()
+
+
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (10, 4, 8, 2), (2, 2, 3, 1)])
+def test_long_reads_on_long_windows_behind_the_prefilter_vs_oracle(ctx, scheme):
+    """K1w on windows of 32 kb and more (csrc/ssw_scan_wide.hip, class -4): the read goes through the bit-vector pass in pieces of
+    <= 254 rows, a seed region says which regime the WINDOW is in (ssw.c:804-809 decides on the whole window), candidate regions
+    run as K1w tasks.  Cases on both sides of the 8-bit limit -- exact copies (word regime), noisy copies (byte regime), copies
+    whose bound allows an overflow that does not happen (both regimes computed), two copies of which only one overflows, reads
+    of several pieces, absent reads -- with score_size 2, 1 and 0.  Scores, coordinates and CIGARs equal the oracle's."""
+    import torch
+    from ciri_long_amd import hip
+    m, x, o, e = scheme
+    rng = np.random.default_rng(1900 + sum(scheme))
+    refs, qs = [], []
+    lo = {1: 255, 2: 127, 10: 30}[m]                   # shortest read outside the 8-bit class (max_match * L + bias >= 255)
+    for R in [32768, 60000, 130000]:
+        for case in range(10):
+            L = int(rng.integers(lo, lo + 60)) if case < 6 else int(rng.integers(300, 1300) if m == 1 else rng.integers(100, 700))
+            ref = _rnd(rng, R)
+            pos = int(rng.integers(0, R - L))
+            err = [0.0, 0.02, 0.03, 0.12, 0.0, 0.02, 0.0, 0.05, 0.15, 0.0][case]
+            q = _mut(ref[pos:pos + L], rng, err) or 'A'
+            if case == 4 and pos > 3 * L + 600:            # a second, noisier copy earlier in the window: one locus overflows, one does not
+                far = pos - 2 * L - 500
+                ref = (ref[:far] + _mut(ref[pos:pos + L], rng, 0.04)[:L].ljust(L, 'C') + ref[far + L:])[:R]
+            if case == 5 and pos > 3 * L:                  # an exact copy earlier: the first end column wins
+                ref = (ref[:pos - 2 * L] + ref[pos:pos + L] + ref[pos - L:])[:R]
+            if case == 9:
+                q = _rnd(rng, L)
+            refs.append(ref); qs.append(q[:4000])
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    d_r = torch.from_numpy(rd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
+    plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=True)
+    assert sum(c for rv, c, _a, _b in plan.segments() if rv == -4) >= len(qs) - 4      # (a noisy copy can come out below the shortest length)
+    plan.run(d_r.data_ptr(), d_f.data_ptr())
+    rows, cig = plan.fetch()
+    st = plan.prefilter_stats()
+    plan.close()
+    assert st['alignments'] == len(qs) and st['pruned'] >= len(qs) // 2, st
+    words = 0
+    for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
+        want = oracle_align(ref, q, *scheme)
+        got = (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1']))
+        assert got == (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end']), (k, len(q), len(ref), got, want)
+        assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref), int(r['status']))
+        words += int(r['status']) & 1
+    assert 0 < words < len(qs) or m != 1               # both regimes occur with 1/1/1/1
+    # score_size 1 (the word pass alone) and 0 (the byte pass alone: an overflow anywhere in the window is the reference's NULL)
+    for ss in (1, 0):
+        plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=ss, want_score2=False, want_cigar=False)
+        plan.run(d_r.data_ptr(), d_f.data_ptr())
+        rows2, _ = plan.fetch()
+        plan.close()
+        for k, (ref, q, r, r2) in enumerate(zip(refs, qs, rows, rows2)):
+            want = oracle_align(ref, q, *scheme, score_size=ss)
+            if want is None:
+                assert int(r2['status']) & 2, (ss, k)
+                continue
+            got = (int(r2['score1']), int(r2['ref_begin1']), int(r2['ref_end1']), int(r2['read_begin1']), int(r2['read_end1']))
+            assert got == (want['score'], want['ref_begin'], want['ref_end'], want['query_begin'], want['query_end']), (ss, k, len(q), got)

@@ -222,7 +222,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
 class FullStep(object):
     """the c3 / c4 step (module docstring): everything the timed region needs, built once"""
 
-    def __init__(self, torch, hip, synth, ctx, wl, nreads, rank, expect):
+    def __init__(self, torch, hip, synth, ctx, wl, nreads, rank, expect, prod_windows=False):
         self.torch, self.nreads = torch, nreads
         reads, wins = make_batch(synth, wl, nreads, rank)
         rd, self.ro = hip.pack(reads)
@@ -256,6 +256,10 @@ class FullStep(object):
         self.d_ccs = torch.as_tensor(_DevArray(p_ccs, int(self.ro[-1])), device='cuda')
         self.win_off = has.astype(np.int64) * WINDOW
         self.win_len = np.full(len(has), WINDOW, dtype=np.int64)
+        if prod_windows:      # the reference's own window: the hit +- 200 kb (find_bsj.py:196-197), here the read's 2 kb stretch of the genome +- 200 kb
+            end = np.minimum(self.win_off + WINDOW + 200000, self.glen)
+            self.win_off = np.maximum(self.win_off - 200000, 0)
+            self.win_len = end - self.win_off
         self.ssw_plan = self.genome.plan_windows(self.co, self.win_off, self.win_len.astype(np.int32), np.zeros(len(has), dtype=np.uint8),
                                                  hip.score_matrix(1, 1), 1, 1, flag=1, score_size=2, want_score2=False, want_cigar=False)
         self.clen = clen
@@ -366,8 +370,8 @@ class FullStep(object):
         return out, valu
 
 
-def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmup, expect, use_dist=False):
-    fs = FullStep(torch, hip, synth, ctx, wl, nreads, rank, expect)
+def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmup, expect, use_dist=False, prod_windows=False):
+    fs = FullStep(torch, hip, synth, ctx, wl, nreads, rank, expect, prod_windows)
     for _ in range(warmup):
         fs.step()
     fs.t_k5 = fs.t_k6 = fs.t_fetch = 0.0
@@ -396,10 +400,37 @@ def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmu
         res_exchange = None
     launches, valu = fs.launches(steps)
     sig = fs.last['sig']
+    pf_stats = fs.ssw_plan.prefilter_stats()
+    pf_check = None
+    if prod_windows:
+        # the filter must not change an answer: a sample of the clips once more with CLH_NO_PREFILTER (static window slices, the
+        # path of rounds 2-3, held to the oracle by tests/test_gpu_ssw_parity.py), rows compared field by field
+        m = min(1500, len(fs.has))
+        sel = np.linspace(0, len(fs.has) - 1, m).astype(np.int64)
+        clips_host = fs.last['clips'].cpu().numpy().view(np.int8)
+        cd, co = hip.pack([clips_host[fs.co[i]:fs.co[i + 1]] for i in sel])
+        d_c = torch.from_numpy(cd.view(np.uint8)).cuda()
+        os.environ['CLH_NO_PREFILTER'] = '1'
+        try:
+            p2 = fs.genome.plan_windows(co, fs.win_off[sel], fs.win_len[sel].astype(np.int32), np.zeros(m, dtype=np.uint8), hip.score_matrix(1, 1), 1, 1,
+                                        flag=1, score_size=2, want_score2=False, want_cigar=False)
+        finally:
+            del os.environ['CLH_NO_PREFILTER']
+        p2.run(d_c.data_ptr(), fs.genome.codes_ptr, fs.stream)
+        r2, _ = p2.fetch()
+        p2.close()
+        r1 = fs.last['rows'][sel]
+        same = all((r1[f] == r2[f]).all() for f in ('score1', 'ref_begin1', 'ref_end1', 'read_begin1', 'read_end1'))
+        assert same, 'prefilter changed an answer'
+        pf_check = '%d clips re-run without the prefilter (static window slices): rows identical' % m
     res = {'value': world * nreads * steps / el, 'ms_per_step': el / steps * 1e3, 'launches': launches, 'valu_roofline': valu, 'valu_roofline_k3': fs.k3_valu,
            'roofline': roofline_of(launches), 'reads_with_consensus': int(len(fs.has)),
            'counters': dict(zip(['total', 'consensus', 'raw_unmapped', 'ccs_mapped', 'bsj', 'signal', 'partial'], [int(x) for x in counters])),
            'splice_handed_back': int((sig[:, 0] != 0).sum()), 'counter_exchange': res_exchange}
+    if pf_stats['alignments']:
+        res['prefilter'] = pf_stats
+    if pf_check:
+        res['prefilter_check'] = pf_check
     fs.genome.close()
     return res
 
@@ -623,6 +654,7 @@ def main():
     ap.add_argument('--reads', type=int, default=0, help='reads per GPU (default: 100000 for c3, 10000 for c2, 125000 for c4)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--prod-windows', action='store_true', help='c3 / c4 with the reference\'s own clip window (hit +- 200 kb, find_bsj.py:196-197) instead of 2 kb: the extra line c3_production_windows as the main workload (for profiling)')
     ap.add_argument('--no-extra', action='store_true', help='skip the extra lines (c2, c4, production shape, collapse, stage 1)')
     args = ap.parse_args()
     wl = args.workload
@@ -669,7 +701,7 @@ def main():
     expect = cpu.pop('_expect') if cpu else None     # None: no CPU leg in this run (multi-GPU, --no-cpu, profiler): no spot check
     ctx = hip.Context(local_rank)
     if full:
-        res = run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, args.steps, args.warmup, expect, use_dist)
+        res = run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, args.steps, args.warmup, None if args.prod_windows else expect, use_dist, prod_windows=args.prod_windows)
     else:
         res = run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, args.steps, args.warmup, expect, use_dist)
 
@@ -689,13 +721,16 @@ def main():
                         ('C2: %d NanoSim-shaped ~1 kb reads per GPU, SSW step only, complete s_align (second best, begin/end, '
                          'CIGAR) vs own 2 kb window, rows and CIGARs to the host in every step; two batches in flight on two '
                          'streams (a step queues the next batch before it waits for its own results)' % nreads),
-            'reads_per_gpu': nreads, 'window': WINDOW, 'scoring': '1/1/1/1',
+            'reads_per_gpu': nreads, 'window': 'hit +- 200 kb' if args.prod_windows else WINDOW, 'scoring': '1/1/1/1',
             'parallelism': 'reads sharded x%d, no data-path collective%s' % (world, '; int64[7] counter all-reduce on RCCL after the timed loop' if world > 1 else ''),
             'consensus_parity': 'unpinned (pyccs/spoa absent from the reference tree; clh-poa v3 restates the published spoa algorithm, no departures, oracle/poa_oracle.c)' if full else None},
         'roofline': res['roofline'], 'valu_roofline': res['valu_roofline'],
     }
     if 'valu_roofline_k3' in res:
         out['valu_roofline_k3'] = res['valu_roofline_k3']      # the kernel that is most of the step
+    for k in ('prefilter', 'prefilter_check'):
+        if k in res:
+            out[k] = res[k]
     if 'reads_with_consensus' in res:
         out['config']['reads_with_consensus'] = res['reads_with_consensus']
         out['counters'] = res['counters']
@@ -709,6 +744,9 @@ def main():
             extra['c2'] = dict(s, unit='reads/s', workload='C2: 10000 ~1 kb reads vs own 2 kb window, complete s_align incl. CIGAR, rows to the host; two batches in flight')
             s = run_full(torch, dist, hip, synth, ctx, 'c4', 125000, 0, 1, 2, 1, None)
             extra['c4'] = dict(s, unit='reads/s', workload='C4 per-GPU share: 125000 reads of 500-4000 bases through the C3 step')
+            s = run_full(torch, dist, hip, synth, ctx, 'c3', 100000, 0, 1, 3, 1, None, prod_windows=True)
+            extra['c3_production_windows'] = dict(s, unit='reads/s', workload='the C3 step with every clip against the reference\'s own window: its stretch of the resident '
+                                                  '200 Mb genome +- 200 kb (find_bsj.py:196-197) instead of the 2 kb window of the headline line')
             extra['production_shape'] = extra_production_shape(torch, hip, synth, ctx)
             extra['production_shape_r03'] = extra_production_shape(torch, hip, synth, ctx, r03_strands=True)
             extra['collapse_c5'] = extra_collapse(torch, hip, synth, ctx)

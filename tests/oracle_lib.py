@@ -47,6 +47,8 @@ class CloAlign(C.Structure):
 
 
 def ensure_built():
+    if os.environ.get('CLH_ORACLE_SO'):      # the sanitizer build of `make -C oracle san` (oracle/Makefile)
+        return os.environ['CLH_ORACLE_SO']
     so = os.path.join(ORACLE_DIR, 'liboracle.so')
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith('.c')]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

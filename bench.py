@@ -474,6 +474,11 @@ def run_c2(torch, dist, hip, synth, ctx, nreads, rank, world, steps, warmup, exp
                 pl.run(d_reads.data_ptr(), d_wins.data_ptr(), st_)
             lanes[s_ & 1][0].fetch()                # rows and CIGARs on the host inside the timed region
 
+    # both lanes warm (events created, first launches done) whatever --warmup is, and the second plan's answers checked against the first's
+    # (the oracle spot check above saw only ssw_plan; plan_b produces half of the timed fetches)
+    plan_b.run(d_reads.data_ptr(), d_wins.data_ptr(), lanes[1][1])
+    brow, bcig = plan_b.fetch()
+    assert all((brow[f] == srow[f]).all() for f in srow.dtype.names) and (bcig == scig).all(), 'the two C2 plans disagree'
     run_steps(warmup)
     if use_dist:
         dist.barrier()

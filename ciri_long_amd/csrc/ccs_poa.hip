@@ -1943,7 +1943,9 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
         else { res.nseg = nseg; res.ccs_len = len; }
         if (lane == 0) {
             p.results[rd] = res; if (p.msa_ncols) p.msa_ncols[rd] = ncols;
-            if (p.stats && res.status != 1) {                // a read handed to the second launch is counted there
+            // a read handed to the second launch is counted there; status 1 is final in that launch, and in the first one when no
+            // second launch will run (no large slots)
+            if (p.stats && (res.status != 1 || p.tier == 1 || p.n_big == 0)) {
                 atomicAdd((unsigned long long*)(p.stats + 2), dp_cells); atomicAdd((unsigned long long*)(p.stats + 4), dp_rows_n);
                 if (band_miss_n) atomicAdd(p.stats + 6, band_miss_n);
                 if (res.status != 0) atomicAdd(p.stats + 8 + (res.status & 7), 1);      // reads lost to a limit of this kernel, by status

@@ -138,7 +138,8 @@ struct clh_plan {
     clh::SswParams params;          // device pointers filled at run time
     bool quirk = false, do_cigar = false;
     std::vector<clh::SswTask> tasks;    // launch order
-    struct Seg { int rv, begin, count; };
+    struct Seg { int rv, begin, count; int64_t ws_off = 0; int ws_slot = 0, ws_wgs = 0; };      // ws_*: K1w classes, the workspaces of their persistent workgroups
+    void* d_seg_ctr = nullptr;               // one work counter per segment
     std::vector<clh::ScanSlice> slices;      // window slices of the sliced scan class (one segment at most)
     void *d_slices = nullptr, *d_parts = nullptr;
     // the long-window classes behind the prefilter (ssw_prefilter.hip): [0] K1s (kRvScanSliced), [1] K1w (kRvScanWideSliced)
@@ -175,7 +176,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     (void)hipSetDevice(c->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
-                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base};
+                    pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base, pl->d_seg_ctr};
     for (void* b : bufs) c->release(b);
     for (auto& f : pl->pf) { void* pb[] = {f.d_win, f.d_pieces, f.d_work, f.d_dmin, f.d_queue, f.d_out, f.d_ctl, f.d_bound, f.d_parts}; for (void* b : pb) c->release(b); }
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
@@ -303,7 +304,6 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
             t.dir_off = (int64_t)pl->strip_bytes;
             pl->strip_bytes += 2 * (size_t)((R + 63) & ~63ll) * 8 + 256;
         }
-        if (rv == clh::kRvScanWide) { t.dir_off = (int64_t)pl->strip_bytes; pl->strip_bytes += clh::scanw_task_bytes((int)L); }
         if (pl->do_cigar) {
             t.cigar_cap = (int32_t)(2 * L + 2);
             if (cig + (size_t)t.cigar_cap > 0x7fffffffull) { fail(CLH_E_CAPACITY, "batch too large for 32-bit CIGAR offsets; split it"); delete pl; return nullptr; }
@@ -370,12 +370,24 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         const int parts = (cls[order[k]] == clh::kRvScanWide && pl->do_cigar && e - k >= 16384 && getenv("CLH_SCANW_PARTS")) ? 4 : 1;   // (measured on C2, 10 000 alignments: 4 parts of 2 500 are each less than one round of the GPU's wave slots -- 28 -> 35 ms; kept for batches far above that, off by default)
         for (int q = 0; q < parts; ++q) {
             const int b = k + (int)((int64_t)(e - k) * q / parts), b2 = k + (int)((int64_t)(e - k) * (q + 1) / parts);
-            pl->segs.push_back({cls[order[k]], b, b2 - b});
+            clh_plan::Seg sg; sg.rv = cls[order[k]]; sg.begin = b; sg.count = b2 - b;
+            pl->segs.push_back(sg);
         }
         k = e;
     }
     pl->tasks.swap(sorted);
     pl->n_rows = n_all;
+    for (auto& sg : pl->segs) {
+        if (sg.rv != clh::kRvScanWide) continue;
+        int lmax = 1;
+        for (int k = 0; k < sg.count; ++k) lmax = std::max(lmax, (int)pl->tasks[sg.begin + k].read_len);
+        sg.ws_slot = (int)((clh::scanw_task_bytes(lmax) + 255) & ~(size_t)255);
+        sg.ws_wgs = std::min(sg.count, ctx->n_cu * 12);
+        pl->strip_bytes = (pl->strip_bytes + 255) & ~(size_t)255;
+        sg.ws_off = (int64_t)pl->strip_bytes;
+        pl->strip_bytes += (size_t)sg.ws_slot * (size_t)sg.ws_wgs;
+    }
+    pl->d_seg_ctr = ctx->alloc(sizeof(int) * std::max<size_t>(pl->segs.size(), 1));
     for (const auto& sg : pl->segs) {
         const int ci = sg.rv == clh::kRvScanSliced ? 0 : (sg.rv == clh::kRvScanWideSliced ? 1 : -1);
         if (ci < 0 || !prefilter_ok(o, mx)) continue;
@@ -489,7 +501,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
             clh_plan_destroy(pl); return nullptr;
         }
     }
-    if (!pl->d_tasks || !pl->d_results || !pl->d_cigar_len || (pl->strip_bytes && !pl->d_strips) || (o->want_score2 && !pl->d_colmax) ||
+    if (!pl->d_tasks || !pl->d_results || !pl->d_cigar_len || !pl->d_seg_ctr || (pl->strip_bytes && !pl->d_strips) || (o->want_score2 && !pl->d_colmax) ||
         (pl->do_cigar && (!pl->d_cigars || !pl->d_pool || !pl->d_pool_head))) {
         fail(CLH_E_HIP, "out of device memory while building the plan");
         clh_plan_destroy(pl); return nullptr;
@@ -660,6 +672,8 @@ extern "C" int clh_splice_signal_batch(clh_genome* g, int32_t n, const int64_t* 
     return rc;
 }
 
+// Plans of one context may be in flight on the device at the same time (bench.py's C2 loop alternates two), but they share the context's
+// side streams and fork/join events: clh_ssw_run must not be called from two host threads at once for plans of the same context.
 extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs, void* stream_)
 {
     if (!pl || !d_reads || !d_refs) return fail(CLH_E_ARG, "clh_ssw_run: null argument");
@@ -753,7 +767,11 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
             P.slices = (const clh::ScanSlice*)pl->d_slices; P.parts = (clh::ScanPart*)pl->d_parts;
             HIPCHK(clh::launch_ssw_scan_sliced(pl->quirk, P, s.count, (int)pl->slices.size(), ls));
         } else if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
-        else if (s.rv == clh::kRvScanWide) HIPCHK(clh::launch_ssw_scanw(pl->quirk, P, s.count, ls));
+        else if (s.rv == clh::kRvScanWide) {
+            int* ctr = (int*)pl->d_seg_ctr + k;
+            HIPCHK(hipMemsetAsync(ctr, 0, sizeof(int), ls));
+            HIPCHK(clh::launch_ssw_scanw(pl->quirk, P, s.count, s.ws_wgs, ctr, (long long)s.ws_off, s.ws_slot, ls));
+        }
         else HIPCHK(clh::launch_ssw(s.rv, pl->quirk, P, s.count, ls));
         if (pl->profiling) HIPCHK(hipEventRecord(pl->ev[2 * k + 1], ls));
         if (chained && ++i_wide < n_wide) {

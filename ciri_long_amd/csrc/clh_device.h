@@ -233,8 +233,8 @@ hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, in
 static constexpr int kRvScanWideSliced = -4;   // pseudo class: K1w on windows of 32 kb and more: prefilter in pieces, seed, candidate tasks, best row
 hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, bool with_prefilter, int nwork, hipStream_t stream);
 static constexpr int kRvScanWide = -3;   // pseudo class: K1w, the row-scan kernel for reads of 255..4096 bases / scores above 254 (ssw_scan_wide.hip);
-                                         // task.dir_off = its workspace inside `dirs` (scanw_task_bytes)
-hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, hipStream_t stream);
+                                         // persistent workgroups; their workspaces inside `dirs` (scanw_task_bytes of the class's longest read)
+hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, int nworkgroups, int* counter, long long ws_off, int ws_slot, hipStream_t stream);
 size_t scanw_task_bytes(int read_len);
 // K1b launches.  All take the plan's WHOLE task table in p.tasks and work on the tasks [task_base, task_base + ntasks) of launch
 // class `seg` (every class has its own hand-over counters and list regions, so the classes' launch chains run on different

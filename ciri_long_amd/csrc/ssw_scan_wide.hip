@@ -449,16 +449,26 @@ __device__ __forceinline__ void scanw_mem_at(WMem& mem, uint8_t* ws, int L)
     WMem mem; \
     mem.prof = s_prof; mem.mat = s_mat;
 
+// persistent workgroups pull the class's tasks (heaviest first) from a counter; the HBM workspace belongs to the workgroup, not to the
+// task (a batch of a million alignments needs no more of it than one of three thousand)
 template <bool GEQ>
-__global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswParams p)
+__global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswParams p, const int ntasks, int* const counter, const long long ws_off, const int ws_slot)
 {
     SCANW_LDS_SETUP
-    const SswTask task = p.tasks[blockIdx.x];
-    scanw_mem_at(mem, p.dirs + task.dir_off, task.read_len);
-    SswResult res;
-    scanw_align<GEQ>(p, p.reads + task.read_off, p.refs + task.ref_off, task.read_len, task.ref_len, task.ref_rc, task.mask_len,
-                     p.colmax ? p.colmax + task.colmax_off : nullptr, mem, false, res);
-    if (lane == 0) p.results[task.out_index] = res;
+    uint8_t* const ws = p.dirs + ws_off + (long long)blockIdx.x * ws_slot;
+    for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(counter, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= ntasks) break;
+        const SswTask task = p.tasks[idx];
+        scanw_mem_at(mem, ws, task.read_len);
+        SswResult res;
+        scanw_align<GEQ>(p, p.reads + task.read_off, p.refs + task.ref_off, task.read_len, task.ref_len, task.ref_rc, task.mask_len,
+                         p.colmax ? p.colmax + task.colmax_off : nullptr, mem, false, res);
+        if (lane == 0) p.results[task.out_index] = res;
+        __syncthreads();
+    }
 }
 
 // ---- K1w on windows of 32 kb and more (class kRvScanWideSliced), behind the prefilter -------------------------------------------
@@ -701,10 +711,10 @@ hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, i
     return hipGetLastError();
 }
 
-hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, hipStream_t stream)
+hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, int nworkgroups, int* counter, long long ws_off, int ws_slot, hipStream_t stream)
 {
-    if (geq) hipLaunchKernelGGL((ssw_scanw_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
-    else hipLaunchKernelGGL((ssw_scanw_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+    if (geq) hipLaunchKernelGGL((ssw_scanw_kernel<true>), dim3(nworkgroups), dim3(64), 0, stream, p, ntasks, counter, ws_off, ws_slot);
+    else hipLaunchKernelGGL((ssw_scanw_kernel<false>), dim3(nworkgroups), dim3(64), 0, stream, p, ntasks, counter, ws_off, ws_slot);
     return hipGetLastError();
 }
 

@@ -81,6 +81,26 @@ def _bcast(obj, src=0):
     return box[0]
 
 
+def _together(stage, fn):
+    """run fn() on this rank; every rank then learns whether ANY rank failed and raises if so -- a rank that dies alone would leave the
+    others blocked in the next collective (broadcast of the record count, gather of the records, the counter all-reduce)"""
+    dist = _dist()
+    err, out = None, None
+    try:
+        out = fn()
+    except Exception as ex:      # noqa: BLE001 -- reported on every rank below
+        err = '%s: %r' % (type(ex).__name__, ex)
+        if dist is None or dist.get_world_size() == 1:
+            raise
+    if dist is not None and dist.get_world_size() > 1:
+        box = [None] * dist.get_world_size()
+        dist.all_gather_object(box, err)
+        bad = [(r, e) for r, e in enumerate(box) if e]
+        if bad:
+            raise RuntimeError('call_sharded: stage %s failed on rank(s) %s' % (stage, '; '.join('%d (%s)' % b for b in bad)))
+    return out
+
+
 def _count_records(in_file, is_fastq):
     """records of the input as find_ccs_reads' loop counts them: native (host only) when libclh.so loads, else the Python loop"""
     from . import find_ccs, hip
@@ -122,7 +142,8 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
     fq, is_fastq, _gz = find_ccs._open_reads(in_file)
     fq.close()
-    n = _bcast(_count_records(in_file, is_fastq) if rank == 0 else None)      # counted once, not once per rank
+    import itertools
+    n = _bcast(_together('count', lambda: _count_records(in_file, is_fastq) if rank == 0 else None))      # counted once, not once per rank
     lo, hi = shard_bounds(n, rank, world)
     tmp = os.path.join(out_dir, 'tmp')
     part = os.path.join(tmp, '%s.part%d' % (prefix, rank))
@@ -130,7 +151,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
         def find_consensus_file(path, fastq, ccs_path, raw_path, first, count):
             return hip.default_context().ccs_file(path, fastq, ccs_path, raw_path, 0, first, count)
     # ---- stage 1 ---------------------------------------------------------------------------------------------------------
-    total, ro, _too_long = find_consensus_file(in_file, is_fastq, part + '.ccs.fa', part + '.raw.fa', lo, hi - lo)
+    total, ro, _too_long = _together('1 (consensus)', lambda: find_consensus_file(in_file, is_fastq, part + '.ccs.fa', part + '.raw.fa', lo, hi - lo))
     ccs_seq = find_ccs.load_ccs_reads(out_dir, '%s.part%d' % (prefix, rank))
     if dist:
         dist.barrier()
@@ -149,20 +170,26 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
             counts[k] += v
     # ---- stage 2.1 -------------------------------------------------------------------------------------------------------
     short, records = [], []
-    for group in grouper(list(ccs_seq), chunk_size * find_bsj.GPU_CHUNKS):
-        chunk = [[i, ] + ccs_seq[i] for i in group if i is not None]
-        cnt, sh, ret = find_bsj.scan_ccs_chunk(chunk, is_canonical)
-        add(cnt)
-        short += sh
-        records += ret
+
+    def stage21():
+        for group in grouper(list(ccs_seq), chunk_size * find_bsj.GPU_CHUNKS):
+            chunk = [[i, ] + ccs_seq[i] for i in group if i is not None]
+            cnt, sh, ret = find_bsj.scan_ccs_chunk(chunk, is_canonical)
+            add(cnt)
+            short.extend(sh)
+            records.extend(ret)
+    _together('2.1 (scan_ccs_chunk)', stage21)
     # ---- stage 2.2: the short consensus reads, second mapper ------------------------------------------------------------------
     if stage_setup is not None:
         stage_setup('recover')
     recovered = []
-    for group in grouper(short, chunk_size * find_bsj.GPU_CHUNKS):
-        cnt, ret = find_bsj.recover_ccs_chunk([i for i in group if i is not None], is_canonical)
-        add(cnt)
-        recovered += ret
+
+    def stage22():
+        for group in grouper(short, chunk_size * find_bsj.GPU_CHUNKS):
+            cnt, ret = find_bsj.recover_ccs_chunk([i for i in group if i is not None], is_canonical)
+            add(cnt)
+            recovered.extend(ret)
+    _together('2.2 (recover_ccs_chunk)', stage22)
     records = gather_records(records)
     recovered = gather_records(recovered)
     if rank == 0:
@@ -174,12 +201,16 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     if stage_setup is not None:
         stage_setup('raw')
     partial, short_raw = [], []
-    mine = (rec for k, rec in enumerate(find_ccs.iter_reads(in_file)) if lo <= k < hi)
-    for group in grouper(mine, 1000):
-        cnt, ret, sh = find_bsj.scan_raw_chunk([r for r in group if r is not None], is_canonical, circ_reads)
-        add(cnt)
-        partial += ret
-        short_raw += sh
+
+    def stage3():
+        # this rank's records only: the iterator stops at `hi` (rounds 2-3 parsed the whole input on every rank)
+        mine = itertools.islice(find_ccs.iter_reads(in_file), lo, hi)
+        for group in grouper(mine, 1000):
+            cnt, ret, sh = find_bsj.scan_raw_chunk([r for r in group if r is not None], is_canonical, circ_reads)
+            add(cnt)
+            partial.extend(ret)
+            short_raw.extend(sh)
+    _together('3 (scan_raw_chunk)', stage3)
     partial = gather_records(partial)
     # ---- the one exchange of counters: after the last stage --------------------------------------------------------------------
     counts = allreduce_counters(counts)

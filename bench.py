@@ -617,6 +617,42 @@ def extra_stage1(hip, synth, ctx, n=100000):
             'roofline': {'bound': 'host', 'note': 'bound by the FASTQ parser thread, not by a kernel (DESIGN.md section 8)'}}
 
 
+def extra_stage2(hip, synth, ctx, n=50000):
+    """file-to-file stage 2 (find_bsj.scan_ccs_reads, find_bsj.py:328-372): the per-read host code of the product around the mapper,
+    the clip re-alignments (K5 + prefilter + K1 on hit +- 200 kb windows of the resident genome) and the splice-signal search (K6) per
+    group of 16 chunks, records to {prefix}.cand_circ.fa.  The external mapper cannot run here: synth.TruthMapper answers from the
+    construction of the reads and keeps its own time, which is stated and taken out."""
+    import shutil
+    import tempfile
+    from ciri_long_amd import env, find_bsj
+    w = synth.circ_world(n)
+
+    class _G(object):
+        genome = {'chr1': w['genome']}
+        contig_len = {'chr1': len(w['genome'])}
+
+        def seq(self, ctg, a, b):
+            return self.genome[ctg][max(a, 0):b]
+    d = tempfile.mkdtemp(dir='/tmp')
+    try:
+        t0 = time.perf_counter()
+        cnt, short = find_bsj.scan_ccs_reads(w['ccs_seq'], None, {}, {}, None, True, d, 'p', 1, aligner=w['mapper'], genome=_G(), contig_len=_G.contig_len)
+        el = time.perf_counter() - t0
+        size = os.path.getsize(os.path.join(d, 'p.cand_circ.fa'))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    if getattr(env.GENOME, 'device', None) is not None:
+        env.GENOME.device.close()
+    m = w['mapper']
+    return {'workload': 'stage 2 file to file: scan_ccs_reads on %d reads with a cyclic consensus (single-exon circRNAs on a 20 Mb genome resident in HBM; half of them '
+                        'leave 20-120 clipped bases for Smith-Waterman against hit +- 200 kb) -> cand_circ.fa (%d MB); mapper double answering from the truth, its time taken out'
+                        % (n, size >> 20),
+            'value': n / (el - m.seconds), 'unit': 'reads/s', 'e2e_stage2_reads_per_s': n / (el - m.seconds), 'seconds': el, 'mapper_double_seconds': m.seconds,
+            'mapper_calls': m.calls, 'reads_per_s_with_the_double': n / el, 'counters': dict(cnt),
+            'roofline': {'bound': 'host', 'note': 'per-read Python around the external mapper (find_bsj.py:236-325, align.py helpers); a real minimap2 call costs '
+                                                  'about a millisecond per read, i.e. far more than everything measured here'}}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def under_profiler():
     """rocprofv3 (or another HSA tool library) is preloaded into this process: the GPU is initialised already"""
@@ -757,6 +793,8 @@ def main():
             extra['collapse_c5'] = extra_collapse(torch, hip, synth, ctx)
             extra['stage1_files'] = extra_stage1(hip, synth, ctx)
             out['e2e_stage1_reads_per_s'] = extra['stage1_files']['e2e_stage1_reads_per_s']
+            extra['stage2_files'] = extra_stage2(hip, synth, ctx)
+            out['e2e_stage2_reads_per_s'] = extra['stage2_files']['e2e_stage2_reads_per_s']
         except Exception as ex:                      # an extra line must not cost the headline
             extra['error'] = repr(ex)
         out['extra'] = extra

@@ -80,18 +80,21 @@ class SubHit(object):
         self.cigar = cigar
         self.r_st = r_st
         r_en, q_en = r_st, q_st
+        mlen = blen = 0           # one walk over the operations (this constructor runs once per mapper hit the stage looks at)
         for n, op in cigar:
             if op == M:
-                q_en += n; r_en += n
+                q_en += n; r_en += n; mlen += n; blen += n
             elif op == I:
-                q_en += n
-            elif op in (D, N):
+                q_en += n; mlen += n; blen += n
+            elif op == D:
+                r_en += n; blen += n
+            elif op == N:
                 r_en += n
             elif op in (S, H) and q_st == 0:
                 q_st += n; q_en += n
         self.r_en, self.q_st, self.q_en = r_en, q_st, q_en
-        self.mlen = sum(n for n, op in cigar if op in (M, I))
-        self.blen = sum(n for n, op in cigar if op in (M, I, D))
+        self.mlen = mlen
+        self.blen = blen
         self.is_primary = 0
 
     @property

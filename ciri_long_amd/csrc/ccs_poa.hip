@@ -910,6 +910,210 @@ __device__ __attribute__((noinline)) void dp_rows(const PoaWs& w, const PoaScore
     bs_out = bs; br_out = br; bc_out = bc;
 }
 
+// ---- the wide (32-bit) form of the pass -------------------------------------------------------------------------------------
+// spoa aligns sequences of any length (its engines fall back to 32-bit cells); the packed pass above holds what fits int16: sequences
+// up to POA_MAX_COPY bases with the call sites' scores.  Everything else -- a longer sequence, scores outside the 16-bit cells, a run
+// of the packed pass that reported a cell at the floor of its range -- takes this form: the same lazy row formulation (tools/poa_model.py:
+// dp_row), one cell per lane-operation in 32 bits, lane l owns C adjacent columns (C = 1..6, 384 columns a pass), H in a plane of
+// int32, the clamped differences in the same 16-bit word as above, every cell stored, every source row that is not the row before read
+// back from the planes, carries between passes and the first column of global mode in int32 arrays behind the planes.  Not tuned:
+// it exists so that nothing the reference would answer is refused for its size.
+static constexpr int POA_NEGW = -(1 << 29);
+__host__ __device__ inline size_t poa_plane_bytes_w(int N, int m) { return (((size_t)(N + 1) * (size_t)poa_pitch(m) * 4 + 15) & ~(size_t)15) + 64; }
+// planes (H int32, D uint16), 6 carry arrays and the global-mode column, all int32 of N + 2 entries
+__host__ __device__ inline size_t poa_dp_bytes_w(int N, int m) { return poa_plane_bytes_w(N, m) + poa_plane_bytes(N, m) + 7 * (((size_t)(N + 2) * 4 + 15) & ~(size_t)15) + 64; }
+struct PoaWide { int* planeH; unsigned short* planeD; int* carry; int cpitch; int* col0; };
+
+template <int C>
+__device__ void dp_pass_w(const PoaWs& w, const PoaWide& W, const PoaScores S, const int N, const int m, const int8_t* seq, const int lane, const int pass, const int colbase,
+                          const bool more, int& bs_io, int& br_io, int& bc_io)
+{
+    const int gp = poa_pitch(m);
+    const bool sw = (S.algorithm & 0xff) == 0, nw = (S.algorithm & 0xff) == 1;
+    const int g = S.g, e = S.e, q = S.q, c = S.c;
+    const int lc0 = C * lane, col0 = colbase + lc0;              // register t = column col0 + t + 1
+    int sb[C], je[C], jc[C];
+    bool inseq[C];
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int j = col0 + t + 1;
+        inseq[t] = j <= m;
+        sb[t] = inseq[t] ? (int)(uint8_t)seq[j - 1] : 0x100;
+        je[t] = (lc0 + t + 1) * e; jc[t] = (lc0 + t + 1) * c;
+    }
+    auto row0_h = [&](int j) -> int {
+        const int l1 = g + (j - 1) * e, l2 = q + (j - 1) * c;
+        return (sw || j == 0) ? 0 : (l1 > l2 ? l1 : l2);
+    };
+    const int cpitch = W.cpitch;
+    const int* cprev = W.carry + (size_t)(pass & 1) * 3 * cpitch;
+    int* cnext = W.carry + (size_t)((pass + 1) & 1) * 3 * cpitch;
+    const bool carried = pass > 0;
+    auto left_of = [&](int qr) -> int { return carried ? cprev[qr] : (nw ? W.col0[qr] : 0); };
+    int px[C], pf[C], po[C];
+#pragma unroll
+    for (int t = 0; t < C; ++t) { px[t] = 0; pf[t] = 0; po[t] = 0; }
+    int pcin = 0;
+    int bs = sw ? 0 : POA_NEGW, br = 0, bc = 0;                 // this lane's end cell: first strict maximum in (rank, column) order
+    int nbest = -(1 << 30), nrow = 0;
+    const int mc = m - 1 - colbase;                              // last pass: where column m lives
+    const int lm = mc / C, tm = mc % C;
+    const bool last = !more;
+    for (int r = 1; r <= N; ++r) {
+        const uint2 rb = w.ri[r];
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rb.x), d1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rb.y);
+        const int vb = (int)(d0 & 0xff), np = (int)((d0 >> 8) & 0xf);
+        const bool sink = (d0 & 0x1000u) != 0;
+        const int cinH = carried ? cprev[r] : (nw ? W.col0[r] : 0);
+        const int cinE = carried ? cprev[cpitch + r] : POA_NEGW, cinQ = carried ? cprev[2 * cpitch + r] : POA_NEGW;
+        int ss[C], dg[C], MF[C], MO[C];
+#pragma unroll
+        for (int t = 0; t < C; ++t) { ss[t] = sb[t] == vb ? S.m : S.n; dg[t] = POA_NEGW; MF[t] = POA_NEGW; MO[t] = POA_NEGW; }
+        auto add_source = [&](int qr) {
+            int h[C], fs[C], os[C], left;
+            if (qr == r - 1 && qr != 0) {
+#pragma unroll
+                for (int t = 0; t < C; ++t) { h[t] = px[t]; fs[t] = pf[t]; os[t] = po[t]; }
+                left = pcin;
+            } else if (qr == 0) {
+#pragma unroll
+                for (int t = 0; t < C; ++t) { h[t] = row0_h(col0 + t + 1); fs[t] = h[t] - 1; os[t] = fs[t]; }
+                left = row0_h(colbase);
+            } else {
+#pragma unroll
+                for (int t = 0; t < C; ++t) {
+                    int hv = 0, dd = 0;
+                    if (inseq[t]) {      // agent-scope loads: the cells were written by these lanes earlier in this pass (a line of the CU's L1 may predate them)
+                        hv = __hip_atomic_load(W.planeH + (size_t)qr * gp + col0 + t + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dd = (int)__hip_atomic_load(W.planeD + (size_t)qr * gp + col0 + t + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    h[t] = hv; fs[t] = hv + (dd & 7) - 1; os[t] = hv + ((dd >> 3) & 31) - 1;
+                }
+                left = left_of(qr);
+            }
+            const int hsh0 = dpp_shr1(left, h[C - 1]);
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+                const int x = (t == 0 ? hsh0 : h[t - 1]) + ss[t];
+                dg[t] = x > dg[t] ? x : dg[t];
+                const int mf = h[t] > fs[t] ? h[t] : fs[t], mo = h[t] > os[t] ? h[t] : os[t];
+                MF[t] = mf > MF[t] ? mf : MF[t]; MO[t] = mo > MO[t] ? mo : MO[t];
+            }
+        };
+        if (np == 0) add_source(0);
+        else {
+            add_source((int)(d0 >> 16));
+            if (np > 1) add_source((int)(d1 & 0xffff));
+            if (np > 2) add_source((int)(d1 >> 16));
+            if (np > 3) {
+                const int vnode = __builtin_amdgcn_readfirstlane(w.order[r - 1]);
+                const int npt = np < 15 ? np : __builtin_amdgcn_readfirstlane((int)w.np[vnode]);
+                for (int s2 = 3; s2 < npt; ++s2) add_source(__builtin_amdgcn_readfirstlane(w.rank[poa_pred_at(w, vnode, s2)]));
+            }
+        }
+        int M0[C], fsn[C], osn[C], X[C], Y[C];
+        const int floorv = sw ? 0 : POA_NEGW;
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+            fsn[t] = MF[t] + e; osn[t] = MO[t] + c;
+            int v = dg[t] > floorv ? dg[t] : floorv;
+            const int a1 = MF[t] + g, a2 = MO[t] + q;
+            v = a1 > v ? a1 : v; v = a2 > v ? a2 : v;
+            M0[t] = v;
+        }
+        {   // the two horizontal states: exclusive prefix maxima in the gap-free frames of the two pieces
+            const int leftE = cinH > cinE + e - g ? cinH : cinE + e - g;
+            const int leftQ = cinH > cinQ + c - q ? cinH : cinQ + c - q;
+            int runA = -(1 << 30), runB = -(1 << 30), pe[C], pq[C];
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+                pe[t] = runA; pq[t] = runB;
+                const int a = M0[t] - je[t], b = M0[t] - jc[t];
+                runA = a > runA ? a : runA; runB = b > runB ? b : runB;
+            }
+            int excA = dpp_shr1(leftE, runA), excB = dpp_shr1(leftQ, runB);
+            wave_prefix_max2(excA, excB);
+#pragma unroll
+            for (int t = 0; t < C; ++t) { X[t] = (pe[t] > excA ? pe[t] : excA) + je[t]; Y[t] = (pq[t] > excB ? pq[t] : excB) + jc[t]; }
+        }
+        int Hf[C], qhat[C], Es[C];
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+            qhat[t] = Y[t] + (q - c);
+            int v = M0[t];
+            const int xe = X[t] + (g - e);
+            v = xe > v ? xe : v; v = qhat[t] > v ? qhat[t] : v;
+            Hf[t] = v;
+        }
+        const int q0 = dpp_shr1(cinQ, qhat[C - 1]);
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+            const int qe = (t == 0 ? q0 : qhat[t - 1]) + e;
+            Es[t] = X[t] > qe ? X[t] : qe;
+            if (inseq[t]) {
+                const int Hm = Hf[t] - 1;
+                int dF = fsn[t] - Hm, dO = osn[t] - Hm, dE = Es[t] - Hm, dQ = Y[t] - Hm;
+                dF = dF < 0 ? 0 : dF; dO = dO < 0 ? 0 : dO; dE = dE < 0 ? 0 : dE; dQ = dQ < 0 ? 0 : dQ;
+                W.planeH[(size_t)r * gp + col0 + t + 8] = Hf[t];
+                W.planeD[(size_t)r * gp + col0 + t + 8] = (unsigned short)((dQ << 11) | (dE << 8) | (dO << 3) | dF);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < C; ++t) { px[t] = Hf[t]; pf[t] = fsn[t]; po[t] = osn[t]; }
+        pcin = cinH;
+        if (sw | (!nw & sink)) {
+#pragma unroll
+            for (int t = 0; t < C; ++t) if (inseq[t] && Hf[t] > bs) { bs = Hf[t]; br = r; bc = col0 + t + 1; }
+        } else if (nw & sink & last) {
+            int pick = 0;
+#pragma unroll
+            for (int t = 0; t < C; ++t) if (t == tm) pick = __builtin_amdgcn_readlane(Hf[t], lm);
+            if (pick > nbest) { nbest = pick; nrow = r; }
+        }
+        if (more) {
+            const int rH = __builtin_amdgcn_readlane(Hf[C - 1], 63), rEs = __builtin_amdgcn_readlane(Es[C - 1], 63), rQ = __builtin_amdgcn_readlane(qhat[C - 1], 63);
+            const int rE = rEs - (e - g);
+            if (lane == 0) { cnext[r] = rH; cnext[cpitch + r] = rE < POA_NEGW ? POA_NEGW : rE; cnext[2 * cpitch + r] = rQ < POA_NEGW ? POA_NEGW : rQ; }
+        }
+    }
+    if (more) phase_sync();
+    if (br == 0) bs = -(1 << 30);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int s2 = __shfl_xor(bs, d), r2 = __shfl_xor(br, d), c2x = __shfl_xor(bc, d);
+        if (s2 > bs || (s2 == bs && (r2 < br || (r2 == br && c2x < bc)))) { bs = s2; br = r2; bc = c2x; }
+    }
+    if (nw) { bs = nbest; br = nrow; bc = m; }
+    if (br > 0 && (bs > bs_io || (bs == bs_io && br < br_io))) { bs_io = bs; br_io = br; bc_io = bc; }
+}
+
+__device__ __attribute__((noinline)) void dp_rows_w(const PoaWs& w, const PoaWide W, const PoaScores S_, int N, int m, const int8_t* seq_, int lane, int& bs_out, int& br_out, int& bc_out)
+{
+    PoaScores S;
+    S.algorithm = __builtin_amdgcn_readfirstlane(S_.algorithm); S.m = __builtin_amdgcn_readfirstlane(S_.m); S.n = __builtin_amdgcn_readfirstlane(S_.n);
+    S.g = __builtin_amdgcn_readfirstlane(S_.g); S.e = __builtin_amdgcn_readfirstlane(S_.e); S.q = __builtin_amdgcn_readfirstlane(S_.q);
+    S.c = __builtin_amdgcn_readfirstlane(S_.c); S.min_cov = 0;
+    const int8_t* seq = uniform_ptr(seq_);
+    N = __builtin_amdgcn_readfirstlane(N); m = __builtin_amdgcn_readfirstlane(m);
+    constexpr int WMAX = 64 * 6;
+    int bs = (S.algorithm & 0xff) == 0 ? 0 : -(1 << 30), br = 0, bc = 0;
+    int pass = 0;
+    for (int colbase = 0; colbase < m; colbase += WMAX, ++pass) {
+        const int rem = m - colbase;
+        const bool more = rem > WMAX;
+        const int cpl = more ? 6 : (rem + 63) / 64;
+        switch (cpl) {
+            case 1: dp_pass_w<1>(w, W, S, N, m, seq, lane, pass, colbase, more, bs, br, bc); break;
+            case 2: dp_pass_w<2>(w, W, S, N, m, seq, lane, pass, colbase, more, bs, br, bc); break;
+            case 3: dp_pass_w<3>(w, W, S, N, m, seq, lane, pass, colbase, more, bs, br, bc); break;
+            case 4: dp_pass_w<4>(w, W, S, N, m, seq, lane, pass, colbase, more, bs, br, bc); break;
+            case 5: dp_pass_w<5>(w, W, S, N, m, seq, lane, pass, colbase, more, bs, br, bc); break;
+            default: dp_pass_w<6>(w, W, S, N, m, seq, lane, pass, colbase, more, bs, br, bc); break;
+        }
+    }
+    bs_out = bs; br_out = br; bc_out = bc;
+}
+
 // Graph::TopologicalSort -- the order spoa's sequential depth-first search produces (oracle/poa_oracle.c: topo_sort), from
 // independent pieces (tools/poa_model.py: topo_sort states and tests the derivation on the CPU):
 //  1. root[x] = the smallest node id among everything that depends on x (descendants over the edges, the members of their
@@ -1197,11 +1401,15 @@ static constexpr int BT_W = POA_LDS_BYTES >= 9216 ? 24 : 20;     // columns per 
 static constexpr int BT_SQ = 128, BT_RING = 1024;    // letters staged with the band; entries of the result ring
 static constexpr int BT_DRIFT = BT_W / 2 - 4;        // how far the walk may leave the band's diagonal before the band is staged again
 static_assert(4 * 64 * BT_W + BT_SQ + 2 * BT_RING <= POA_LDS_BYTES, "back-track LDS");
+static constexpr int BT_W32 = 16;                  // the wide form (int32 H): 6 bytes per staged cell
+static_assert(6 * 64 * BT_W32 + BT_SQ + 2 * BT_RING <= POA_LDS_BYTES, "back-track LDS, wide form");
 // A function of its own, NOT inlined: inside the kernel's one big body the register allocator spilled a value of this loop and
 // reloaded it every iteration -- and the wait for that reload is a wait for every store in flight, i.e. for the walk's own result
 // stores to reach memory: 2 us per step.  With its own frame the loop keeps its registers.
-struct BtArgs { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; const int8_t* seq; int N, m, r, j, slope16; const int32_t* ovn; const int32_t* ovp; const int32_t* ovc; const int8_t* np; };
+struct BtArgs { int32_t* pn; void* planeH; unsigned short* planeD; uint2* ri; void* col0; int32_t* rank; int32_t* pred; int32_t* order; const int8_t* seq; int N, m, r, j, slope16; const int32_t* ovn; const int32_t* ovp; const int32_t* ovc; const int8_t* np; };
 // returns 2 * (column the walk ends in) + (1 if the alignment holds a step), -1 (guard) or BT_MISS (a cell outside the band the planes hold)
+// HT = short: the planes of the packed pass; HT = int: the wide form (BW columns per band row)
+template <typename HT, int BW>
 __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const PoaScores S_ DBGARG)
 {
     PoaScores S;                                             // (arguments arrive in vector registers; a test on one is a divergent branch)
@@ -1209,9 +1417,11 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
     S.g = __builtin_amdgcn_readfirstlane(S_.g); S.e = __builtin_amdgcn_readfirstlane(S_.e); S.q = __builtin_amdgcn_readfirstlane(S_.q);
     S.c = __builtin_amdgcn_readfirstlane(S_.c); S.min_cov = 0;
     // the walk is wave-uniform: say so (scalar registers, scalar branches)
-    struct { int32_t* pn; short* planeH; unsigned short* planeD; uint2* ri; short* col0; int32_t* rank; int32_t* pred; int32_t* order; } w;
-    w.pn = uniform_ptr(A.pn); w.planeH = uniform_ptr(A.planeH); w.planeD = uniform_ptr(A.planeD); w.ri = uniform_ptr(A.ri);
-    w.col0 = uniform_ptr(A.col0); w.rank = uniform_ptr(A.rank); w.pred = uniform_ptr(A.pred); w.order = uniform_ptr(A.order);
+    constexpr int BT_W = BW, BT_DRIFT = BW / 2 - 4;
+    constexpr int POA_H_NONE = sizeof(HT) == 2 ? -32768 : (int)0x80000000;      // (shadows the packed form's constant: a staged cell the planes do not hold)
+    struct { int32_t* pn; HT* planeH; unsigned short* planeD; uint2* ri; HT* col0; int32_t* rank; int32_t* pred; int32_t* order; } w;
+    w.pn = uniform_ptr(A.pn); w.planeH = uniform_ptr((HT*)A.planeH); w.planeD = uniform_ptr(A.planeD); w.ri = uniform_ptr(A.ri);
+    w.col0 = uniform_ptr((HT*)A.col0); w.rank = uniform_ptr(A.rank); w.pred = uniform_ptr(A.pred); w.order = uniform_ptr(A.order);
     const int8_t* seq = uniform_ptr(A.seq);
     const int lane = threadIdx.x & 63;
     const int N = __builtin_amdgcn_readfirstlane(A.N), m = __builtin_amdgcn_readfirstlane(A.m), slope16 = __builtin_amdgcn_readfirstlane(A.slope16);
@@ -1227,12 +1437,12 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
     // where it is used.  Handing the address in as an argument removes the look-ups and measured 2.6 ms SLOWER on C3: through a pointer
     // made from an integer the compiler no longer tells the band, the letters and the ring apart and serialises their accesses.)
     uint32_t* const lds = poa_lds;
-    short* Hb = (short*)lds;
-    unsigned short* Db = (unsigned short*)lds + 64 * BT_W;
+    HT* Hb = (HT*)lds;
+    unsigned short* Db = (unsigned short*)(Hb + 64 * BT_W);
     // The walk's results (pn[column] = rank) go to a ring in LDS and from there to HBM in blocks: a store to HBM inside the loop stays in
     // flight for a microsecond, and any wait the compiler places in the loop for whatever reason (a register about to be reused by a
     // rare path's load is enough) then waits for it -- once per step.  The sequence's letters around the band are staged with it.
-    uint8_t* lsq = (uint8_t*)lds + 4 * 64 * BT_W;                   // letters of columns sb0 + 1 .. sb0 + BT_SQ
+    uint8_t* lsq = (uint8_t*)(Db + 64 * BT_W);                   // letters of columns sb0 + 1 .. sb0 + BT_SQ
     unsigned short* lpn = (unsigned short*)(lsq + BT_SQ);           // ring: entry t & (BT_RING - 1) = pn[t]; 0 = none
     for (int i = lane; i < BT_RING / 2; i += 64) ((uint32_t*)lpn)[i] = 0;
     int jflush = j, sb0 = 0;                                        // pn[t] for t in [j, jflush) is in the ring
@@ -1267,24 +1477,24 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
             rim = w.ri[rr];
             chain = (((rim.x >> 8) & 0xf) == 0 ? 0 : (int)(rim.x >> 16)) == rr - 1;
             if (csk + BT_W > 1) {
-                uint32_t t[BT_W / 2];
-                __builtin_memcpy(t, (const uint32_t*)(w.planeH + (size_t)rr * gp + csk + 7), BT_W * 2);
-                __builtin_memcpy(Hb + lane * BT_W, t, BT_W * 2);
+                uint32_t t[BT_W * sizeof(HT) / 4];
+                __builtin_memcpy(t, (const uint32_t*)(w.planeH + (size_t)rr * gp + csk + 7), BT_W * sizeof(HT));
+                __builtin_memcpy(Hb + lane * BT_W, t, BT_W * sizeof(HT));
                 __builtin_memcpy(t, (const uint32_t*)(w.planeD + (size_t)rr * gp + csk + 7), BT_W * 2);
                 __builtin_memcpy(Db + lane * BT_W, t, BT_W * 2);
                 if (slope16 && !(rim.x & 0x8000u)) {        // cells of this row that the planes do not hold (POA_BAND): marked, so that using one is seen
                     const int cen = (int)(((unsigned)rr * (unsigned)slope16) >> 16);
                     const int xlo = cen - POA_BAND - csk, xhi = cen + POA_BAND - csk;      // band row indices of the first and last cell held
-                    for (int x = 0; x < xlo && x < BT_W; ++x) Hb[lane * BT_W + x] = (short)POA_H_NONE;
-                    for (int x = xhi + 1 > 0 ? xhi + 1 : 0; x < BT_W; ++x) Hb[lane * BT_W + x] = (short)POA_H_NONE;
+                    for (int x = 0; x < xlo && x < BT_W; ++x) Hb[lane * BT_W + x] = (HT)POA_H_NONE;
+                    for (int x = xhi + 1 > 0 ? xhi + 1 : 0; x < BT_W; ++x) Hb[lane * BT_W + x] = (HT)POA_H_NONE;
                 }
             }
         }
         if (r0 < 64) {                                       // the block reaches row 0
-            if (rr == 0) for (int x = 0; x < BT_W; ++x) { Hb[lane * BT_W + x] = (short)(csk + x >= 0 ? row0_h(csk + x) : 0); Db[lane * BT_W + x] = 0; }
+            if (rr == 0) for (int x = 0; x < BT_W; ++x) { Hb[lane * BT_W + x] = (HT)(csk + x >= 0 ? row0_h(csk + x) : 0); Db[lane * BT_W + x] = 0; }
         }
         if (j0 - BT_W / 2 - 64 <= 0) {                       // some window reaches column 0
-            if (rr >= 1 && csk <= 0 && csk + BT_W > 0) { Hb[lane * BT_W - csk] = (short)(nw ? (int)w.col0[rr] : 0); Db[lane * BT_W - csk] = 0; }
+            if (rr >= 1 && csk <= 0 && csk + BT_W > 0) { Hb[lane * BT_W - csk] = (HT)(nw ? (int)w.col0[rr] : 0); Db[lane * BT_W - csk] = 0; }
         }
         __syncthreads();
     };
@@ -1451,6 +1661,9 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
 // returns the new node count; -1 graph limits, -2 workspace, -3 back-track guard, -4 a cell at the floor of the int16 range
 // (global / overlap modes with costly gaps).  *score_out = end-cell score.
 // path_out (may be null): node of every base (for the MSA)
+// WIDE: the 32-bit form of the pass and of the back-track (its own kernel, poa_consensus_wide_kernel: in the packed kernel's body the extra
+// code cost the common path 19 % -- register allocation)
+template <bool WIDE>
 __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int ncap, const int8_t* seq, int m_, int lane, int* score_out, int32_t* path_out, unsigned long long* tacc, int* band_misses, const int mref)
 {
     // wave-uniform by construction; say so, or every quantity derived from them lives in VGPRs behind exec-mask branches
@@ -1461,7 +1674,10 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
 #endif
     *score_out = 0;
     if (m == 0) return N;
+    constexpr bool wide = WIDE;
     int bs = 0, br = 0, bc = 0, slope16 = 0;
+    PoaWide W;
+    W.planeH = nullptr; W.planeD = nullptr; W.carry = nullptr; W.cpitch = 0; W.col0 = nullptr;
     if (N > 0) {
         if (N > POA_MAX_ROWS || (S.algorithm == 1 && N > 25000)) return -1;
         // ---- graph rows in rank space (w.ri: base, in-degree, sink, ranks of the first three sources) ---------------------
@@ -1489,9 +1705,16 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
             if (np > 2) mark(p2);
             if (np > 3) { const int v = w.order[r - 1]; const int npt = w.np[v]; for (int s2 = 3; s2 < npt; ++s2) mark(w.rank[poa_pred_at(w, v, s2)]); }
         }
-        if (poa_dp_bytes(N, m) > w.dp_bytes) return -2;
+        if ((wide ? poa_dp_bytes_w(N, m) : poa_dp_bytes(N, m)) > w.dp_bytes) return -2;
         w.planeH = (short*)w.dp;
         w.planeD = (unsigned short*)(w.dp + poa_plane_bytes(N, m));
+        if constexpr (WIDE) {      // H in int32, the differences behind it, then the carries of the passes and the first column of global mode
+            W.planeH = (int*)w.dp;
+            W.planeD = (unsigned short*)(w.dp + poa_plane_bytes_w(N, m));
+            W.cpitch = (N + 2 + 3) & ~3;
+            W.carry = (int*)((uint8_t*)W.planeD + poa_plane_bytes(N, m));
+            W.col0 = W.carry + 6 * (size_t)W.cpitch;
+        }
         if (S.algorithm == 1) {
             // global mode: H[i][0] = max(F, O)[i][0], F[i][0] = e + max over sources (a node without in-edges: g), O likewise.
             // A chain over the ranks, wave-uniform (every lane computes and stores the same values); not a hot path.
@@ -1506,8 +1729,11 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
                 f += S.e; o += S.c;
                 w.score[r] = f; w.bp[r] = o;
                 const int h = f > o ? f : o;
-                if (h <= POA_NEG) return -4;                 // column 0 leaves the int16 range (wave-uniform)
-                w.col0[r] = (short)h;
+                if constexpr (WIDE) W.col0[r] = h;
+                else {
+                    if (h <= POA_NEG) return -4;             // column 0 leaves the int16 range (wave-uniform)
+                    w.col0[r] = (short)h;
+                }
                 __syncthreads();
             }
         }
@@ -1518,7 +1744,8 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
 #ifdef POA_NO_BAND
         slope16 = 0;
 #endif
-        dp_rows(w, S, N, m, seq, lane, slope16, bs, br, bc DBGPASS);
+        if constexpr (WIDE) { slope16 = 0; dp_rows_w(w, W, S, N, m, seq, lane, bs, br, bc); }
+        else dp_rows(w, S, N, m, seq, lane, slope16, bs, br, bc DBGPASS);
 #ifdef POA_EXP_DP2          // timing experiments (tools/dev/k3_ab.py): a phase run twice costs its marginal time once more
         phase_sync();
 #ifdef POA_EXP_DP2_NOSTORE
@@ -1548,22 +1775,24 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
         je = j - 1;
         if (br > 0) {
             phase_sync();
-            BtArgs A = {w.pn, w.planeH, w.planeD, w.ri, w.col0, w.rank, w.pred, w.order, seq, N, m, __builtin_amdgcn_readfirstlane(br), j, slope16, w.ovn, w.ovp, w.ovc, w.np};
+            BtArgs A = {w.pn, wide ? (void*)W.planeH : (void*)w.planeH, wide ? W.planeD : w.planeD, w.ri, wide ? (void*)W.col0 : (void*)w.col0, w.rank, w.pred, w.order, seq, N, m,
+                        __builtin_amdgcn_readfirstlane(br), j, slope16, w.ovn, w.ovp, w.ovc, w.np};
 #ifdef POA_EXP_BT2
-            { (void)poa_backtrack(A, S DBGPASS); phase_sync(); }
+            { (void)poa_backtrack<short, BT_W>(A, S DBGPASS); phase_sync(); }
 #endif
-            int rc = poa_backtrack(A, S DBGPASS);
-            if (rc == BT_MISS) {
+            int rc;
+            if constexpr (WIDE) rc = poa_backtrack<int, BT_W32>(A, S DBGPASS); else rc = poa_backtrack<short, BT_W>(A, S DBGPASS);
+            if (!WIDE && rc == BT_MISS) {
                 // the walk left the band of cells the planes hold: the pass once more, every cell stored (the end cell is the same), and
                 // the walk again.  Rare; counted (clh_ccs_plan_stats) so that it is seen if it ever is not
                 if (band_misses) *band_misses += 1;
                 phase_sync();
                 int b1 = S.algorithm == 0 ? 0 : -(1 << 30), b2 = 0, b3 = 0;
-                dp_rows(w, S, N, m, seq, lane, 0, b1, b2, b3 DBGPASS);
+                if constexpr (!WIDE) dp_rows(w, S, N, m, seq, lane, 0, b1, b2, b3 DBGPASS);
                 for (int t = lane; t < m; t += 64) w.pn[t] = 0;
                 phase_sync();
                 A.slope16 = 0;
-                rc = poa_backtrack(A, S DBGPASS);
+                if constexpr (!WIDE) rc = poa_backtrack<short, BT_W>(A, S DBGPASS);
             }
             if (rc < 0) return -3;
             j = rc >> 1; moved = (rc & 1) != 0;
@@ -1821,21 +2050,28 @@ __device__ int poa_msa_columns(const PoaWs& w, int N, int lane)
     return nc;
 }
 
-__global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsParams p)
+// the body of K3's kernels.  WIDE = false: the packed (16-bit) form; a read it cannot take -- a copy above POA_MAX_COPY bases, scores
+// outside the 16-bit cells, a cell that reached the floor of the range -- goes on the wide list.  WIDE = true: the reads of that list
+// in the 32-bit form, by persistent waves over the plan's worst-case slots.
+template <bool WIDE>
+__device__ __forceinline__ void poa_kernel_body(const CcsParams& p)
 {
     const int lane = threadIdx.x & 63;
     uint8_t* slot = p.poa_ws + (size_t)blockIdx.x * p.slot_bytes;
-    const PoaScores S = p.sc;
+    PoaScores S = p.sc;
+    const bool force_wide = (S.algorithm & 0x200) != 0;     // the host saw scores outside the 16-bit cells (or a test asks for the wide form)
+    S.algorithm &= 0xff;
+    const int n_items = WIDE ? __builtin_amdgcn_readfirstlane(*p.wide_count) : p.n;
     for (int turns = 0; turns <= p.n; ++turns) {             // a wave takes at most every read once
         int idx = 0;
         if (lane == 0) idx = atomicAdd(p.work_counter, 1);
         idx = __builtin_amdgcn_readfirstlane(idx);    // wave-uniform in the compiler's eyes too: scalar loads, scalar branches, SGPR pointers below
-        if (idx >= p.n) break;
-        const int rd = p.work_order ? p.work_order[idx] : idx;
+        if (idx >= n_items) break;
+        const int rd = WIDE ? __builtin_amdgcn_readfirstlane(p.wide_list[idx]) : (p.work_order ? p.work_order[idx] : idx);
         const int64_t off = p.read_off[rd];
         const int L = (int)(p.read_off[rd + 1] - off);
         const int8_t* seq = p.reads + off;
-        if (p.tier == 1 && __builtin_amdgcn_readfirstlane(p.results[rd].status) != 1) continue;   // second tier: only what did not fit a first-tier slot
+        if (!WIDE && p.tier == 1 && __builtin_amdgcn_readfirstlane(p.results[rd].status) != 1) continue;   // second tier: only what did not fit a first-tier slot
         CcsResult res;
         res.nseg = 0; res.ccs_len = 0; res.period = 0; res.status = 0;
         // the sequences: copies found by K2, or the explicit sequences of a group (poa API)
@@ -1866,13 +2102,16 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
             b = cut; ++nseg;
         }
         const int ncap = total + 8, mcap = maxlen + 1;
-        if (maxlen > POA_MAX_COPY) { res.status = 4; if (lane == 0) { p.results[rd] = res; if (p.stats) atomicAdd(p.stats + 8 + 4, 1); } continue; }   // cells are int16
+        // cells beyond int16: the wide form of the pass (spoa's engines do the same), in its own kernel
+        auto to_wide_list = [&]() { if (lane == 0) { const int k = atomicAdd(p.wide_count, 1); p.wide_list[k] = rd; } };
+        if (!WIDE && (force_wide || maxlen > POA_MAX_COPY)) { if (p.tier == 0) to_wide_list(); continue; }
+        constexpr bool wide = WIDE;
         // workspace: this wave's slot, or -- a read that needs more -- one of the large slots, claimed for the duration of
         // the read; none free (or none large enough): status 1, the second launch over the large slots takes the read
         uint8_t* ws = slot;
         size_t ws_bytes = p.slot_bytes;
         int big = -1;
-        const size_t need_min = poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(maxlen + 8, maxlen) + 64;
+        const size_t need_min = poa_fixed_bytes(ncap, mcap, nullptr) + (wide ? poa_dp_bytes_w(maxlen + 8, maxlen) : poa_dp_bytes(maxlen + 8, maxlen)) + 64;
         bool use_big = need_min > p.slot_bytes;
         int N = 0, len = -1, ncols = 0;
         unsigned long long dp_cells = 0, dp_rows_n = 0;      // work of this read: DP cells and row steps (the bench's cell-update rate)
@@ -1901,7 +2140,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
                 const int cut = i < ncuts ? __builtin_amdgcn_readfirstlane(cuts[i]) : L;
                 int sc1 = 0;
                 if (N > 0 && cut > b) { dp_cells += (unsigned long long)N * (unsigned)(cut - b); dp_rows_n += (unsigned long long)N * (unsigned)((cut - b + 128 * POA_MAXCP - 1) / (128 * POA_MAXCP)); }
-                N = poa_add(w, S, N, ncap, seq + b, cut - b, lane, &sc1, p.msa_col ? p.msa_col + off + b : nullptr, tacc, &band_miss_n, mref);
+                N = poa_add<WIDE>(w, S, N, ncap, seq + b, cut - b, lane, &sc1, p.msa_col ? p.msa_col + off + b : nullptr, tacc, &band_miss_n, mref);
                 mref = cut - b > mref ? cut - b : mref;
                 if (p.aln_score && si < CCS_SEG_CAP && lane == 0) p.aln_score[(size_t)rd * CCS_SEG_CAP + si] = sc1;
                 b = cut; ++si;
@@ -1934,6 +2173,12 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
             }
             break;
         }
+        if (!WIDE && N == -4 && p.tier == 0) {            // a cell left the int16 range: the read once more in the wide form (a read of the
+            to_wide_list();                                // second launch keeps status 6: the wide kernel's list is closed by then)
+            __syncthreads();
+            if (big >= 0) { __threadfence(); if (lane == 0) atomicExch(&p.big_busy[big], 0); }
+            continue;
+        }
         if (N == -2) res.status = 1;
         else if (N == -3) res.status = 5;
         else if (N == -4) res.status = 6;
@@ -1945,7 +2190,7 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
             p.results[rd] = res; if (p.msa_ncols) p.msa_ncols[rd] = ncols;
             // a read handed to the second launch is counted there; status 1 is final in that launch, and in the first one when no
             // second launch will run (no large slots)
-            if (p.stats && (res.status != 1 || p.tier == 1 || p.n_big == 0)) {
+            if (p.stats && (WIDE || res.status != 1 || p.tier == 1 || p.n_big == 0)) {
                 atomicAdd((unsigned long long*)(p.stats + 2), dp_cells); atomicAdd((unsigned long long*)(p.stats + 4), dp_rows_n);
                 if (band_miss_n) atomicAdd(p.stats + 6, band_miss_n);
                 if (res.status != 0) atomicAdd(p.stats + 8 + (res.status & 7), 1);      // reads lost to a limit of this kernel, by status
@@ -1958,6 +2203,9 @@ __global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsP
         }
     }
 }
+
+__global__ void __launch_bounds__(64, POA_WAVES) poa_consensus_kernel(const CcsParams p) { poa_kernel_body<false>(p); }
+__global__ void __launch_bounds__(64, 2) poa_consensus_wide_kernel(const CcsParams p) { poa_kernel_body<true>(p); }
 
 // one launch class of K2: `count` reads from p.work_order[p.k2_begin ...], none longer than p.lcap (reads above p.k2_lds_max
 // return at once); with_long: also the HBM-workspace kernel for those
@@ -2026,7 +2274,16 @@ hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream)
     return hipGetLastError();
 }
 
+// the reads on the wide list (p.wide_list / p.wide_count, filled by the launches above), over p.poa_ws = worst-case slots
+hipError_t launch_poa_wide(const CcsParams& p, int nslots, hipStream_t stream)
+{
+    hipLaunchKernelGGL(poa_consensus_wide_kernel, dim3(nslots), dim3(64), (size_t)POA_LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
 size_t poa_slot_bytes_host(int ncap, int mcap) { return poa_slot_bytes(ncap, mcap); }
 size_t poa_slot_min_bytes_host(int ncap, int mcap) { return poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes(mcap + 8, mcap - 1) + 64; }
+// the same for the wide (32-bit) form of the pass: sequences above 2800 bases, scores outside the 16-bit cells
+size_t poa_slot_bytes_host_w(int ncap, int mcap) { return poa_fixed_bytes(ncap, mcap, nullptr) + poa_dp_bytes_w(ncap, mcap - 1) + 64; }
 
 }  // namespace clh

@@ -1248,7 +1248,7 @@ extern "C" uint32_t cigar_int_to_len(uint32_t cigar_int) { return cigar_int >> 4
 // cyclic consensus: find_consensus for a batch of reads (K2 + K3)
 // ------------------------------------------------------------------------------------------------------------
 struct clh_ccs_plan;
-static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off, int mcap_hint);
+static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off, int mcap_hint, bool wide_hint = false);
 extern "C" clh_ccs_plan* clh_ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off) { return ccs_plan_create(ctx, n, read_off, 0); }
 
 struct clh_ccs_plan {
@@ -1260,7 +1260,7 @@ struct clh_ccs_plan {
     int64_t total = 0;
     size_t slot_bytes = 0, slot_bytes_big = 0;      // second tier: a few slots sized for the worst case of the batch
     void *d_off = nullptr, *d_scan = nullptr, *d_res = nullptr, *d_segs = nullptr, *d_ccs = nullptr, *d_ws = nullptr, *d_ws_big = nullptr,
-         *d_counter = nullptr, *d_order = nullptr, *d_order3 = nullptr, *d_reads = nullptr, *d_score = nullptr;
+         *d_counter = nullptr, *d_order = nullptr, *d_order3 = nullptr, *d_reads = nullptr, *d_score = nullptr, *d_wide = nullptr;
     hipStream_t last_stream = nullptr;
     bool ran = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // K2 start, K2 stop = K3 start, K3 stop
@@ -1271,7 +1271,7 @@ extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     if (pl->ran) (void)hipStreamSynchronize(pl->last_stream);
-    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_order3, pl->d_reads, pl->d_long, pl->d_k2ws, pl->d_busy, pl->d_score};
+    void* bufs[] = {pl->d_off, pl->d_scan, pl->d_res, pl->d_segs, pl->d_ccs, pl->d_ws, pl->d_ws_big, pl->d_counter, pl->d_order, pl->d_order3, pl->d_reads, pl->d_long, pl->d_k2ws, pl->d_busy, pl->d_score, pl->d_wide};
     for (void* b : bufs) pl->ctx->release(b);
     for (hipEvent_t e : pl->ev) if (e) (void)hipEventDestroy(e);
     delete pl;
@@ -1281,7 +1281,7 @@ extern "C" void clh_ccs_plan_destroy(clh_ccs_plan* pl)
 // (tests/test_poa.py:30), consensus over the nodes crossed by at least half of the copies (oracle/ccs_oracle.c)
 static clh::PoaScores ccs_scores() { clh::PoaScores s; s.algorithm = 0; s.m = 10; s.n = -4; s.g = -8; s.e = -2; s.q = -24; s.c = -1; s.min_cov = -1; return s; }
 
-static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off, int mcap_hint)
+static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* read_off, int mcap_hint, bool wide_hint)
 {
     if (!ctx || n < 0 || !read_off) { fail(CLH_E_ARG, "clh_ccs_plan_create: null argument"); return nullptr; }
     if (hipSetDevice(ctx->device) != hipSuccess) { fail(CLH_E_HIP, "hipSetDevice failed"); return nullptr; }
@@ -1311,13 +1311,15 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     }
     pl->lmax = lmax; pl->n_long = (int)long_idx.size();
     // Workspace.  The worst case of a read of L bases is a graph of L+8 nodes against copies of L/2 + L/16 bases (period
-    // <= L/2, tolerance period/8; sequences above 2800 bases are refused by the kernel), every row kept and with several
+    // <= L/2, tolerance period/8), every row kept and with several
     // in-edges -- ~6 bytes per cell of that -- while the common case (period of a few hundred bases) needs a small
     // fraction.  So the first-tier slots (16 waves per CU x 256 CUs) share a budget, a wave whose read outgrows its slot
     // claims one of a few worst-case slots, and whatever found none free runs in a second launch over those.  Both budgets
     // follow the free memory of the device (HBM is 288 GB on an MI355X; nothing here assumes it).
-    const int mcap_worst = mcap_hint > 0 ? std::min(mcap_hint + 1, 2801) : std::min(lmax / 2 + lmax / 16 + 8, 2801);
-    const size_t need_worst = clh::poa_slot_bytes_host(lmax + 8, mcap_worst);
+    // (A copy above 2800 bases, or scores outside the 16-bit cells, runs the wide form of the pass: 6 bytes per cell instead of 4.)
+    const int mcap_worst = mcap_hint > 0 ? mcap_hint + 1 : lmax / 2 + lmax / 16 + 8;
+    const bool wide_worst = mcap_worst > 2801 || wide_hint || getenv("CLH_POA_FORCE_WIDE") != nullptr;
+    const size_t need_worst = wide_worst ? clh::poa_slot_bytes_host_w(lmax + 8, mcap_worst) : clh::poa_slot_bytes_host(lmax + 8, mcap_worst);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { fail(CLH_E_HIP, "hipMemGetInfo failed"); delete pl; return nullptr; }
     { std::lock_guard<std::mutex> g(ctx->mu); for (auto& kv : ctx->cache) free_b += kv.first; }      // parked blocks are ours to reuse
@@ -1331,7 +1333,8 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     if (pl->slot_bytes < need_worst) {
         const unsigned long long budget_big = std::min<unsigned long long>(64ull << 30, (unsigned long long)(free_b * 0.35));
         pl->slot_bytes_big = need_worst;
-        pl->nslots_big = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(1024, budget_big / need_worst));
+        if (const char* e = getenv("CLH_POA_BIG_BYTES")) pl->slot_bytes_big = std::max<size_t>(4096, std::min<size_t>(need_worst, strtoull(e, nullptr, 10)));   // tests: large slots too small (status 1)
+        pl->nslots_big = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(1024, budget_big / pl->slot_bytes_big));
         pl->nslots_big = std::min(pl->nslots_big, std::max(n, 1));
         if (const char* e = getenv("CLH_POA_BIG_SLOTS")) pl->nslots_big = std::max(1, std::min(pl->nslots_big, atoi(e)));       // tests: make the large slots scarce
     }
@@ -1357,7 +1360,8 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->d_counter = ctx->alloc(256);
     pl->d_order = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));
     pl->d_order3 = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));     // K3's work list by cost (clh_ccs_run)
-    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || (pl->nslots_big && (!pl->d_ws_big || !pl->d_busy)) || !pl->d_counter || !pl->d_order || !pl->d_order3) {
+    pl->d_wide = ctx->alloc(sizeof(int32_t) * (size_t)std::max(n, 1));       // reads for the wide form of K3's pass
+    if (!pl->d_off || !pl->d_scan || !pl->d_res || !pl->d_segs || !pl->d_ccs || !pl->d_ws || (pl->nslots_big && (!pl->d_ws_big || !pl->d_busy)) || !pl->d_counter || !pl->d_order || !pl->d_order3 || !pl->d_wide) {
         fail(CLH_E_HIP, "out of device memory while building the consensus plan");
         clh_ccs_plan_destroy(pl); return nullptr;
     }
@@ -1374,6 +1378,7 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
 static int launch_poa_tiers(clh_ccs_plan* pl, clh::CcsParams& P, hipStream_t st, bool by_cost = false)
 {
     P.poa_ws = (uint8_t*)pl->d_ws; P.work_counter = (int*)pl->d_counter; P.stats = (int*)pl->d_counter + 2;
+    P.wide_list = (int32_t*)pl->d_wide; P.wide_count = (int*)pl->d_counter + 32;
     P.work_order = (const int32_t*)(by_cost ? pl->d_order3 : pl->d_order);
     P.slot_bytes = pl->slot_bytes; P.n = pl->n; P.lcap = pl->lcap; P.tier = 0;
     if (pl->nslots_big) { P.big_ws = (uint8_t*)pl->d_ws_big; P.big_slot_bytes = pl->slot_bytes_big; P.big_busy = (int*)pl->d_busy; P.n_big = pl->nslots_big; }
@@ -1382,6 +1387,14 @@ static int launch_poa_tiers(clh_ccs_plan* pl, clh::CcsParams& P, hipStream_t st,
         clh::CcsParams Q = P;
         Q.poa_ws = (uint8_t*)pl->d_ws_big; Q.slot_bytes = pl->slot_bytes_big; Q.work_counter = (int*)pl->d_counter + 1; Q.tier = 1;
         HIPCHK(clh::launch_poa(Q, pl->nslots_big, st));
+    }
+    {   // what the packed kernel put on the wide list (copies above 2800 bases, scores outside the 16-bit cells, a cell at the floor of
+        // the range): the 32-bit form, over worst-case slots; nothing on the list: the waves leave at once
+        clh::CcsParams Q = P;
+        Q.work_counter = (int*)pl->d_counter + 33; Q.tier = 2; Q.n_big = 0;
+        int slots = pl->nslots;
+        if (pl->nslots_big) { Q.poa_ws = (uint8_t*)pl->d_ws_big; Q.slot_bytes = pl->slot_bytes_big; slots = pl->nslots_big; }
+        HIPCHK(clh::launch_poa_wide(Q, std::min(slots, 512), st));
     }
     return 0;
 }
@@ -1400,6 +1413,7 @@ extern "C" int clh_ccs_run(clh_ccs_plan* pl, const void* d_reads, void* stream_)
     P.long_idx = (const int32_t*)pl->d_long; P.k2_ws = (uint8_t*)pl->d_k2ws; P.k2_slot = clh::k2_long_slot_bytes(pl->lmax);
     P.n_long = pl->n_long; P.k2_lmax = pl->lmax; P.k2_lds_max = clh::kK2LdsMax;
     P.sc = ccs_scores();
+    if (getenv("CLH_POA_FORCE_WIDE")) P.sc.algorithm |= 0x200;      // tests: every read through the wide (32-bit) form of the pass
     P.aln_score = (int32_t*)pl->d_score;
     if (!pl->ev[0]) for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMemsetAsync(pl->d_counter, 0, 256, st));        // the two work counters and every statistic of the run
@@ -1532,13 +1546,17 @@ static int poa_check_opts(const clh_poa_opts* o, clh::PoaScores* s)
     if (d.e > 0 || d.c > 0) return fail(CLH_E_ARG, "poa: gap extension penalty must be non-positive");
     if (d.g >= d.e) return fail(CLH_E_UNSUPPORTED, "poa: linear gap cost (g >= e) is not built into the kernel");
     if (d.g <= d.q || d.e >= d.c) { d.q = d.g; d.c = d.e; }          // affine: one piece
-    if (d.m < 1 || d.m > 11 || d.n > d.m || d.n < -100) return fail(CLH_E_UNSUPPORTED, "poa: match score must be 1..11, mismatch -100..match (16-bit cells)");
+    if (d.m < 1 || d.n > d.m) return fail(CLH_E_UNSUPPORTED, "poa: match score must be positive and not below the mismatch score");
     if (d.e - d.g > 6 || d.c - d.q > 30) return fail(CLH_E_UNSUPPORTED, "poa: e - g <= 6 and c - q <= 30 required (vertical gap states are kept as small differences)");
-    if (std::max(d.g + 2799 * d.e, d.q + 2799 * d.c) < -30000) return fail(CLH_E_UNSUPPORTED, "poa: gap extension too costly for 16-bit cells");
-    // the row scans run in frames H - j*e and H - j*c over the <= 512 columns of a pass
-    if (d.m * 2800 + 512 * std::max(-d.e, -d.c) > 32767) return fail(CLH_E_UNSUPPORTED, "poa: match * 2800 + 512 * gap extension must fit 16 bits");
+    if (d.m > 100000 || d.n < -100000 || d.g < -100000 || d.q < -100000) return fail(CLH_E_UNSUPPORTED, "poa: scores beyond +-100000");
+    // scores that leave the 16-bit cells of the packed pass (match above 11, a mismatch or gap extension that drives 2800 bases below
+    // -30000, the row scans' frames H - j*e, H - j*c over the 512 columns of a pass) run the wide form of the pass for every sequence
+    bool wide = d.m > 11 || d.n < -100;
+    wide = wide || std::max(d.g + 2799 * d.e, d.q + 2799 * d.c) < -30000;
+    wide = wide || d.m * 2800 + 512 * std::max(-d.e, -d.c) > 32767;
+    if (getenv("CLH_POA_FORCE_WIDE")) wide = true;
     if (d.min_coverage < 0) return fail(CLH_E_ARG, "poa: min_coverage must be >= 0");
-    s->algorithm = d.algorithm; s->m = d.m; s->n = d.n; s->g = d.g; s->e = d.e; s->q = d.q; s->c = d.c; s->min_cov = d.min_coverage;
+    s->algorithm = d.algorithm | (wide ? 0x200 : 0); s->m = d.m; s->n = d.n; s->g = d.g; s->e = d.e; s->q = d.q; s->c = d.c; s->min_cov = d.min_coverage;
     return 0;
 }
 
@@ -1566,7 +1584,7 @@ extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, 
     if (ngroups == 0) return 0;
     int mcap = 1;
     for (int64_t i = 0; i < group_off[ngroups]; ++i) mcap = std::max<int>(mcap, (int)(seq_off[i + 1] - seq_off[i]));
-    clh_ccs_plan* pl = ccs_plan_create(ctx, ngroups, roff.data(), mcap);
+    clh_ccs_plan* pl = ccs_plan_create(ctx, ngroups, roff.data(), mcap, (sc.algorithm & 0x200) != 0);
     if (!pl) return CLH_E_ARG;
     int rc = 0;
     const size_t total = (size_t)roff[ngroups];

@@ -178,13 +178,17 @@ struct CcsParams {
     int32_t* msa_col;          // optional, packed like reads: MSA column of every base; msa_ncols[rd] = number of columns
     int32_t* msa_ncols;
     int32_t* aln_score;        // optional, [n][CCS_SEG_CAP]: end-cell score of the alignment of each of the first 65 sequences (tests)
+    int32_t* wide_list;        // K3: reads that need the wide (32-bit) form of the pass, appended by the packed kernel
+    int* wide_count;
 };
 
 hipError_t launch_ccs_scan(const CcsParams& p, int count, bool with_long, hipStream_t stream);
 hipError_t launch_poa(const CcsParams& p, int nslots, hipStream_t stream);
+hipError_t launch_poa_wide(const CcsParams& p, int nslots, hipStream_t stream);
 hipError_t launch_ccs_work_order(const CcsScan* scan, int n, int32_t* order, hipStream_t stream);   // K3's work list by cost after K2
 size_t poa_slot_bytes_host(int ncap, int mcap);
 size_t poa_slot_min_bytes_host(int ncap, int mcap);
+size_t poa_slot_bytes_host_w(int ncap, int mcap);
 static constexpr int kK2LdsMax = 16000;
 inline size_t k2_long_slot_bytes(int lmax) { return ((size_t)8 * ((size_t)lmax / 2 + 2) + (size_t)6 * (size_t)lmax + 255) & ~(size_t)255; }
 

@@ -20,7 +20,7 @@ _BASES = np.frombuffer(b'ACGTN', dtype=np.uint8)
 # more than 48 in-edges at a node, a copy above 2800 bases, ...), by status, since import.  Such a read comes back as (None, None)
 # like a read without a repeat -- but it is counted here and logged once per batch, never dropped silently.
 capacity_dropped = {}
-STATUS_TEXT = {1: 'workspace', 2: 'graph limits (48 in-edges, 8 letters in a column, 65000 nodes)', 3: 'output', 4: 'a copy above 2800 bases',
+STATUS_TEXT = {1: 'workspace', 2: 'graph limits (48 in-edges, 8 letters in a column, 65000 nodes)', 3: 'output', 4: '(unused since round 4: copies above 2800 bases run the wide form of the pass)',
                5: 'back-track guard', 6: '16-bit score range', 7: 'an alignment without a base'}
 
 

@@ -8,8 +8,10 @@ are raw characters ('a' is not 'A'); ``algorithm`` 0 local / 1 global / 2 overla
 max(g + (k-1) e, q + (k-1) c), with spoa's rule for falling back to the one-piece (affine) model; the graph is sorted
 depth-first after every sequence as spoa sorts it; heaviest-bundle consensus; ``genmsa`` returns one row per non-empty
 sequence.  Nothing is accepted and ignored: what the kernel does not honour raises -- the linear model (g >= e), scores
-outside its 16-bit cells (match 1..11, e - g <= 6, c - q <= 30), a sequence above 2800 bases, a graph node with more than
+whose gap pieces differ by more than the kernel's difference fields hold (e - g <= 6, c - q <= 30), a graph node with more than
 48 in-edges (12 in place, the rest in an overflow table of 2048 entries per graph), more than 8 different letters in one column (``hip.ClhError``).
+Sequences of any length and scores of any size are taken: what does not fit the 16-bit cells of the packed pass (a sequence above 2800
+bases, a match score above 11, costly extensions) runs the kernel's wide, 32-bit form -- as spoa's engines fall back to wider cells.
 """
 import numpy as np
 

@@ -28,7 +28,8 @@
  *    score of 0 takes the candidate closest to prev.  Cut at b+delta, prev = delta.  At most 64 cuts.
  *    Fewer than 2 full copies -> no repeat.  A tail of >= 20 bases after the last cut is kept as a partial copy, unless
  *    the 64-cut cap ended the search (the rest of the read is then an unscanned stretch of copies and is left out).
- *    A copy longer than 2800 bases -> no consensus (limit of v1: 16-bit cells of the alignment kernel).
+ *    (Until round 4 a copy longer than 2800 bases gave no consensus -- a limit of the alignment kernel's 16-bit cells written into
+ *    the specification.  pyccs has no reason to refuse such a read; the kernel now has a wide form of its pass and the limit is gone.)
  * 3. consensus.  Partial-order alignment of the copies in read order (poa_oracle.c), heaviest bundle, restricted to the
  *    nodes crossed by at least (copies + 1) / 2 of the copies (the partial last copy counts as a copy).
  *
@@ -45,7 +46,6 @@
 #define CCS_SMOOTH 3
 #define CCS_MAX_CUTS 64
 #define CCS_MIN_TAIL 20
-#define POA_MAX_COPY 2800
 
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
@@ -150,8 +150,6 @@ int clo_find_consensus(const int8_t *seq, int32_t L, int32_t *segs, int32_t *nse
     /* the rest of the read is a (partial) last copy -- unless the boundary search stopped at its cap, in which case the rest
        is an unscanned stretch of many copies and is left out */
     if (L - b >= CCS_MIN_TAIL && nc < CCS_MAX_CUTS) { segs[2 * n] = b; segs[2 * n + 1] = L; ++n; }
-    /* limit of specification v1: a copy longer than POA_MAX_COPY bases (a period above ~2.5 kb) yields no consensus */
-    for (int i = 0; i < n; ++i) if (segs[2 * i + 1] - segs[2 * i] > POA_MAX_COPY) return 0;
     *nseg = n;
     int32_t *off = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
     int8_t *buf = (int8_t *)malloc((size_t)L + 1);

@@ -134,13 +134,15 @@ def test_spoa_call_shape():
     got = [spoa.poa(SEGMENTS, a, True, 10, -4, -8, -2, -24, -1)[1][5] for a in (0, 1, 2)]
     assert got == rows and rows[0] != rows[1]
     assert spoa.poa(['ACGTACGTAA'], 0, True, 10, -4, -8, -2, -24, -1) == ('ACGTACGTAA', ['ACGTACGTAA'])
-    # nothing is accepted and ignored: the linear model, scores outside the 16-bit cells, invalid modes raise
+    # nothing is accepted and ignored: the linear model, gap pieces further apart than the difference fields hold, invalid modes raise
     for bad in ((1, True, -1, -1, -1, -1, -1, -1),                       # find_bsj.py:496 (dead code in the reference): m < 1
                 (0, True, 5, -4, -8, -8, -8, -8),                         # linear
-                (3, True, 10, -4, -8, -2, -24, -1), (0, True, 10, -4, 8, -2, -24, -1), (0, True, 12, -4, -8, -2, -24, -1),
+                (3, True, 10, -4, -8, -2, -24, -1), (0, True, 10, -4, 8, -2, -24, -1),
                 (0, True, 10, -4, -8, -1, -40, -1)):
         with pytest.raises(hip.ClhError):
             spoa.poa(SEGMENTS, *bad)
+    # a match score above 11 leaves the 16-bit cells of the packed pass: the wide form answers (refused until round 4)
+    assert spoa.poa(SEGMENTS, 0, True, 12, -4, -8, -2, -24, -1) == tuple(oracle_lib.oracle_poa(SEGMENTS, 0, True, 12, -4, -8, -2, -24, -1))
 
 
 def _family(rng, t_len, n, rate, alphabet='ACGT'):
@@ -237,7 +239,7 @@ def test_poa_letters_are_raw_characters_and_spoa_corner_cases():
 
 def test_poa_batch_of_groups_large_clusters_and_limits():
     """Several groups in one call (the batch form of collapse.py:504), a cluster of 150 sequences (the reference's
-    correct_cluster takes up to 200 reads), and the stated limits: a sequence above 2800 bases raises."""
+    correct_cluster takes up to 200 reads), and what used to be refused for its size: a sequence above 2800 bases, scores outside the 16-bit cells."""
     import random
     from ciri_long_amd import hip, spoa
     rng = random.Random(9)
@@ -250,16 +252,18 @@ def test_poa_batch_of_groups_large_clusters_and_limits():
     got = ctx.poa_batch(data, off, goff, algorithm=2, scores=PARS[0])
     for k, g in enumerate(groups):
         assert got[k] == oracle_lib.oracle_poa(g, 2, False, *PARS[0]), k
-    with pytest.raises(hip.ClhError):
-        spoa.poa(['ACGT' * 701, 'ACGT' * 700], 2, False, 10, -4, -8, -2, -24, -1)
-    # 16-bit cells: a score set whose row frames cannot fit is refused up front ...
-    with pytest.raises(hip.ClhError):
-        spoa.poa(['ACGTACGT', 'ACGTTCGT'], 0, False, 11, -4, -8, -6, -10, -5)
-    # ... and a global alignment that does reach the floor of the range says so (status 6) instead of answering inexactly:
-    # two unrelated 2600-base sequences under an affine cost of 6 per gap base sink below -30000; the same pair fits in local mode
+    # what the 16-bit cells of the packed pass cannot hold runs the wide (32-bit) form of the pass, as spoa's engines fall back to
+    # wider cells: a sequence above 2800 bases (round 3 refused it) ...
+    long_pair = ['ACGT' * 701, 'ACGT' * 700]
+    assert spoa.poa(long_pair, 2, False, 10, -4, -8, -2, -24, -1)[0] == oracle_lib.oracle_poa(long_pair, 2, False, 10, -4, -8, -2, -24, -1)
+    # ... a score set whose row frames do not fit 16 bits (refused up front before) ...
+    pair = ['ACGTACGT' * 9, 'ACGTTCGT' * 9]
+    assert spoa.poa(pair, 0, True, 11, -4, -8, -6, -10, -5) == tuple(oracle_lib.oracle_poa(pair, 0, True, 11, -4, -8, -6, -10, -5))
+    assert spoa.poa(pair, 1, True, 40, -30, -50, -44, -60, -30) == tuple(oracle_lib.oracle_poa(pair, 1, True, 40, -30, -50, -44, -60, -30))
+    # ... and a global alignment that reaches the floor of the 16-bit range in the middle of the packed pass (status 6 before): two
+    # unrelated 2600-base sequences under an affine cost of 6 per gap base sink below -30000 -- the read runs once more in the wide form
     a = ''.join(rng.choice('AC') for _ in range(2600)); b = ''.join(rng.choice('GT') for _ in range(2600))
-    with pytest.raises(hip.ClhError, match='status 6'):
-        spoa.poa([a, b], 1, False, 2, -100, -9, -6, -9, -6)
+    assert spoa.poa([a, b], 1, False, 2, -100, -9, -6, -9, -6)[0] == oracle_lib.oracle_poa([a, b], 1, False, 2, -100, -9, -6, -9, -6)
     assert spoa.poa([a, b], 0, False, 2, -100, -9, -6, -9, -6)[0] == oracle_lib.oracle_poa([a, b], 0, False, 2, -100, -9, -6, -9, -6)
 
 
@@ -357,13 +361,14 @@ def test_native_file_stage_buffer_borders_and_a_trailing_header(tmp_path):
     assert hip.fastx_count(str(fq), 1) == 6501
 
 
-def test_reads_lost_to_a_kernel_limit_are_counted_and_reported(tmp_path, caplog):
+def test_reads_lost_to_a_kernel_limit_are_counted_and_reported(tmp_path, caplog, monkeypatch):
     """A limit of the kernel never passes for "no repeat".  (1) spoa.poa: sequences that each skip a different number of letters in
     front of the same node give that node one in-edge each (the letters of the stretch are all different, so no deletion can slide):
     14 and 31 in-edges -- more than the 12 a node holds in place -- go through the graph's overflow table and equal the oracle; 51 are
-    more than the kernel keeps (48): status 2, raised; so are 9 different letters in one column.  (2) find_consensus: a copy above
-    2800 bases (16-bit cells): status 4 in the rows, in the plan's statistics, in pyccs' counter and log line and in the file stage's
-    counter.  The oracle has none of these limits."""
+    more than the kernel keeps (48): status 2, raised; so are 9 different letters in one column.  (2) find_consensus: a read the
+    kernel's workspace cannot take (budget squeezed, no large slot: status 1) is counted in the rows, in the plan's statistics, in
+    pyccs' counter and log line and in the file stage's counter.  (A copy above 2800 bases was such a loss until round 4; it now runs
+    the wide form of the pass and equals the oracle.)  The oracle has none of these limits."""
     import logging
     import random
     from ciri_long_amd import find_ccs, hip, pyccs, spoa
@@ -396,21 +401,30 @@ def test_reads_lost_to_a_kernel_limit_are_counted_and_reported(tmp_path, caplog)
     d = torch.from_numpy(data.view(np.uint8)).cuda()
     plan.run(d.data_ptr(), torch.cuda.current_stream().cuda_stream)
     rows, _segs, _ccs = plan.fetch()
-    assert [int(x) for x in rows['status']] == [4, 0]
-    st = plan.stats()
-    assert st['dropped'] == {4: 1} and st['dp_cells'] > 0 and st['dp_row_steps'] > 0
+    assert [int(x) for x in rows['status']] == [0, 0]         # the 3000-base copies: the wide form of the pass
     plan.close()
+    want = oracle_lib.oracle_find_consensus(read)
+    assert pyccs.find_consensus_batch([read, short])[0] == want[:2] and want[0] is not None
+    # a read the workspace cannot take: the budget squeezed to 1 MiB per ... and a single large slot too small for it -> status 1
+    monkeypatch.setenv('CLH_POA_BUDGET_MB', '1'); monkeypatch.setenv('CLH_POA_BIG_BYTES', '4096')
+    plan = ctx.ccs_plan(off)
+    plan.run(d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rows, _segs, _ccs = plan.fetch()
+    st = plan.stats()
+    plan.close()
+    lost = int((rows['status'] == 1).sum())
+    assert lost >= 1 and st['dropped'].get(1, 0) == lost and st['dp_row_steps'] >= 0
     before = dict(pyccs.capacity_dropped)
     with caplog.at_level(logging.WARNING, logger='CIRI-long'):
         got = pyccs.find_consensus_batch([read, short])
-    assert got[0] == (None, None) and got[1][0] is not None
-    assert pyccs.capacity_dropped.get(4, 0) == before.get(4, 0) + 1
+    assert got[0] == (None, None)
+    assert pyccs.capacity_dropped.get(1, 0) == before.get(1, 0) + lost
     assert any('got no consensus' in r.getMessage() for r in caplog.records)
     (tmp_path / 'tmp').mkdir()
     fa = tmp_path / 'in.fa'
     fa.write_text('>lost\n%s\n>kept\n%s\n' % (read, short))
     total, ro, ccs_seq = find_ccs.find_ccs_reads(str(fa), str(tmp_path), 'p', 1, False)
-    assert (total, ro, list(ccs_seq)) == (2, 1, ['kept']) and ctx.last_capacity_dropped == 1
+    assert total == 2 and 'lost' not in ccs_seq and ctx.last_capacity_dropped >= 1
 
 
 def test_walks_that_leave_the_band_of_stored_cells_fall_back_to_the_full_planes():
@@ -436,3 +450,30 @@ def test_walks_that_leave_the_band_of_stored_cells_fall_back_to_the_full_planes(
         assert spoa.poa(seqs, algorithm, True, 10, -4, -8, -2, -24, -1) == tuple(want), it
         total += ctx.poa_last_stats()['band_misses']
     assert total >= 12
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_the_wide_form_of_the_pass_equals_the_oracle(mode, monkeypatch):
+    """The 32-bit form of K3's pass (sequences above 2800 bases, scores outside the 16-bit cells; csrc/ccs_poa.hip: dp_pass_w): forced
+    for every sequence (CLH_POA_FORCE_WIDE) it must give what the packed form gives on the shapes that reach every path of the pass --
+    one to six columns per lane, several column passes with carries, far source rows, many in-edges, raw letters -- and on sequences
+    of 3000-5200 bases nothing but it can take; consensus, MSA rows and end-cell scores against oracle/poa_oracle.c."""
+    import random
+    from ciri_long_amd import hip, spoa
+    rng = random.Random(500 + mode)
+    monkeypatch.setenv('CLH_POA_FORCE_WIDE', '1')
+    ctx = hip.default_context()
+    for it in range(14):
+        L = [25, 70, 130, 200, 330, 390, 500, 800, 1300][it % 9]
+        fam = _family(rng, L, rng.randint(2, 9), rng.choice([0.03, 0.12, 0.25]))
+        if it % 4 == 3:
+            fam.append(fam[0][len(fam[0]) // 3:] + fam[1][:len(fam[1]) // 2])      # joins far from the diagonal: far source rows
+        for pars in (PARS[0], PARS[it % len(PARS)]):
+            want = oracle_lib.oracle_poa(fam, mode, True, *pars)
+            assert spoa.poa(fam, mode, True, *pars) == tuple(want), (it, L, pars)
+    monkeypatch.delenv('CLH_POA_FORCE_WIDE')
+    for L in (3000, 5200):
+        base = ''.join(rng.choice('ACGT') for _ in range(L))
+        fam = [base] + [''.join(rng.choice('ACGT') if rng.random() < 0.04 else ch for ch in base if rng.random() > 0.03) for _ in range(2)]
+        want = oracle_lib.oracle_poa(fam, mode, True, 10, -4, -8, -2, -24, -1)
+        assert spoa.poa(fam, mode, True, 10, -4, -8, -2, -24, -1) == tuple(want), L

@@ -71,7 +71,7 @@ def find_ccs_reads(in_file, out_dir, prefix, threads, debugging):
         logging.getLogger('CIRI-long').warning('%d reads longer than 16 M bases were not scanned for a consensus', too_long)
     if ctx.last_capacity_dropped:       # counted by the native stage (clh_ccs_file_stats.capacity_dropped): never dropped silently
         logging.getLogger('CIRI-long').warning('%d reads hold a tandem repeat but got no consensus: a limit of the GPU kernel (workspace, 48 in-edges '
-                                               'at a node, a copy above 2800 bases)', ctx.last_capacity_dropped)
+                                               'at a node, no workspace)', ctx.last_capacity_dropped)
     prog.update(100)
     return total_reads, ro_reads, load_ccs_reads(out_dir, prefix)
 

@@ -260,7 +260,7 @@ class Context(object):
         """spoa.poa per group of sequences: -> list of consensus str, or list of (consensus, msa rows[, end-cell scores of
         the first 65 sequences]) with genmsa / with_scores.  The letters of `seqs` are bytes compared for equality only;
         raw=False reads them as the codes 0..4 of `encode` and writes ACGTN, raw=True hands them through as characters
-        (`pack_raw`).  Raises ClhError when a group has no consensus (a sequence above 2800 bases, a node with more than 48
+        (`pack_raw`).  Raises ClhError when a group has no consensus (a node with more than 48
         in-edges, more than 8 different letters in a column) or the scores are outside what the kernel honours."""
         seqs = np.ascontiguousarray(seqs, dtype=np.int8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
@@ -282,7 +282,7 @@ class Context(object):
         for k in range(ng):
             if lens[k] < 0:
                 raise ClhError('poa: no consensus for group %d (status %d: 1 workspace, 2 graph limits -- more than 48 in-edges, more than 8 '
-                               'letters in a column or 65000 nodes, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 a cell left the '
+                               'letters in a column or 65000 nodes, 3 output, 4 (unused since round 4), 5 back-track guard, 6 a cell left the '
                                '16-bit score range, 7 an alignment without a base: spoa throws)' % (k, -1 - int(lens[k])))
             o = int(seq_off[group_off[k]])
             text = (lambda a: a.view(np.uint8).tobytes().decode('latin-1')) if raw else (lambda a: bases[np.minimum(a, 4)].tobytes().decode())
@@ -673,7 +673,7 @@ class CcsPlan(object):
 
     def stats(self):
         """dict(dp_cells, dp_row_steps, dropped = {status: reads}) of the last run; `dropped` lists the reads a limit of the kernel left
-        without a consensus (status 1 workspace, 2 graph limits, 3 output, 4 sequence above 2800 bases, 5 back-track guard, 6 16-bit
+        without a consensus (status 1 workspace, 2 graph limits, 3 output, 4 (unused since round 4), 5 back-track guard, 6 16-bit
         range, 7 alignment without a base)"""
         out = np.zeros(16, dtype=np.int64)
         if lib().clh_ccs_plan_stats(self._h, out.ctypes.data) != 0:

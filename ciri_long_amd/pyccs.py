@@ -17,7 +17,7 @@ from . import hip
 
 _BASES = np.frombuffer(b'ACGTN', dtype=np.uint8)
 # reads with a tandem repeat that a limit of the consensus kernel left without a consensus (clh_ccs_t.status > 0: workspace,
-# more than 48 in-edges at a node, a copy above 2800 bases, ...), by status, since import.  Such a read comes back as (None, None)
+# more than 48 in-edges at a node, no workspace slot large enough, ...), by status, since import.  Such a read comes back as (None, None)
 # like a read without a repeat -- but it is counted here and logged once per batch, never dropped silently.
 capacity_dropped = {}
 STATUS_TEXT = {1: 'workspace', 2: 'graph limits (48 in-edges, 8 letters in a column, 65000 nodes)', 3: 'output', 4: '(unused since round 4: copies above 2800 bases run the wide form of the pass)',

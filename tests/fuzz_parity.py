@@ -96,12 +96,15 @@ while time.time() < t_end:
     # ---- consensus: random periods / lengths / error rates ----
     reads = []
     for _ in range(120):
-        p = int(rng.choice([35, 60, 100, 180, 300, 500, 800, 1300, 2000, 2900])); L = int(rng.choice([300, 900, 1800, 3500, 7000]))
+        p = int(rng.choice([35, 60, 100, 180, 300, 500, 800, 1300, 2000, 2900, 3400, 6000])); L = int(rng.choice([300, 900, 1800, 3500, 7000, 13000]))      # (periods above 2800: the wide form of K3's pass)
         e = float(rng.choice([0.0, 0.02, 0.05, 0.1]))
         tm = rng.integers(0, 4, p, dtype=np.int8)
         raw = np.tile(tm, L // p + 2)[int(rng.integers(0, p)):][:L]
         reads.append(synth.mutate(raw, rng, sub=e, ins=e, dele=e) if e else raw.copy())
+    dropped_before = sum(pyccs.capacity_dropped.values())
     got = pyccs.find_consensus_batch(reads)
+    if sum(pyccs.capacity_dropped.values()) != dropped_before:
+        print('CCS: a read was lost to a kernel limit, seed', seed + it - 1, dict(pyccs.capacity_dropped)); sys.exit(1)
     for k, r in enumerate(reads):
         w = oracle_lib.oracle_find_consensus(r)
         if got[k] != w[:2]:

@@ -13,6 +13,10 @@
 #include <stdio.h>
 #include <string.h>
 #include <zlib.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <atomic>
+#include <algorithm>
 #include <limits.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -30,13 +34,18 @@
 namespace {
 
 struct Batch {
-    std::vector<char> text;            // headers and raw sequences, back to back
-    std::vector<int64_t> hdr_off, hdr_len, seq_off, seq_len;   // into text
+    // the file's own bytes of this batch: `raw[lead .. lead + len)` holds whole records (the reader thread fills raw from kReserve on;
+    // the parser puts the tail of the batch before -- a record cut by the chunk border -- in front of it).  Headers and sequences are
+    // offsets into raw: nothing of the text is copied again
+    std::vector<char> raw;
+    size_t lead = 0, len = 0;
+    bool eof = false;                  // the reader saw the end of the file while filling this batch
+    std::vector<int64_t> hdr_off, hdr_len, seq_off, seq_len;   // into raw
     std::vector<int8_t> codes;         // packed base codes of the reads handed to the GPU
     std::vector<int64_t> read_off;     // n_gpu + 1
     std::vector<int32_t> gpu_index;    // record -> row of the GPU batch, -1 = skipped (longer than the kernel's limit)
     bool last = false;
-    void clear() { text.clear(); hdr_off.clear(); hdr_len.clear(); seq_off.clear(); seq_len.clear(); codes.clear(); read_off.assign(1, 0); gpu_index.clear(); last = false; }
+    void clear() { hdr_off.clear(); hdr_len.clear(); seq_off.clear(); seq_len.clear(); codes.clear(); read_off.assign(1, 0); gpu_index.clear(); last = false; }
 };
 
 struct LineReader {
@@ -91,26 +100,9 @@ struct LineReader {
 };
 
 inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
-inline void rstrip(std::string& s) { while (!s.empty() && (s.back() == ' ' || s.back() == '\t' || s.back() == '\r' || s.back() == '\n' || s.back() == '\v' || s.back() == '\f')) s.pop_back(); }
 
 const int kMaxRead = 1 << 24;          // sanity bound of clh_ccs_plan_create
 
-// One read: keep the text, encode the bases (ssw_wrap.py:50,243-250: A/a 0, C/c 1, G/g 2, T/t 3, anything else 4).  The table
-// look-up per byte ran at 1 GB/s and was two thirds of the reader thread's time; as arithmetic on the letter's bits -- bits 1-2 of
-// A C G T and of a c g t are 00 01 11 10 -- the loop vectorises (measured 6 GB/s with AVX2).
-#if defined(__x86_64__)
-__attribute__((target("avx2")))
-void encode_copy_avx2(char* td, int8_t* cd, const char* sp, size_t n)
-{
-    memcpy(td, sp, n);
-    for (size_t i = 0; i < n; ++i) {
-        const unsigned char ch = (unsigned char)sp[i], u = (unsigned char)(ch | 0x20);
-        const unsigned char valid = (unsigned char)((u == 'a') | (u == 'c') | (u == 'g') | (u == 't'));
-        const unsigned char x = (unsigned char)((ch >> 1) & 3);
-        cd[i] = (int8_t)(valid ? (x ^ (x >> 1)) : 4);
-    }
-}
-#endif
 // base codes -> letters of the consensus line ("ACGTN"[code], anything outside 0..4 reads N)
 #if defined(__x86_64__)
 __attribute__((target("avx2")))
@@ -144,13 +136,28 @@ inline void put_int(std::string& s, int v)       // decimal digits of v (snprint
     while (k) s.push_back(t[--k]);
 }
 
-void encode_copy(char* td, int8_t* cd, const char* sp, size_t n, const int8_t* lut)
+// One read: encode the bases (ssw_wrap.py:50,243-250: A/a 0, C/c 1, G/g 2, T/t 3, anything else 4).  The table look-up per byte ran
+// at 1 GB/s; as arithmetic on the letter's bits -- bits 1-2 of A C G T and of a c g t are 00 01 11 10 -- the loop vectorises
+// (measured 6 GB/s with AVX2).  The text itself stays where the reader put it.
+#if defined(__x86_64__)
+__attribute__((target("avx2")))
+void encode_avx2(int8_t* cd, const char* sp, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char ch = (unsigned char)sp[i], u = (unsigned char)(ch | 0x20);
+        const unsigned char valid = (unsigned char)((u == 'a') | (u == 'c') | (u == 'g') | (u == 't'));
+        const unsigned char x = (unsigned char)((ch >> 1) & 3);
+        cd[i] = (int8_t)(valid ? (x ^ (x >> 1)) : 4);
+    }
+}
+#endif
+void encode_only(int8_t* cd, const char* sp, size_t n, const int8_t* lut)
 {
 #if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2) { encode_copy_avx2(td, cd, sp, n); return; }
+    if (avx2) { encode_avx2(cd, sp, n); return; }
 #endif
-    for (size_t i = 0; i < n; ++i) { const unsigned char ch = (unsigned char)sp[i]; td[i] = (char)ch; cd[i] = lut[ch]; }
+    for (size_t i = 0; i < n; ++i) cd[i] = lut[(unsigned char)sp[i]];
 }
 
 }  // namespace
@@ -200,77 +207,133 @@ extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fast
     // three batches rotate through three threads: the reader parses and encodes, this thread runs the batch on the GPU, the
     // writer formats and writes the two files -- each takes the slots in order and waits for the state it consumes
     // (0 free -> 1 parsed -> 2 computed -> 0)
-    static const int NSLOT = 3;
+    // four batches rotate through four threads: the READER fills a batch with file bytes (read(2) on a plain file, gzread on a
+    // compressed one), the PARSER finds the records in them and encodes the bases, this thread runs the batch on the GPU, the WRITER
+    // formats and writes the two files -- each takes the slots in order and waits for the state it consumes
+    // (0 free -> 1 bytes read -> 2 parsed -> 3 computed -> 0).  Round 3 had one thread read, copy and encode: 1.3 GB/s of FASTQ.
+    static const int NSLOT = 4;
+    static const size_t kReserve = 4u << 20;         // room in front of a chunk for the record the previous chunk's border cut
     struct Results { std::vector<clh_ccs_t> rows; std::vector<int32_t> segs; std::vector<int8_t> ccs; };
     Batch slot[NSLOT];
     Results result[NSLOT];
     std::mutex mu;
     std::condition_variable cv;
-    int state[NSLOT] = {0, 0, 0};
+    int state[NSLOT] = {0, 0, 0, 0};
+    std::atomic<bool> stop_reader{false};             // the parser has all it wants (max_records): the reader shall not wait for a slot again
     auto wait_state = [&](int s, int want) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return state[s] == want; }); };
     auto set_state = [&](int s, int v) { { std::lock_guard<std::mutex> lk(mu); state[s] = v; } cv.notify_all(); };
+    // plain or gzip?  (the magic bytes; gzread serves both, but copies a plain file once more on the way)
+    int fd = -1;
+    {
+        unsigned char magic[2] = {0, 0};
+        FILE* probe = fopen(in_path, "rb");
+        const size_t got = probe ? fread(magic, 1, 2, probe) : 0;
+        if (probe) fclose(probe);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) fd = open(in_path, O_RDONLY);
+    }
+    size_t chunk_bytes = (size_t)32 << 20;
+    if (const char* e = getenv("CLH_FILE_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(e)) << 20;
+    double t_read = 0, t_parse = 0, t_write = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto reader = [&]() {
-        LineReader lr(in);
-        std::string header, seq;
-        int s = 0;
-        bool done = false;
-        // this rank's shard starts at record `first_record`: the records in front are read past, not parsed
-        for (int64_t k = 0; k < first_record && !done; ++k)
-            for (int l = 0; l < (is_fastq ? 4 : 2); ++l) if (!lr.skip_line()) { done = true; break; }
-        int64_t left = max_records < 0 ? INT64_MAX : max_records;
-        if (left == 0) done = true;
-        if (done) {       // nothing to do: hand the consumer an empty last batch
-            wait_state(s, 0);
-            slot[s].clear(); slot[s].last = true;
+        bool eof = false;
+        for (int s = 0; !eof; s = (s + 1) % NSLOT) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return state[s] == 0 || stop_reader.load(); }); }
+            if (stop_reader.load()) break;
+            const double t0 = now();
+            Batch& b = slot[s];
+            if (b.raw.size() < kReserve + chunk_bytes) b.raw.resize(kReserve + chunk_bytes);
+            size_t have = 0;
+            while (have < chunk_bytes) {
+                const size_t want = chunk_bytes - have;
+                long got;
+                if (fd >= 0) got = (long)read(fd, b.raw.data() + kReserve + have, want);
+                else got = (long)gzread(in, b.raw.data() + kReserve + have, (unsigned)std::min<size_t>(want, 1u << 30));
+                if (got <= 0) { eof = true; break; }
+                have += (size_t)got;
+            }
+            b.lead = kReserve; b.len = have; b.eof = eof;
+            t_read += now() - t0;
             set_state(s, 1);
         }
-        while (!done) {
-            wait_state(s, 0);
+    };
+    auto parser = [&]() {
+        std::vector<char> carry;                   // the bytes of a record the previous chunk's border cut
+        const int per = is_fastq ? 4 : 2;
+        int64_t to_skip = first_record;            // this rank's shard starts at record `first_record`: the records in front are read past
+        int64_t left = max_records < 0 ? INT64_MAX : max_records;
+        bool done = false;
+        for (int s = 0; !done; s = (s + 1) % NSLOT) {
+            wait_state(s, 1);
+            const double t0 = now();
             Batch& b = slot[s];
             b.clear();
-            while ((int)b.hdr_off.size() < batch_reads && b.codes.size() < (size_t)256 << 20) {
-                if (left == 0) { done = true; break; }
-                if (!lr.next(header)) { done = true; break; }
+            if (!carry.empty()) {
+                if (carry.size() > b.lead) {       // a record longer than the reserve: make room (rare)
+                    std::vector<char> bigger(carry.size() + b.len);
+                    memcpy(bigger.data() + carry.size(), b.raw.data() + b.lead, b.len);
+                    b.raw.swap(bigger);
+                    b.lead = carry.size();
+                }
+                b.lead -= carry.size();
+                memcpy(b.raw.data() + b.lead, carry.data(), carry.size());
+                b.len += carry.size();
+                carry.clear();
+            }
+            const char* base = b.raw.data();
+            const char* p = base + b.lead;
+            const char* const end = p + b.len;
+            while (p < end && left > 0) {
+                // the record's lines: whole lines only, unless the file ends here (then what is left is the last record, with the
+                // lines it has: a header without its sequence line is a record with an empty sequence, find_ccs.py:51-64)
+                const char* ls[4]; const char* le[4];
+                int nl = 0;
+                const char* q = p;
+                while (nl < per && q < end) {
+                    const char* e = (const char*)memchr(q, '\n', (size_t)(end - q));
+                    if (!e) { if (!b.eof) break; ls[nl] = q; le[nl] = end; ++nl; q = end; break; }
+                    ls[nl] = q; le[nl] = e; ++nl; q = e + 1;
+                }
+                if (nl < per && !b.eof) break;     // cut by the chunk border: the next chunk completes it
+                if (nl == 0) break;
+                p = q;
+                if (to_skip > 0) { --to_skip; continue; }
                 --left;
-                const char* sp_ = nullptr; size_t sn = 0;
-                const bool have_seq = lr.next_view(sp_, sn, seq);       // NB: invalidates nothing of `header` (a std::string)
-                (void)have_seq;     // a header line without a sequence line is a record with an empty sequence (as in the reference's loop)
-                if (!have_seq) sn = 0;
-                while (sn > 0 && is_space(sp_[sn - 1])) --sn;           // str.rstrip
-                rstrip(header);
-                size_t sp = header.find(' ');
-                if (sp != std::string::npos) header.resize(sp);
-                size_t lead = 0;
+                const char* h0 = ls[0]; const char* h1 = le[0];
+                while (h1 > h0 && is_space(h1[-1])) --h1;                           // str.rstrip
+                const char* sp = (const char*)memchr(h0, ' ', (size_t)(h1 - h0));    // first space-separated token
+                if (sp) h1 = sp;
                 const char mark = is_fastq ? '@' : '>';
-                while (lead < header.size() && header[lead] == mark) ++lead;   // str.lstrip: every leading marker character
-                b.hdr_off.push_back((int64_t)b.text.size()); b.hdr_len.push_back((int64_t)(header.size() - lead));
-                b.text.insert(b.text.end(), header.begin() + (long)lead, header.end());
-                b.seq_off.push_back((int64_t)b.text.size()); b.seq_len.push_back((int64_t)sn);
-                const size_t t0 = b.text.size();
-                b.text.resize(t0 + sn);
-                if (sn == 0 || (int64_t)sn > kMaxRead) {
-                    if (sn) memcpy(b.text.data() + t0, sp_, sn);
-                    b.gpu_index.push_back(-1);
-                } else {
+                while (h0 < h1 && *h0 == mark) ++h0;                                // str.lstrip: every leading marker character
+                const char* s0 = nl > 1 ? ls[1] : end; const char* s1 = nl > 1 ? le[1] : end;
+                while (s1 > s0 && is_space(s1[-1])) --s1;
+                const size_t sn = (size_t)(s1 - s0);
+                b.hdr_off.push_back((int64_t)(h0 - base)); b.hdr_len.push_back((int64_t)(h1 - h0));
+                b.seq_off.push_back((int64_t)(s0 - base)); b.seq_len.push_back((int64_t)sn);
+                if (sn == 0 || (int64_t)sn > kMaxRead) b.gpu_index.push_back(-1);
+                else {
                     b.gpu_index.push_back((int32_t)(b.read_off.size() - 1));
                     const size_t o = b.codes.size();
                     b.codes.resize(o + sn);
-                    char* td = b.text.data() + t0; int8_t* cd = b.codes.data() + o;
-                    encode_copy(td, cd, sp_, sn, lut);
+                    encode_only(b.codes.data() + o, s0, sn, lut);
                     b.read_off.push_back((int64_t)b.codes.size());
                 }
-                if (is_fastq) { lr.skip_line(); lr.skip_line(); }       // '+' line and qualities: read past, not copied
             }
+            if (left == 0 || (b.eof && p >= end)) done = true;
+            else if (p < end) carry.assign(p, end);
+            if (b.eof) done = true;
             b.last = done;
-            set_state(s, 1);
-            s = (s + 1) % NSLOT;
+            t_parse += now() - t0;
+            set_state(s, 2);
         }
+        // (the reader may still be filling slots nobody will parse: it stops at the end of the file by itself; its slots are released below)
     };
     int wrc = 0;
     auto writer = [&]() {
         std::string oc, orw;                     // the two files' text of one batch: formatted in memory, written with one call each
         for (int s = 0;; s = (s + 1) % NSLOT) {
-            wait_state(s, 2);
+            wait_state(s, 3);
+            const double tw0_ = now();
             Batch& b = slot[s];
             const Results& R = result[s];
             const int nrec = (int)b.hdr_off.size();
@@ -285,7 +348,7 @@ extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fast
                     if (r.status != 0) { stats->capacity_dropped += 1; continue; }      // lost to a limit of the kernel: counted, reported by the caller
                     if (r.nseg <= 0) continue;
                     stats->ro_reads += 1;
-                    const char* hdr = b.text.data() + b.hdr_off[(size_t)k];
+                    const char* hdr = b.raw.data() + b.hdr_off[(size_t)k];
                     const size_t hl = (size_t)b.hdr_len[(size_t)k];
                     oc.push_back('>'); oc.append(hdr, hl); oc.push_back('\t');
                     for (int i = 0; i < r.nseg; ++i) {
@@ -298,25 +361,25 @@ extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fast
                     decode_bases(&oc[l0], R.ccs.data() + b.read_off[(size_t)g], (size_t)r.ccs_len);
                     oc[l0 + (size_t)r.ccs_len] = '\n';
                     orw.push_back('>'); orw.append(hdr, hl); orw.push_back('\n');
-                    orw.append(b.text.data() + b.seq_off[(size_t)k], (size_t)b.seq_len[(size_t)k]); orw.push_back('\n');
+                    orw.append(b.raw.data() + b.seq_off[(size_t)k], (size_t)b.seq_len[(size_t)k]); orw.push_back('\n');
                 }
                 if (!oc.empty() && fwrite(oc.data(), 1, oc.size(), fc) != oc.size()) wrc = CLH_E_ARG;
                 if (!orw.empty() && fwrite(orw.data(), 1, orw.size(), fr) != orw.size()) wrc = CLH_E_ARG;
             }
             const bool last = b.last;
+            t_write += now() - tw0_;
             set_state(s, 0);
             if (last) break;
         }
     };
     const bool ftrace = getenv("CLH_FILE_TRACE") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_wait = 0, t_gpu = 0;
-    std::thread th(reader), tw(writer);
+    std::thread th(reader), tp(parser), tw(writer);
 
     int rc = 0;
     for (int s = 0;; s = (s + 1) % NSLOT) {
         const double tw0 = now();
-        wait_state(s, 1);
+        wait_state(s, 2);
         const double tw1 = now();
         t_wait += tw1 - tw0;
         Batch& b = slot[s];
@@ -330,12 +393,17 @@ extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fast
         }
         t_gpu += now() - tw1;
         const bool last = b.last;
-        set_state(s, 2);
+        set_state(s, 3);
         if (last) break;
     }
     tw.join();
+    tp.join();
+    // the parser may have stopped before the end of the file (max_records): a reader waiting for a free slot is told to stop
+    stop_reader = true;
+    cv.notify_all();
     th.join();
-    if (ftrace) fprintf(stderr, "[clh] file stage: GPU thread waited for the reader %.3f s, clh_ccs_batch %.3f s\n", t_wait, t_gpu);
+    if (fd >= 0) close(fd);
+    if (ftrace) fprintf(stderr, "[clh] file stage: read %.3f s, parse + encode %.3f s, GPU thread waited %.3f s, clh_ccs_batch %.3f s, format + write %.3f s\n", t_read, t_parse, t_wait, t_gpu, t_write);
     if (!rc && wrc) rc = wrc;
     gzclose(in);
     if (fclose(fc) != 0 || fclose(fr) != 0) rc = rc ? rc : CLH_E_ARG;

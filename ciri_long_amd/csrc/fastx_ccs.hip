@@ -178,16 +178,67 @@ extern "C" int clh_fastx_count(const char* in_path, int is_fastq, int64_t* n_rec
     return 0;
 }
 
+// number of records, and the byte offset of every `every`-th record (records 0, every, 2 every, ...) of an UNCOMPRESSED file: a
+// rank of a sharded run seeks to the indexed record at or before its shard instead of reading past everything in front of it.  A
+// gzip file cannot be entered in the middle: *n_offsets = 0.  Host only.
+extern "C" int clh_fastx_index(const char* in_path, int is_fastq, int64_t every, int64_t* n_records, int64_t* offsets, int64_t cap, int64_t* n_offsets)
+{
+    if (!in_path || !n_records || !n_offsets || every < 1 || (cap > 0 && !offsets)) return CLH_E_ARG;
+    *n_offsets = 0;
+    unsigned char magic[2] = {0, 0};
+    FILE* probe = fopen(in_path, "rb");
+    if (!probe) return CLH_E_ARG;
+    const size_t got = fread(magic, 1, 2, probe);
+    fclose(probe);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return clh_fastx_count(in_path, is_fastq, n_records);
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) return CLH_E_ARG;
+    std::vector<char> buf((size_t)8 << 20);
+    const int per = is_fastq ? 4 : 2;
+    int64_t lines = 0, pos = 0, no = 0;
+    bool at_line_start = true, any_tail = false;
+    for (;;) {
+        const long n = (long)read(fd, buf.data(), buf.size());
+        if (n <= 0) break;
+        const char* p = buf.data();
+        const char* const end = p + n;
+        while (p < end) {
+            if (at_line_start) {
+                if (lines % per == 0 && (lines / per) % every == 0 && no < cap) offsets[no++] = pos + (int64_t)(p - buf.data());
+                at_line_start = false; any_tail = true;
+            }
+            const char* e = (const char*)memchr(p, '\n', (size_t)(end - p));
+            if (!e) break;
+            ++lines; at_line_start = true; any_tail = false;
+            p = e + 1;
+        }
+        pos += n;
+    }
+    close(fd);
+    if (any_tail) ++lines;                       // a last line without its terminator
+    *n_records = (lines + per - 1) / per;
+    *n_offsets = no;
+    return 0;
+}
+
 extern "C" int clh_ccs_file(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
                             int32_t batch_reads, clh_ccs_file_stats* stats)
 {
-    return clh_ccs_file_range(ctx, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads, 0, -1, stats);
+    return clh_ccs_file_at(ctx, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads, 0, 0, -1, stats);
 }
 
 extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
                                   int32_t batch_reads, int64_t first_record, int64_t max_records, clh_ccs_file_stats* stats)
 {
-    if (!ctx || !in_path || !ccs_fa_path || !raw_fa_path || !stats || first_record < 0) return CLH_E_ARG;
+    return clh_ccs_file_at(ctx, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads, 0, first_record, max_records, stats);
+}
+
+// the records [first_record, first_record + max_records) counted from byte `byte_offset` of the file, which must be the first byte of a
+// record (clh_fastx_index); a compressed file is read from its start whatever byte_offset says (the caller passes 0)
+extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
+                               int32_t batch_reads, int64_t byte_offset, int64_t first_record, int64_t max_records, clh_ccs_file_stats* stats)
+{
+    if (!ctx || !in_path || !ccs_fa_path || !raw_fa_path || !stats || first_record < 0 || byte_offset < 0) return CLH_E_ARG;
     if (batch_reads <= 0) batch_reads = 16384;      // small enough that the three stages overlap on files of 10^5 reads (measured: 65536 -> 0.54, 16384 -> 0.89 M reads/s)
     memset(stats, 0, sizeof(*stats));
     gzFile in = gzopen(in_path, "rb");
@@ -230,6 +281,8 @@ extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fast
         const size_t got = probe ? fread(magic, 1, 2, probe) : 0;
         if (probe) fclose(probe);
         if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) fd = open(in_path, O_RDONLY);
+        if (fd >= 0 && byte_offset > 0 && lseek(fd, (off_t)byte_offset, SEEK_SET) < 0) { close(fd); fd = -1; fclose(fc); fclose(fr); gzclose(in); return CLH_E_ARG; }
+        if (fd < 0 && byte_offset > 0) { fclose(fc); fclose(fr); gzclose(in); return CLH_E_ARG; }      // a compressed file cannot be entered in the middle
     }
     size_t chunk_bytes = (size_t)32 << 20;
     if (const char* e = getenv("CLH_FILE_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(e)) << 20;

@@ -101,13 +101,25 @@ def _together(stage, fn):
     return out
 
 
+INDEX_EVERY = 1024        # records between two entries of the byte-offset index of the input
+
+
 def _count_records(in_file, is_fastq):
-    """records of the input as find_ccs_reads' loop counts them: native (host only) when libclh.so loads, else the Python loop"""
+    """(records of the input as find_ccs_reads' loop counts them, byte offsets of the records 0, INDEX_EVERY, 2 INDEX_EVERY ... -- empty
+    for a gzip file): native (host only) when libclh.so loads, else the Python loop"""
     from . import find_ccs, hip
     try:
-        return hip.fastx_count(in_file, is_fastq)
+        return hip.fastx_index(in_file, is_fastq, INDEX_EVERY)
     except (hip.HipUnavailable, OSError):
-        return sum(1 for _ in find_ccs.iter_reads(in_file))
+        return sum(1 for _ in find_ccs.iter_reads(in_file)), []
+
+
+def _entry(index, lo):
+    """(byte offset, record number) of the indexed record at or before record `lo`"""
+    if not index:
+        return 0, 0
+    k = min(lo // INDEX_EVERY, len(index) - 1)
+    return index[k], k * INDEX_EVERY
 
 
 def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_file=None, chunk_size=250, stage_setup=None):
@@ -130,8 +142,8 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     {out_dir}/{prefix}.cand_circ.fa (find_bsj.py:364-366, 471-483), {prefix}.low_confidence.fa (:708-710), {prefix}.json
     (main.py:102-103).  Returns (counters of all ranks, short reads of stage 3 of this rank).
 
-    find_consensus_file(in_file, is_fastq, ccs_path, raw_path, first_record, max_records) -> (total, ro, too_long) replaces
-    the native stage 1 (`hip.Context.ccs_file`) in CPU tests."""
+    find_consensus_file(in_file, is_fastq, ccs_path, raw_path, first_record, max_records, byte_offset) -> (total, ro, too_long)
+    replaces the native stage 1 (`hip.Context.ccs_file`) in CPU tests; records are counted from byte_offset, the first byte of a record."""
     import json
     import os
     import shutil
@@ -143,15 +155,18 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     fq, is_fastq, _gz = find_ccs._open_reads(in_file)
     fq.close()
     import itertools
-    n = _bcast(_together('count', lambda: _count_records(in_file, is_fastq) if rank == 0 else None))      # counted once, not once per rank
+    # counted once, on rank 0, which also notes the byte offset of every 1024th record: a rank enters an uncompressed file at its shard
+    # (rounds 2-3: every rank read past everything in front of its shard, and stage 3 parsed the whole input on every rank)
+    n, index = _bcast(_together('count', lambda: _count_records(in_file, is_fastq) if rank == 0 else None))
     lo, hi = shard_bounds(n, rank, world)
+    byte_off, rec0 = _entry(index, lo)
     tmp = os.path.join(out_dir, 'tmp')
     part = os.path.join(tmp, '%s.part%d' % (prefix, rank))
     if find_consensus_file is None:
-        def find_consensus_file(path, fastq, ccs_path, raw_path, first, count):
-            return hip.default_context().ccs_file(path, fastq, ccs_path, raw_path, 0, first, count)
+        def find_consensus_file(path, fastq, ccs_path, raw_path, first, count, byte_offset=0):
+            return hip.default_context().ccs_file(path, fastq, ccs_path, raw_path, 0, first, count, byte_offset)
     # ---- stage 1 ---------------------------------------------------------------------------------------------------------
-    total, ro, _too_long = _together('1 (consensus)', lambda: find_consensus_file(in_file, is_fastq, part + '.ccs.fa', part + '.raw.fa', lo, hi - lo))
+    total, ro, _too_long = _together('1 (consensus)', lambda: find_consensus_file(in_file, is_fastq, part + '.ccs.fa', part + '.raw.fa', lo - rec0, hi - lo, byte_off))
     ccs_seq = find_ccs.load_ccs_reads(out_dir, '%s.part%d' % (prefix, rank))
     if dist:
         dist.barrier()
@@ -204,7 +219,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
 
     def stage3():
         # this rank's records only: the iterator stops at `hi` (rounds 2-3 parsed the whole input on every rank)
-        mine = itertools.islice(find_ccs.iter_reads(in_file), lo, hi)
+        mine = itertools.islice(find_ccs.iter_reads(in_file, byte_off), lo - rec0, hi - rec0)
         for group in grouper(mine, 1000):
             cnt, ret, sh = find_bsj.scan_raw_chunk([r for r in group if r is not None], is_canonical, circ_reads)
             add(cnt)

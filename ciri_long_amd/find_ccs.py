@@ -34,10 +34,15 @@ def _open_reads(in_file):
     sys.exit('Wrong format of input')
 
 
-def iter_reads(in_file):
+def iter_reads(in_file, byte_offset=0):
     """(header, seq) per record: header = first space-separated token without the leading '>'/'@', one sequence line per
-    record, FASTQ '+'/quality lines skipped (find_ccs.py:51-64)."""
+    record, FASTQ '+'/quality lines skipped (find_ccs.py:51-64).  byte_offset: start at this byte of an uncompressed file, the
+    first byte of a record (hip.fastx_index) -- a rank of a sharded run enters the file at its shard."""
     fq, is_fastq, is_gz = _open_reads(in_file)
+    if byte_offset:
+        if is_gz:
+            raise ValueError('a compressed file cannot be entered in the middle')
+        fq.seek(byte_offset)
     try:
         for line in fq:
             header = to_str(line).rstrip().split(' ')[0]

@@ -123,6 +123,18 @@ def lib():
     return _lib
 
 
+def fastx_index(in_path, is_fastq, every=4096):
+    """(records, [byte offset of record 0, every, 2 every, ...]) of a FASTA/FASTQ file; no offsets for a gzip file (host only)"""
+    n = C.c_int64(0); no = C.c_int64(0)
+    L = lib()
+    L.clh_fastx_index.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    cap = max(16, os.path.getsize(in_path) // max(1, 20 * every) + 16)
+    off = np.zeros(cap, dtype=np.int64)
+    if L.clh_fastx_index(os.fsencode(in_path), int(bool(is_fastq)), int(every), C.byref(n), off.ctypes.data, cap, C.byref(no)) != 0:
+        raise ClhError('clh_fastx_index failed for %s' % in_path)
+    return int(n.value), [int(x) for x in off[:no.value]]
+
+
 def fastx_count(in_path, is_fastq):
     """records of a FASTA/FASTQ(.gz) file as find_ccs_reads' loop counts them (host only, no GPU)"""
     n = C.c_int64(0)
@@ -331,13 +343,16 @@ class Context(object):
     def edit_plan(self, xs, ys):
         return EditPlan(self, xs, ys)
 
-    def ccs_file(self, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads=0, first_record=0, max_records=-1):
+    def ccs_file(self, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads=0, first_record=0, max_records=-1, byte_offset=0):
         """Stage 1 from file to file in native code -> (total_reads, reads_with_consensus, reads_too_long); with
-        first_record / max_records for one rank's contiguous shard of the records.  Reads that a limit of the kernel left
-        without a consensus are counted in self.capacity_dropped (and logged by find_ccs_reads)."""
+        first_record / max_records for one rank's contiguous shard of the records, counted from `byte_offset` (the first byte of a
+        record, `fastx_index`).  Reads that a limit of the kernel left without a consensus are counted in self.capacity_dropped
+        (and logged by find_ccs_reads)."""
         st = (C.c_int64 * 4)()
-        rc = lib().clh_ccs_file_range(self._h, os.fsencode(in_path), int(bool(is_fastq)), os.fsencode(ccs_fa_path), os.fsencode(raw_fa_path),
-                                      int(batch_reads), int(first_record), int(max_records), C.byref(st))
+        L = lib()
+        L.clh_ccs_file_at.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+        rc = L.clh_ccs_file_at(self._h, os.fsencode(in_path), int(bool(is_fastq)), os.fsencode(ccs_fa_path), os.fsencode(raw_fa_path),
+                               int(batch_reads), int(byte_offset), int(first_record), int(max_records), C.byref(st))
         if rc != 0:
             raise ClhError('clh_ccs_file failed (%d): %s' % (rc, last_error()))
         self.capacity_dropped = getattr(self, 'capacity_dropped', 0) + int(st[3])

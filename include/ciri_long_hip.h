@@ -194,6 +194,13 @@ int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fastq, const ch
                        int32_t batch_reads, int64_t first_record, int64_t max_records, clh_ccs_file_stats* stats);
 /* number of records of a FASTA/FASTQ(.gz) file as that loop counts them (host only) */
 int clh_fastx_count(const char* in_path, int is_fastq, int64_t* n_records);
+/* the same count plus the byte offset of every `every`-th record (0, every, 2 every ...; at most `cap`) of an uncompressed file
+ * (*n_offsets = 0 for a gzip file), and stage 1 for the records [first_record, first_record + max_records) counted from such an
+ * offset: a rank of a sharded `call` (the reference hands chunks of the record stream to its pool, find_ccs.py:66-75) seeks to its
+ * shard instead of reading past what lies in front of it (host I/O only; find_ccs.py:29-64 for what a record is) */
+int clh_fastx_index(const char* in_path, int is_fastq, int64_t every, int64_t* n_records, int64_t* offsets, int64_t cap, int64_t* n_offsets);
+int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
+                    int32_t batch_reads, int64_t byte_offset, int64_t first_record, int64_t max_records, clh_ccs_file_stats* stats);
 
 /* ---- Resident genome ---------------------------------------------------------------------
  * The reference builds, per clipped read, a window string of hit +- 200 kb, counts its 'N', reverse-complements it for

@@ -80,13 +80,14 @@ def test_two_ranks_equal_one(tmp_path):
 # ---------------------------------------------------------------------------------------------------------------------
 # the whole of `call` sharded over two ranks: files byte-identical to the one-rank run
 # ---------------------------------------------------------------------------------------------------------------------
-def _cpu_stage1(path, is_fastq, ccs_path, raw_path, first, count):
-    """stand-in for hip.Context.ccs_file on a box without a GPU: the same files from the CPU statement of the consensus"""
+def _cpu_stage1(path, is_fastq, ccs_path, raw_path, first, count, byte_offset=0):
+    """stand-in for hip.Context.ccs_file on a box without a GPU: the same files from the CPU statement of the consensus (records
+    counted from byte_offset, where a rank enters the file)"""
     import oracle_lib
     from ciri_long_amd import find_ccs
     total = ro = 0
     with open(ccs_path, 'w') as out, open(raw_path, 'w') as trimmed:
-        for k, (header, seq) in enumerate(find_ccs.iter_reads(path)):
+        for k, (header, seq) in enumerate(find_ccs.iter_reads(path, byte_offset)):
             if k < first or k >= first + count:
                 continue
             total += 1
@@ -128,6 +129,7 @@ def _call_worker(rank, world, port, out_dir, in_file, q):
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from ciri_long_amd import dist as cdist
+    cdist.INDEX_EVERY = 3         # a byte offset for every third record: rank 1 enters the file in the middle (stage 1 and stage 3)
     w = _setup_call_world()
     counts, short = cdist.call_sharded(in_file, out_dir, 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1, stage_setup=w['stage_setup'])
     q.put((rank, dict(counts), len(short)))

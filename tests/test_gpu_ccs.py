@@ -335,7 +335,7 @@ def test_native_file_stage_equals_the_python_loop(tmp_path):
         assert (tot_d, ro_d) == (tot_p, ro_p) and d_d == d_p
 
 
-def test_native_file_stage_buffer_borders_and_a_trailing_header(tmp_path):
+def test_native_file_stage_buffer_borders_and_a_trailing_header(tmp_path, monkeypatch):
     """a file larger than the reader's 4 MiB buffer (lines split across refills take the assembling path), a last header
     without its sequence line, batches of 1000 rotating through the three threads: byte-identical to the Python loop"""
     from ciri_long_amd import find_ccs, hip, synth
@@ -359,6 +359,23 @@ def test_native_file_stage_buffer_borders_and_a_trailing_header(tmp_path):
     for name in ('x.ccs.fa', 'x.raw.fa'):
         assert (tmp_path / 'a' / 'tmp' / name).read_bytes() == (tmp_path / 'b' / 'tmp' / name).read_bytes(), name
     assert hip.fastx_count(str(fq), 1) == 6501
+    # shards of a sharded run (dist.call_sharded): a rank enters the file at the indexed record at or before its shard; the shards'
+    # files one after the other are the unsharded files; a small chunk size makes records straddle many chunk borders
+    n, index = hip.fastx_index(str(fq), 1, every=500)
+    assert n == 6501 and len(index) == 14 and index[0] == 0
+    monkeypatch.setenv('CLH_FILE_CHUNK_MB', '1')
+    parts = {'x.ccs.fa': b'', 'x.raw.fa': b''}
+    tot = 0
+    for lo, hi in ((0, 1700), (1700, 1701), (1701, 4999), (4999, 6501)):
+        k = lo // 500
+        t, _ro, _l = hip.default_context().ccs_file(str(fq), 1, str(tmp_path / 'a' / 'tmp' / 's.ccs.fa'), str(tmp_path / 'a' / 'tmp' / 's.raw.fa'), 700,
+                                                    first_record=lo - 500 * k, max_records=hi - lo, byte_offset=index[k])
+        tot += t
+        for name in parts:
+            parts[name] += (tmp_path / 'a' / 'tmp' / name.replace('x.', 's.')).read_bytes()
+    assert tot == 6501
+    for name in parts:
+        assert parts[name] == (tmp_path / 'b' / 'tmp' / name).read_bytes(), name
 
 
 def test_reads_lost_to_a_kernel_limit_are_counted_and_reported(tmp_path, caplog, monkeypatch):

@@ -240,7 +240,7 @@ static bool scanw_sliced_ok(int64_t L, int64_t R, const clh_ssw_opts* o, int max
     if (off || !prefilter_ok(o, max_match)) return false;
     const int64_t overlap = L + (L * max_match + o->gap_extend - 1) / o->gap_extend + 32;
     const int64_t own = std::max<int64_t>(std::max<int64_t>(8192, 2 * overlap), (R + 63) / 64);
-    return L <= 4096 && R >= kSliceMinWindow && own + overlap < 32768 && (int64_t)max_match * L < 32000 && o->gap_extend <= 16 && o->gap_open <= 255;
+    return L <= 4096 && R >= kSliceMinWindow && R <= 1500000 && own + overlap < 32768 && (int64_t)max_match * L < 32000 && o->gap_extend <= 16 && o->gap_open <= 255;
 }
 
 // ref_off != nullptr: packed references, alignment a against [ref_off[a], ref_off[a+1]).  Otherwise windows of a resident

@@ -407,7 +407,8 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
     const uint8_t* dmin = p.pf_dmin ? p.pf_dmin + p.pf_tasks[pt.piece_first].sub_off : nullptr;     // (one piece: reads of this class have <= 254 bases)
     int own = (R + 63) / 64; own = own < 8192 ? 8192 : own;
     const int nstatic = (R + own - 1) / own;
-    int S0 = 0, nrun = 0, pruned = 0, thr = 0;
+    int S0 = 0, nrun = 0, pruned = 0, thr = 0, seed_block = -1;
+    ScanOut seed; seed.max = 0; seed.col = -1; seed.row = 0;
     if (dmin) {
         int key = 0x7fffffff;
         for (int k = lane; k < pt.nsub; k += 64) { const int v = ((int)dmin[k] << 20) | k; key = v < key ? v : key; }
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
         c0 = c0 < 0 ? 0 : c0; c1 = c1 > R ? R : c1;
         const int cb = c0 - overlap < 0 ? 0 : c0 - overlap;
         const ScanOut fw = scan_forward<GEQ>(p, task, lds, cb, c0, c1);
-        S0 = fw.max;
+        S0 = fw.max; seed = fw; seed_block = kb;
         if (S0 > 0) {
             const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
             thr = (p.max_match * L - S0) / cc;
@@ -457,8 +458,12 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
                 ScanSlice sl;
                 sl.task = blockIdx.x; sl.own_begin = b0; sl.c_begin = b0 - overlap < 0 ? 0 : b0 - overlap; sl.c_end = b1;
                 sl.part = first + done + rank; sl.pad0 = sl.pad1 = sl.pad2 = 0;
+                if (len == 1 && k == seed_block) {       // the seed's own region: its best cell is known already
+                    ScanPart pt2; pt2.max = seed.max; pt2.col = seed.col; pt2.row = seed.row; pt2.pad = 0;
+                    p.parts[sl.part] = pt2;
+                    sl.task = -1;
+                } else cols += (unsigned long long)(b1 - sl.c_begin);
                 p.pf_slices[sl.part] = sl;
-                cols += (unsigned long long)(b1 - sl.c_begin);
             }
             done += __popcll(starts);
         }
@@ -494,6 +499,7 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_queue_kernel(const Ss
         idx = __builtin_amdgcn_readfirstlane(idx);
         if (idx >= total) break;
         const ScanSlice sl = p.pf_slices[idx];
+        if (sl.task < 0) continue;                 // the seed's region: done by the pick kernel
         const SswTask task = p.tasks[sl.task];
         const ScanOut fw = scan_forward<GEQ>(p, task, lds, sl.c_begin, sl.own_begin, sl.c_end);
         if (lane == 0) { ScanPart pt; pt.max = fw.max; pt.col = fw.col; pt.row = fw.row; pt.pad = 0; p.parts[sl.part] = pt; }

@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswPar
 template <bool GEQ>
 __global__ void __launch_bounds__(64) ssw_scanw_seed_kernel(const SswParams p)
 {
+    __shared__ uint8_t s_dm[6144];                 // block minima of one piece (windows below 1.5 Mb: at most 5861 blocks)
     const int lane = threadIdx.x & 63;
     const int a = blockIdx.x;
     const SswTask task = p.tasks[a];
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(64) ssw_scanw_seed_kernel(const SswParams p)
     WsTask t0, t1;
     t0.task = -1; t0.c_begin = t0.c_end = 0; t0.row = 0; t0.force_word = 0; t0.pad0 = t0.pad1 = t0.pad2 = 0;
     t1 = t0; t1.row = 1; t1.force_word = 1;
-    int ub = 1 << 30;
+    int ub = 1 << 30, seed_block = -1;
     if (p.pf_dmin) {
         const int R = task.ref_len, L = task.read_len;
         const int span = L + (L * p.max_match + p.gapE - 1) / p.gapE;
@@ -507,21 +508,24 @@ __global__ void __launch_bounds__(64) ssw_scanw_seed_kernel(const SswParams p)
         const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
         uint16_t* D = p.ws_bound + pt.d_off;
         int key = 0x7fffffff;
-        for (int b = lane; b < pt.nsub; b += 64) {
-            int sum = 0;
-            for (int k = 0; k < pt.piece_count; ++k) {
-                const uint8_t* dm = p.pf_dmin + p.pf_tasks[pt.piece_first + k].sub_off;
+        // the minima of one piece at a time through LDS (coalesced in, the window of sb + 1 blocks read from there), the sums in D
+        for (int k = 0; k < pt.piece_count; ++k) {
+            const uint8_t* dm = p.pf_dmin + p.pf_tasks[pt.piece_first + k].sub_off;
+            for (int b = lane; b < pt.nsub; b += 64) s_dm[b] = dm[b];
+            __syncthreads();
+            for (int b = lane; b < pt.nsub; b += 64) {
                 int mn = 255;
-                for (int q = b - sb < 0 ? 0 : b - sb; q <= b; ++q) { const int v = dm[q]; mn = v < mn ? v : mn; }
-                sum += mn;
+                for (int q = b - sb < 0 ? 0 : b - sb; q <= b; ++q) { const int v = s_dm[q]; mn = v < mn ? v : mn; }
+                const int sum = (k ? (int)D[b] : 0) + mn;
+                D[b] = (uint16_t)sum;
+                if (k == pt.piece_count - 1) { const int v = (sum << 16) | (b & 0xffff); key = v < key ? v : key; }
             }
-            D[b] = (uint16_t)sum;
-            const int v = (sum << 16) | (b & 0xffff);
-            key = v < key ? v : key;
+            __syncthreads();
         }
         // (blocks above 65535 -- windows above 16 Mb -- are not a case: the class rule keeps windows below 1.5 Mb)
         key = wave_min(key);
         const int kb = key & 0xffff, dmin = key >> 16;
+        seed_block = kb;
         ub = p.max_match * L - cc * dmin;
         int c0 = kb * kPfBlock - pt.phase, c1 = c0 + kPfBlock;
         c0 = c0 < 0 ? 0 : c0; c1 = c1 > R ? R : c1;
@@ -530,7 +534,7 @@ __global__ void __launch_bounds__(64) ssw_scanw_seed_kernel(const SswParams p)
     }
     if (lane == 0) {
         p.ws_tasks[2 * a] = t0; p.ws_tasks[2 * a + 1] = t1;
-        PfOut o; o.first = 0; o.count = 0; o.s0 = ub; o.pruned = 0;
+        PfOut o; o.first = seed_block; o.count = 0; o.s0 = ub; o.pruned = 0;
         p.pf_out[a] = o;
     }
 }
@@ -574,8 +578,8 @@ __global__ void __launch_bounds__(64) ssw_scanw_pick_kernel(const SswParams p)
     const int overlap = span + 32;
     int own = (R + 63) / 64; own = own < 8192 ? 8192 : own; own = own < 2 * overlap ? 2 * overlap : own;
     const int nstatic = (R + own - 1) / own;
-    const SswResult* rows = p.results + p.ws_row0 + a * kWsRows;
-    const int ub = p.pf_out[a].s0;
+    SswResult* const rows = p.results + p.ws_row0 + a * kWsRows;
+    const int ub = p.pf_out[a].s0, seed_block = p.pf_out[a].first;
     // mode 1: tasks as they come (byte first); 2: word regime only; 3: both
     int mode = 3, S0 = 0, thr = 0, nrun = 0, pruned = 0;
     const uint16_t* D = p.ws_bound ? p.ws_bound + pt.d_off : nullptr;
@@ -611,12 +615,14 @@ __global__ void __launch_bounds__(64) ssw_scanw_pick_kernel(const SswParams p)
     first = __builtin_amdgcn_readfirstlane(first);
     WsTask* q = p.ws_tasks + 2 * gridDim.x + first;
     unsigned long long cols = 0;
-    auto emit = [&](int k, int b0, int b1) {
+    // reuse: the run is the seed block alone -- its region is the seed's, whose rows are there already (the seed that overflowed IS
+    // the word-regime row: the byte pass was abandoned and the word pass ran)
+    auto emit = [&](int k, int b0, int b1, bool reuse) {
         WsTask t;
-        t.task = a; t.c_begin = b0 - overlap < 0 ? 0 : b0 - overlap; t.c_end = b1; t.pad0 = t.pad1 = t.pad2 = 0;
-        if (mode != 2) { t.row = 2 + 2 * k; t.force_word = 0; q[per * k] = t; }
-        if (mode != 1) { t.row = 3 + 2 * k; t.force_word = 1; q[per * k + per - 1] = t; }
-        cols += (unsigned long long)(t.c_end - t.c_begin) * per;
+        t.task = reuse ? -1 : a; t.c_begin = b0 - overlap < 0 ? 0 : b0 - overlap; t.c_end = b1; t.pad0 = t.pad1 = t.pad2 = 0;
+        if (mode != 2) { t.row = 2 + 2 * k; t.force_word = 0; q[per * k] = t; if (reuse) rows[2 + 2 * k] = rows[0]; }
+        if (mode != 1) { t.row = 3 + 2 * k; t.force_word = 1; q[per * k + per - 1] = t; if (reuse) rows[3 + 2 * k] = rows[mode == 2 ? 0 : 1]; }
+        if (!reuse) cols += (unsigned long long)(t.c_end - t.c_begin) * per;
     };
     if (pruned) {
         int done = 0;
@@ -630,14 +636,14 @@ __global__ void __launch_bounds__(64) ssw_scanw_pick_kernel(const SswParams p)
                 const int rank = done + __popcll(starts & ((1ull << lane) - 1ull));
                 int b0 = k * kPfBlock - pt.phase, b1 = (k + len) * kPfBlock - pt.phase;
                 b0 = b0 < 0 ? 0 : b0; b1 = b1 > R ? R : b1;
-                emit(rank, b0, b1);
+                emit(rank, b0, b1, len == 1 && k == seed_block);
             }
             done += __popcll(starts);
         }
     } else {
         for (int sidx = lane; sidx < nstatic; sidx += 64) {
             const long long b = (long long)sidx * own;
-            emit(sidx, (int)b, (int)(b + own > R ? R : b + own));
+            emit(sidx, (int)b, (int)(b + own > R ? R : b + own), false);
         }
     }
 #pragma unroll

@@ -196,7 +196,10 @@ def _assemble(read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_s
             '{}|{}-{}'.format(junc, clip_base, len(circ)), segments, seq)
 
 
-THREADS = 1               # mapper calls of a chunk run on this many threads (set by the stage drivers from `threads`)
+THREADS = 1               # mapper calls of a chunk run on this many threads (set by the stage drivers from `threads`).  UNVERIFIED: whether
+                          # mappy.Aligner.map / bwapy release the GIL could not be checked (neither package is installable here); if they hold
+                          # it, `threads` buys nothing for the mapper phase and only this pool would have to change (a process pool in front of
+                          # the GPU process).  Results do not depend on it (tests/test_dist_gloo.py runs with three threads).
 _POOL = None
 
 

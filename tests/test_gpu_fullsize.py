@@ -197,3 +197,22 @@ def test_c4_full_per_gpu_share_125000_reads_order_and_split_invariance():
     for part in (order[:n // 2], order[n // 2:]):
         rows_c, sums_c, _s = consensus(part)
         assert np.array_equal(rows_a['ccs_len'][part], rows_c['ccs_len']) and np.array_equal(sums_a[part], sums_c)
+
+
+def test_one_round_of_the_fuzz_harness(monkeypatch, capsys):
+    """tests/fuzz_parity.py is the long-running parity hunt (run by hand for minutes); one short run of it belongs to
+    the suite, so that the driver's GPU run exercises every kernel family on fresh random shapes too: alignments (six scoring schemes,
+    long windows with and without the second best), consensus calls (periods up to 6 kb: both forms of K3's pass), spoa-shaped
+    families, edit distances and splice-signal searches against the CPU oracles.  In this process (a process that has initialised the
+    GPU must not start another program)."""
+    import runpy
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    monkeypatch.setattr(sys, 'argv', ['fuzz_parity.py', '0.25'])
+    monkeypatch.chdir(os.path.dirname(here))
+    os.makedirs('gpurun_out', exist_ok=True)
+    try:
+        runpy.run_path(os.path.join(here, 'fuzz_parity.py'), run_name='__main__')
+    except SystemExit as ex:
+        assert not ex.code, capsys.readouterr().out[-1500:]
+    assert 'fuzz ok:' in capsys.readouterr().out

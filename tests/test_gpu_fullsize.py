@@ -1,6 +1,7 @@
 """BASELINE.json's full sizes (C2: 10 000 alignments of ~1 kb reads vs 2 kb windows; C3: 100 000 reads through the
 consensus kernels) checked through properties that do not need the oracle on every item: a read's result must not depend
 on the batch it travels in (order reversed, batch split into pieces), and a seeded sample must equal the oracle."""
+import os
 import zlib
 
 import numpy as np

@@ -756,6 +756,9 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
             for (int t = 0; t < CP; ++t) {
                 Es[t] = pk_max(X[t], pk_adds(t == 0 ? q0 : qhat[t - 1], e2));       // E + e - g with E = max(Ehat, Qhat[j-1] + g), spoa's array
+#ifdef POA_EXP_NOD          // timing experiment: the second of two runs of the pass without the difference words (what they cost)
+                if (S.algorithm & 0x100) { D[t] = Es[t]; continue; }
+#endif
                 const uint32_t Hm = pk_subs(Hf[t], ONE2);
                 const uint32_t dF = pk_max(pk_subs(fsn[t], Hm), 0u), dO = pk_max(pk_subs(osn[t], Hm), 0u);
                 const uint32_t dE = pk_max(pk_subs(Es[t], Hm), 0u), dQ = pk_max(pk_subs(Y[t], Hm), 0u);

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
     const uint8_t* dmin = p.pf_dmin ? p.pf_dmin + p.pf_tasks[pt.piece_first].sub_off : nullptr;     // (one piece: reads of this class have <= 254 bases)
     int own = (R + 63) / 64; own = own < 8192 ? 8192 : own;
     const int nstatic = (R + own - 1) / own;
-    int S0 = 0, nrun = 0, pruned = 0, thr = 0, seed_block = -1;
+    int S0 = 0, nrun = 0, pruned = 0, thr = 0, seed_block = -1, ov_c = overlap;
     ScanOut seed; seed.max = 0; seed.col = -1; seed.row = 0;
     if (dmin) {
         int key = 0x7fffffff;
@@ -422,6 +422,10 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
         if (S0 > 0) {
             const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
             thr = (p.max_match * L - S0) / cc;
+            // an alignment that scores S0 or more deletes at most (M L - S0) / gapE window bases: it spans no more than L + that many
+            // columns, so the candidate slices start that far (+ 32) early -- cells that cannot reach S0 may come out lower, they cannot win
+            const int span_s0 = L + (p.max_match * L - S0) / p.gapE + 32;
+            ov_c = span_s0 < overlap ? span_s0 : overlap;
             long long cost = 0;
             for (int g = 0; g < pt.nsub; g += 64) {
                 const int k = g + lane;
@@ -429,7 +433,7 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
                 nrun += __popcll(m & ~(m << 1));
                 cost += (long long)__popcll(m) * kPfBlock;
             }
-            cost += (long long)nrun * overlap;
+            cost += (long long)nrun * ov_c;
             const int cap = pt.nsub / 8 + 1 > 64 ? pt.nsub / 8 + 1 : 64;
             pruned = nrun <= cap && cost < (long long)R + (long long)nstatic * overlap;
         }
@@ -456,7 +460,7 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
                 int b0 = k * kPfBlock - pt.phase, b1 = (k + len) * kPfBlock - pt.phase;
                 b0 = b0 < 0 ? 0 : b0; b1 = b1 > R ? R : b1;
                 ScanSlice sl;
-                sl.task = blockIdx.x; sl.own_begin = b0; sl.c_begin = b0 - overlap < 0 ? 0 : b0 - overlap; sl.c_end = b1;
+                sl.task = blockIdx.x; sl.own_begin = b0; sl.c_begin = b0 - ov_c < 0 ? 0 : b0 - ov_c; sl.c_end = b1;
                 sl.part = first + done + rank; sl.pad0 = sl.pad1 = sl.pad2 = 0;
                 if (len == 1 && k == seed_block) {       // the seed's own region: its best cell is known already
                     ScanPart pt2; pt2.max = seed.max; pt2.col = seed.col; pt2.row = seed.row; pt2.pad = 0;

@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(64) ssw_scanw_pick_kernel(const SswParams p)
     SswResult* const rows = p.results + p.ws_row0 + a * kWsRows;
     const int ub = p.pf_out[a].s0, seed_block = p.pf_out[a].first;
     // mode 1: tasks as they come (byte first); 2: word regime only; 3: both
-    int mode = 3, S0 = 0, thr = 0, nrun = 0, pruned = 0;
+    int mode = 3, S0 = 0, thr = 0, nrun = 0, pruned = 0, ov_c = overlap;
     const uint16_t* D = p.ws_bound ? p.ws_bound + pt.d_off : nullptr;
     if (p.score_size == 1) mode = 1;             // the caller asked for the word pass alone: one regime by construction
     if (p.pf_dmin) {
@@ -593,6 +593,9 @@ __global__ void __launch_bounds__(64) ssw_scanw_pick_kernel(const SswParams p)
         if (S0 > 0) {
             const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
             thr = (p.max_match * L - S0) / cc;
+            // (an alignment that scores S0 or more spans at most L + (M L - S0) / gapE columns: the candidate regions start that far early)
+            const int span_s0 = L + (p.max_match * L - S0) / p.gapE + 32;
+            ov_c = span_s0 < overlap ? span_s0 : overlap;
             long long cost = 0;
             for (int g = 0; g < pt.nsub; g += 64) {
                 const int k = g + lane;
@@ -600,7 +603,7 @@ __global__ void __launch_bounds__(64) ssw_scanw_pick_kernel(const SswParams p)
                 nrun += __popcll(m & ~(m << 1));
                 cost += (long long)__popcll(m) * kPfBlock;
             }
-            cost += (long long)nrun * overlap;
+            cost += (long long)nrun * ov_c;
             pruned = nrun <= 64 && cost < (long long)R + (long long)nstatic * overlap;
         }
     }
@@ -619,7 +622,8 @@ __global__ void __launch_bounds__(64) ssw_scanw_pick_kernel(const SswParams p)
     // the word-regime row: the byte pass was abandoned and the word pass ran)
     auto emit = [&](int k, int b0, int b1, bool reuse) {
         WsTask t;
-        t.task = reuse ? -1 : a; t.c_begin = b0 - overlap < 0 ? 0 : b0 - overlap; t.c_end = b1; t.pad0 = t.pad1 = t.pad2 = 0;
+        const int ovx = pruned ? ov_c : overlap;
+        t.task = reuse ? -1 : a; t.c_begin = b0 - ovx < 0 ? 0 : b0 - ovx; t.c_end = b1; t.pad0 = t.pad1 = t.pad2 = 0;
         if (mode != 2) { t.row = 2 + 2 * k; t.force_word = 0; q[per * k] = t; if (reuse) rows[2 + 2 * k] = rows[0]; }
         if (mode != 1) { t.row = 3 + 2 * k; t.force_word = 1; q[per * k + per - 1] = t; if (reuse) rows[3 + 2 * k] = rows[mode == 2 ? 0 : 1]; }
         if (!reuse) cols += (unsigned long long)(t.c_end - t.c_begin) * per;

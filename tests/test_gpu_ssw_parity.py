@@ -110,6 +110,53 @@ def test_production_shape_testfa(ctx, testfa):
     assert cigar_to_string(cg, 20, 436, len(seq1)).startswith('20S6M1D2M2I2M1I1M1I5M3I7M2I3M1D5M3D96M1D2M2D8M1D5M1D1M1D58M1I118M2D38M2I48M')
 
 
+def test_production_shape_testfa_call_path_options(ctx, testfa, golden_cases):
+    """The same alignment the way find_bsj.py:204-216 asks for it (no second best, no CIGAR wanted): the 437-base clip is above the
+    8-bit class, the 430 kb window above 32 kb -- K1w tasks behind the prefilter (class -4), the window's regime decided for the window.
+    Expected values: the reference library's own (Appendix B of SURVEY.md / the golden vectors).  And every golden case whose window has
+    32 kb or more, again with call-path options, against its recorded answer."""
+    from ciri_long_amd import hip
+    seq1, seq2 = testfa
+    rd, ro = hip.pack([seq1]); fd, fo = hip.pack([seq2])
+    plan = ctx.plan(ro, fo, hip.score_matrix(1, 1), 1, 1, flag=1, score_size=2, want_score2=False, want_cigar=True)
+    assert [rv for rv, _c, _a, _b in plan.segments()] == [-4]
+    plan.close()
+    rows, cig = _run(ctx, [seq2], [seq1], (1, 1, 1, 1), want_score2=False, want_cigar=True)
+    r = rows[0]
+    assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])) == (349, 229790, 230207, 20, 436)
+    cg = cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]
+    assert cigar_to_string(cg, 20, 436, len(seq1)).startswith('20S6M1D2M2I2M1I1M1I5M3I7M2I3M1D5M3D96M1D2M2D8M1D5M1D1M1D58M1I118M2D38M2I48M')
+    # tests/golden/long_window_golden.json.gz: 44 clips against windows of 33..402 kb, answers of the reference library itself
+    # (make_long_window_golden.py; a window is rebuilt from its recipe), by scoring scheme in one batch each -- both long-window classes
+    import gzip
+    import json
+    import os
+    import sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, gdir)
+    from make_long_window_golden import build_window
+    with gzip.open(os.path.join(gdir, 'long_window_golden.json.gz'), 'rt') as f:
+        cases = json.load(f)['cases']
+    by_scheme = {}
+    for c in cases:
+        by_scheme.setdefault((c['match'], c['mismatch'], c['gap_open'], c['gap_extend']), []).append(c)
+    seen = set()
+    for scheme, cs in by_scheme.items():
+        refs = [build_window(c['seed'], c['length'], c['patches']) for c in cs]
+        qs = [c['query'] for c in cs]
+        rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+        plan = ctx.plan(ro, fo, hip.score_matrix(scheme[0], scheme[1]), scheme[2], scheme[3], flag=1, score_size=2, want_score2=False, want_cigar=True)
+        seen |= {rv for rv, _c, _a, _b in plan.segments()}
+        plan.close()
+        rows, cig = _run(ctx, refs, qs, scheme, want_score2=False, want_cigar=True)
+        for c, r in zip(cs, rows):
+            assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])) == \
+                (c['score'], c['ref_begin'], c['ref_end'], c['query_begin'], c['query_end']), c['name']
+            cg = cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]
+            assert cigar_to_string(cg, c['query_begin'], c['query_end'], len(c['query'])) == c['cigar_string'], c['name']
+    assert seen == {-1, -4}
+
+
 def test_options_score_size_flag_and_skips(ctx):
     rng = np.random.default_rng(99)
     refs = [_rnd(rng, 500) for _ in range(40)]

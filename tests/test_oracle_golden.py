@@ -58,3 +58,26 @@ def test_stale_walk_goldens_oracle_equals_the_reference_library():
         assert lib.clo_last_oob_steps() == c['stale_steps'] > 0
         for k, v in c['want'].items():
             assert w[k] == v, (c['rank'], c['index'], k)
+
+
+def test_oracle_matches_the_long_window_goldens():
+    """tests/golden/long_window_golden.json.gz (made by the reference's own wrapper over its own library, make_long_window_golden.py):
+    clips of 20..600 bases against windows of 33..402 kb -- the shape of find_bsj.py:196-216 -- in three scoring schemes; the oracle
+    must give the reference's scores, coordinates and CIGARs (the GPU test runs the same cases through both long-window classes)"""
+    import gzip
+    import json
+    import os
+    import sys
+    from oracle_lib import cigar_to_string, oracle_align
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, gdir)
+    from make_long_window_golden import build_window
+    with gzip.open(os.path.join(gdir, 'long_window_golden.json.gz'), 'rt') as f:
+        cases = json.load(f)['cases']
+    assert len(cases) == 44
+    for c in cases:
+        ref = build_window(c['seed'], c['length'], c['patches'])
+        w = oracle_align(ref, c['query'], c['match'], c['mismatch'], c['gap_open'], c['gap_extend'])
+        assert (w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']) == \
+            (c['score'], c['ref_begin'], c['ref_end'], c['query_begin'], c['query_end']), c['name']
+        assert cigar_to_string(w['cigar'], w['query_begin'], w['query_end'], len(c['query'])) == c['cigar_string'], c['name']

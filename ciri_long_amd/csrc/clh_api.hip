@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1515,16 +1516,25 @@ extern "C" int clh_ccs_results_dev(const clh_ccs_plan* pl, const void** rows, co
 extern "C" int clh_ccs_batch(clh_ctx* ctx, int32_t n, const int8_t* reads, const int64_t* read_off, clh_ccs_t* out, int32_t* segs, int8_t* ccs)
 {
     if (!ctx || !reads || !read_off || !out) return fail(CLH_E_ARG, "clh_ccs_batch: null argument");
+    static const bool trace = getenv("CLH_FILE_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = trace ? now() : 0;
     clh_ccs_plan* pl = clh_ccs_plan_create(ctx, n, read_off);
     if (!pl) return CLH_E_ARG;
+    const double t1 = trace ? now() : 0;
     int rc = 0;
     pl->d_reads = ctx->alloc((size_t)read_off[n] + 64);
     if (!pl->d_reads) rc = fail(CLH_E_HIP, "out of device memory for the batch");
     if (!rc && read_off[n] > 0 && hipMemcpyAsync(pl->d_reads, reads, (size_t)read_off[n], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         rc = fail(CLH_E_HIP, "H2D reads failed");
     if (!rc) rc = clh_ccs_run(pl, pl->d_reads, nullptr);
+    double t2 = 0, t3 = 0;
+    if (trace) { t2 = now(); (void)hipStreamSynchronize(ctx->stream); t3 = now(); }
     if (!rc) rc = clh_ccs_fetch(pl, out, segs, ccs);
+    const double t4 = trace ? now() : 0;
     clh_ccs_plan_destroy(pl);
+    if (trace) fprintf(stderr, "[clh] ccs batch of %d reads: plan %.2f ms, H2D + launches %.2f, kernels (wait) %.2f, fetch %.2f, destroy %.2f\n", n,
+                       (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);
     return rc;
 }
 

@@ -685,6 +685,7 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     P.results = (clh::SswResult*)pl->d_results;
     P.colmax = (uint16_t*)pl->d_colmax;
     P.cigars = (uint32_t*)pl->d_cigars; P.cigar_len = (int32_t*)pl->d_cigar_len; P.dirs = (uint8_t*)pl->d_strips;
+    P.no_guess = getenv("CLH_NO_GUESS") != nullptr;
     if (pl->profiling && pl->ev.empty()) {
         pl->ev.resize(pl->segs.size() * 2 + 4);
         for (auto& e : pl->ev) HIPCHK(hipEventCreate(&e));

@@ -117,6 +117,7 @@ struct SswParams {
     int32_t ws_row0;           // first scratch result row of the class (alignment a: ws_row0 + a * kWsRows)
     int32_t ws_slot_bytes;     // K1w workspace of one persistent workgroup inside `dirs`
     int64_t ws_dirs_off;       // where those workspaces start inside `dirs`
+    int32_t no_guess;          // K1w: 1 = always the byte pass first (CLH_NO_GUESS: A/B of the overflow guess, ssw_scan_wide.hip)
 };
 
 // ---- cyclic consensus (K2/K3, csrc/ccs_poa.hip) ----------------------------------------------------------------

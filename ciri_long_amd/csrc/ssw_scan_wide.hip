@@ -370,6 +370,47 @@ size_t scanw_task_bytes(int read_len) {
     return (size_t)W_NB * 2 * W_CPR_MAX * 64 * 4 + 2 * 2 * rows_cap * 2 + 256;
 }
 
+// Which forward pass first?  The reference runs the byte pass and, if a cell reached 255 - bias, the word pass (ssw.c:804-809).  The
+// ORDER is free: a word pass whose maximum reaches 255 - bias proves that the byte pass would have overflowed (byte H >= word H), and
+// then the byte pass need not run at all -- it costs an overflowing alignment half a pass on average before it is abandoned.  So the
+// kernel guesses: exact 11-mers shared by the read and the window, counted through a hash table in the (still unused) profile block
+// of LDS; an alignment long enough to overflow at ~13 % errors shares more than a hundred, unrelated sequences none.  A wrong guess costs
+// time only: a word pass below 255 - bias is followed by the byte pass, whose verdict stands (scanw_align).
+__device__ bool scanw_guess_overflow(const SswParams& p, const int8_t* read, const int L, const int8_t* ref, const int refLen, const int rdir, const int comp, uint32_t* lds_words)
+{
+    constexpr int K = 11, TAB = 4096;
+    const int lane = threadIdx.x & 63;
+    uint16_t* tab = (uint16_t*)lds_words;                // 8 KiB of the 12 KiB profile block
+    for (int i = lane; i < TAB; i += 64) tab[i] = 0;
+    __syncthreads();
+    {
+        const int per = (L + 63) / 64, i0 = lane * per, i1 = i0 + per < L ? i0 + per : L;
+        uint32_t code = 0; int valid = 0;
+        for (int i = i0; i < i1 + K - 1 && i < L; ++i) {
+            const int c = (int)read[i] & 7;
+            if (c > 3) { valid = 0; code = 0; continue; }
+            code = ((code << 2) | (uint32_t)c) & ((1u << (2 * K)) - 1); ++valid;
+            if (valid >= K) tab[code & (TAB - 1)] = (uint16_t)(0x8000u | (code >> 12));
+        }
+    }
+    __syncthreads();
+    int hits = 0;
+    {
+        const int per = (refLen + 63) / 64, j0 = lane * per, j1 = j0 + per < refLen ? j0 + per : refLen;
+        uint32_t code = 0; int valid = 0;
+        for (int j = j0; j < j1 + K - 1 && j < refLen; ++j) {
+            const int c = ref_code((int)ref[(int64_t)j * rdir], comp);
+            if (c > 3) { valid = 0; code = 0; continue; }
+            code = ((code << 2) | (uint32_t)c) & ((1u << (2 * K)) - 1); ++valid;
+            if (valid >= K) hits += tab[code & (TAB - 1)] == (uint16_t)(0x8000u | (code >> 12));
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) hits += __shfl_xor(hits, d);
+    __syncthreads();                 // the table's block becomes the profile again
+    return hits * p.max_match >= 64;
+}
+
 // one alignment, start to finish: the read against refLen columns from `ref` on (read backwards and complemented when ref_rc).
 // force_word: the word regime without asking the byte pass (the decision was made for the whole window, see ssw_scanw_pick_kernel).
 // Returns false when the reference would have returned NULL (score_size 0 and an 8-bit overflow): res.status says so.
@@ -395,6 +436,8 @@ __device__ bool scanw_align(const SswParams& p, const int8_t* read, const int8_t
     // alignment that does overflow pays a fraction of a pass for it, and one that does not (half of a mixed batch) needs no second pass
     // -- the anti-diagonal kernel's "word first when the bound allows an overflow" pays a whole pass there.
     int job_word = (p.score_size == 1 || force_word) ? 1 : 0;
+    if (!job_word && p.score_size == 2 && L * p.max_match + bias >= 255 && refLen >= 64 && !p.no_guess)
+        job_word = scanw_guess_overflow(p, read, L, ref, refLen, rdir, ref_rc, mem.prof) ? 1 : 0;
     while (regime < 0) {
         if (job_word) {
             word_rows(in);

@@ -220,6 +220,9 @@ static const int kSliceMinWindow = 32768, kSliceMinCols = 8192;
 static bool scan_sliced(int64_t R, const clh_ssw_opts* o)
 {
     static const bool off = getenv("CLH_NO_SLICES") != nullptr;
+    // (experiment: CLH_PF_MIN_WINDOW lowers the window length from which K1s goes behind the prefilter -- call-path options only)
+    static const int pf_min = getenv("CLH_PF_MIN_WINDOW") ? atoi(getenv("CLH_PF_MIN_WINDOW")) : kSliceMinWindow;
+    if (!o->want_score2 && R >= pf_min && o->gap_extend >= 1 && !off && getenv("CLH_NO_PREFILTER") == nullptr) return true;
     return !off && R >= kSliceMinWindow && o->gap_extend >= 1;
 }
 

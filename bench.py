@@ -427,6 +427,11 @@ def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmu
            'roofline': roofline_of(launches), 'reads_with_consensus': int(len(fs.has)),
            'counters': dict(zip(['total', 'consensus', 'raw_unmapped', 'ccs_mapped', 'bsj', 'signal', 'partial'], [int(x) for x in counters])),
            'splice_handed_back': int((sig[:, 0] != 0).sum()), 'counter_exchange': res_exchange}
+    if prod_windows and res['roofline']['kernel'].startswith('ssw_prefilter_kernel'):      # (its own counters: profiles/r04c_c3prod_pmc_summary.csv)
+        try:
+            res['roofline']['traffic'] = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'))).get('c3_production_windows: ' + res['roofline']['kernel'])
+        except Exception:
+            res['roofline']['traffic'] = None
     if pf_stats['alignments']:
         res['prefilter'] = pf_stats
     if pf_check:

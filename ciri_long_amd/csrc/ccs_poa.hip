@@ -826,7 +826,13 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
                 for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
                 const uint32_t imp = pk_sra15(pk_subs(bsP, rm));                  // halves whose best is exceeded (strictly: the first row stays)
+#ifndef POA_ENDCELL_VOTE
+                // no vote: along an alignment nearly every row improves some lane's best, and a wave-wide vote feeding a scalar branch
+                // is a VALU -> SALU hand-over that stalls the step -- the update is a few masked moves, done unconditionally
+                {
+#else
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(imp != 0u) != 0, 0)) {
+#endif
                     uint32_t colP = 0;
 #pragma unroll
                     for (int t = CP - 1; t >= 0; --t) {

@@ -759,6 +759,17 @@ def test_long_reads_on_long_windows_behind_the_prefilter_vs_oracle(ctx, scheme):
             if case == 9:
                 q = _rnd(rng, L)
             refs.append(ref); qs.append(q[:4000])
+    if m == 1:
+        # the seed (fewest edits: five substitutions, 262 - 10 = 252) stays below the 8-bit limit while a locus with MORE edits (six
+        # extra window bases, 262 - 6 = 256) overflows: the window's regime is the word regime, decided by a region that is not the seed
+        # (tests/test_longwin_model.py has the same construction on the CPU)
+        import sys as _sys, os as _os
+        _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+        from test_longwin_model import _two_loci
+        g2 = np.random.Generator(np.random.PCG64(4242))
+        for _ in range(4):
+            r2, q2 = _two_loci(g2, R=40000)
+            refs.append(''.join('ACGT'[v] for v in r2)); qs.append(''.join('ACGT'[v] for v in q2))
     rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
     d_r = torch.from_numpy(rd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
     plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=True)

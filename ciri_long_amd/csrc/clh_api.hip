@@ -371,7 +371,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         while (e < n_all && cls[order[e]] == cls[order[k]]) ++e;
         // a large K1w class with CIGARs goes as up to four launches: the traceback of one runs under the score kernel of the next
         // (clh_ssw_run) instead of all of it behind the one score kernel
-        const int parts = (cls[order[k]] == clh::kRvScanWide && pl->do_cigar && e - k >= 16384 && getenv("CLH_SCANW_PARTS")) ? 4 : 1;   // (measured on C2, 10 000 alignments: 4 parts of 2 500 are each less than one round of the GPU's wave slots -- 28 -> 35 ms; kept for batches far above that, off by default)
+        const int parts = (cls[order[k]] == clh::kRvScanWide && pl->do_cigar && e - k >= 4096 && getenv("CLH_SCANW_PARTS")) ? std::max(1, std::min(8, atoi(getenv("CLH_SCANW_PARTS")))) : 1;   // (measured on C2, 10 000 alignments: 4 parts of 2 500 are each less than one round of the GPU's wave slots -- 28 -> 35 ms; kept for batches far above that, off by default)
         for (int q = 0; q < parts; ++q) {
             const int b = k + (int)((int64_t)(e - k) * q / parts), b2 = k + (int)((int64_t)(e - k) * (q + 1) / parts);
             clh_plan::Seg sg; sg.rv = cls[order[k]]; sg.begin = b; sg.count = b2 - b;

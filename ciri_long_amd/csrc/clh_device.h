@@ -247,7 +247,10 @@ size_t scanw_task_bytes(int read_len);
 // [36 + seg] alignments handed on to the anti-diagonal kernel; the task indices from word 68 on, two arrays of n_total, a
 // class's entries at the offset of its first task.
 static constexpr int kTbMaxSeg = 32;
-inline size_t tb_head_bytes(int n_total) { return 4 * 68 + 2 * sizeof(int) * (size_t)(n_total > 0 ? n_total : 1); }
+inline size_t tb_head_bytes(int n_total) { return 4 * 68 + 6 * sizeof(int) * (size_t)(n_total > 0 ? n_total : 1); }
+// behind the two lists: per entry of the first list, where the narrow kernel left the band doubling (ssw.c:560-632):
+// {band half-width of the next iteration, running maximum, iterations done, 0}
+inline int* tb_state_of(unsigned long long* head, int n_total, int task_base) { return (int*)head + 68 + 2 * (size_t)(n_total > 0 ? n_total : 1) + 4 * (size_t)task_base; }
 inline void tb_lists_of(unsigned long long* head, int n_total, int seg, int task_base, int** n_small, int** n_big, int** list_small, int** list_big)
 {
     int* w = (int*)head;

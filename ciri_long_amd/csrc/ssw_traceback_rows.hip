@@ -26,6 +26,11 @@
 
 namespace clh {
 
+#ifdef CLH_TBW_TRACE
+__device__ long long g_tbw_dbg[8 * 1024];
+__device__ int g_tbw_n;
+#endif
+
 namespace {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -76,25 +81,40 @@ struct TbIn {
     const uint2* tab;       // LDS: per read code q, the 5 scores + bias against reference codes 0..4 as bytes {0..3},{4}
 };
 
-// One band iteration with band half-width w (2w+1 <= 128*CP).  DIRS: direction nibbles of every cell, row-major:
+// What the waves of one alignment hand each other when a band is split over NW > 1 waves (wave v owns the 128*CP virtual lanes
+// from v*128*CP): a row is then two barriers -- partial F scans, barrier, carries and H, barrier.  Double-buffered by row parity.
+struct TbX {
+    int T[2][8];            // inclusive F-scan total of the wave (the workgroup's frame)
+    uint32_t he[2][8];      // by offset: H | E << 16 of the wave's lowest cell; by column: H of its highest cell
+    int dd[2][8];           // DIRS: (h - gapO) - (f - gapE) of the wave's highest cell
+    int mx[8];              // iteration maximum per wave
+    unsigned long long at;  // pool offset of a plane
+    int cmd;                // the walk (wave 0) asks every wave for the plane of an earlier iteration
+};
+// the rows' barrier: the LDS words above must have landed; the row's direction bytes on their way to HBM need not (a
+// __syncthreads() waits for them as well, ~700 clocks per row)
+__device__ __forceinline__ void tb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One band iteration with band half-width w (2w+1 <= 128*CP*NW).  DIRS: direction nibbles of every cell, row-major:
 // row i = 64*CP bytes at dir + i*64*CP, cell at offset o' = j - i + w + (128*CP - 1 - 2w) in nibble o' of the row.
 // Returns the maximum H of the iteration.
 // COLS: the virtual lanes own reference COLUMNS instead (cell j in nibble j; refLen <= 128*CP, any w) -- the layout for
 // bands that are wider than 2048 cells only on paper (a row never has more than refLen cells): the upper neighbour is then
 // the same register, the diagonal one is the shifted one, the bases stay put and the band is a per-row mask.
-template <int CP, bool DIRS, bool COLS>
-__device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
+template <int CP, bool DIRS, bool COLS, int NW = 1>
+__device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir, TbX* xs = nullptr)
 {
-    constexpr int NV = 128 * CP;
-    const int lane = threadIdx.x & 63;
+    constexpr int NV = 128 * CP * NW;
+    const int lane = threadIdx.x & 63, wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
+    const int gl = wave * 64 + lane;                    // the lane's place among all the virtual lanes of the row
     const int shiftc = COLS ? 0 : NV - 1 - 2 * w;
     const int gO = in.gO, gE = in.gE;
     const uint32_t gO2 = dup16(gO), gE2 = dup16(gE), bias2 = dup16(in.bias), xfix = dup16(gO - gE), dG2 = dup16(gO - gE);
-    const int K = CP * gE, kLo = 2 * lane * K;
+    const int K = CP * gE, kLo = 2 * gl * K;
     uint32_t inb[CP], refsel[CP], Hp[CP], Ep[CP];      // inb: offsets inside the band (COLS: the lane's two column numbers)
 #pragma unroll
     for (int t = 0; t < CP; ++t) {
-        const int olo = lane * 2 * CP + t, ohi = olo + CP;
+        const int olo = gl * 2 * CP + t, ohi = olo + CP;
         inb[t] = COLS ? ((uint32_t)olo | ((uint32_t)ohi << 16)) : ((olo >= shiftc ? 0xffffu : 0u) | (ohi >= shiftc ? 0xffff0000u : 0u));
         const int jlo = COLS ? olo : olo - shiftc - w, jhi = COLS ? ohi : ohi - shiftc - w;   // row 0: j = o' - shiftc - w
         const bool vlo = olo >= shiftc && jlo >= 0 && jlo < in.refLen, vhi = ohi >= shiftc && jhi >= 0 && jhi < in.refLen;
@@ -105,19 +125,27 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
     uint32_t itmaxP = 0;
     const int nb0 = COLS ? 0 : shiftc - shiftc % (2 * CP);      // first stored nibble of a row: the lane that holds the band's first offset
     const int first_lane = nb0 / (2 * CP), rowbytes = (NV - nb0) / 2;
+    const int top_back = (NW - 1 - wave) * 128 * CP;    // the wave's highest offset sits this far below the band's top
+    if constexpr (NW > 1) {
+        if (lane == 0) { xs->he[1][wave] = 0; }
+        __syncthreads();
+    }
     for (int rb = 0; rb < in.readLen; rb += 64) {
         const int row = rb + lane;
         const int qv = row < in.readLen ? ((int)in.read[row] & 7) : 0;
         int nv = 0x0c;                                                        // the base entering at the top offset: ref[row + w]
-        if (!COLS && row < in.readLen && row + w < in.refLen) nv = ref_code((int)in.ref[(int64_t)(row + w) * in.rdir], in.rc);
+        if (!COLS && row < in.readLen && row + w - top_back >= 0 && row + w - top_back < in.refLen) nv = ref_code((int)in.ref[(int64_t)(row + w - top_back) * in.rdir], in.rc);
         const int cnt = in.readLen - rb < 64 ? in.readLen - rb : 64;
         for (int k = 0; k < cnt; ++k) {
             const int i = rb + k;
             const int q = __builtin_amdgcn_readlane(qv, k);
             const uint2 tb = in.tab[q];
             uint32_t Hu[CP], Eu[CP], Hd[CP], bandinv[COLS ? CP : 1];
+            [[maybe_unused]] const int par = i & 1;
             if constexpr (COLS) {
-                const uint32_t d0 = hand_down(Hp[CP - 1], 0);
+                int below = 0;
+                if constexpr (NW > 1) below = wave > 0 ? (int)xs->he[par ^ 1][wave - 1] : 0;
+                const uint32_t d0 = hand_down(Hp[CP - 1], below);
                 const uint32_t lo2 = dup16(i - w), hi2 = dup16(i + w);
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
@@ -125,7 +153,9 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
                     bandinv[t] = pk_sra15(pk_subs(inb[t], lo2)) | pk_sra15(pk_subs(hi2, inb[t]));      // j < i - w or i + w < j
                 }
             } else {   // the previous row seen from one offset lower; the reference bases slide the same way
-                const uint32_t h0 = hand_up(Hp[0], 0), e0 = hand_up(Ep[0], 0);
+                uint32_t above = 0;
+                if constexpr (NW > 1) above = wave + 1 < NW ? xs->he[par ^ 1][wave + 1] : 0u;
+                const uint32_t h0 = hand_up(Hp[0], (int)(above & 0xffffu)), e0 = hand_up(Ep[0], (int)(above >> 16));
 #pragma unroll
                 for (int t = 0; t < CP; ++t) Hd[t] = Hp[t];
 #pragma unroll
@@ -144,7 +174,7 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
                 const int oc = COLS ? in.refLen - 1 : in.refLen - 1 - i + w + shiftc;     // where column refLen-1 sits in this row
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
-                    const int olo = lane * 2 * CP + t, ohi = olo + CP;
+                    const int olo = gl * 2 * CP + t, ohi = olo + CP;
                     const uint32_t keep = (olo == oc ? 0u : 0xffffu) | (ohi == oc ? 0u : 0xffff0000u);
                     Hu[t] &= keep; Eu[t] &= keep;
                 }
@@ -173,7 +203,13 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
                 const uint32_t U = CP == 1 ? c[0] : pk_max(c[CP - 1], pk_subs(floc[CP - 1], gE2));
                 const int Blo = (int)(short)(U & 0xffffu) + kLo, Bhi = ((int)U >> 16) + kLo + K;
                 const int inc = wave_prefix_max(Blo > Bhi ? Blo : Bhi);
-                const int fill = -gE - K;                                     // the cell left of offset 0: H = F = 0
+                int fill = -gE - K;                                           // the cell left of offset 0: H = F = 0
+                if constexpr (NW > 1) {                                       // the waves below: their totals, same frame
+                    if (lane == 63) xs->T[par][wave] = inc;
+                    tb_barrier();
+#pragma unroll
+                    for (int v = 0; v + 1 < NW; ++v) { const int tv = xs->T[par][v]; fill = (v < wave && tv > fill) ? tv : fill; }
+                }
                 int exc = dpp_shr1(fill, inc);
                 exc = exc > fill ? exc : fill;
                 int finLo = exc - kLo + K;
@@ -192,8 +228,16 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
                 itmaxP = pk_max(itmaxP, h);
                 if (DIRS) dd[t] = pk_subs(pk_subs(h, bfi(inv[t], 0u, f[t])), dG2);   // (h - gapO) - (f - gapE), what the right neighbour compares
             }
+            if constexpr (NW > 1) {      // what the neighbouring waves read in the next row (and, with DIRS, in this one)
+                if constexpr (COLS) { if (lane == 63) xs->he[par][wave] = hn[CP - 1] >> 16; }
+                else if (lane == 0) xs->he[par][wave] = (hn[0] & 0xffffu) | (bfi(inv[0], 0u, e[0]) << 16);
+                if (DIRS && lane == 63) xs->dd[par][wave] = (int)(dd[CP - 1] >> 16);
+                tb_barrier();
+            }
             if (DIRS) {
-                const uint32_t d0 = hand_down(dd[CP - 1], -(gO - gE));
+                int ddb = -(gO - gE);
+                if constexpr (NW > 1) ddb = wave > 0 ? xs->dd[par][wave - 1] : ddb;
+                const uint32_t d0 = hand_down(dd[CP - 1], ddb);
                 uint32_t x[CP];
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
@@ -205,8 +249,8 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
                     const uint32_t mef = pk_sra15(pk_subs(f1, e1[t]));        // E rather than F: e1 > f1 (ssw.c:627)
                     x[t] = (mgt & bfi(mef, 0x00010001u, 0x00020002u)) | (mde[t] & 0x00040004u) | (mdf & 0x00080008u);
                 }
-                uint8_t* drow = dir + (size_t)i * rowbytes + (size_t)(lane - first_lane) * CP;
-                if (lane < first_lane) {}
+                uint8_t* drow = dir + (size_t)i * rowbytes + (size_t)(gl - first_lane) * CP;
+                if (gl < first_lane) {}
                 else if constexpr (CP == 1) { *drow = (uint8_t)((x[0] & 0xfu) | ((x[0] >> 12) & 0xf0u)); }
                 else if constexpr (CP == 2) { const uint32_t y = x[0] | (x[1] << 4); *(uint16_t*)drow = (uint16_t)((y & 0xffu) | ((y >> 8) & 0xff00u)); }
                 else {
@@ -231,29 +275,44 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir)
         }
     }
     const int lo = (int)(short)(itmaxP & 0xffffu), hi = (int)itmaxP >> 16;
-    return __builtin_amdgcn_readfirstlane(wave_max(lo > hi ? lo : hi));
+    int best = __builtin_amdgcn_readfirstlane(wave_max(lo > hi ? lo : hi));
+    if constexpr (NW > 1) {
+        if (lane == 0) xs->mx[wave] = best;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < NW; ++v) { const int m = xs->mx[v]; best = m > best ? m : best; }
+        __syncthreads();
+    }
+    return best;
 }
 
+// one wave, bands up to 128*MAXCP cells (MAXCP = 4)
 template <int MAXCP, bool DIRS>
 __device__ int tb_rows_iter(const TbIn& in, int w, uint8_t* dir)
 {
     if (2 * w + 1 <= 128) return tb_rows_pass<1, DIRS, false>(in, w, dir);
     if (2 * w + 1 <= 256) return tb_rows_pass<2, DIRS, false>(in, w, dir);
-    if (MAXCP <= 4 || 2 * w + 1 <= 512) return tb_rows_pass<4, DIRS, false>(in, w, dir);
-    if constexpr (MAXCP > 4) {
-        if (2 * w + 1 <= 1024) return tb_rows_pass<8, DIRS, false>(in, w, dir);
-        if (2 * w + 1 <= 2048) return tb_rows_pass<16, DIRS, false>(in, w, dir);
-        if (in.refLen <= 1024) return tb_rows_pass<8, DIRS, true>(in, w, dir);
-        return tb_rows_pass<16, DIRS, true>(in, w, dir);
-    }
-    return 0;
+    return tb_rows_pass<4, DIRS, false>(in, w, dir);
 }
-// registers per lane of the iteration with band w, and whether it is laid out by reference column
-__device__ __forceinline__ int cp_of(int w) { const int c = 2 * w + 1; return c <= 128 ? 1 : (c <= 256 ? 2 : (c <= 512 ? 4 : (c <= 1024 ? 8 : 16))); }
-__device__ __forceinline__ bool fits(int maxcp, int w, int refLen, int readLen)
+// a workgroup of kMw waves: bands up to 2048 cells, or by reference column (refLen <= 2048, any band), 1..2 registers per lane.
+// (One wave with 8..16 registers per lane issues ~500..1000 instructions per row, four clocks each; split over 8 waves on the
+// CU's four SIMDs a row is ~100 instructions and two barriers.)
+static constexpr int kMw = 8;
+template <bool DIRS>
+__device__ int tb_rows_iter_mw(const TbIn& in, int w, uint8_t* dir, TbX* xs)
 {
-    if (2 * w + 1 <= 128 * maxcp) return true;
-    return maxcp > 4 && refLen <= 2048 && w + readLen < 32000;       // by column: i + w must fit 16 bits
+    if (2 * w + 1 <= 128 * kMw) return tb_rows_pass<1, DIRS, false, kMw>(in, w, dir, xs);
+    if (2 * w + 1 <= 256 * kMw) return tb_rows_pass<2, DIRS, false, kMw>(in, w, dir, xs);
+    if (in.refLen <= 128 * kMw) return tb_rows_pass<1, DIRS, true, kMw>(in, w, dir, xs);
+    return tb_rows_pass<2, DIRS, true, kMw>(in, w, dir, xs);
+}
+// registers per lane of the one-wave iteration with band w
+__device__ __forceinline__ int cp_of(int w) { const int c = 2 * w + 1; return c <= 128 ? 1 : (c <= 256 ? 2 : 4); }
+__device__ __forceinline__ bool fits(int maxcp, int w) { return 2 * w + 1 <= 128 * maxcp; }
+__device__ __forceinline__ bool fits_mw(int w, int refLen, int readLen)
+{
+    if (2 * w + 1 <= 256 * kMw) return true;
+    return refLen <= 256 * kMw && w + readLen < 32000;       // by column: i + w must fit 16 bits
 }
 
 }  // namespace
@@ -262,104 +321,127 @@ namespace {
 
 // the direction codes of one band iteration in the pool: geometry as in tb_rows_pass
 struct TbPlane { int w, by_col, shiftc, nb0, nvb, rowbytes; uint8_t* dir; };
+__device__ __forceinline__ void tb_plane_geom(TbPlane& pl, int w, bool by_col, int cpf, int nv)
+{
+    pl.w = w; pl.by_col = by_col;
+    pl.shiftc = by_col ? 0 : nv - 1 - 2 * w;
+    pl.nb0 = by_col ? 0 : pl.shiftc - pl.shiftc % (2 * cpf);       // as in tb_rows_pass: only the band's lanes store
+    pl.nvb = nv - pl.nb0; pl.rowbytes = pl.nvb / 2;
+}
+__device__ __forceinline__ unsigned long long tb_plane_bytes(const TbPlane& pl, int readLen)
+{
+    return ((unsigned long long)readLen * (unsigned long long)pl.rowbytes + 64ull + 63ull) & ~63ull;   // + 64: the walk reads 16 bytes from a row's start
+}
 
-// computes iteration w with direction codes into fresh pool space; false: pool exhausted
+// computes iteration w with direction codes into fresh pool space (one wave; the codes are then read by this wave only);
+// false: pool exhausted.  itmax: the iteration's maximum.
 template <int MAXCP>
-__device__ bool tb_make_plane(const TbIn& in, const int w, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size, TbPlane& pl)
+__device__ bool tb_make_plane(const TbIn& in, const int w, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size, TbPlane& pl, int* itmax = nullptr)
 {
     const int lane = threadIdx.x & 63;
-    pl.w = w;
-    pl.by_col = 2 * w + 1 > 128 * MAXCP;
-    const int CPf = pl.by_col ? (in.refLen <= 1024 ? 8 : 16) : cp_of(w);
-    pl.shiftc = pl.by_col ? 0 : 128 * CPf - 1 - 2 * w;
-    pl.nb0 = pl.by_col ? 0 : pl.shiftc - pl.shiftc % (2 * CPf);       // as in tb_rows_pass: only the band's lanes store
-    pl.nvb = 128 * CPf - pl.nb0; pl.rowbytes = pl.nvb / 2;
-    const unsigned long long need = ((unsigned long long)in.readLen * (unsigned long long)pl.rowbytes + 64ull + 63ull) & ~63ull;   // + 64: the walk reads 16 bytes from a row's start
+    const int cpf = cp_of(w);
+    tb_plane_geom(pl, w, false, cpf, 128 * cpf);
+    const unsigned long long need = tb_plane_bytes(pl, in.readLen);
     unsigned long long at = 0;
     if (lane == 0) at = atomicAdd(pool_head, need);
     at = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffull)) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32);
     if (at + need > pool_size) return false;
     pl.dir = pool_base + at;
-    (void)tb_rows_iter<MAXCP, true>(in, w, pl.dir);
+    const int it = tb_rows_iter<MAXCP, true>(in, w, pl.dir);
+    if (itmax) *itmax = it;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+// the same by the whole workgroup (every wave calls it with the same arguments and gets the same answers)
+__device__ bool tb_make_plane_mw(const TbIn& in, const int w, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size, TbPlane& pl, TbX* xs, int* itmax = nullptr)
+{
+    const bool by_col = 2 * w + 1 > 256 * kMw;
+    const int cpf = (by_col ? in.refLen <= 128 * kMw : 2 * w + 1 <= 128 * kMw) ? 1 : 2;
+    tb_plane_geom(pl, w, by_col, cpf, 128 * cpf * kMw);
+    const unsigned long long need = tb_plane_bytes(pl, in.readLen);
+    if (threadIdx.x == 0) xs->at = atomicAdd(pool_head, need);
+    __syncthreads();
+    unsigned long long at = xs->at;
+    __syncthreads();
+    at = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffull)) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32);
+    if (at + need > pool_size) return false;
+    pl.dir = pool_base + at;
+    const int it = tb_rows_iter_mw<true>(in, w, pl.dir, xs);
+    if (itmax) *itmax = it;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return true;
 }
 
-// One alignment.  MAXCP = 4: bands up to 512 cells (the launch over all alignments, 4 waves per SIMD); MAXCP = 16: up to
-// 2048 cells (the few wide ones, one wave per SIMD).  What this width cannot take goes on `next_list`.
-template <int MAXCP>
-__device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
-                            const int task_index, int* next_n, int* next_list)
+// What both launches do first: the row of the score pass, whether a CIGAR is wanted at all (ssw.c:840-869), the aligned parts.
+// Returns false when the alignment is finished (no CIGAR / the 1x1 problem).
+struct TbJob { SswTask task; SswResult res; uint32_t* cig; int* cig_len; TbIn in; };
+__device__ __forceinline__ bool tb_rows_setup(const SswParams& p, const uint2* s_tab, const int task_index, const bool clear_big, const bool writer, TbJob& jb)
 {
-    const int lane = threadIdx.x & 63;
-    const SswTask task = p.tasks[task_index];
-    if (task.out_index >= p.n_real) return;            // a window slice of an anti-diagonal class: scratch row, no CIGAR
-    SswResult res = p.results[task.out_index];
+    jb.task = p.tasks[task_index];
+    const SswTask& task = jb.task;
+    if (task.out_index >= p.n_real) return false;      // a window slice of an anti-diagonal class: scratch row, no CIGAR
+    SswResult& res = jb.res;
+    res = p.results[task.out_index];
     res.score1 = __builtin_amdgcn_readfirstlane(res.score1); res.status = __builtin_amdgcn_readfirstlane(res.status);
     res.ref_begin1 = __builtin_amdgcn_readfirstlane(res.ref_begin1); res.ref_end1 = __builtin_amdgcn_readfirstlane(res.ref_end1);
     res.read_begin1 = __builtin_amdgcn_readfirstlane(res.read_begin1); res.read_end1 = __builtin_amdgcn_readfirstlane(res.read_end1);
-    if (MAXCP > 4) res.status &= ~CLH_STATUS_NEED_BIG;      // set by the narrow launch that handed this alignment over
-    uint32_t* cig = p.cigars + task.cigar_off;
-    int* cig_len = p.cigar_len + task.out_index;
+    if (clear_big) res.status &= ~CLH_STATUS_NEED_BIG;      // set by the narrow launch that handed this alignment over
+    jb.cig = p.cigars + task.cigar_off;
+    jb.cig_len = p.cigar_len + task.out_index;
     const bool no_cigar = (res.status & CLH_STATUS_OVERFLOW8) || (7 & p.flag) == 0 ||
                           ((2 & p.flag) != 0 && res.score1 < p.filters) ||
                           ((4 & p.flag) != 0 && (res.ref_end1 - res.ref_begin1 > p.filterd || res.read_end1 - res.read_begin1 > p.filterd));
     if (no_cigar) {
-        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_NO_CIGAR; }
-        return;
+        if (writer) { *jb.cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_NO_CIGAR; }
+        return false;
     }
     if (res.ref_begin1 < 0) {   // score 0: the reference's 1x1 problem never enters its traceback loop -> 1M
-        if (lane == 0) { cig[0] = (1u << 4); *cig_len = 1; }
-        return;
+        if (writer) { jb.cig[0] = (1u << 4); *jb.cig_len = 1; }
+        return false;
     }
-    auto hand_over = [&]() {
-        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_NEED_BIG; next_list[atomicAdd(next_n, 1)] = task_index; }
-    };
-    TbIn in;
+    TbIn& in = jb.in;
     in.rdir = task.ref_rc ? -1 : 1; in.rc = task.ref_rc;
     in.ref = p.refs + task.ref_off + (int64_t)res.ref_begin1 * in.rdir;
     in.read = p.reads + task.read_off + res.read_begin1;
     in.refLen = res.ref_end1 - res.ref_begin1 + 1; in.readLen = res.read_end1 - res.read_begin1 + 1;
     in.gO = p.gapO; in.gE = p.gapE; in.bias = p.bias; in.tab = s_tab;
-    const int readLen = in.readLen, refLen = in.refLen, score = res.score1;
-    if (p.gapE > 60 || p.gapO > 255) { hand_over(); return; }       // the frames of the F scan are 16-bit
+    return true;
+}
 
-    // ---- band doubling (ssw.c:560-632), score-only: which band is the final one ------------------------------------
-    int w = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
-    const int w0 = w;
-    int maxv = 0, niter = 0;
-    bool covered = false;
-    for (;;) {
-        ++niter;
-        if (!covered) {
-            if (!fits(MAXCP, w, refLen, readLen)) { hand_over(); return; }
-            const int it = tb_rows_iter<MAXCP, false>(in, w, nullptr);
-            maxv = it > maxv ? it : maxv;
-            covered = w >= readLen && w >= refLen;      // a wider band holds the same cells: same values
-        }
-        w *= 2;
-        if (!(maxv < score && w < 2 * readLen)) break;
-    }
-    w /= 2;
-    if (!fits(MAXCP, w, refLen, readLen)) { hand_over(); return; }
-    // ---- the final band once more, with direction codes -------------------------------------------------------------
-    TbPlane fin, old;
-    old.w = -1; old.dir = nullptr;
-    if (!tb_make_plane<MAXCP>(in, w, pool_base, pool_head, pool_size, fin)) {
-        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
-        return;
-    }
+// The walk back from the bottom-right corner (ssw.c:636-725) over the final band's codes `fin` (iteration number niter, band
+// w; the first iteration had w0), one wave, wave-uniform; lane r holds 32 nibbles of row ib - r.  `old`: the plane of an
+// earlier iteration if one is at hand (w = -1: none; `kept`: further ones, MW only).  The walk's state lives in TbWalk so that it can stop and go on:
+// returns 0 done, 2 = this launch cannot finish it (pool exhausted or a band it cannot hold), 3 (MW only) = the codes of the
+// earlier iteration with band `need_w` are wanted, a job for the whole workgroup: make `old` and call again.
+struct TbWalk {
+    int i, j, state, run, nops, op, prev_op, ib, pb, need_w;
+    uint32_t pw0, pw1, pw2, pw3;
+};
+__device__ __forceinline__ void tb_walk_init(TbWalk& k, int readLen, int refLen)
+{
+    k.i = readLen - 1; k.j = refLen - 1; k.state = 2; k.run = 0; k.nops = 0; k.op = 0; k.prev_op = 0; k.ib = -1; k.pb = 0; k.need_w = 0;
+    k.pw0 = k.pw1 = k.pw2 = k.pw3 = 0;
+}
+template <int MAXCP, bool MW>
+__device__ int tb_rows_walk(const SswParams& p, const TbJob& jb, const TbPlane& fin, TbPlane& old, const TbPlane* kept, const int nkept, TbWalk& k, const int niter, const int w0, const int w,
+                            uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size)
+{
+    const int lane = threadIdx.x & 63;
+    const SswTask& task = jb.task;
+    const TbIn& in = jb.in;
+    uint32_t* const cig = jb.cig;
+    const int readLen = in.readLen, refLen = in.refLen;
     const bool by_col = fin.by_col != 0;
     const int shiftc = fin.shiftc, nb0 = fin.nb0, nvb = fin.nvb, rowbytes = fin.rowbytes;
     uint8_t* const dir = fin.dir;
-
-    // ---- walk back from the bottom-right corner (ssw.c:636-696), wave-uniform; lane r holds 32 nibbles of row ib - r ----
-    int i = readLen - 1, j = refLen - 1, state = 2, run = 0, nops = 0, fail = 0;
-    int op = 0, prev_op = 0;             // 0 M, 1 I, 2 D
-    int ib = -1, pb = 0;
-    uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
+    int i = k.i, j = k.j, state = k.state, run = k.run, nops = k.nops, fail = 0;
+    int op = k.op, prev_op = k.prev_op;  // 0 M, 1 I, 2 D
+    int ib = k.ib, pb = k.pb;
+    uint32_t pw0 = k.pw0, pw1 = k.pw1, pw2 = k.pw2, pw3 = k.pw3;
+    int need_w = 0;
     while (i > 0) {
         int nb;
         if (!(j >= 0 && j <= i + w && j >= i - w && j < refLen)) {
@@ -370,25 +452,30 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
             const long long wdF = 2ll * w + 1, xi = i - w > 0 ? i - w : 0, C = (long long)i * wdF + ((long long)j - xi);
             if (C < 0) { fail = 1; break; }
             nb = -1;
-            for (int k = niter - 1; k >= 0; --k) {
-                const long long wk = (long long)w0 << k, wd = 2 * wk + 1;
+            for (int q = niter - 1; q >= 0; --q) {
+                const long long wk = (long long)w0 << q, wd = 2 * wk + 1;
                 const long long ii = C / wd, pos = C % wd;
                 if (ii >= readLen) continue;
                 const long long xk = ii - wk > 0 ? ii - wk : 0, jj = xk + pos, endk = ii + wk < refLen - 1 ? ii + wk : refLen - 1;
                 if (jj > endk) continue;
                 const TbPlane* pl = &fin;
-                if (k != niter - 1) {
-                    if (old.w != (int)wk) {
-                        if (!fits(MAXCP, (int)wk, refLen, readLen) || !tb_make_plane<MAXCP>(in, (int)wk, pool_base, pool_head, pool_size, old)) { fail = 2; break; }
+                if (q != niter - 1) {
+                    const TbPlane* have = old.w == (int)wk ? &old : nullptr;
+                    if constexpr (MW) { for (int u = 0; u < nkept && !have; ++u) have = kept[u].w == (int)wk ? &kept[u] : nullptr; }
+                    if (!have) {
+                        if constexpr (MW) {
+                            if (!fits_mw((int)wk, refLen, readLen)) { fail = 2; break; }
+                            need_w = (int)wk; break;
+                        } else if (!fits(MAXCP, (int)wk) || !tb_make_plane<MAXCP>(in, (int)wk, pool_base, pool_head, pool_size, old)) { fail = 2; break; }
                     }
-                    pl = &old;
+                    pl = have ? have : &old;
                 }
                 const int o2 = (pl->by_col ? (int)jj : (int)(jj - ii) + pl->w + pl->shiftc) - pl->nb0;
                 const int byte = __builtin_amdgcn_readfirstlane((int)pl->dir[(size_t)ii * pl->rowbytes + (o2 >> 1)]);
                 nb = (byte >> ((o2 & 1) * 4)) & 15;
                 break;
             }
-            if (fail) break;
+            if (fail || need_w) break;
             if (nb < 0) { fail = 1; break; }             // no iteration wrote that byte: the reference reads uninitialised memory
         } else {
         const int o = (by_col ? j : j - i + w + shiftc) - nb0;     // nibble within the stored row
@@ -423,10 +510,15 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
             ++nops; prev_op = op; run = 1;
         }
     }
-    if (fail == 2) { hand_over(); return; }        // pool exhausted or a band this launch cannot hold: the other kernels
+    if (MW && need_w) {
+        k.i = i; k.j = j; k.state = state; k.run = run; k.nops = nops; k.op = op; k.prev_op = prev_op; k.ib = ib; k.pb = pb; k.need_w = need_w;
+        k.pw0 = pw0; k.pw1 = pw1; k.pw2 = pw2; k.pw3 = pw3;
+        return 3;
+    }
+    if (fail == 2) return 2;
     if (fail) {
-        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_TRACE_ERR; }
-        return;
+        if (lane == 0) { *jb.cig_len = 0; p.results[task.out_index].status = jb.res.status | CLH_STATUS_TRACE_ERR; }
+        return 0;
     }
     if (op == 0) {                                   // ssw.c:697-714
         if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)(run + 1) << 4);
@@ -438,17 +530,146 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
         ++nops;
     }
     if (nops > task.cigar_cap) {
-        if (lane == 0) { *cig_len = 0; p.results[task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
+        if (lane == 0) { *jb.cig_len = 0; p.results[task.out_index].status = jb.res.status | CLH_STATUS_CIGAR_TRUNC; }
+        return 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // lane 0's entries, read back by every lane of this wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int q = lane; q < nops / 2; q += 64) {      // reverse in place, ssw.c:716-725
+        const uint32_t x = cig[q], y = cig[nops - 1 - q];
+        cig[q] = y; cig[nops - 1 - q] = x;
+    }
+    if (lane == 0) *jb.cig_len = nops;
+    return 0;
+}
+
+// One alignment, one wave: bands up to 512 cells (the launch over all alignments, 4 waves per SIMD).  What this width cannot
+// take goes on `next_list` together with the state of the band doubling, so that the wide launch goes on where this one stopped.
+__device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                            const int task_index, int* next_n, int* next_list, int* next_state)
+{
+    constexpr int MAXCP = 4;
+    const int lane = threadIdx.x & 63;
+    TbJob jb;
+    if (!tb_rows_setup(p, s_tab, task_index, false, lane == 0, jb)) return;
+    const SswResult& res = jb.res;
+    const TbIn& in = jb.in;
+    auto hand_over = [&](int w_next, int maxv, int done) {
+        if (lane == 0) {
+            *jb.cig_len = 0; p.results[jb.task.out_index].status = res.status | CLH_STATUS_NEED_BIG;
+            const int slot = atomicAdd(next_n, 1);
+            next_list[slot] = task_index;
+            *(int4*)(next_state + 4 * (size_t)slot) = make_int4(w_next, maxv, done, 0);
+        }
+    };
+    const int readLen = in.readLen, refLen = in.refLen, score = res.score1;
+    int w = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+    const int w0 = w;
+    if (p.gapE > 60 || p.gapO > 255) { hand_over(w0, 0, 0); return; }       // the frames of the F scan are 16-bit
+
+    // ---- band doubling (ssw.c:560-632), score-only: which band is the final one ------------------------------------
+    int maxv = 0, niter = 0;
+    bool covered = false;
+    for (;;) {
+        ++niter;
+        if (!covered) {
+            if (!fits(MAXCP, w)) { hand_over(w, maxv, niter - 1); return; }
+            const int it = tb_rows_iter<MAXCP, false>(in, w, nullptr);
+            maxv = it > maxv ? it : maxv;
+            covered = w >= readLen && w >= refLen;      // a wider band holds the same cells: same values
+        }
+        w *= 2;
+        if (!(maxv < score && w < 2 * readLen)) break;
+    }
+    w /= 2;
+    if (!fits(MAXCP, w)) { hand_over(w, maxv, niter - 1); return; }      // (the iteration of this band once more over there: same values)
+    // ---- the final band once more, with direction codes -------------------------------------------------------------
+    TbPlane fin, old;
+    old.w = -1; old.dir = nullptr;
+    if (!tb_make_plane<MAXCP>(in, w, pool_base, pool_head, pool_size, fin)) {
+        if (lane == 0) { *jb.cig_len = 0; p.results[jb.task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
         return;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int k = lane; k < nops / 2; k += 64) {      // reverse in place, ssw.c:716-725
-        const uint32_t x = cig[k], y = cig[nops - 1 - k];
-        cig[k] = y; cig[nops - 1 - k] = x;
+    TbWalk wk;
+    tb_walk_init(wk, readLen, refLen);
+    if (tb_rows_walk<MAXCP, false>(p, jb, fin, old, nullptr, 0, wk, niter, w0, w, pool_base, pool_head, pool_size) == 2) hand_over(w0, 0, 0);   // pool exhausted or an earlier band this launch cannot hold
+}
+
+// One handed-over alignment, a workgroup of kMw waves, every band split over the waves (tb_rows_iter_mw).  A row is a dependent
+// chain, so the time of one alignment is its number of band passes: the narrow launch's iterations are not repeated (state),
+// and every iteration here leaves its direction codes, so the last one is not run twice (the one before it stays at hand for
+// the walk's reads outside the band).  Wave 0 walks.  What this launch cannot take goes on `next_list`.
+__device__ void tb_rows_wide_one(const SswParams& p, const uint2* s_tab, TbX* xs, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                                 const int task_index, const int4 st, int* next_n, int* next_list)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool writer = threadIdx.x == 0;
+    TbJob jb;
+    const bool go = tb_rows_setup(p, s_tab, task_index, true, writer, jb);
+    __syncthreads();                                   // every wave has the row before wave 0 may change its status
+    if (!go) return;
+    const SswResult& res = jb.res;
+    const TbIn& in = jb.in;
+    auto hand_over = [&]() {
+        if (writer) { *jb.cig_len = 0; p.results[jb.task.out_index].status = res.status | CLH_STATUS_NEED_BIG; next_list[atomicAdd(next_n, 1)] = task_index; }
+    };
+    auto no_pool = [&]() {
+        if (writer) { *jb.cig_len = 0; p.results[jb.task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
+    };
+    const int readLen = in.readLen, refLen = in.refLen, score = res.score1;
+    const int w0 = (refLen > readLen ? refLen - readLen : readLen - refLen) + 1;
+    if (p.gapE > 60 || p.gapO > 255) { hand_over(); return; }
+    long long w = st.x;
+    int maxv = st.y, niter = st.z;
+    constexpr int NKEPT = 4;                           // the codes of this launch's earlier iterations stay at hand
+    TbPlane fin, old, kept[NKEPT];
+    int nkept = 0;
+    old = TbPlane{-1, 0, 0, 0, 0, 0, nullptr}; fin = old;
+#ifdef CLH_TBW_TRACE
+    const long long tw0 = __builtin_readcyclecounter();
+    long long t_walk = 0, t_lazy = 0; int n_lazy = 0;
+#endif
+    for (;;) {                                         // ssw.c:560-632 from where the narrow launch stopped
+        if (w > 0x3fffffff || !fits_mw((int)w, refLen, readLen)) { hand_over(); return; }
+        if (fin.w > 0 && nkept < NKEPT) kept[nkept++] = fin;
+        int it = 0;
+        if (!tb_make_plane_mw(in, (int)w, pool_base, pool_head, pool_size, fin, xs, &it)) { no_pool(); return; }
+        ++niter; maxv = it > maxv ? it : maxv;
+        if (!(maxv < score && 2 * w < 2ll * readLen)) break;
+        w *= 2;
     }
-    if (lane == 0) *cig_len = nops;
+    // wave 0 walks; when it wants the codes of an earlier iteration the whole workgroup computes them and it goes on
+    TbWalk wk;
+    tb_walk_init(wk, readLen, refLen);
+#ifdef CLH_TBW_TRACE
+    const long long tw2 = __builtin_readcyclecounter();
+#endif
+    for (;;) {
+        int rc = 0;
+#ifdef CLH_TBW_TRACE
+        const long long ta = __builtin_readcyclecounter();
+#endif
+        if (wave == 0) rc = tb_rows_walk<4, true>(p, jb, fin, old, kept, nkept, wk, niter, w0, (int)w, pool_base, pool_head, pool_size);
+        if (writer) xs->cmd = rc == 3 ? wk.need_w : (rc == 2 ? -1 : 0);
+        __syncthreads();
+        const int cmd = xs->cmd;
+        __syncthreads();
+#ifdef CLH_TBW_TRACE
+        const long long tb_ = __builtin_readcyclecounter();
+        t_walk += tb_ - ta;
+        if (cmd == 0 && writer) {
+            const int slot = atomicAdd(&g_tbw_n, 1) & 1023;
+            long long* d = g_tbw_dbg + 8 * slot;
+            d[0] = ((long long)readLen << 32) | (unsigned)refLen; d[1] = ((long long)w0 << 32) | (unsigned)w; d[2] = ((long long)niter << 32) | (unsigned)n_lazy;
+            d[3] = tw2 - tw0; d[4] = 0; d[5] = t_walk; d[6] = t_lazy; d[7] = st.x;
+        }
+#endif
+        if (cmd == 0) return;
+        if (cmd < 0 || !tb_make_plane_mw(in, cmd, pool_base, pool_head, pool_size, old, xs)) { hand_over(); return; }
+#ifdef CLH_TBW_TRACE
+        t_lazy += __builtin_readcyclecounter() - tb_; ++n_lazy;
+#endif
+    }
 }
 
 }  // namespace
@@ -466,22 +687,25 @@ __device__ __forceinline__ void tb_rows_table(const SswParams& p, uint2* s_tab)
 
 // every alignment of the launch class, one per workgroup (= one wave)
 __global__ void __launch_bounds__(64, 4) ssw_traceback_rows_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
-                                                                   int task_base, int* n_small, int* list_small)
+                                                                   int task_base, int* n_small, int* list_small, int* state_small)
 {
     __shared__ uint2 s_tab[8];
     tb_rows_table(p, s_tab);
-    tb_rows_one<4>(p, s_tab, pool_base, pool_head, pool_size, task_base + (int)blockIdx.x, n_small, list_small);
+    tb_rows_one(p, s_tab, pool_base, pool_head, pool_size, task_base + (int)blockIdx.x, n_small, list_small, state_small);
 }
 
 // the alignments the narrow launch handed over: the workgroups share the list
-__global__ void __launch_bounds__(64, 1) ssw_traceback_rows_wide_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
-                                                                        const int* n_small, const int* list_small, int* n_big, int* list_big)
+__global__ void __launch_bounds__(64 * kMw, 1) ssw_traceback_rows_wide_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                                                                                    const int* n_small, const int* list_small, const int* state_small, int* n_big, int* list_big)
 {
     __shared__ uint2 s_tab[8];
+    __shared__ TbX s_x;
     tb_rows_table(p, s_tab);
     const int n = __builtin_amdgcn_readfirstlane(*n_small);
     for (int k = (int)blockIdx.x; k < n; k += (int)gridDim.x) {
-        tb_rows_one<16>(p, s_tab, pool_base, pool_head, pool_size, __builtin_amdgcn_readfirstlane(list_small[k]), n_big, list_big);
+        int4 st = *(const int4*)(state_small + 4 * (size_t)k);
+        st.x = __builtin_amdgcn_readfirstlane(st.x); st.y = __builtin_amdgcn_readfirstlane(st.y); st.z = __builtin_amdgcn_readfirstlane(st.z);
+        tb_rows_wide_one(p, s_tab, &s_x, pool_base, pool_head, pool_size, __builtin_amdgcn_readfirstlane(list_small[k]), st, n_big, list_big);
         __syncthreads();
     }
 }
@@ -491,7 +715,8 @@ hipError_t launch_traceback_rows(const SswParams& p, int task_base, int ntasks, 
 {
     int *n_small, *n_big, *list_small, *list_big;
     tb_lists_of(pool_head, n_total, seg, task_base, &n_small, &n_big, &list_small, &list_big);
-    hipLaunchKernelGGL(ssw_traceback_rows_kernel, dim3(ntasks), dim3(64), 0, stream, p, pool_base, pool_head, pool_size, task_base, n_small, list_small);
+    hipLaunchKernelGGL(ssw_traceback_rows_kernel, dim3(ntasks), dim3(64), 0, stream, p, pool_base, pool_head, pool_size, task_base, n_small, list_small,
+                       tb_state_of(pool_head, n_total, task_base));
     return hipGetLastError();
 }
 
@@ -500,8 +725,21 @@ hipError_t launch_traceback_rows_wide(const SswParams& p, int task_base, int nta
 {
     int *n_small, *n_big, *list_small, *list_big;
     tb_lists_of(pool_head, n_total, seg, task_base, &n_small, &n_big, &list_small, &list_big);
-    hipLaunchKernelGGL(ssw_traceback_rows_wide_kernel, dim3(std::min(std::max(ntasks, 1), 1024)), dim3(64), 0, stream, p, pool_base, pool_head, pool_size, n_small, list_small, n_big, list_big);
+    hipLaunchKernelGGL(ssw_traceback_rows_wide_kernel, dim3(std::min(std::max(ntasks, 1), 1024)), dim3(64 * kMw), 0, stream, p, pool_base, pool_head, pool_size,
+                       n_small, list_small, tb_state_of(pool_head, n_total, task_base), n_big, list_big);
     return hipGetLastError();
 }
 
 }  // namespace clh
+
+#ifdef CLH_TBW_TRACE
+// trace builds only (tools/dev/c2_tbw.py): per handed-over alignment {lengths, bands, iterations, clocks of the rounds / the final plane / the walk / the planes the walk asked for}
+extern "C" __attribute__((visibility("default"))) int clh_debug_tbw(long long* out, int reset)
+{
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(clh::g_tbw_n), sizeof(int)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(clh::g_tbw_dbg), sizeof(long long) * 8 * 1024) != hipSuccess) return -1;
+    if (reset) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(clh::g_tbw_n), &z, sizeof(int)); }
+    return n;
+}
+#endif

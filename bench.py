@@ -208,9 +208,9 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         nwide = int(ssw_plan.traceback_counts()[0])
-        out.append({'kernel': 'ssw_traceback_rows_wide_kernel + ssw_traceback_kernel (handed-over alignments)', 'alignments': nwide, 'ms': accb[1] / PROF,
+        out.append({'kernel': 'ssw_traceback_rows_wide_pass_kernel + ssw_traceback_rows_wide_kernel + ssw_traceback_kernel (handed-over alignments)', 'alignments': nwide, 'ms': accb[1] / PROF,
                     'alg_bytes': int(b_alg.mean() * nwide) if len(qlen) else 0,
-                    'note': 'latency of the few wide-band alignments, one wave or workgroup each; bytes = their number x the mean B_ssw of the batch'})
+                    'note': 'latency of the few wide-band alignments (ssw_traceback_rows_wide_pass_kernel: their next band passes side by side, a workgroup each; then the walks); bytes = their number x the mean B_ssw of the batch'})
     valu = {'bound': 'valu', 'kernel': 'ssw_scan_kernel + ssw_scanw_kernel + ssw_align_kernel (all classes)', 'unit': 'GCUPS',
             'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
             'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,

@@ -90,6 +90,7 @@ struct TbX {
     int mx[8];              // iteration maximum per wave
     unsigned long long at;  // pool offset of a plane
     int cmd;                // the walk (wave 0) asks every wave for the plane of an earlier iteration
+    int lz[8][8];           // the planes of the narrow launch's iterations, one per wave (TbPlane as 8 ints, dir as an offset)
 };
 // the rows' barrier: the LDS words above must have landed; the row's direction bytes on their way to HBM need not (a
 // __syncthreads() waits for them as well, ~700 clocks per row)
@@ -492,6 +493,27 @@ __device__ int tb_rows_walk(const SswParams& p, const TbJob& jb, const TbPlane& 
         }
         const int kk = o - pb, src = ib - i;
         const uint32_t wsel = (kk >> 3) == 0 ? pw0 : ((kk >> 3) == 1 ? pw1 : ((kk >> 3) == 2 ? pw2 : pw3));
+        if (state == 2) {
+            // a run of diagonal moves keeps the band offset: the same nibble of the rows above, which the lanes behind `src` hold
+            // (by column: one nibble lower per row) -- taken in one go (the codes say "diagonal" in H's two low bits; ssw.c:650-654)
+            unsigned long long dm;
+            if (!by_col) dm = __ballot(((wsel >> ((kk & 7) * 4)) & 3u) == 0u) >> src;
+            else {
+                const int idx = kk - (lane - src);
+                const uint32_t wv = (idx >> 3) == 0 ? pw0 : ((idx >> 3) == 1 ? pw1 : ((idx >> 3) == 2 ? pw2 : pw3));
+                dm = __ballot(idx >= 0 && idx < 32 && ((wv >> ((idx & 7) * 4)) & 3u) == 0u) >> src;
+            }
+            int r = ~dm == 0ull ? 64 : __builtin_ctzll(~dm);
+            r = r < 64 - src ? r : 64 - src; r = r < i ? r : i; r = r < j + 1 ? r : j + 1;
+            if (r >= 2) {
+                if (prev_op != 0) {
+                    if (nops < task.cigar_cap && lane == 0) cig[nops] = ((uint32_t)run << 4) | (uint32_t)prev_op;
+                    ++nops; prev_op = 0; run = 0;
+                }
+                run += r; i -= r; j -= r; op = 0;
+                continue;
+            }
+        }
         nb = ((uint32_t)__builtin_amdgcn_readlane((int)wsel, src) >> ((kk & 7) * 4)) & 15;
         }
         const int sel = nb & 3;
@@ -543,6 +565,11 @@ __device__ int tb_rows_walk(const SswParams& p, const TbJob& jb, const TbPlane& 
     return 0;
 }
 
+// The next kSpec iterations of a handed-over alignment's band doubling run at once, each in a workgroup of its own (tb_rows_wide_pass),
+// and leave {maximum, plane} in a record in the pool: ints [0, kSpec) the maxima (or a code below), then 8 ints per plane.
+static constexpr int kSpec = 3, kSpecBytes = 128;
+static constexpr int TB_NONE = -1, TB_UNFIT = -2, TB_NOPOOL = -3, TB_NOTRUN = -5;
+
 // One alignment, one wave: bands up to 512 cells (the launch over all alignments, 4 waves per SIMD).  What this width cannot
 // take goes on `next_list` together with the state of the band doubling, so that the wide launch goes on where this one stopped.
 __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
@@ -559,7 +586,14 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
             *jb.cig_len = 0; p.results[jb.task.out_index].status = res.status | CLH_STATUS_NEED_BIG;
             const int slot = atomicAdd(next_n, 1);
             next_list[slot] = task_index;
-            *(int4*)(next_state + 4 * (size_t)slot) = make_int4(w_next, maxv, done, 0);
+            const unsigned long long at = atomicAdd(pool_head, (unsigned long long)kSpecBytes);      // where the wide launch's passes leave their results
+            int rec = 0;
+            if (at + kSpecBytes <= pool_size) {
+                rec = (int)(at >> 6) + 1;
+                int* r = (int*)(pool_base + at);
+                for (int j = 0; j < kSpec; ++j) r[j] = TB_NOTRUN;
+            }
+            *(int4*)(next_state + 4 * (size_t)slot) = make_int4(w_next, maxv, done, rec);
         }
     };
     const int readLen = in.readLen, refLen = in.refLen, score = res.score1;
@@ -595,12 +629,40 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
     if (tb_rows_walk<MAXCP, false>(p, jb, fin, old, nullptr, 0, wk, niter, w0, w, pool_base, pool_head, pool_size) == 2) hand_over(w0, 0, 0);   // pool exhausted or an earlier band this launch cannot hold
 }
 
-// One handed-over alignment, a workgroup of kMw waves, every band split over the waves (tb_rows_iter_mw).  A row is a dependent
-// chain, so the time of one alignment is its number of band passes: the narrow launch's iterations are not repeated (state),
-// and every iteration here leaves its direction codes, so the last one is not run twice (the one before it stays at hand for
-// the walk's reads outside the band).  Wave 0 walks.  What this launch cannot take goes on `next_list`.
+// One band pass of a handed-over alignment, a workgroup of kMw waves (the band split over the waves, tb_rows_iter_mw): iteration
+// j after the point where the narrow launch stopped (state st), with direction codes.  A row is a dependent chain, so the time of
+// one alignment is its number of band passes IN A ROW: the narrow launch's iterations are not repeated, the next kSpec run side by
+// side in different workgroups (most alignments need one; the launch is a handful of workgroups on an idle GPU), every one leaves
+// its codes so that the last is not run twice.  tb_rows_wide_one replays the loop of ssw.c:560-632 over the maxima.
+__device__ void tb_rows_wide_pass(const SswParams& p, const uint2* s_tab, TbX* xs, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                                  const int task_index, const int4 st, const int j)
+{
+    if (st.w <= 0) return;
+    int* const rec = (int*)(pool_base + ((unsigned long long)(st.w - 1) << 6));
+    const bool writer = threadIdx.x == 0;
+    TbJob jb;
+    int it = TB_NONE;
+    TbPlane pl = TbPlane{-1, 0, 0, 0, 0, 0, nullptr};
+    if (tb_rows_setup(p, s_tab, task_index, true, false, jb) && !(p.gapE > 60 || p.gapO > 255)) {
+        const long long wj = (long long)st.x << j;
+        if (j == 0 || wj < 2ll * jb.in.readLen) {      // (ssw.c:632: the doubling gets here only while w < 2 readLen)
+            if (wj > 0x3fffffff || !fits_mw((int)wj, jb.in.refLen, jb.in.readLen)) it = TB_UNFIT;
+            else { int m = 0; it = tb_make_plane_mw(jb.in, (int)wj, pool_base, pool_head, pool_size, pl, xs, &m) ? m : TB_NOPOOL; }
+        }
+    }
+    if (writer) {
+        const unsigned long long off = pl.dir ? (unsigned long long)(pl.dir - pool_base) : 0ull;
+        int* q = rec + 4 + 8 * j;
+        q[0] = pl.w; q[1] = pl.by_col; q[2] = pl.shiftc; q[3] = pl.nb0; q[4] = pl.nvb; q[5] = pl.rowbytes; q[6] = (int)(off & 0xffffffffull); q[7] = (int)(off >> 32);
+        rec[j] = it;
+    }
+}
+
+// The rest of a handed-over alignment, a workgroup of kMw waves: the doubling loop replayed over the passes' maxima (and gone on
+// with, pass by pass, if they did not reach the end), then wave 0 walks; when it wants the codes of an iteration that is not at
+// hand the whole workgroup computes them and it goes on.  What this launch cannot take goes on `next_list`.
 __device__ void tb_rows_wide_one(const SswParams& p, const uint2* s_tab, TbX* xs, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
-                                 const int task_index, const int4 st, int* next_n, int* next_list)
+                                 const int task_index, const int4 st, const int nspec, int* next_n, int* next_list)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const bool writer = threadIdx.x == 0;
@@ -621,15 +683,34 @@ __device__ void tb_rows_wide_one(const SswParams& p, const uint2* s_tab, TbX* xs
     if (p.gapE > 60 || p.gapO > 255) { hand_over(); return; }
     long long w = st.x;
     int maxv = st.y, niter = st.z;
-    constexpr int NKEPT = 4;                           // the codes of this launch's earlier iterations stay at hand
+    constexpr int NKEPT = 4 + kMw;                     // the codes of earlier iterations at hand
     TbPlane fin, old, kept[NKEPT];
     int nkept = 0;
+    bool narrow_made = false;
     old = TbPlane{-1, 0, 0, 0, 0, 0, nullptr}; fin = old;
 #ifdef CLH_TBW_TRACE
     const long long tw0 = __builtin_readcyclecounter();
     long long t_walk = 0, t_lazy = 0; int n_lazy = 0;
 #endif
-    for (;;) {                                         // ssw.c:560-632 from where the narrow launch stopped
+    bool done = false;
+    if (st.w > 0) {                                    // what the passes left
+        const int* rec = (const int*)(pool_base + ((unsigned long long)(st.w - 1) << 6));
+        for (int j = 0; j < nspec && !done; ++j) {
+            const int v = __builtin_amdgcn_readfirstlane(rec[j]);
+            if (v == TB_NOTRUN || v == TB_NONE) break;
+            if (v == TB_UNFIT) { hand_over(); return; }
+            if (v == TB_NOPOOL) { no_pool(); return; }
+            if (fin.w > 0 && nkept < NKEPT) kept[nkept++] = fin;
+            const int* q = rec + 4 + 8 * j;
+            fin.w = __builtin_amdgcn_readfirstlane(q[0]); fin.by_col = __builtin_amdgcn_readfirstlane(q[1]); fin.shiftc = __builtin_amdgcn_readfirstlane(q[2]);
+            fin.nb0 = __builtin_amdgcn_readfirstlane(q[3]); fin.nvb = __builtin_amdgcn_readfirstlane(q[4]); fin.rowbytes = __builtin_amdgcn_readfirstlane(q[5]);
+            fin.dir = pool_base + ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(q[6]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(q[7]) << 32));
+            ++niter; maxv = v > maxv ? v : maxv;
+            if (!(maxv < score && 2 * w < 2ll * readLen)) done = true;
+            else w *= 2;
+        }
+    }
+    while (!done) {                                    // ssw.c:560-632 from there on
         if (w > 0x3fffffff || !fits_mw((int)w, refLen, readLen)) { hand_over(); return; }
         if (fin.w > 0 && nkept < NKEPT) kept[nkept++] = fin;
         int it = 0;
@@ -638,7 +719,6 @@ __device__ void tb_rows_wide_one(const SswParams& p, const uint2* s_tab, TbX* xs
         if (!(maxv < score && 2 * w < 2ll * readLen)) break;
         w *= 2;
     }
-    // wave 0 walks; when it wants the codes of an earlier iteration the whole workgroup computes them and it goes on
     TbWalk wk;
     tb_walk_init(wk, readLen, refLen);
 #ifdef CLH_TBW_TRACE
@@ -665,7 +745,42 @@ __device__ void tb_rows_wide_one(const SswParams& p, const uint2* s_tab, TbX* xs
         }
 #endif
         if (cmd == 0) return;
-        if (cmd < 0 || !tb_make_plane_mw(in, cmd, pool_base, pool_head, pool_size, old, xs)) { hand_over(); return; }
+        if (cmd < 0) { hand_over(); return; }
+        if (!narrow_made) {
+            // the first time the walk leaves the band: the codes of ALL the narrow launch's iterations (it ran them without),
+            // one band per wave side by side -- a walk that reads stale codes once tends to do so in several iterations' areas
+            narrow_made = true;
+            TbPlane mine = TbPlane{-1, 0, 0, 0, 0, 0, nullptr};
+            const long long wq = (long long)w0 << wave;
+            bool have = wave >= niter - 1 || wq > 255 || !fits(4, (int)wq);
+            for (int u = 0; u < nkept; ++u) have = have || kept[u].w == (int)wq;
+            if (!have && !tb_make_plane<4>(in, (int)wq, pool_base, pool_head, pool_size, mine)) mine.w = -1;
+            if ((threadIdx.x & 63) == 0) {
+                const unsigned long long off = mine.dir ? (unsigned long long)(mine.dir - pool_base) : 0ull;
+                int* q = xs->lz[wave];
+                q[0] = mine.w; q[1] = mine.by_col; q[2] = mine.shiftc; q[3] = mine.nb0; q[4] = mine.nvb; q[5] = mine.rowbytes; q[6] = (int)(off & 0xffffffffull); q[7] = (int)(off >> 32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int v = 0; v < kMw; ++v) {
+                const int* q = xs->lz[v];
+                if (q[0] <= 0 || nkept >= NKEPT) continue;
+                TbPlane& t = kept[nkept++];
+                t.w = q[0]; t.by_col = q[1]; t.shiftc = q[2]; t.nb0 = q[3]; t.nvb = q[4]; t.rowbytes = q[5];
+                t.dir = pool_base + ((unsigned long long)(unsigned)q[6] | ((unsigned long long)(unsigned)q[7] << 32));
+            }
+            __syncthreads();
+            bool now = false;
+            for (int u = 0; u < nkept; ++u) now = now || kept[u].w == cmd;
+            if (now) {
+#ifdef CLH_TBW_TRACE
+                t_lazy += __builtin_readcyclecounter() - tb_; ++n_lazy;
+#endif
+                continue;
+            }
+        }
+        if (!tb_make_plane_mw(in, cmd, pool_base, pool_head, pool_size, old, xs)) { hand_over(); return; }
 #ifdef CLH_TBW_TRACE
         t_lazy += __builtin_readcyclecounter() - tb_; ++n_lazy;
 #endif
@@ -694,18 +809,36 @@ __global__ void __launch_bounds__(64, 4) ssw_traceback_rows_kernel(const SswPara
     tb_rows_one(p, s_tab, pool_base, pool_head, pool_size, task_base + (int)blockIdx.x, n_small, list_small, state_small);
 }
 
-// the alignments the narrow launch handed over: the workgroups share the list
-__global__ void __launch_bounds__(64 * kMw, 1) ssw_traceback_rows_wide_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
-                                                                                    const int* n_small, const int* list_small, const int* state_small, int* n_big, int* list_big)
+// the alignments the narrow launch handed over, two launches: the next band passes of all of them side by side, then the rest.
+// The workgroups share the list.  Only a short list is worth passes that may not be needed (an idle GPU, time = the longest chain);
+// a long one is throughput work: one pass each, the others as they turn out to be needed.
+__device__ __forceinline__ int tb_nspec(int n) { return n <= 256 ? kSpec : 1; }
+__global__ void __launch_bounds__(64 * kMw, 1) ssw_traceback_rows_wide_pass_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                                                                                  const int* n_small, const int* list_small, const int* state_small)
 {
     __shared__ uint2 s_tab[8];
     __shared__ TbX s_x;
     tb_rows_table(p, s_tab);
-    const int n = __builtin_amdgcn_readfirstlane(*n_small);
+    const int n = __builtin_amdgcn_readfirstlane(*n_small), nspec = tb_nspec(n);
+    for (int item = (int)blockIdx.x; item < n * nspec; item += (int)gridDim.x) {
+        const int k = item / nspec, j = item % nspec;
+        int4 st = *(const int4*)(state_small + 4 * (size_t)k);
+        st.x = __builtin_amdgcn_readfirstlane(st.x); st.y = __builtin_amdgcn_readfirstlane(st.y); st.z = __builtin_amdgcn_readfirstlane(st.z); st.w = __builtin_amdgcn_readfirstlane(st.w);
+        tb_rows_wide_pass(p, s_tab, &s_x, pool_base, pool_head, pool_size, __builtin_amdgcn_readfirstlane(list_small[k]), st, j);
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(64 * kMw, 1) ssw_traceback_rows_wide_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+                                                                             const int* n_small, const int* list_small, const int* state_small, int* n_big, int* list_big)
+{
+    __shared__ uint2 s_tab[8];
+    __shared__ TbX s_x;
+    tb_rows_table(p, s_tab);
+    const int n = __builtin_amdgcn_readfirstlane(*n_small), nspec = tb_nspec(n);
     for (int k = (int)blockIdx.x; k < n; k += (int)gridDim.x) {
         int4 st = *(const int4*)(state_small + 4 * (size_t)k);
-        st.x = __builtin_amdgcn_readfirstlane(st.x); st.y = __builtin_amdgcn_readfirstlane(st.y); st.z = __builtin_amdgcn_readfirstlane(st.z);
-        tb_rows_wide_one(p, s_tab, &s_x, pool_base, pool_head, pool_size, __builtin_amdgcn_readfirstlane(list_small[k]), st, n_big, list_big);
+        st.x = __builtin_amdgcn_readfirstlane(st.x); st.y = __builtin_amdgcn_readfirstlane(st.y); st.z = __builtin_amdgcn_readfirstlane(st.z); st.w = __builtin_amdgcn_readfirstlane(st.w);
+        tb_rows_wide_one(p, s_tab, &s_x, pool_base, pool_head, pool_size, __builtin_amdgcn_readfirstlane(list_small[k]), st, nspec, n_big, list_big);
         __syncthreads();
     }
 }
@@ -725,7 +858,10 @@ hipError_t launch_traceback_rows_wide(const SswParams& p, int task_base, int nta
 {
     int *n_small, *n_big, *list_small, *list_big;
     tb_lists_of(pool_head, n_total, seg, task_base, &n_small, &n_big, &list_small, &list_big);
-    hipLaunchKernelGGL(ssw_traceback_rows_wide_kernel, dim3(std::min(std::max(ntasks, 1), 1024)), dim3(64 * kMw), 0, stream, p, pool_base, pool_head, pool_size,
+    const int grid = std::min(std::max(ntasks, 1), 1024);
+    hipLaunchKernelGGL(ssw_traceback_rows_wide_pass_kernel, dim3(grid), dim3(64 * kMw), 0, stream, p, pool_base, pool_head, pool_size,
+                       n_small, list_small, tb_state_of(pool_head, n_total, task_base));
+    hipLaunchKernelGGL(ssw_traceback_rows_wide_kernel, dim3(grid), dim3(64 * kMw), 0, stream, p, pool_base, pool_head, pool_size,
                        n_small, list_small, tb_state_of(pool_head, n_total, task_base), n_big, list_big);
     return hipGetLastError();
 }

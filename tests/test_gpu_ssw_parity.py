@@ -423,6 +423,57 @@ def test_cigars_of_wide_bands_row_traceback_vs_oracle(ctx, scheme):
         assert wide >= nwide > 5 and anti <= wide // 2 + 2, (wide, anti, nwide)
 
 
+@pytest.mark.parametrize('many', [False, True])
+def test_wide_bands_many_doublings_and_long_hand_over_lists(ctx, many):
+    """The wide form of K1b's row kernel (a workgroup per band pass, ssw_traceback_rows_wide_pass_kernel / _wide_kernel).
+    many = False: insertions and deletions that cancel -- the band starts narrow (|refLen - readLen| + 1 is small) and doubles many
+    times before it holds the path, so the narrow launch hands over in mid-loop (its state travels), several further iterations run
+    side by side, the widest bands are laid out by reference column and the walk reads stale codes of earlier iterations
+    (scores 10/9/8/2, inserted bases all A against skipped reference without A: two long gaps beat a diagonal of mismatches).
+    many = True: more than 256 alignments handed over at once (one pass each, the rest in turn).  CIGARs equal the oracle's."""
+    from ciri_long_amd import hip
+    rng = np.random.default_rng(77 + many)
+    refs, qs = [], []
+    if not many:
+        for gap in (150, 300, 420, 640, 900):
+            for rep in range(6):
+                blk = int(rng.integers(250, 420))
+                ref = _rnd(rng, 3 * blk + 2 * gap + 200)
+                a = int(rng.integers(0, 60))
+                lo = a + blk if not rep & 1 else a + 2 * blk           # the reference stretch the read skips: no A
+                ref = ref[:lo] + ref[lo:lo + gap].replace('A', 'C') + ref[lo + gap:]
+                skew = int(rng.integers(0, 40)) * (rep % 3)               # net length difference: the first band
+                if rep & 1:     # insertion first, then a deletion of about the same length
+                    q = ref[a:a + blk] + 'A' * gap + ref[a + blk:a + 2 * blk] + ref[a + 2 * blk + gap - skew:a + 3 * blk + gap - skew]
+                else:           # deletion first
+                    q = ref[a:a + blk] + ref[a + blk + gap:a + 2 * blk + gap] + 'A' * (gap - skew) + ref[a + 2 * blk + gap:a + 3 * blk + gap]
+                refs.append(ref); qs.append(_mut(q, rng, float(rng.choice([0.0, 0.02, 0.06])))[:4090])
+    else:
+        for _ in range(300):
+            blk = int(rng.integers(200, 320)); gap = int(rng.integers(260, 330))
+            ref = _rnd(rng, 2 * blk + gap + 100)
+            a = int(rng.integers(0, 50))
+            q = ref[a:a + blk] + ref[a + blk + gap:a + 2 * blk + gap] if rng.random() < 0.5 else ref[a:a + blk] + 'A' * gap + ref[a + blk:a + 2 * blk]
+            refs.append(ref); qs.append(_mut(q, rng, 0.02))
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    import torch
+    d_r = torch.from_numpy(rd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
+    ts = torch.cuda.Stream()
+    plan = ctx.plan(ro, fo, hip.score_matrix(10, 9), 8, 2, flag=1, score_size=2, want_score2=True, want_cigar=True)
+    plan.run(d_r.data_ptr(), d_f.data_ptr(), ts.cuda_stream)
+    rows, cig = plan.fetch()
+    wide, anti = plan.traceback_counts()
+    plan.close()
+    for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):
+        want = oracle_align(ref, q, 10, 9, 8, 2)
+        assert _row_tuple(r) == (want['score'], want['score2'], want['ref_begin'], want['ref_end'], want['query_begin'],
+                                 want['query_end'], want['ref_end2']), (k, len(q), len(ref))
+        assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == want['cigar'], (k, len(q), len(ref), int(r['status']))
+    import os
+    if not os.environ.get('CLH_NO_TB_ROWS'):
+        assert wide > (256 if many else 10), (wide, anti)
+
+
 @pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (2, 3, 5, 2), (1, 1, 3, 1)])
 def test_long_windows_in_slices_vs_oracle(ctx, scheme):
     """Windows of 32 kb and more are cut into slices whose forward passes run as separate workgroups (ssw_scan.hip:

@@ -312,10 +312,10 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
             t.cigar_cap = (int32_t)(2 * L + 2);
             if (cig + (size_t)t.cigar_cap > 0x7fffffffull) { fail(CLH_E_CAPACITY, "batch too large for 32-bit CIGAR offsets; split it"); delete pl; return nullptr; }
             cig += (size_t)t.cigar_cap;
-            // traceback workspace: the row kernel keeps 4 bits per cell of the final band only, 64 bytes per read row for
-            // bands up to 128 cells, 128 up to 256 (ssw_traceback_rows.hip); the few wide bands and the anti-diagonal
-            // kernel's per-iteration byte planes come out of the fixed slack added below
-            pool += (unsigned long long)(L + 64) * 160ull;
+            // traceback workspace: the row kernel keeps 4 bits per cell of the band, 64 bytes per read row for bands up to
+            // 128 cells, 128 up to 256 (ssw_traceback_rows.hip), of every iteration after the first (each twice the one
+            // before); the few wide bands and the anti-diagonal kernel's per-iteration byte planes come out of the fixed slack added below
+            pool += (unsigned long long)(L + 64) * 320ull;
         }
     }
     // Long windows of the anti-diagonal classes (reads outside K1s's 8-bit class), call-path options (no second best): the

@@ -601,28 +601,34 @@ __device__ void tb_rows_one(const SswParams& p, const uint2* s_tab, uint8_t* poo
     const int w0 = w;
     if (p.gapE > 60 || p.gapO > 255) { hand_over(w0, 0, 0); return; }       // the frames of the F scan are 16-bit
 
-    // ---- band doubling (ssw.c:560-632), score-only: which band is the final one ------------------------------------
+    // ---- band doubling (ssw.c:560-632).  The first iteration score-only (it is the last one for a fifth of C2's alignments, and
+    // the narrowest); every later one with direction codes, so that the last is not run twice -------------------------
     int maxv = 0, niter = 0;
     bool covered = false;
-    for (;;) {
-        ++niter;
-        if (!covered) {
+    TbPlane fin, old;
+    old = TbPlane{-1, 0, 0, 0, 0, 0, nullptr}; fin = old;
+    auto no_pool = [&]() { if (lane == 0) { *jb.cig_len = 0; p.results[jb.task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; } };
+    for (bool last = false;;) {                        // last: the final band once more, for its codes (one call site of the pass with codes)
+        if (!last) ++niter;
+        if (last || !covered) {
             if (!fits(MAXCP, w)) { hand_over(w, maxv, niter - 1); return; }
-            const int it = tb_rows_iter<MAXCP, false>(in, w, nullptr);
+            int it = 0;
+            if (niter == 1 && !last) it = tb_rows_iter<MAXCP, false>(in, w, nullptr);
+            else {
+                if (fin.w > 0) old = fin;
+                if (!tb_make_plane<MAXCP>(in, w, pool_base, pool_head, pool_size, fin, &it)) { no_pool(); return; }
+            }
+            if (last) break;
             maxv = it > maxv ? it : maxv;
             covered = w >= readLen && w >= refLen;      // a wider band holds the same cells: same values
         }
         w *= 2;
-        if (!(maxv < score && w < 2 * readLen)) break;
-    }
-    w /= 2;
-    if (!fits(MAXCP, w)) { hand_over(w, maxv, niter - 1); return; }      // (the iteration of this band once more over there: same values)
-    // ---- the final band once more, with direction codes -------------------------------------------------------------
-    TbPlane fin, old;
-    old.w = -1; old.dir = nullptr;
-    if (!tb_make_plane<MAXCP>(in, w, pool_base, pool_head, pool_size, fin)) {
-        if (lane == 0) { *jb.cig_len = 0; p.results[jb.task.out_index].status = res.status | CLH_STATUS_CIGAR_TRUNC; }
-        return;
+        if (!(maxv < score && w < 2 * readLen)) {
+            w /= 2;
+            if (!fits(MAXCP, w)) { hand_over(w, maxv, niter - 1); return; }      // (the iteration of this band once more over there: same values)
+            if (fin.w == w) break;
+            last = true;                               // the first iteration was the last, or the band went on doubling over the same cells
+        }
     }
     TbWalk wk;
     tb_walk_init(wk, readLen, refLen);

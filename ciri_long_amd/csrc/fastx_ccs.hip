@@ -33,20 +33,66 @@
 
 namespace {
 
+// a host buffer that outlives the call: a file stage of 10^5 reads does not spend a third of its time faulting in and unmapping
+// 300 MB of fresh pages.  CLH_FILE_PINNED=1: page-locked (copies without staging: ~0.4 ms less per 32 MB batch, but ~1 ms per MB to
+// allocate -- for a process that runs many files)
+struct HostBuf {
+    char* p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    bool ensure(size_t n)              // contents are not kept
+    {
+        if (n <= cap) return true;
+        release();
+        static const bool want_pinned = getenv("CLH_FILE_PINNED") != nullptr && atoi(getenv("CLH_FILE_PINNED")) != 0;
+        const size_t c = n + (n >> 3) + 4096;
+        if (want_pinned && hipHostMalloc((void**)&p, c, hipHostMallocDefault) == hipSuccess) pinned = true;
+        else { if (want_pinned) (void)hipGetLastError(); p = (char*)malloc(c); pinned = false; }
+        cap = p ? c : 0;
+        return p != nullptr;
+    }
+    void release() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
+};
+
 struct Batch {
     // the file's own bytes of this batch: `raw[lead .. lead + len)` holds whole records (the reader thread fills raw from kReserve on;
     // the parser puts the tail of the batch before -- a record cut by the chunk border -- in front of it).  Headers and sequences are
     // offsets into raw: nothing of the text is copied again
-    std::vector<char> raw;
+    HostBuf raw_buf;
+    std::vector<char> raw_big;         // takes raw's place for one batch when a record is longer than the reserve (rare)
+    char* raw = nullptr;
     size_t lead = 0, len = 0;
     bool eof = false;                  // the reader saw the end of the file while filling this batch
     std::vector<int64_t> hdr_off, hdr_len, seq_off, seq_len;   // into raw
-    std::vector<int8_t> codes;         // packed base codes of the reads handed to the GPU
+    HostBuf codes_buf;                 // packed base codes of the reads handed to the GPU (never more than the batch has bytes)
+    int8_t* codes = nullptr;
+    size_t ncodes = 0;
     std::vector<int64_t> read_off;     // n_gpu + 1
     std::vector<int32_t> gpu_index;    // record -> row of the GPU batch, -1 = skipped (longer than the kernel's limit)
     bool last = false;
-    void clear() { hdr_off.clear(); hdr_len.clear(); seq_off.clear(); seq_len.clear(); codes.clear(); read_off.assign(1, 0); gpu_index.clear(); last = false; }
+    void clear() { hdr_off.clear(); hdr_len.clear(); seq_off.clear(); seq_len.clear(); ncodes = 0; read_off.assign(1, 0); gpu_index.clear(); last = false; }
 };
+struct Results { HostBuf rows_buf, segs_buf, ccs_buf; int nrows = 0; };
+
+// the four rotating batches, their results and the device side of two batches in flight; kept between calls (one set per process:
+// a second call at the same time works on a set of its own)
+struct FileCache {
+    static const int NSLOT = 6;        // one being read, one parsed, two on the device, one written, one spare
+    Batch slot[NSLOT];
+    Results result[NSLOT];
+    void* d_reads[2] = {nullptr, nullptr};
+    size_t d_cap[2] = {0, 0};
+    hipStream_t stream[2] = {nullptr, nullptr};
+    int device = -1;
+    void release()
+    {
+        for (auto& b : slot) { b.raw_buf.release(); b.codes_buf.release(); }
+        for (auto& r : result) { r.rows_buf.release(); r.segs_buf.release(); r.ccs_buf.release(); }
+        for (int i = 0; i < 2; ++i) { if (d_reads[i]) (void)hipFree(d_reads[i]); if (stream[i]) (void)hipStreamDestroy(stream[i]); d_reads[i] = nullptr; stream[i] = nullptr; d_cap[i] = 0; }
+    }
+};
+std::mutex g_cache_mu;
+FileCache* g_cache = nullptr;          // parked between calls
 
 struct LineReader {
     gzFile f;
@@ -233,12 +279,20 @@ extern "C" int clh_ccs_file_range(clh_ctx* ctx, const char* in_path, int is_fast
     return clh_ccs_file_at(ctx, in_path, is_fastq, ccs_fa_path, raw_fa_path, batch_reads, 0, first_record, max_records, stats);
 }
 
+extern "C" void clh_ccs_file_release_buffers(void)
+{
+    FileCache* c = nullptr;
+    { std::lock_guard<std::mutex> g(g_cache_mu); c = g_cache; g_cache = nullptr; }
+    if (c) { c->release(); delete c; }
+}
+
 // the records [first_record, first_record + max_records) counted from byte `byte_offset` of the file, which must be the first byte of a
 // record (clh_fastx_index); a compressed file is read from its start whatever byte_offset says (the caller passes 0)
 extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
                                int32_t batch_reads, int64_t byte_offset, int64_t first_record, int64_t max_records, clh_ccs_file_stats* stats)
 {
     if (!ctx || !in_path || !ccs_fa_path || !raw_fa_path || !stats || first_record < 0 || byte_offset < 0) return CLH_E_ARG;
+    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (batch_reads <= 0) batch_reads = 16384;      // small enough that the three stages overlap on files of 10^5 reads (measured: 65536 -> 0.54, 16384 -> 0.89 M reads/s)
     memset(stats, 0, sizeof(*stats));
     gzFile in = gzopen(in_path, "rb");
@@ -255,21 +309,27 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
     for (int i = 0; i < 256; ++i) lut[i] = 4;                       // ssw_wrap.py:50,243-250: A/a C/c G/g T/t, anything else 4
     lut['A'] = lut['a'] = 0; lut['C'] = lut['c'] = 1; lut['G'] = lut['g'] = 2; lut['T'] = lut['t'] = 3;
 
-    // three batches rotate through three threads: the reader parses and encodes, this thread runs the batch on the GPU, the
-    // writer formats and writes the two files -- each takes the slots in order and waits for the state it consumes
-    // (0 free -> 1 parsed -> 2 computed -> 0)
-    // four batches rotate through four threads: the READER fills a batch with file bytes (read(2) on a plain file, gzread on a
+    // six batches rotate through four threads: the READER fills a batch with file bytes (read(2) on a plain file, gzread on a
     // compressed one), the PARSER finds the records in them and encodes the bases, this thread runs the batch on the GPU, the WRITER
     // formats and writes the two files -- each takes the slots in order and waits for the state it consumes
     // (0 free -> 1 bytes read -> 2 parsed -> 3 computed -> 0).  Round 3 had one thread read, copy and encode: 1.3 GB/s of FASTQ.
-    static const int NSLOT = 4;
+    static const int NSLOT = FileCache::NSLOT;
     static const size_t kReserve = 4u << 20;         // room in front of a chunk for the record the previous chunk's border cut
-    struct Results { std::vector<clh_ccs_t> rows; std::vector<int32_t> segs; std::vector<int8_t> ccs; };
-    Batch slot[NSLOT];
-    Results result[NSLOT];
+    // the buffers: the set parked by the last call, or a new one (all page-locked allocations happen on this thread, which is the one
+    // that has the context's device current)
+    FileCache* fcache = nullptr;
+    { std::lock_guard<std::mutex> g(g_cache_mu); fcache = g_cache; g_cache = nullptr; }
+    if (!fcache) fcache = new FileCache();
+    Batch* const slot = fcache->slot;
+    Results* const result = fcache->result;
+    auto park = [&]() {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        if (!g_cache) { g_cache = fcache; fcache = nullptr; }
+        if (fcache) { fcache->release(); delete fcache; fcache = nullptr; }
+    };
     std::mutex mu;
     std::condition_variable cv;
-    int state[NSLOT] = {0, 0, 0, 0};
+    int state[NSLOT] = {};
     std::atomic<bool> stop_reader{false};             // the parser has all it wants (max_records): the reader shall not wait for a slot again
     auto wait_state = [&](int s, int want) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return state[s] == want; }); };
     auto set_state = [&](int s, int v) { { std::lock_guard<std::mutex> lk(mu); state[s] = v; } cv.notify_all(); };
@@ -281,11 +341,33 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
         const size_t got = probe ? fread(magic, 1, 2, probe) : 0;
         if (probe) fclose(probe);
         if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) fd = open(in_path, O_RDONLY);
-        if (fd >= 0 && byte_offset > 0 && lseek(fd, (off_t)byte_offset, SEEK_SET) < 0) { close(fd); fd = -1; fclose(fc); fclose(fr); gzclose(in); return CLH_E_ARG; }
-        if (fd < 0 && byte_offset > 0) { fclose(fc); fclose(fr); gzclose(in); return CLH_E_ARG; }      // a compressed file cannot be entered in the middle
+        if (fd >= 0 && byte_offset > 0 && lseek(fd, (off_t)byte_offset, SEEK_SET) < 0) { park(); close(fd); fd = -1; fclose(fc); fclose(fr); gzclose(in); return CLH_E_ARG; }
+        if (fd < 0 && byte_offset > 0) { park(); fclose(fc); fclose(fr); gzclose(in); return CLH_E_ARG; }      // a compressed file cannot be entered in the middle
     }
     size_t chunk_bytes = (size_t)32 << 20;
     if (const char* e = getenv("CLH_FILE_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(e)) << 20;
+    {
+        // a plan of one read makes the context's device this thread's current one (and tells whether there is a GPU at all)
+        const int64_t one[2] = {0, 1};
+        clh_ccs_plan* probe = clh_ccs_plan_create(ctx, 1, one);
+        if (!probe) { park(); if (fd >= 0) close(fd); fclose(fc); fclose(fr); gzclose(in); return CLH_E_HIP; }
+        clh_ccs_plan_destroy(probe);
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        if (fcache->device != dev) { fcache->release(); fcache->device = dev; }
+        bool ok = true;
+        for (int i = 0; i < NSLOT; ++i) ok = ok && slot[i].raw_buf.ensure(kReserve + chunk_bytes) && slot[i].codes_buf.ensure(kReserve + chunk_bytes + 64);
+        for (int i = 0; i < 2 && ok; ++i) {
+            const size_t need = kReserve + chunk_bytes + 256;
+            if (fcache->d_cap[i] < need) {
+                if (fcache->d_reads[i]) (void)hipFree(fcache->d_reads[i]);
+                fcache->d_reads[i] = nullptr; fcache->d_cap[i] = 0;
+                if (hipMalloc(&fcache->d_reads[i], need) == hipSuccess) fcache->d_cap[i] = need; else { (void)hipGetLastError(); ok = false; }
+            }
+            if (ok && !fcache->stream[i] && hipStreamCreateWithFlags(&fcache->stream[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        }
+        if (!ok) { park(); if (fd >= 0) close(fd); fclose(fc); fclose(fr); gzclose(in); return CLH_E_HIP; }
+    }
     double t_read = 0, t_parse = 0, t_write = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto reader = [&]() {
@@ -295,13 +377,13 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
             if (stop_reader.load()) break;
             const double t0 = now();
             Batch& b = slot[s];
-            if (b.raw.size() < kReserve + chunk_bytes) b.raw.resize(kReserve + chunk_bytes);
+            b.raw = b.raw_buf.p;
             size_t have = 0;
             while (have < chunk_bytes) {
                 const size_t want = chunk_bytes - have;
                 long got;
-                if (fd >= 0) got = (long)read(fd, b.raw.data() + kReserve + have, want);
-                else got = (long)gzread(in, b.raw.data() + kReserve + have, (unsigned)std::min<size_t>(want, 1u << 30));
+                if (fd >= 0) got = (long)read(fd, b.raw + kReserve + have, want);
+                else got = (long)gzread(in, b.raw + kReserve + have, (unsigned)std::min<size_t>(want, 1u << 30));
                 if (got <= 0) { eof = true; break; }
                 have += (size_t)got;
             }
@@ -321,19 +403,23 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
             const double t0 = now();
             Batch& b = slot[s];
             b.clear();
+            b.codes = (int8_t*)b.codes_buf.p;
             if (!carry.empty()) {
-                if (carry.size() > b.lead) {       // a record longer than the reserve: make room (rare)
-                    std::vector<char> bigger(carry.size() + b.len);
-                    memcpy(bigger.data() + carry.size(), b.raw.data() + b.lead, b.len);
-                    b.raw.swap(bigger);
+                if (carry.size() > b.lead) {       // a record longer than the reserve: this batch in a buffer of its own, text then codes (rare)
+                    const size_t text = carry.size() + b.len;
+                    b.raw_big.assign(2 * text + 64, 0);
+                    memcpy(b.raw_big.data() + carry.size(), b.raw + b.lead, b.len);
+                    b.raw = b.raw_big.data();
                     b.lead = carry.size();
+                    b.codes = (int8_t*)b.raw_big.data() + text;
                 }
                 b.lead -= carry.size();
-                memcpy(b.raw.data() + b.lead, carry.data(), carry.size());
+                memcpy(b.raw + b.lead, carry.data(), carry.size());
                 b.len += carry.size();
                 carry.clear();
             }
-            const char* base = b.raw.data();
+            const char* base = b.raw;
+            int8_t* const codes = b.codes;
             const char* p = base + b.lead;
             const char* const end = p + b.len;
             while (p < end && left > 0) {
@@ -366,10 +452,9 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
                 if (sn == 0 || (int64_t)sn > kMaxRead) b.gpu_index.push_back(-1);
                 else {
                     b.gpu_index.push_back((int32_t)(b.read_off.size() - 1));
-                    const size_t o = b.codes.size();
-                    b.codes.resize(o + sn);
-                    encode_only(b.codes.data() + o, s0, sn, lut);
-                    b.read_off.push_back((int64_t)b.codes.size());
+                    encode_only(codes + b.ncodes, s0, sn, lut);
+                    b.ncodes += sn;
+                    b.read_off.push_back((int64_t)b.ncodes);
                 }
             }
             if (left == 0 || (b.eof && p >= end)) done = true;
@@ -389,32 +474,35 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
             const double tw0_ = now();
             Batch& b = slot[s];
             const Results& R = result[s];
+            const clh_ccs_t* const rows = (const clh_ccs_t*)R.rows_buf.p;
+            const int32_t* const segs = (const int32_t*)R.segs_buf.p;
+            const int8_t* const ccs = (const int8_t*)R.ccs_buf.p;
             const int nrec = (int)b.hdr_off.size();
             oc.clear(); orw.clear();
-            if (!R.rows.empty() || nrec > 0) {
+            if (R.nrows > 0 || nrec > 0) {
                 for (int k = 0; k < nrec; ++k) {
                     stats->total_reads += 1;
                     const int g = b.gpu_index[(size_t)k];
                     if (g < 0) { if (b.seq_len[(size_t)k] > kMaxRead) stats->too_long += 1; continue; }
-                    if (R.rows.empty()) continue;                 // the GPU step failed: only the counters go on
-                    const clh_ccs_t& r = R.rows[(size_t)g];
+                    if (R.nrows == 0) continue;                   // the GPU step failed: only the counters go on
+                    const clh_ccs_t& r = rows[(size_t)g];
                     if (r.status != 0) { stats->capacity_dropped += 1; continue; }      // lost to a limit of the kernel: counted, reported by the caller
                     if (r.nseg <= 0) continue;
                     stats->ro_reads += 1;
-                    const char* hdr = b.raw.data() + b.hdr_off[(size_t)k];
+                    const char* hdr = b.raw + b.hdr_off[(size_t)k];
                     const size_t hl = (size_t)b.hdr_len[(size_t)k];
                     oc.push_back('>'); oc.append(hdr, hl); oc.push_back('\t');
                     for (int i = 0; i < r.nseg; ++i) {
                         if (i) oc.push_back(';');
-                        put_int(oc, R.segs[((size_t)g * 65 + (size_t)i) * 2]); oc.push_back('-'); put_int(oc, R.segs[((size_t)g * 65 + (size_t)i) * 2 + 1]);
+                        put_int(oc, segs[((size_t)g * 65 + (size_t)i) * 2]); oc.push_back('-'); put_int(oc, segs[((size_t)g * 65 + (size_t)i) * 2 + 1]);
                     }
                     oc.push_back('\t'); put_int(oc, r.ccs_len); oc.push_back('\n');
                     const size_t l0 = oc.size();
                     oc.resize(l0 + (size_t)r.ccs_len + 1);
-                    decode_bases(&oc[l0], R.ccs.data() + b.read_off[(size_t)g], (size_t)r.ccs_len);
+                    decode_bases(&oc[l0], ccs + b.read_off[(size_t)g], (size_t)r.ccs_len);
                     oc[l0 + (size_t)r.ccs_len] = '\n';
                     orw.push_back('>'); orw.append(hdr, hl); orw.push_back('\n');
-                    orw.append(b.raw.data() + b.seq_off[(size_t)k], (size_t)b.seq_len[(size_t)k]); orw.push_back('\n');
+                    orw.append(b.raw + b.seq_off[(size_t)k], (size_t)b.seq_len[(size_t)k]); orw.push_back('\n');
                 }
                 if (!oc.empty() && fwrite(oc.data(), 1, oc.size(), fc) != oc.size()) wrc = CLH_E_ARG;
                 if (!orw.empty() && fwrite(orw.data(), 1, orw.size(), fr) != orw.size()) wrc = CLH_E_ARG;
@@ -427,9 +515,28 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
     };
     const bool ftrace = getenv("CLH_FILE_TRACE") != nullptr;
     double t_wait = 0, t_gpu = 0;
+    const double t_start = now();
     std::thread th(reader), tp(parser), tw(writer);
 
+    // This thread keeps TWO batches on the device: batch s is planned, copied and launched (its own stream) before the rows of batch
+    // s - 1 are waited for and fetched, so planning and the copies of one batch run under the kernels of the other.
     int rc = 0;
+    clh_ccs_plan* prev_pl = nullptr;
+    void* prev_own = nullptr;
+    int prev_slot = -1, lane = 0;
+    auto complete = [&]() {           // the batch in flight: its rows to the writer
+        if (prev_slot < 0) return;
+        Results& R = result[prev_slot];
+        if (prev_pl) {
+            if (!rc) rc = clh_ccs_fetch(prev_pl, (clh_ccs_t*)R.rows_buf.p, (int32_t*)R.segs_buf.p, (int8_t*)R.ccs_buf.p);
+            clh_ccs_plan_destroy(prev_pl);
+            prev_pl = nullptr;
+        }
+        if (prev_own) { (void)hipFree(prev_own); prev_own = nullptr; }
+        if (rc) R.nrows = 0;
+        set_state(prev_slot, 3);
+        prev_slot = -1;
+    };
     for (int s = 0;; s = (s + 1) % NSLOT) {
         const double tw0 = now();
         wait_state(s, 2);
@@ -438,17 +545,30 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
         Batch& b = slot[s];
         Results& R = result[s];
         const int ngpu = (int)b.read_off.size() - 1;
-        R.rows.clear();
+        R.nrows = 0;
+        clh_ccs_plan* pl = nullptr;
+        void* own = nullptr;
         if (!rc && ngpu > 0) {
-            R.rows.resize((size_t)ngpu); R.segs.resize((size_t)ngpu * 2 * 65); R.ccs.resize(b.codes.size() + 64);
-            rc = clh_ccs_batch(ctx, ngpu, b.codes.data(), b.read_off.data(), R.rows.data(), R.segs.data(), R.ccs.data());
-            if (rc) R.rows.clear();
+            if (!R.rows_buf.ensure(sizeof(clh_ccs_t) * (size_t)ngpu) || !R.segs_buf.ensure(sizeof(int32_t) * (size_t)ngpu * 2 * 65) || !R.ccs_buf.ensure(b.ncodes + 64)) rc = CLH_E_HIP;
+            if (!rc && !(pl = clh_ccs_plan_create(ctx, ngpu, b.read_off.data()))) rc = CLH_E_ARG;
+            void* d_reads = fcache->d_reads[lane];
+            if (!rc && b.ncodes + 64 > fcache->d_cap[lane]) {       // (a batch in a buffer of its own, see the parser)
+                if (hipMalloc(&own, b.ncodes + 64) != hipSuccess) { (void)hipGetLastError(); own = nullptr; rc = CLH_E_HIP; }
+                d_reads = own;
+            }
+            if (!rc && b.ncodes > 0 && hipMemcpyAsync(d_reads, b.codes, b.ncodes, hipMemcpyHostToDevice, fcache->stream[lane]) != hipSuccess) { (void)hipGetLastError(); rc = CLH_E_HIP; }
+            if (!rc) rc = clh_ccs_run(pl, d_reads, fcache->stream[lane]);
+            if (!rc) R.nrows = ngpu;
         }
-        t_gpu += now() - tw1;
         const bool last = b.last;
-        set_state(s, 3);
+        complete();                    // the batch before: its kernels ran while this one was planned, copied and launched
+        prev_pl = pl; prev_own = own; prev_slot = s;
+        lane ^= 1;
+        if (last || own) complete();
+        t_gpu += now() - tw1;
         if (last) break;
     }
+    const double t_loop = now();
     tw.join();
     tp.join();
     // the parser may have stopped before the end of the file (max_records): a reader waiting for a free slot is told to stop
@@ -456,9 +576,14 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
     cv.notify_all();
     th.join();
     if (fd >= 0) close(fd);
+    if (ftrace) fprintf(stderr, "[clh] file stage wall: set-up %.3f s, GPU thread's loop %.3f s, joins %.3f s\n", t_start - t_enter, t_loop - t_start, now() - t_loop);
     if (ftrace) fprintf(stderr, "[clh] file stage: read %.3f s, parse + encode %.3f s, GPU thread waited %.3f s, clh_ccs_batch %.3f s, format + write %.3f s\n", t_read, t_parse, t_wait, t_gpu, t_write);
     if (!rc && wrc) rc = wrc;
+    for (int i = 0; i < NSLOT; ++i) { std::vector<char>().swap(slot[i].raw_big); }
+    park();
+    const double t_c0 = now();
     gzclose(in);
     if (fclose(fc) != 0 || fclose(fr) != 0) rc = rc ? rc : CLH_E_ARG;
+    if (ftrace) fprintf(stderr, "[clh] file stage wall: closing the three files %.3f s; %.3f s since the call began\n", now() - t_c0, now() - t_enter);
     return rc;
 }

@@ -359,6 +359,11 @@ class Context(object):
         self.last_capacity_dropped = int(st[3])
         return int(st[0]), int(st[1]), int(st[2])
 
+    @staticmethod
+    def release_file_buffers():
+        """give back the host and device buffers the file stage (ccs_file) keeps between calls"""
+        lib().clh_ccs_file_release_buffers()
+
     def ccs_plan(self, read_off):
         return CcsPlan(self, read_off)
 

@@ -201,6 +201,9 @@ int clh_fastx_count(const char* in_path, int is_fastq, int64_t* n_records);
 int clh_fastx_index(const char* in_path, int is_fastq, int64_t every, int64_t* n_records, int64_t* offsets, int64_t cap, int64_t* n_offsets);
 int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, const char* ccs_fa_path, const char* raw_fa_path,
                     int32_t batch_reads, int64_t byte_offset, int64_t first_record, int64_t max_records, clh_ccs_file_stats* stats);
+/* The file stage keeps its host buffers (six batches of file text and base codes, ~70 MB each) and two device buffers between calls,
+ * one set per process; this gives them back. */
+void clh_ccs_file_release_buffers(void);
 
 /* ---- Resident genome ---------------------------------------------------------------------
  * The reference builds, per clipped read, a window string of hit +- 200 kb, counts its 'N', reverse-complements it for

@@ -354,7 +354,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
     pl->n_all = n_all;
     P.n_real = n;
     pl->colmax_elems = colmax; pl->cigar_elems = cig;
-    if (pl->do_cigar) pl->pool_bytes = std::min<unsigned long long>(pool + (512ull << 20), 16ull << 30);
+    if (pl->do_cigar) pl->pool_bytes = std::min<unsigned long long>(pool + (1024ull << 20), 16ull << 30);
 
     // launch order: by row class, heaviest alignments first inside a class
     std::vector<int> order(n_all);

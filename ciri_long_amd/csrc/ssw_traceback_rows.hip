@@ -652,8 +652,17 @@ __device__ void tb_rows_wide_pass(const SswParams& p, const uint2* s_tab, TbX* x
     if (tb_rows_setup(p, s_tab, task_index, true, false, jb) && !(p.gapE > 60 || p.gapO > 255)) {
         const long long wj = (long long)st.x << j;
         if (j == 0 || wj < 2ll * jb.in.readLen) {      // (ssw.c:632: the doubling gets here only while w < 2 readLen)
+            // a pass that may not be needed (j > 0) leaves the last quarter of the pool to those that are
+            unsigned long long used = 0;
+            if (j > 0) {                           // (one thread reads the moving counter: every wave must take the same branch)
+                if (threadIdx.x == 0) xs->at = *(volatile unsigned long long*)pool_head;
+                __syncthreads();
+                used = xs->at;
+                __syncthreads();
+            }
             if (wj > 0x3fffffff || !fits_mw((int)wj, jb.in.refLen, jb.in.readLen)) it = TB_UNFIT;
-            else { int m = 0; it = tb_make_plane_mw(jb.in, (int)wj, pool_base, pool_head, pool_size, pl, xs, &m) ? m : TB_NOPOOL; }
+            else if (j > 0 && used + (unsigned long long)jb.in.readLen * 1100ull > pool_size - pool_size / 4) it = TB_NOTRUN;
+            else { int m = 0; it = tb_make_plane_mw(jb.in, (int)wj, pool_base, pool_head, pool_size, pl, xs, &m) ? m : (j > 0 ? TB_NOTRUN : TB_NOPOOL); }
         }
     }
     if (writer) {

@@ -1410,7 +1410,7 @@ static constexpr int BT_W = POA_LDS_BYTES >= 9216 ? 24 : 20;     // columns per 
 static constexpr int BT_SQ = 128, BT_RING = 1024;    // letters staged with the band; entries of the result ring
 static constexpr int BT_DRIFT = BT_W / 2 - 4;        // how far the walk may leave the band's diagonal before the band is staged again
 static_assert(4 * 64 * BT_W + BT_SQ + 2 * BT_RING <= POA_LDS_BYTES, "back-track LDS");
-static constexpr int BT_W32 = 16;                  // the wide form (int32 H): 6 bytes per staged cell
+static constexpr int BT_W32 = POA_LDS_BYTES >= 9216 ? 16 : 14;                  // the wide form (int32 H): 6 bytes per staged cell
 static_assert(6 * 64 * BT_W32 + BT_SQ + 2 * BT_RING <= POA_LDS_BYTES, "back-track LDS, wide form");
 // A function of its own, NOT inlined: inside the kernel's one big body the register allocator spilled a value of this loop and
 // reloaded it every iteration -- and the wait for that reload is a wait for every store in flight, i.e. for the walk's own result

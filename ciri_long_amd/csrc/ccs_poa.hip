@@ -92,13 +92,16 @@ static constexpr int K2_BUCKETS = 2048;         // most buckets (the HBM-workspa
 // the LDS latency of the chain walks; measured on ~1 kb reads: 2048 -> 1.24 ms, 1024 -> 1.19, 512 -> 1.06, 256 -> 1.15, 128 -> 1.39)
 // at ~2 positions per bucket.  The counts do not depend on it: equal k-mers share a bucket whatever the number of buckets.
 __host__ __device__ inline int k2_buckets(int lcap) { return lcap <= 1536 ? 512 : (lcap <= 3072 ? 1024 : 2048); }
+static constexpr int K2_WIDE_FROM = 1024;      // launch classes from this many bases on: four waves per read (ccs_scan_kernel_x4)
 static constexpr int K2_LDS_MAX = 16000;       // longest read scanned out of LDS (8 bytes per base + 8 KiB of 160 KiB)
 __host__ __device__ inline size_t k2_lds_bytes(int lcap) { return 4 * (size_t)k2_buckets(lcap) + 8 * ((size_t)lcap / 2 + 2) + 4 * (size_t)lcap; }
 
 // The scan of one read.  NextT = int16_t with every array in LDS (reads up to K2_LDS_MAX bases), int32_t with cnt/sm/
 // code/next in an HBM workspace (longer reads: rare, so the slower memory does not matter; no length limit).
-template <typename NextT>
-__device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, int32_t* head, const int nbuckets, int32_t* cnt, int32_t* sm, uint16_t* code, NextT* next)
+// NT threads work on the read (64, or 256 for the launch classes of long reads: their LDS block admits only 3..7 workgroups per
+// CU, and one wave each leaves the chain walks' LDS latency bare); `lane` is the thread's index among them.
+template <typename NextT, int NT = 64>
+__device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, int32_t* head, const int nbuckets, int32_t* cnt, int32_t* sm, uint16_t* code, NextT* next, int* red = nullptr)
 {
     const int64_t off = p.read_off[rd];
     const int L = (int)(p.read_off[rd + 1] - off);
@@ -113,10 +116,10 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
     // PAIR of equal k-mers.  A read of L bases has O(L * copies) such pairs, not O(L^2/4): the positions are chained per
     // hash bucket and every pair is visited once, instead of comparing all (i, d).
     const int dmax = L / 2;
-    for (int i = lane; i < nbuckets; i += 64) head[i] = -1;
-    for (int d = lane; d <= dmax + 1; d += 64) cnt[d] = 0;
+    for (int i = lane; i < nbuckets; i += NT) head[i] = -1;
+    for (int d = lane; d <= dmax + 1; d += NT) cnt[d] = 0;
     sync();
-    for (int i = lane; i < L; i += 64) {
+    for (int i = lane; i < L; i += NT) {
         int32_t c = 0, ok = i + CCS_K <= L;
         if (ok)
             for (int t = 0; t < CCS_K; ++t) {
@@ -128,7 +131,7 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
         next[i] = ok ? (NextT)atomicExch(&head[(c ^ (c >> 5)) & (nbuckets - 1)], i) : (NextT)-2;
     }
     sync();
-    for (int i = lane; i < L; i += 64) {
+    for (int i = lane; i < L; i += NT) {
         int j = next[i];
         if (j == -2) continue;
         const int ci = code[i];
@@ -142,7 +145,7 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
     }
     sync();
     int best = -1, bestd = 0x7fffffff;
-    for (int d = CCS_DMIN + lane; d <= dmax; d += 64) {
+    for (int d = CCS_DMIN + lane; d <= dmax; d += NT) {
         int s = 0;
         const int lo = d - CCS_SMOOTH < CCS_DMIN ? CCS_DMIN : d - CCS_SMOOTH, hi = d + CCS_SMOOTH > dmax ? dmax : d + CCS_SMOOTH;
         for (int e = lo; e <= hi; ++e) s += cnt[e];
@@ -153,6 +156,12 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
     for (int d = 1; d < 64; d <<= 1) {
         const int b2 = __shfl_xor(best, d), d2 = __shfl_xor(bestd, d);
         if (b2 > best || (b2 == best && d2 < bestd)) { best = b2; bestd = d2; }
+    }
+    if constexpr (NT > 64) {                           // the waves' answers through LDS
+        if ((lane & 63) == 0) { red[2 * (lane >> 6)] = best; red[2 * (lane >> 6) + 1] = bestd; }
+        __syncthreads();
+        best = red[0]; bestd = red[1];
+        for (int v = 1; v < NT / 64; ++v) { const int b2 = red[2 * v], d2 = red[2 * v + 1]; if (b2 > best || (b2 == best && d2 < bestd)) { best = b2; bestd = d2; } }
     }
     sync();
     if (best < CCS_MIN_SUPPORT) { if (lane == 0) p.scan[rd] = out; return; }
@@ -175,9 +184,9 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
     sync();
     int b = 0, prev = p0, n = 0;
     while (n < CCS_MAX_CUTS) {
-        for (int t = lane; t < nd; t += 64) dh[t] = 0;
+        for (int t = lane; t < nd; t += NT) dh[t] = 0;
         sync();
-        for (int i = b + lane; i < b + W && i < L; i += 64) {
+        for (int i = b + lane; i < b + W && i < L; i += NT) {
             if (next[i] == -2) continue;
             const int ci = code[i];
             int j = head[(ci ^ (ci >> 5)) & (nbuckets - 1)];
@@ -189,7 +198,7 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
         }
         sync();
         int bs = -1, bdel = 0, bdist = 0x7fffffff;
-        for (int t = lane; t < nd; t += 64) {
+        for (int t = lane; t < nd; t += NT) {
             const int delta = dlo + t;
             if (delta >= 1 && b + delta <= L) {
                 const int sc = dh[t];
@@ -202,6 +211,15 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
             const int s2 = __shfl_xor(bs, d), e2 = __shfl_xor(bdel, d), t2 = __shfl_xor(bdist, d);
             if (s2 > bs || (s2 == bs && (t2 < bdist || (t2 == bdist && e2 < bdel)))) { bs = s2; bdel = e2; bdist = t2; }
         }
+        if constexpr (NT > 64) {
+            if ((lane & 63) == 0) { red[8 + 3 * (lane >> 6)] = bs; red[9 + 3 * (lane >> 6)] = bdel; red[10 + 3 * (lane >> 6)] = bdist; }
+            __syncthreads();
+            bs = red[8]; bdel = red[9]; bdist = red[10];
+            for (int v = 1; v < NT / 64; ++v) {
+                const int s2 = red[8 + 3 * v], e2 = red[9 + 3 * v], t2 = red[10 + 3 * v];
+                if (s2 > bs || (s2 == bs && (t2 < bdist || (t2 == bdist && e2 < bdel)))) { bs = s2; bdel = e2; bdist = t2; }
+            }
+        }
         sync();
         if (bs < 0) break;
         b += bdel;
@@ -213,10 +231,10 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
     if (lane == 0) p.scan[rd] = out;
 }
 
-__global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
+template <int NT>
+__device__ __forceinline__ void ccs_scan_body(const CcsParams& p, int32_t* k2_lds, int* red)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t k2_lds[];
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
     const int rd = p.work_order[p.k2_begin + blockIdx.x];   // launch classes by read length: a short read gets a small LDS block
     if ((int)(p.read_off[rd + 1] - p.read_off[rd]) > p.k2_lds_max) return;        // ccs_scan_long_kernel takes it
     int32_t* head = k2_lds;                         // bucket -> last inserted position, -1 = empty
@@ -225,7 +243,19 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
     int32_t* sm = cnt + p.lcap / 2 + 2;             // smoothed counts; later the per-cut histogram of offsets
     uint16_t* code = (uint16_t*)(sm + p.lcap / 2 + 2);
     int16_t* next = (int16_t*)(code + p.lcap);      // chain of the positions of a bucket; -1 = end (invalid k-mers are in no chain)
-    ccs_scan_read<int16_t>(p, rd, lane, head, nb, cnt, sm, code, next);
+    ccs_scan_read<int16_t, NT>(p, rd, tid, head, nb, cnt, sm, code, next, red);
+}
+__global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t k2_lds[];
+    ccs_scan_body<64>(p, k2_lds, nullptr);
+}
+// the same by four waves per read: the launch classes whose LDS block is large (K2_WIDE_FROM bases and more)
+__global__ void __launch_bounds__(256) ccs_scan_kernel_x4(const CcsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t k2_lds[];
+    __shared__ int red[24];
+    ccs_scan_body<256>(p, k2_lds, red);
 }
 
 __global__ void __launch_bounds__(64) ccs_scan_long_kernel(const CcsParams p)
@@ -2225,9 +2255,13 @@ hipError_t launch_ccs_scan(const CcsParams& p, int count, bool with_long, hipStr
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)ccs_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)ccs_scan_kernel_x4, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        if (e != hipSuccess) return e;
         attr = true;
     }
-    if (count > 0) hipLaunchKernelGGL(ccs_scan_kernel, dim3(count), dim3(64), lds, stream, p);
+    static const int wide_from = getenv("CLH_K2_WIDE_FROM") ? atoi(getenv("CLH_K2_WIDE_FROM")) : K2_WIDE_FROM;
+    if (count > 0 && p.lcap >= wide_from && !getenv("CLH_K2_ONE_WAVE")) hipLaunchKernelGGL(ccs_scan_kernel_x4, dim3(count), dim3(256), lds, stream, p);
+    else if (count > 0) hipLaunchKernelGGL(ccs_scan_kernel, dim3(count), dim3(64), lds, stream, p);
     if (with_long && p.n_long > 0) hipLaunchKernelGGL(ccs_scan_long_kernel, dim3(p.n_long), dim3(64), 0, stream, p);
     return hipGetLastError();
 }

@@ -378,6 +378,33 @@ def test_native_file_stage_buffer_borders_and_a_trailing_header(tmp_path, monkey
         assert parts[name] == (tmp_path / 'b' / 'tmp' / name).read_bytes(), name
 
 
+@pytest.mark.gpu
+def test_native_file_stage_a_record_longer_than_the_reserve(tmp_path, monkeypatch):
+    """a sequence line of 17 M bases between ordinary records, chunks of 1 MiB: the record is carried over many chunk borders and
+    outgrows the 4 MiB in front of a chunk (the batch moves to a buffer of its own); it is above the kernels' sanity bound, so it is
+    counted as too long, and every other record comes out as in the file without it"""
+    from ciri_long_amd import hip, synth
+    rng = np.random.Generator(np.random.PCG64(29))
+    recs = []
+    for k in range(120):
+        tm = synth.template(rng)
+        recs.append(('p%03d' % k, oracle_lib.decode(synth.rolling_circle_read(rng, tm, int(rng.integers(400, 1200))))))
+    big = ('ACGT' * (17 * 262144 + 11))
+    plain = tmp_path / 'plain.fa'; withbig = tmp_path / 'big.fa'
+    plain.write_text(''.join('>%s\n%s\n' % hs for hs in recs))
+    withbig.write_text(''.join('>%s\n%s\n' % hs for hs in recs[:60]) + '>huge\n' + big + '\n' + ''.join('>%s\n%s\n' % hs for hs in recs[60:]))
+    monkeypatch.setenv('CLH_FILE_CHUNK_MB', '1')
+    ctx = hip.default_context()
+    t0, r0, l0 = ctx.ccs_file(str(plain), 0, str(tmp_path / 'a.ccs.fa'), str(tmp_path / 'a.raw.fa'), 64)
+    t1, r1, l1 = ctx.ccs_file(str(withbig), 0, str(tmp_path / 'b.ccs.fa'), str(tmp_path / 'b.raw.fa'), 64)
+    assert (t0, l0) == (120, 0) and (t1, r1, l1) == (121, r0, 1) and r0 > 60
+    for name in ('ccs.fa', 'raw.fa'):
+        assert (tmp_path / ('a.' + name)).read_bytes() == (tmp_path / ('b.' + name)).read_bytes(), name
+    ctx.release_file_buffers()
+    t2, r2, l2 = ctx.ccs_file(str(plain), 0, str(tmp_path / 'c.ccs.fa'), str(tmp_path / 'c.raw.fa'), 64)       # buffers made anew
+    assert (t2, r2, l2) == (t0, r0, l0) and (tmp_path / 'c.ccs.fa').read_bytes() == (tmp_path / 'a.ccs.fa').read_bytes()
+
+
 def test_reads_lost_to_a_kernel_limit_are_counted_and_reported(tmp_path, caplog, monkeypatch):
     """A limit of the kernel never passes for "no repeat".  (1) spoa.poa: sequences that each skip a different number of letters in
     front of the same node give that node one in-edge each (the letters of the stretch are all different, so no deletion can slide):

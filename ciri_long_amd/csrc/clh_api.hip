@@ -148,7 +148,7 @@ struct clh_plan {
         bool on = false;
         int ntasks = 0, nwork = 0, bpl = 0, cap = 0;
         void *d_win = nullptr, *d_pieces = nullptr, *d_work = nullptr, *d_dmin = nullptr, *d_queue = nullptr, *d_out = nullptr, *d_ctl = nullptr,
-             *d_bound = nullptr, *d_parts = nullptr;
+             *d_bound = nullptr, *d_parts = nullptr, *d_q2 = nullptr;
         int ws_row0 = 0, ws_slot = 0, ws_wgs = 0;
         int64_t ws_dirs_off = 0;
     } pf[2];
@@ -179,7 +179,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     void* bufs[] = {pl->d_tasks, pl->d_results, pl->d_colmax, pl->d_cigars, pl->d_cigar_len, pl->d_pool, pl->d_pool_head,
                     pl->d_reads, pl->d_refs, pl->d_strips, pl->d_slices, pl->d_parts, pl->d_slice_base, pl->d_seg_ctr};
     for (void* b : bufs) c->release(b);
-    for (auto& f : pl->pf) { void* pb[] = {f.d_win, f.d_pieces, f.d_work, f.d_dmin, f.d_queue, f.d_out, f.d_ctl, f.d_bound, f.d_parts}; for (void* b : pb) c->release(b); }
+    for (auto& f : pl->pf) { void* pb[] = {f.d_win, f.d_pieces, f.d_work, f.d_dmin, f.d_queue, f.d_out, f.d_ctl, f.d_bound, f.d_parts, f.d_q2}; for (void* b : pb) c->release(b); }
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : pl->chain_ev) (void)hipEventDestroy(e);
     if (pl->done_ev) (void)hipEventDestroy(pl->done_ev);
@@ -424,8 +424,12 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
         }
         int bpl = (int)std::min<int64_t>(16, std::max<int64_t>(4, total / (64 * 12288)));
         if (const char* e = getenv("CLH_PF_BPL")) bpl = std::max(1, atoi(e));
-        for (int q = 0; q < (int)pieces.size(); ++q)
-            for (int fb = 0; fb < wins[pieces[q].task].nsub; fb += 64 * bpl) work.push_back({q, fb});
+        for (int q = 0; q < (int)pieces.size(); ++q) {
+            clh::PfWin& w = wins[pieces[q].task];
+            if (q == w.piece_first) w.work_first = (int32_t)work.size();
+            for (int fb = 0; fb < w.nsub; fb += 64 * bpl) work.push_back({q, fb});
+            w.work_count = (int32_t)work.size() - w.work_first;
+        }
         f.on = true; f.ntasks = sg.count; f.bpl = bpl; f.cap = (int)cap; f.nwork = (int)work.size();
         f.d_win = ctx->alloc(sizeof(clh::PfWin) * wins.size());
         f.d_pieces = ctx->alloc(sizeof(clh::PfTask) * pieces.size());
@@ -438,6 +442,10 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
             f.d_queue = ctx->alloc(sizeof(clh::ScanSlice) * (size_t)cap);
             f.d_parts = ctx->alloc(sizeof(clh::ScanPart) * (size_t)cap);
             ok = ok && f.d_queue && f.d_parts;
+            if (!getenv("CLH_NO_PF2")) {       // the second stage's queue: at most every entry of the work list (A/B: one stage only)
+                f.d_q2 = ctx->alloc(sizeof(int32_t) * std::max<size_t>(work.size(), 1));
+                ok = ok && f.d_q2;
+            }
         } else {
             // 2 seed tasks per alignment in fixed places, then the candidate queue; 130 scratch result rows per alignment behind every other
             // row; the K1w workspaces belong to the persistent workgroups, not to the tasks
@@ -760,9 +768,9 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
             P.pf_dmin = ((uintptr_t)d_refs & 255) == 0 ? (uint8_t*)f.d_dmin : nullptr;
             HIPCHK(hipMemsetAsync(f.d_ctl, 0, sizeof(clh::PfCtl), ls));
             if (s.rv == clh::kRvScanSliced) {
-                P.pf_slices = (clh::ScanSlice*)f.d_queue; P.parts = (clh::ScanPart*)f.d_parts;
+                P.pf_slices = (clh::ScanSlice*)f.d_queue; P.parts = (clh::ScanPart*)f.d_parts; P.pf_q2 = (int32_t*)f.d_q2; P.pf2_always = getenv("CLH_PF2_ALWAYS") != nullptr;
                 if (P.pf_dmin) HIPCHK(clh::launch_ssw_prefilter(P, f.nwork, ls));
-                HIPCHK(clh::launch_ssw_scan_filtered(pl->quirk, P, s.count, std::min(f.cap, c->n_cu * 12), ls));
+                HIPCHK(clh::launch_ssw_scan_filtered(pl->quirk, P, s.count, std::min(f.cap, c->n_cu * 12), std::min(f.nwork, c->n_cu * 16), ls));
             } else {
                 P.ws_tasks = (clh::WsTask*)f.d_queue; P.ws_bound = (uint16_t*)f.d_bound; P.ws_row0 = f.ws_row0; P.ws_slot_bytes = f.ws_slot;
                 P.ws_dirs_off = f.ws_dirs_off;
@@ -877,7 +885,7 @@ extern "C" int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts)
 extern "C" int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out)
 {
     if (!pl || !out) return fail(CLH_E_ARG, "clh_plan_prefilter_stats: null argument");
-    for (int k = 0; k < 5; ++k) out[k] = 0;
+    for (int k = 0; k < 6; ++k) out[k] = 0;
     if (!pl->ran) return 0;
     HIPCHK(hipSetDevice(pl->ctx->device));
     HIPCHK(hipStreamSynchronize(pl->last_stream));
@@ -885,7 +893,7 @@ extern "C" int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out)
         if (!f.on) continue;
         clh::PfCtl c;
         HIPCHK(hipMemcpy(&c, f.d_ctl, sizeof(c), hipMemcpyDeviceToHost));
-        out[0] += f.ntasks; out[1] += c.n_pruned; out[2] += c.qcount; out[3] += (int64_t)c.cols_scanned; out[4] += (int64_t)c.cols_window;
+        out[0] += f.ntasks; out[1] += c.n_pruned; out[2] += c.qcount; out[3] += (int64_t)c.cols_scanned; out[4] += (int64_t)c.cols_window; out[5] += c.n_stage2;
     }
     return 0;
 }

@@ -58,7 +58,7 @@ struct PfWin {            // host-built, one per alignment (task of the class): 
     int32_t piece_first;  // the alignment's pieces in the piece table
     int32_t piece_count;  // 1 for reads up to 254 bases; longer reads go through the bit-vector pass in pieces of <= 254 rows
     int32_t d_off;        // K1w class: first entry of the alignment's summed block bound (uint16 per block)
-    int32_t pad0, pad1;
+    int32_t work_first, work_count;   // K1s class: the alignment's entries of the work list (the second stage runs them again)
 };
 struct PfTask {           // host-built, one per PIECE of a read
     int32_t task;         // alignment (index into the class's tasks and PfWin table)
@@ -74,6 +74,7 @@ struct PfOut {            // device-filled per alignment: its slices / tasks in 
 struct PfCtl {            // device control block of one run (zeroed before it)
     int32_t qcount, qnext, n_pruned, seed_next;
     unsigned long long cols_scanned, cols_window;
+    int32_t q2count, q2next, n_stage2, pad;      // second stage (indel distance): work items queued / taken, alignments sent there
 };
 // K1w on long windows (ssw_scan_wide.hip): per alignment 2 seed rows + 2 x 64 candidate rows behind the real result rows
 static constexpr int kWsRows = 130;       // scratch rows per alignment: [0] seed, [1] seed in the word regime, [2 + 2 k] / [3 + 2 k] candidate k as-is / word regime
@@ -112,6 +113,8 @@ struct SswParams {
     PfOut* pf_out;
     PfCtl* pf_ctl;
     int32_t pf_bpl, pf_cap;    // blocks per lane of the prefilter; capacity of the queue
+    int32_t* pf_q2;            // K1s class: work items of the second stage (indel distance), or nullptr: one stage
+    int32_t pf2_always;        // tests: every window of the class through the second stage, whatever the first left (CLH_PF2_ALWAYS)
     uint16_t* ws_bound;        // K1w class: summed block bound D per alignment (PfWin.d_off)
     WsTask* ws_tasks;          // K1w class: [0, 2 n) seed tasks (fixed places), then the candidate queue
     int32_t ws_row0;           // first scratch result row of the class (alignment a: ws_row0 + a * kWsRows)
@@ -234,7 +237,8 @@ hipError_t launch_ssw_scan_sliced(bool geq, const SswParams& p, int ntasks, int 
 // the same class behind the prefilter: block minima (ssw_prefilter.hip), then seed + candidate slices, the slices by persistent
 // workgroups, the finish (ssw_scan.hip)
 hipError_t launch_ssw_prefilter(const SswParams& p, int nwork, hipStream_t stream);
-hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, hipStream_t stream);
+hipError_t launch_ssw_prefilter_indel(const SswParams& p, int nworkgroups, hipStream_t stream);     // the second stage: persistent workgroups over the device-made queue
+hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, int nworkgroups2, hipStream_t stream);
 static constexpr int kRvScanWideSliced = -4;   // pseudo class: K1w on windows of 32 kb and more: prefilter in pieces, seed, candidate tasks, best row
 hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, bool with_prefilter, int nwork, hipStream_t stream);
 static constexpr int kRvScanWide = -3;   // pseudo class: K1w, the row-scan kernel for reads of 255..4096 bases / scores above 254 (ssw_scan_wide.hip);

@@ -78,7 +78,53 @@ __device__ __forceinline__ void pf_column(uint32_t (&Pv)[W], uint32_t (&Mv)[W], 
     }
 }
 
+// one window column of the SECOND stage: the indel distance (a pair that is not "equal2" costs an insertion and a deletion).  With v the
+// vertical deltas of the column before and h the horizontal delta a row hands down (0 into row 1), a row maps its h to: "equal2": -v;
+// not, v = -1: +1; not, v = 0 (G): -1 -> 0, else +1; not, v = +1 (I): h handed on.  So h = -1 exactly on the rows reached from a
+// constant -1 through rows of I (A), h = 0 on the rows reached through I from a constant 0, from the top, or from a G row whose input is
+// -1 (Z), +1 elsewhere; "reached through a run" is one addition, as in Myers' algorithm.  tools/prefilter_model.py: indel_semiglobal.
 template <int W>
+__device__ __forceinline__ void pf_column_indel(uint32_t (&Pv)[W], uint32_t (&Mv)[W], int& score, const uint32_t (&Eq)[W], const int lastbit)
+{
+    uint32_t I[W], A[W], Z[W];
+    unsigned int carry = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        I[w] = ~Eq[w] & Pv[w];
+        const uint32_t Km = Eq[w] & Pv[w], Kmb = w ? Eq[w - 1] & Pv[w - 1] : 0u;
+        const uint32_t u = (w ? __builtin_amdgcn_alignbit(Km, Kmb, 31) : Km << 1) & I[w];
+        unsigned int co;
+        const uint32_t sum = __builtin_addc(u, I[w], carry, &co);
+        carry = co;
+        A[w] = Km | ((sum ^ I[w]) & I[w]);
+    }
+    carry = 0;
+    uint32_t szb = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t ash = w ? __builtin_amdgcn_alignbit(A[w], A[w - 1], 31) : A[0] << 1;
+        const uint32_t nz = Pv[w] | Mv[w];
+        const uint32_t Sz = (Eq[w] & ~nz) | (~(Eq[w] | nz) & ash);
+        const uint32_t u = (w ? __builtin_amdgcn_alignbit(Sz, szb, 31) : (Sz << 1) | 1u) & I[w];
+        szb = Sz;
+        unsigned int co;
+        const uint32_t sum = __builtin_addc(u, I[w], carry, &co);
+        carry = co;
+        Z[w] = Sz | ((sum ^ I[w]) & I[w]);
+    }
+    score += (int)((~(A[W - 1] | Z[W - 1]) >> lastbit) & 1u) - (int)((A[W - 1] >> lastbit) & 1u);
+#pragma unroll
+    for (int w = W - 1; w >= 0; --w) {
+        const uint32_t Ph = ~(A[w] | Z[w]), Phb = w ? ~(A[w - 1] | Z[w - 1]) : 0u;
+        const uint32_t phi = w ? __builtin_amdgcn_alignbit(Ph, Phb, 31) : Ph << 1;
+        const uint32_t mhi = w ? __builtin_amdgcn_alignbit(A[w], A[w - 1], 31) : A[0] << 1;
+        const uint32_t pv = Pv[w], mv = Mv[w], eq = Eq[w];
+        Pv[w] = (eq & mhi) | (~eq & (pv | (~pv & ~mv & ~phi) | (mv & mhi)));
+        Mv[w] = phi & (eq | mv);
+    }
+}
+
+template <int W, bool INDEL = false>
 __device__ void pf_walk(const SswParams& p, const PfTask& pc, const PfWin& pt, const PfWork& wk, const SswTask& task, const uint32_t* s_eq)
 {
     constexpr int P = PfRow<W>::P;
@@ -128,7 +174,8 @@ __device__ void pf_walk(const SswParams& p, const PfTask& pc, const PfWin& pt, c
                     const uint32_t off = 8 * b >= SH ? (wd >> (8 * b - SH)) & (31u << SH) : (wd << (SH - 8 * b)) & (31u << SH);
                     uint32_t Eq[W];
                     pf_load_eq<W>(Eq, s_eq, off);
-                    pf_column<W>(Pv, Mv, score, Eq, lastbit);
+                    if constexpr (INDEL) pf_column_indel<W>(Pv, Mv, score, Eq, lastbit);
+                    else pf_column<W>(Pv, Mv, score, Eq, lastbit);
                     cur_min = score < cur_min ? score : cur_min;
                 }
             }
@@ -142,13 +189,11 @@ __device__ void pf_walk(const SswParams& p, const PfTask& pc, const PfWin& pt, c
 
 }  // namespace
 
-__global__ void __launch_bounds__(64, 6) ssw_prefilter_kernel(const SswParams p)
+// one entry of the work list: 64 lanes x bpl blocks of one piece's window
+template <bool INDEL>
+__device__ __forceinline__ void pf_work_item(const SswParams& p, const PfWork wk, uint32_t* s_eq, uint32_t* s_peq, int* s_mat)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_eq[32 * 8];
-    __shared__ uint32_t s_peq[5 * 8];
-    __shared__ int s_mat[48];
     const int lane = threadIdx.x & 63;
-    const PfWork wk = p.pf_work[blockIdx.x];
     const PfTask pc = p.pf_tasks[wk.piece];
     const SswTask task = p.tasks[pc.task];
     const PfWin pt = p.pf_win[pc.task];
@@ -156,9 +201,9 @@ __global__ void __launch_bounds__(64, 6) ssw_prefilter_kernel(const SswParams p)
     const int W = (L + 31) >> 5;
     if (lane < 48) { const int b_ = lane >> 3, q_ = lane & 7; s_mat[lane] = (b_ < p.n && q_ < p.n) ? (int)p.mat[b_ * p.n + q_] : 0; }
     __syncthreads();
-    // match vectors of the five window codes: bit i = read base i and the code are "equal" (mat[code][q] > M - c)
+    // match vectors of the five window codes: bit i = read base i and the code are "equal" (mat[code][q] > M - c; second stage: M - 2c)
     const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
-    const int eq_above = p.max_match - cc;
+    const int eq_above = p.max_match - (INDEL ? 2 * cc : cc);
     const int8_t* read = p.reads + task.read_off + pc.row0;
     for (int half = 0; half < (W + 1) / 2; ++half) {
         const int row = 64 * half + lane;
@@ -177,14 +222,42 @@ __global__ void __launch_bounds__(64, 6) ssw_prefilter_kernel(const SswParams p)
     }
     __syncthreads();
     switch (W) {
-        case 1: pf_walk<1>(p, pc, pt, wk, task, s_eq); break;
-        case 2: pf_walk<2>(p, pc, pt, wk, task, s_eq); break;
-        case 3: pf_walk<3>(p, pc, pt, wk, task, s_eq); break;
-        case 4: pf_walk<4>(p, pc, pt, wk, task, s_eq); break;
-        case 5: pf_walk<5>(p, pc, pt, wk, task, s_eq); break;
-        case 6: pf_walk<6>(p, pc, pt, wk, task, s_eq); break;
-        case 7: pf_walk<7>(p, pc, pt, wk, task, s_eq); break;
-        default: pf_walk<8>(p, pc, pt, wk, task, s_eq); break;
+        case 1: pf_walk<1, INDEL>(p, pc, pt, wk, task, s_eq); break;
+        case 2: pf_walk<2, INDEL>(p, pc, pt, wk, task, s_eq); break;
+        case 3: pf_walk<3, INDEL>(p, pc, pt, wk, task, s_eq); break;
+        case 4: pf_walk<4, INDEL>(p, pc, pt, wk, task, s_eq); break;
+        case 5: pf_walk<5, INDEL>(p, pc, pt, wk, task, s_eq); break;
+        case 6: pf_walk<6, INDEL>(p, pc, pt, wk, task, s_eq); break;
+        case 7: pf_walk<7, INDEL>(p, pc, pt, wk, task, s_eq); break;
+        default: pf_walk<8, INDEL>(p, pc, pt, wk, task, s_eq); break;
+    }
+}
+
+__global__ void __launch_bounds__(64, 6) ssw_prefilter_kernel(const SswParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[32 * 8];
+    __shared__ uint32_t s_peq[5 * 8];
+    __shared__ int s_mat[48];
+    pf_work_item<false>(p, p.pf_work[blockIdx.x], s_eq, s_peq, s_mat);
+}
+
+// The second stage (tools/prefilter_model.py, "second stage"): the windows the unit-cost bound fails to thin out (ssw_scan_pick_kernel
+// queues their entries of the work list) once more with the INDEL distance -- H(j) <= M L - c d2(j), d2 >= d and larger by a quarter on
+// random text; about twice the instructions per column.  It overwrites the windows' block minima; ssw_scan_pick2_kernel reads them.
+// Persistent workgroups: the number of entries is only known on the device.
+__global__ void __launch_bounds__(64, 4) ssw_prefilter_indel_kernel(const SswParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[32 * 8];
+    __shared__ uint32_t s_peq[5 * 8];
+    __shared__ int s_mat[48];
+    const int total = p.pf_ctl->q2count;
+    for (;;) {
+        int idx = 0;
+        if ((threadIdx.x & 63) == 0) idx = atomicAdd(&p.pf_ctl->q2next, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= total) break;
+        pf_work_item<true>(p, p.pf_work[p.pf_q2[idx]], s_eq, s_peq, s_mat);
+        __syncthreads();
     }
 }
 
@@ -192,6 +265,13 @@ hipError_t launch_ssw_prefilter(const SswParams& p, int nwork, hipStream_t strea
 {
     if (nwork <= 0) return hipSuccess;
     hipLaunchKernelGGL(ssw_prefilter_kernel, dim3(nwork), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_ssw_prefilter_indel(const SswParams& p, int nworkgroups, hipStream_t stream)
+{
+    if (nworkgroups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ssw_prefilter_indel_kernel, dim3(nworkgroups), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

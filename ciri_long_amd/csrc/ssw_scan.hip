@@ -395,48 +395,40 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_finish_kernel(const S
 // candidate blocks (cut at groups of 64) become slices in the queue, each started `overlap` columns early like a static slice;
 // (3) when the runs outnumber the task's share of the queue or cover about as much as the window, the static slices of
 // clh_api.hip are written instead.  p.pf_dmin == nullptr (filter off for this run): static slices at once.
+// What the pick kernels share: with the seed's score S0 in hand, the candidate blocks of the alignment (minimum <= (M L - S0) / c), their
+// runs as slices in the queue -- or the static slices when the runs outnumber the alignment's share of the queue or cover about as much as
+// the window -- and the alignment's PfOut.  stage2_ok: the caller may still send the window to the second stage; returns true when it
+// should (the candidates cover more than an eighth of the window: the indel-distance pass over the window costs about as much as the
+// score pass over a twelfth of it; and the threshold is below what that distance is on random text) and then writes nothing.
 template <bool GEQ>
-__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const SswParams p)
+__device__ bool pf_pick_emit(const SswParams& p, const SswTask& task, const PfWin& pt, const uint8_t* dmin, const int S0, const ScanOut& seed, const int seed_block,
+                             const bool stage2_ok)
 {
-    SCAN_LDS_SETUP
     const int lane = threadIdx.x & 63;
-    const SswTask task = p.tasks[blockIdx.x];
-    const PfWin pt = p.pf_win[blockIdx.x];
     const int R = task.ref_len, L = task.read_len;
     const int overlap = L + (L * p.max_match + p.gapE - 1) / p.gapE + 32;
-    const uint8_t* dmin = p.pf_dmin ? p.pf_dmin + p.pf_tasks[pt.piece_first].sub_off : nullptr;     // (one piece: reads of this class have <= 254 bases)
     int own = (R + 63) / 64; own = own < 8192 ? 8192 : own;
     const int nstatic = (R + own - 1) / own;
-    int S0 = 0, nrun = 0, pruned = 0, thr = 0, seed_block = -1, ov_c = overlap;
-    ScanOut seed; seed.max = 0; seed.col = -1; seed.row = 0;
-    if (dmin) {
-        int key = 0x7fffffff;
-        for (int k = lane; k < pt.nsub; k += 64) { const int v = ((int)dmin[k] << 20) | k; key = v < key ? v : key; }
-        key = wave_min(key);
-        const int kb = key & 0xfffff;
-        int c0 = kb * kPfBlock - pt.phase, c1 = c0 + kPfBlock;
-        c0 = c0 < 0 ? 0 : c0; c1 = c1 > R ? R : c1;
-        const int cb = c0 - overlap < 0 ? 0 : c0 - overlap;
-        const ScanOut fw = scan_forward<GEQ>(p, task, lds, cb, c0, c1);
-        S0 = fw.max; seed = fw; seed_block = kb;
-        if (S0 > 0) {
-            const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
-            thr = (p.max_match * L - S0) / cc;
-            // an alignment that scores S0 or more deletes at most (M L - S0) / gapE window bases: it spans no more than L + that many
-            // columns, so the candidate slices start that far (+ 32) early -- cells that cannot reach S0 may come out lower, they cannot win
-            const int span_s0 = L + (p.max_match * L - S0) / p.gapE + 32;
-            ov_c = span_s0 < overlap ? span_s0 : overlap;
-            long long cost = 0;
-            for (int g = 0; g < pt.nsub; g += 64) {
-                const int k = g + lane;
-                const unsigned long long m = __ballot(k < pt.nsub && (int)dmin[k] <= thr);
-                nrun += __popcll(m & ~(m << 1));
-                cost += (long long)__popcll(m) * kPfBlock;
-            }
-            cost += (long long)nrun * ov_c;
-            const int cap = pt.nsub / 8 + 1 > 64 ? pt.nsub / 8 + 1 : 64;
-            pruned = nrun <= cap && cost < (long long)R + (long long)nstatic * overlap;
+    int nrun = 0, pruned = 0, thr = 0, ov_c = overlap;
+    if (dmin && S0 > 0) {
+        const int cc = p.max_match < p.gapE ? p.max_match : p.gapE;
+        thr = (p.max_match * L - S0) / cc;
+        // an alignment that scores S0 or more deletes at most (M L - S0) / gapE window bases: it spans no more than L + that many
+        // columns, so the candidate slices start that far (+ 32) early -- cells that cannot reach S0 may come out lower, they cannot win
+        const int span_s0 = L + (p.max_match * L - S0) / p.gapE + 32;
+        ov_c = span_s0 < overlap ? span_s0 : overlap;
+        long long cost = 0;
+        for (int g = 0; g < pt.nsub; g += 64) {
+            const int k = g + lane;
+            const unsigned long long m = __ballot(k < pt.nsub && (int)dmin[k] <= thr);
+            nrun += __popcll(m & ~(m << 1));
+            cost += (long long)__popcll(m) * kPfBlock;
         }
+        cost += (long long)nrun * ov_c;
+        const int cap = pt.nsub / 8 + 1 > 64 ? pt.nsub / 8 + 1 : 64;
+        pruned = nrun <= cap && cost < (long long)R + (long long)nstatic * overlap;
+        // (the indel distance of a clip to random text is ~0.58 L, less for short clips: above 0.55 L the second stage cannot help either)
+        if (stage2_ok && (p.pf2_always || ((!pruned || cost > (long long)R / 8) && 20 * thr < 11 * L))) return true;
     }
     const int count = pruned ? nrun : nstatic;
     int first = 0;
@@ -488,6 +480,64 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const Ssw
         PfOut o; o.first = first; o.count = count; o.s0 = S0; o.pruned = pruned;
         p.pf_out[blockIdx.x] = o;
     }
+    return false;
+}
+
+// ---- the sliced class behind the prefilter (ssw_prefilter.hip; tools/prefilter_model.py) --------------------------------------
+// One wave per task: (1) the block with the smallest minimum of d; a forward pass around it ATTAINS a score S0; (2) every
+// block whose minimum is at most (M L - S0) / c is a candidate -- no other block can hold the maximum or tie it; runs of
+// candidate blocks (cut at groups of 64) become slices in the queue, each started `overlap` columns early like a static slice;
+// (3) when the runs outnumber the task's share of the queue or cover about as much as the window, the static slices of
+// clh_api.hip are written instead -- or, with a second stage (p.pf_q2), the window's entries of the work list are queued for the
+// indel-distance pass and ssw_scan_pick2_kernel decides.  p.pf_dmin == nullptr (filter off for this run): static slices at once.
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick_kernel(const SswParams p)
+{
+    SCAN_LDS_SETUP
+    const int lane = threadIdx.x & 63;
+    const SswTask task = p.tasks[blockIdx.x];
+    const PfWin pt = p.pf_win[blockIdx.x];
+    const int R = task.ref_len, L = task.read_len;
+    const int overlap = L + (L * p.max_match + p.gapE - 1) / p.gapE + 32;
+    const uint8_t* dmin = p.pf_dmin ? p.pf_dmin + p.pf_tasks[pt.piece_first].sub_off : nullptr;     // (one piece: reads of this class have <= 254 bases)
+    int S0 = 0, seed_block = -1;
+    ScanOut seed; seed.max = 0; seed.col = -1; seed.row = 0;
+    if (dmin) {
+        int key = 0x7fffffff;
+        for (int k = lane; k < pt.nsub; k += 64) { const int v = ((int)dmin[k] << 20) | k; key = v < key ? v : key; }
+        key = wave_min(key);
+        const int kb = key & 0xfffff;
+        int c0 = kb * kPfBlock - pt.phase, c1 = c0 + kPfBlock;
+        c0 = c0 < 0 ? 0 : c0; c1 = c1 > R ? R : c1;
+        const int cb = c0 - overlap < 0 ? 0 : c0 - overlap;
+        const ScanOut fw = scan_forward<GEQ>(p, task, lds, cb, c0, c1);
+        S0 = fw.max; seed = fw; seed_block = kb;
+    }
+    if (pf_pick_emit<GEQ>(p, task, pt, dmin, S0, seed, seed_block, p.pf_q2 != nullptr && dmin != nullptr)) {
+        // the unit-cost bound leaves too much of this window: its entries of the work list once more, with the indel distance
+        int base = 0;
+        if (lane == 0) {
+            base = atomicAdd(&p.pf_ctl->q2count, pt.work_count);
+            atomicAdd(&p.pf_ctl->n_stage2, 1);
+            PfOut o; o.first = 0; o.count = 0; o.s0 = S0; o.pruned = 2;          // 2: pending (ssw_scan_pick2_kernel)
+            p.pf_out[blockIdx.x] = o;
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int k = lane; k < pt.work_count; k += 64) p.pf_q2[base + k] = pt.work_first + k;
+    }
+}
+
+// after the second stage: the windows it took (PfOut.pruned == 2), by its block minima
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_pick2_kernel(const SswParams p)
+{
+    const PfOut po = p.pf_out[blockIdx.x];
+    if (po.pruned != 2) return;
+    const SswTask task = p.tasks[blockIdx.x];
+    const PfWin pt = p.pf_win[blockIdx.x];
+    const uint8_t* dmin = p.pf_dmin + p.pf_tasks[pt.piece_first].sub_off;
+    ScanOut seed; seed.max = 0; seed.col = -1; seed.row = 0;
+    (void)pf_pick_emit<GEQ>(p, task, pt, dmin, po.s0, seed, -1, false);
 }
 
 // the queue's slices by persistent workgroups (the number of slices is only known on the device)
@@ -535,14 +585,23 @@ __global__ void __launch_bounds__(64, SCAN_WAVES) ssw_scan_finish_queue_kernel(c
     scan_finish<GEQ>(p, task, fw, lds);
 }
 
-hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, hipStream_t stream)
+hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, int nworkgroups2, hipStream_t stream)
 {
+    const bool stage2 = p.pf_q2 != nullptr && p.pf_dmin != nullptr;
     if (geq) {
         hipLaunchKernelGGL((ssw_scan_pick_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+        if (stage2) {
+            if (hipError_t e = launch_ssw_prefilter_indel(p, nworkgroups2, stream)) return e;
+            hipLaunchKernelGGL((ssw_scan_pick2_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
+        }
         hipLaunchKernelGGL((ssw_scan_queue_kernel<true>), dim3(nworkgroups), dim3(64), 0, stream, p);
         hipLaunchKernelGGL((ssw_scan_finish_queue_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
     } else {
         hipLaunchKernelGGL((ssw_scan_pick_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+        if (stage2) {
+            if (hipError_t e = launch_ssw_prefilter_indel(p, nworkgroups2, stream)) return e;
+            hipLaunchKernelGGL((ssw_scan_pick2_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
+        }
         hipLaunchKernelGGL((ssw_scan_queue_kernel<false>), dim3(nworkgroups), dim3(64), 0, stream, p);
         hipLaunchKernelGGL((ssw_scan_finish_queue_kernel<false>), dim3(ntasks), dim3(64), 0, stream, p);
     }

@@ -630,11 +630,12 @@ class Plan(object):
 
     def prefilter_stats(self):
         """what the exact column prefilter (csrc/ssw_prefilter.hip) did in the last run: alignments of the sliced scan class, of
-        them with candidate slices, slices run, window columns computed, window columns of the class"""
-        c = np.zeros(5, dtype=np.int64)
+        them with candidate slices, slices run, window columns computed, window columns of the class, alignments that also went
+        through the second stage (indel-distance bound)"""
+        c = np.zeros(6, dtype=np.int64)
         if lib().clh_plan_prefilter_stats(self._h, c.ctypes.data) != 0:
             raise ClhError('clh_plan_prefilter_stats: %s' % last_error())
-        return dict(zip(('alignments', 'pruned', 'slices', 'cols_computed', 'cols_window'), (int(x) for x in c)))
+        return dict(zip(('alignments', 'pruned', 'slices', 'cols_computed', 'cols_window', 'second_stage'), (int(x) for x in c)))
 
     def timing(self):
         """([K1 ms per segment], (K1b small-window ms, K1b large-window ms)) for the last run"""

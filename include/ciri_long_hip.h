@@ -94,7 +94,8 @@ int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts);
  * the shape of find_bsj.py:196-216, a 20..254-base clip against hit +- 200 kb: a bit-vector edit-distance bound finds the blocks
  * of the window that can hold the maximum of sw_sse2_byte (ssw.c:123-345) and only those are computed; results are identical with
  * and without it.  out[0] = alignments of that class in the last run, out[1] = of them with candidate slices instead of the
- * whole window, out[2] = slices run, out[3] = window columns computed, out[4] = window columns of the class.  Waits for the run. */
+ * whole window, out[2] = slices run, out[3] = window columns computed, out[4] = window columns of the class, out[5] = alignments whose
+ * window went through the second stage as well (the indel-distance bound, for windows the first leaves too much of).  Waits for the run. */
 int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out);
 
 /* Launch the batch on packed code arrays that already live in HBM (device pointers).  Asynchronous on `stream`

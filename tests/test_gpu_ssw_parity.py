@@ -713,6 +713,71 @@ def _clip_cases(rng, m, R, n):
     return refs, qs
 
 
+@pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (2, 2, 3, 1), (10, 4, 8, 2)])
+def test_second_stage_of_the_prefilter_vs_oracle(ctx, scheme, monkeypatch):
+    """Clips whose best score leaves the unit-cost bound without grip -- nearly half of the clip foreign, many substitutions, two weak loci --
+    on windows of 40..250 kb: the window goes through the indel-distance pass as well (ssw_prefilter_indel_kernel, ssw_scan_pick2_kernel;
+    tools/prefilter_model.py "second stage").  Rows equal the oracle's, equal the one-stage run's (CLH_NO_PF2), and the second stage is
+    what prunes here."""
+    import torch
+    from ciri_long_amd import hip
+    m, x, o, e = scheme
+    rng = np.random.default_rng(2300 + sum(scheme))
+    refs, qs = [], []
+    for case in range(36):
+        R = int(rng.choice([40000, 70000, 131072, 250000]))
+        L = int(rng.integers(70, 200)) if m < 10 else int(rng.integers(18, 25))
+        ref = _rnd(rng, R)
+        pos = int(rng.integers(0, R - L))
+        kind = case % 6
+        q = ref[pos:pos + L]
+        if kind in (0, 1):                       # nearly half of the clip does not belong here
+            cut = (L * 9) // 20
+            q = (_rnd(rng, cut) + q[cut:]) if kind == 0 else (q[:L - cut] + _rnd(rng, cut))
+        if kind == 2:                            # substitutions only, a quarter of the bases: they cost the indel distance 2 each
+            q = ''.join(c if rng.random() > 0.27 else 'ACGT'[(('ACGT'.index(c)) + 1 + int(rng.integers(0, 3))) % 4] for c in q)
+        if kind == 3:                            # indels and substitutions
+            q = _mut(q, rng, 0.45)[:L] or 'A'
+        if kind == 4 and pos > 3 * L:            # two weak loci: the same damaged clip earlier in the window (the first column wins a tie)
+            q = ''.join(c if rng.random() > 0.3 else 'ACGT'[int(rng.integers(0, 4))] for c in q)
+            ref = (ref[:pos - 2 * L] + ref[pos:pos + L] + ref[pos - L:])[:R]
+        if kind == 5:                            # N on both sides
+            q = _rnd(rng, (L * 2) // 5) + q[(L * 2) // 5:]
+            ref = ref[:pos + L // 2] + 'N' * 7 + ref[pos + L // 2 + 7:]
+            q = q[:L // 2] + 'N' + q[L // 2 + 1:]
+        refs.append(ref); qs.append(q)
+    rd, ro = hip.pack(qs); fd, fo = hip.pack(refs)
+    d_r = torch.from_numpy(rd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
+    want = [oracle_align(ref, q, *scheme) for ref, q in zip(refs, qs)]
+    got = {}
+    for one_stage in (False, True):
+        if one_stage:
+            monkeypatch.setenv('CLH_NO_PF2', '1')
+        plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=False)
+        plan.run(d_r.data_ptr(), d_f.data_ptr())
+        rows, _ = plan.fetch()
+        st = plan.prefilter_stats()
+        plan.close()
+        got[one_stage] = (rows, st)
+        for k, (w, r) in enumerate(zip(want, rows)):
+            g = (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1']))
+            assert g == (w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']), (one_stage, k, len(qs[k]), len(refs[k]), g)
+    monkeypatch.delenv('CLH_NO_PF2')
+    assert (got[False][0] == got[True][0]).all()
+    two, one = got[False][1], got[True][1]
+    assert one['second_stage'] == 0
+    if m == 1:      # (with M > c the threshold (M L - S0) / c is beyond what either distance reaches on random text: the kernel's rule keeps the second stage out)
+        assert two['second_stage'] >= 5 and two['cols_computed'] < one['cols_computed'], (two, one, [round(w['score'] / len(q), 2) for w, q in zip(want, qs)])
+    # every window through the second stage, whatever the first left (the rule is a matter of time, not of the answer)
+    monkeypatch.setenv('CLH_PF2_ALWAYS', '1')
+    plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=False)
+    plan.run(d_r.data_ptr(), d_f.data_ptr())
+    rows, _ = plan.fetch()
+    st = plan.prefilter_stats()
+    plan.close()
+    assert (rows == got[True][0]).all() and st['second_stage'] >= 10, st       # (longer clips of the larger match scores are K1w's class: one stage)
+
+
 @pytest.mark.parametrize('scheme', [(1, 1, 1, 1), (2, 2, 3, 1), (1, 3, 5, 2), (3, 1, 2, 2)])
 def test_prefilter_on_long_windows_vs_oracle(ctx, scheme, monkeypatch):
     """The exact column prefilter in front of K1s on windows of 32 kb and more (csrc/ssw_prefilter.hip, find_bsj.py:196-216's

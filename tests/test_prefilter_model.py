@@ -10,8 +10,8 @@ import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
 from oracle_lib import make_mat  # noqa: E402
-from prefilter_model import (PF_B, block_minima, bound_consts, candidate_runs, myers_semiglobal, prefilter_forward,  # noqa: E402
-                             semiglobal_dp)
+from prefilter_model import (PF_B, block_minima, bound_consts, candidate_runs, indel_semiglobal, indel_semiglobal_dp,  # noqa: E402
+                             myers_semiglobal, prefilter_forward, semiglobal_dp)
 from scan_model import scan_pass  # noqa: E402
 
 SCORINGS = [(1, 1, 1, 1), (2, 2, 3, 1), (1, 3, 5, 2), (3, 1, 2, 2)]
@@ -96,6 +96,78 @@ def test_filtered_forward_pass_equals_the_whole_window_pass(sc):
             assert got[:3] == want, (k, phase, cap, got, want)
             pruned += int(got[3]['pruned'])
     assert pruned > 4
+
+
+@pytest.mark.parametrize('sc', SCORINGS + [(10, 4, 8, 2)])
+def test_indel_distance_bit_vector_recurrence_equals_the_plain_programme(sc):
+    """the second stage's recurrence (csrc/ssw_prefilter.hip: pf_column_indel): constants, G rows and runs of I rows"""
+    m, x, go, ge = sc
+    mat = make_mat(m, x)
+    rng = np.random.Generator(np.random.PCG64(51 + m))
+    for k in range(30):
+        L = int(rng.integers(1, 100))
+        ref, read = _case(rng, int(rng.integers(1, 400)), L, float(rng.choice([0.05, 0.2, 0.4])), nrich=k % 3 == 1, plant=k % 4 != 3)
+        assert (indel_semiglobal(ref, read, mat, 5, ge) == indel_semiglobal_dp(ref, read, mat, 5, ge)).all(), (k, L)
+
+
+@pytest.mark.parametrize('sc', SCORINGS + [(10, 4, 8, 2)])
+def test_the_indel_distance_bound_holds_in_every_column(sc):
+    """H(j) <= M L - c d2(j) against the exact column maxima of the 8-bit pass -- planted clips with substitutions, insertions and
+    deletions, partial clips, N on either side"""
+    m, x, go, ge = sc
+    mat = make_mat(m, x)
+    M, c = bound_consts(mat, 5, ge)
+    rng = np.random.Generator(np.random.PCG64(61 + m))
+    tight = 0
+    for k in range(24):
+        L = int(rng.integers(4, min(250 // m, 120)))
+        R = int(rng.integers(50, 900))
+        ref, read = _case(rng, R, L, float(rng.choice([0.0, 0.1, 0.3])), nrich=k % 3 == 1, plant=k % 5 != 4)
+        if k % 4 == 2 and len(read) > 20:            # only a part of the clip belongs here
+            read[:len(read) // 3] = rng.integers(0, 4, len(read) // 3)
+        L = len(read)
+        colmax = scan_pass(ref, read, mat, 5, go, ge, L, want_colmax=True)[3]['colmax'] if 'want_colmax' in scan_pass.__code__.co_varnames else None
+        d2 = indel_semiglobal(ref, read, mat, 5, ge)
+        if colmax is None:
+            # column maxima by the plain recurrences (the 8-bit pass without overflow: scores stay below 255 here)
+            H = np.zeros(L + 1, dtype=np.int64); E = np.zeros(L + 1, dtype=np.int64)
+            colmax = np.zeros(R, dtype=np.int64)
+            for j in range(R):
+                Hn = np.zeros(L + 1, dtype=np.int64); F = 0
+                for i in range(1, L + 1):
+                    E[i] = max(H[i] - go, E[i] - ge)
+                    F = max(Hn[i - 1] - go, F - ge)
+                    s = int(mat[int(ref[j]) * 5 + int(read[i - 1])])
+                    Hn[i] = max(0, H[i - 1] + s, E[i], F)
+                H = Hn
+                colmax[j] = H.max()
+        assert (colmax <= M * L - c * d2).all(), (k, L, R)
+        tight += int((colmax == M * L - c * d2).any())
+    assert tight > 3
+
+
+@pytest.mark.parametrize('sc', SCORINGS)
+def test_two_stage_filtered_forward_pass_equals_the_whole_window_pass(sc):
+    """clips whose best score leaves the unit-cost bound useless (a third of the clip replaced, many errors): the second stage takes
+    the window, the answer stays the whole-window pass's"""
+    m, x, go, ge = sc
+    mat = make_mat(m, x)
+    rng = np.random.Generator(np.random.PCG64(71 + m))
+    second = pruned = 0
+    for k in range(14):
+        L = int(rng.integers(40, min(250 // m, 110)))
+        R = int(rng.choice([3000, 6000, 9000]))
+        ref, read = _case(rng, R, L, float(rng.choice([0.1, 0.25, 0.35])), nrich=k % 4 == 1, plant=k % 6 != 5)
+        if k % 2 == 0 and len(read) > 30:
+            read[len(read) // 2:len(read) // 2 + len(read) // 3] = rng.integers(0, 4, len(read) // 3)
+        L = len(read)
+        phase = int(rng.integers(0, PF_B))
+        want = scan_pass(ref, read, mat, 5, go, ge, L)[:3]
+        for always in (False, True):                     # by the kernel's rule, and with the second stage forced
+            got = prefilter_forward(ref, read, mat, 5, go, ge, phase=phase, two_stage=True, stage2_share=64, stage2_always=always)
+            assert got[:3] == want, (k, phase, always, got, want)
+            second += int(got[3]['second_stage']); pruned += int(got[3]['pruned'])
+    assert second > 10 and pruned > 6
 
 
 def test_candidate_runs_cover_exactly_the_blocks_under_the_threshold():

@@ -126,7 +126,7 @@ def candidate_runs(dmin, thr, max_run=64):
     return runs
 
 
-def prefilter_forward(ref, read, mat, n, gapO, gapE, phase=0, cap=None, chunk=256):
+def prefilter_forward(ref, read, mat, n, gapO, gapE, phase=0, cap=None, chunk=256, two_stage=False, stage2_share=8, stage2_always=False):
     """forward pass of the 8-bit class through the prefilter: (max, col, row, info) as scan_pass returns them for the whole
     window.  info: what the filter did."""
     ref = np.asarray(ref); read = np.asarray(read)
@@ -155,6 +155,15 @@ def prefilter_forward(ref, read, mat, n, gapO, gapE, phase=0, cap=None, chunk=25
     cost = sum(min(R, e * PF_B - phase) - max(0, b * PF_B - phase) + overlap for b, e in runs)
     own = max(8192, (R + 63) // 64)
     nstatic = (R + own - 1) // own
+    info['second_stage'] = False
+    # (when the second stage is worth its cost is a matter of time only -- the kernel: candidates over an eighth of the window and a threshold
+    # below what the indel distance is on random text, ~0.55 L; stage2_always: whenever the first stage leaves anything, for the tests)
+    if two_stage and S0 > 0 and (stage2_always or ((len(runs) > cap or cost >= R + nstatic * overlap or cost > R // stage2_share) and 20 * thr < 11 * L)):
+        # the unit-cost bound leaves too much of the window: the indel distance over it (csrc/ssw_scan.hip: pf_pick_emit, ssw_scan_pick2_kernel)
+        info['second_stage'] = True
+        dmin = block_minima(indel_semiglobal(ref, read, mat, n, gapE), phase)
+        runs = candidate_runs(dmin, thr)
+        cost = sum(min(R, e * PF_B - phase) - max(0, b * PF_B - phase) + overlap for b, e in runs)
     if S0 == 0 or len(runs) > cap or cost >= R + nstatic * overlap:
         info['pruned'] = False
         slices = [(b, min(R, b + own)) for b in range(0, R, own)]
@@ -206,3 +215,88 @@ def piecewise_block_bound(ref, read, mat, n, gapE, phase=0, max_rows=254):
         wm = np.array([dm[max(0, b - sb):b + 1].min() for b in range(len(dm))], dtype=np.int64)
         D = wm if D is None else D + wm
     return D, sb
+
+
+# ---- second stage: the indel distance (round 4) -------------------------------------------------------------------------------
+# Let c = min(M, gapE) as before and call a pair "equal2" when mat[r][q] > M - 2c.  Let d2(j) be the INDEL distance (insertions and
+# deletions of unit cost, no substitutions: a pair that is not "equal2" costs an insertion and a deletion, 2) of the whole clip to the best
+# window substring ending at column j.  Then H(j) <= M L - c d2(j): against M L an alignment loses at least M >= c for every clip base it
+# leaves out or inserts, at least gapE >= c for every deleted window base, and at least 2c for every aligned pair that is not "equal2"
+# (by the definition), which the indel script charges as one insertion and one deletion.  d2 >= d, and on random text it is larger by a
+# quarter (~0.58 L against ~0.46 L), so clips whose best score is 0.45..0.55 L -- for which EVERY block passes the unit-cost test --
+# are cut down to a few per cent of their window (tools/dev/indel_bound_probe.py).  The bit-vector form costs about twice the unit-cost
+# one per column, so it runs only on the windows the first stage fails to thin out.
+def eq2_masks(read, mat, n, M, c):
+    out = []
+    for r in range(5):
+        m = 0
+        for i, q in enumerate(read):
+            s = int(mat[r * n + int(q)]) if (r < n and int(q) < n) else 0
+            if s > M - 2 * c:
+                m |= 1 << i
+        out.append(m)
+    return out
+
+
+def indel_semiglobal_dp(ref, read, mat, n, gapE):
+    """d2(j) by the plain dynamic programme"""
+    L = len(read)
+    M, c = bound_consts(mat, n, gapE)
+    peq = eq2_masks(read, mat, n, M, c)
+    col = np.arange(L + 1, dtype=np.int64)
+    d = np.zeros(len(ref), dtype=np.int64)
+    for j, r in enumerate(ref):
+        e = peq[int(r) if int(r) < 5 else 4]
+        new = np.zeros(L + 1, dtype=np.int64)
+        for i in range(1, L + 1):
+            best = min(col[i] + 1, new[i - 1] + 1)
+            if (e >> (i - 1)) & 1:
+                best = min(best, col[i - 1])
+            new[i] = best
+        col = new
+        d[j] = col[L]
+    return d
+
+
+def indel_semiglobal(ref, read, mat, n, gapE):
+    """d2(j) by the bit-vector recurrence of csrc/ssw_prefilter.hip (pf_column_indel): per column, with v = the vertical deltas of the
+    column before (Pv / Mv = +1 / -1) and h the horizontal delta a row hands down (0 into row 1), row i maps its h to
+        "equal2":            -v                         (a constant)
+        not, v = -1:         +1                         (a constant)
+        not, v =  0:         -1 -> 0, 0 -> 1, 1 -> 1    (G)
+        not, v = +1:         h                          (I: handed on)
+    so h = -1 exactly on the rows reached from a constant -1 through rows of I (set A), h = 0 on the rows reached through I from a
+    constant 0, from the top, or from a G row whose input is -1 (set Z), and +1 elsewhere; "reached through a run" is one addition
+    as in Myers' algorithm.  The new vertical deltas follow row by row from h shifted down by one."""
+    L = len(read)
+    M, c = bound_consts(mat, n, gapE)
+    peq = eq2_masks(read, mat, n, M, c)
+    full = (1 << L) - 1
+    Pv, Mv, score = full, 0, L
+    top = 1 << (L - 1)
+    d = np.zeros(len(ref), dtype=np.int64)
+
+    def through(seed_below, run):          # rows of `run` reached from the bits of seed_below (already shifted onto the run's first row)
+        u = seed_below & run
+        return (((u + run) & full) ^ run) & run
+
+    for j, r in enumerate(ref):
+        Eq = peq[int(r) if int(r) < 5 else 4]
+        I = ~Eq & Pv & full
+        G = ~(Eq | Pv | Mv) & full
+        Km = Eq & Pv
+        Kz = Eq & ~Pv & ~Mv & full
+        A = Km | through((Km << 1) & full, I)
+        Sz = Kz | (G & (A << 1) & full)
+        Z = Sz | through(((Sz << 1) | 1) & full, I)
+        Ph = ~(A | Z) & full
+        Mh = A
+        if Ph & top:
+            score += 1
+        if Mh & top:
+            score -= 1
+        Phi = (Ph << 1) & full
+        Mhi = (Mh << 1) & full
+        Pv, Mv = ((Eq & Mhi) | (~Eq & (Pv | (~Pv & ~Mv & ~Phi) | (Mv & Mhi)))) & full, Phi & (Eq | Mv) & full
+        d[j] = score
+    return d

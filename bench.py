@@ -204,7 +204,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel', -4: 'ssw_prefilter_kernel + ssw_scanw_seed/pick/queue/combine kernels (K1w tasks on long windows)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_prefilter_indel_kernel + ssw_scan_pick2_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel', -4: 'ssw_prefilter_kernel + ssw_scanw_seed/pick/queue/combine kernels (K1w tasks on long windows)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         nwide = int(ssw_plan.traceback_counts()[0])

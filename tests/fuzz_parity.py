@@ -63,6 +63,12 @@ while time.time() < t_end:
         ref = rng.integers(0, 4, R, dtype=np.int8)
         st = int(rng.integers(0, R - L))
         q = synth.mutate(ref[st:st + L], rng, sub=float(rng.choice([0.0, 0.05])), ins=0.03, dele=0.03)
+        if _ % 2 and len(q) > 30:      # clips the unit-cost bound of the prefilter has no grip on (its second stage): a foreign part, many substitutions
+            q = q.copy()
+            if rng.random() < 0.5:
+                cut = int(len(q) * rng.uniform(0.3, 0.55)); q[:cut] = rng.integers(0, 4, cut, dtype=np.int8)
+            else:
+                hit = rng.random(len(q)) < float(rng.choice([0.2, 0.3])); q[hit] = rng.integers(0, 4, int(hit.sum()), dtype=np.int8)
         refs.append(ref); qs.append(q.astype(np.int8) if len(q) else np.zeros(3, dtype=np.int8))
     for _ in range(10):
         blk = int(rng.choice([300, 600, 1100])); gap = int(rng.choice([40, 150, 320, 700])); R = 2 * blk + gap + 300

@@ -768,7 +768,7 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
             P.pf_dmin = ((uintptr_t)d_refs & 255) == 0 ? (uint8_t*)f.d_dmin : nullptr;
             HIPCHK(hipMemsetAsync(f.d_ctl, 0, sizeof(clh::PfCtl), ls));
             if (s.rv == clh::kRvScanSliced) {
-                P.pf_slices = (clh::ScanSlice*)f.d_queue; P.parts = (clh::ScanPart*)f.d_parts; P.pf_q2 = (int32_t*)f.d_q2; P.pf2_always = getenv("CLH_PF2_ALWAYS") != nullptr;
+                P.pf_slices = (clh::ScanSlice*)f.d_queue; P.parts = (clh::ScanPart*)f.d_parts; P.pf_q2 = (int32_t*)f.d_q2; P.pf2_always = getenv("CLH_PF2_ALWAYS") != nullptr; P.pf2_share = getenv("CLH_PF2_SHARE") ? std::max(1, atoi(getenv("CLH_PF2_SHARE"))) : 8;
                 if (P.pf_dmin) HIPCHK(clh::launch_ssw_prefilter(P, f.nwork, ls));
                 HIPCHK(clh::launch_ssw_scan_filtered(pl->quirk, P, s.count, std::min(f.cap, c->n_cu * 12), std::min(f.nwork, c->n_cu * 16), ls));
             } else {

@@ -115,6 +115,7 @@ struct SswParams {
     int32_t pf_bpl, pf_cap;    // blocks per lane of the prefilter; capacity of the queue
     int32_t* pf_q2;            // K1s class: work items of the second stage (indel distance), or nullptr: one stage
     int32_t pf2_always;        // tests: every window of the class through the second stage, whatever the first left (CLH_PF2_ALWAYS)
+    int32_t pf2_share;         // a window goes to the second stage when the first leaves more than 1 / pf2_share of it (default 8; CLH_PF2_SHARE)
     uint16_t* ws_bound;        // K1w class: summed block bound D per alignment (PfWin.d_off)
     WsTask* ws_tasks;          // K1w class: [0, 2 n) seed tasks (fixed places), then the candidate queue
     int32_t ws_row0;           // first scratch result row of the class (alignment a: ws_row0 + a * kWsRows)

@@ -428,7 +428,7 @@ __device__ bool pf_pick_emit(const SswParams& p, const SswTask& task, const PfWi
         const int cap = pt.nsub / 8 + 1 > 64 ? pt.nsub / 8 + 1 : 64;
         pruned = nrun <= cap && cost < (long long)R + (long long)nstatic * overlap;
         // (the indel distance of a clip to random text is ~0.58 L, less for short clips: above 0.55 L the second stage cannot help either)
-        if (stage2_ok && (p.pf2_always || ((!pruned || cost > (long long)R / 8) && 20 * thr < 11 * L))) return true;
+        if (stage2_ok && (p.pf2_always || ((!pruned || cost > (long long)R / p.pf2_share) && 20 * thr < 11 * L))) return true;
     }
     const int count = pruned ? nrun : nstatic;
     int first = 0;

@@ -816,7 +816,10 @@ __device__ __forceinline__ void tb_rows_table(const SswParams& p, uint2* s_tab)
 }
 
 // every alignment of the launch class, one per workgroup (= one wave)
-__global__ void __launch_bounds__(64, 4) ssw_traceback_rows_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
+#ifndef TB_NARROW_WAVES
+#define TB_NARROW_WAVES 4      // measured on C2 (row traceback, ms): 3 -> 5.67, 4 -> 5.38, 5 -> 5.37, 6 -> 5.55
+#endif
+__global__ void __launch_bounds__(64, TB_NARROW_WAVES) ssw_traceback_rows_kernel(const SswParams p, uint8_t* pool_base, unsigned long long* pool_head, unsigned long long pool_size,
                                                                    int task_base, int* n_small, int* list_small, int* state_small)
 {
     __shared__ uint2 s_tab[8];

@@ -556,7 +556,7 @@ static constexpr int D_F = 0x0007, D_O_SHIFT = 3, D_E_SHIFT = 8, D_Q_SHIFT = 11;
 // and the back-track, which knows the same rule, answers "miss" when it is about to use a cell that was not left: the pass is
 // then run once more with every cell stored.  Results never depend on the band.
 #ifndef POA_BAND_W
-#define POA_BAND_W 32      // measured, C3 / C4 ms per launch (walks that left the band and ran their pass again): 64 -> 19.90 (0) / 78.3 (27), 48 -> 19.65 (0) / 77.9 (78), 32 -> 19.30 (22 of 85 000) / 77.3 (353 of 250 000)
+#define POA_BAND_W 32      // measured, C3 / C4 ms per launch (walks that left the band and ran their pass again): 64 -> 19.90 (0) / 78.3 (27), 48 -> 19.65 (0) / 77.9 (78), 32 -> 19.30 (22 of 85 000) / 77.3 (353 of 250 000); round 4 at 18.5 / 60.8: 24 -> 18.44 (109) / 61.4 (1491), 16 -> 18.31 (1711)
 #endif
 static constexpr int POA_BAND = POA_BAND_W;
 static constexpr int POA_H_NONE = -32768;            // a cell of the staged band that the planes do not hold (H is never below POA_NEG)

@@ -200,6 +200,77 @@ def test_c4_full_per_gpu_share_125000_reads_order_and_split_invariance():
         assert np.array_equal(rows_a['ccs_len'][part], rows_c['ccs_len']) and np.array_equal(sums_a[part], sums_c)
 
 
+def test_c5_full_per_gpu_share_125000_reads_of_the_collapse_kernels():
+    """BASELINE config 5 at its per-GPU size (1 M reads of the collapse stage over 8 GPUs: 125 000 reads, here 2 500 clusters of 50): every
+    pairwise edit distance of the homopolymer-compressed reads of a cluster (K4; collapse.py:373-387) and every read's junction alignment
+    with CIGAR at 10/4/8/2 (K1w + K1b; collapse.py:466-473).  Size-independent properties over the whole batch -- d(x, y) = d(y, x),
+    d(x, x) = 0, the triangle inequality on triples of a cluster, a CIGAR that spells the read's span -- a sample against the oracles,
+    and the first clusters again as a batch of their own."""
+    import torch
+    torch.cuda.init()
+    import oracle_lib
+    from ciri_long_amd import hip, synth, utils
+    rng = np.random.Generator(np.random.PCG64(synth.SEEDS['C3'] + 5))
+    ncl, per = 2500, 50
+    B = 'ACGT'
+    reads, juncs, xs, ys, first_pair = [], [], [], [], []
+    for _c in range(ncl):
+        tm = synth.template(rng)
+        circ = ''.join(B[b] for b in tm)
+        cl = [''.join(B[b] for b in synth.mutate(np.roll(tm, int(rng.integers(0, len(tm)))), rng)) for _ in range(per)]
+        hpc = [utils.compress_seq(r) for r in cl]
+        first_pair.append(len(xs))
+        for i in range(per):
+            reads.append(cl[i]); juncs.append(circ[-25:] + circ[:25])
+            for j in range(i + 1, per):
+                xs.append(hpc[i]); ys.append(hpc[j])
+    npairs = len(xs)
+    assert len(reads) == 125000 and npairs == ncl * per * (per - 1) // 2
+    ctx = hip.default_context()
+    st = torch.cuda.current_stream().cuda_stream
+    ep = ctx.edit_plan(xs, ys); ep.run(st); d = ep.fetch()
+    # symmetry, identity: a second plan with 200 000 sampled pairs swapped and 5 000 (x, x)
+    pick = rng.integers(0, npairs, 200000)
+    ep2 = ctx.edit_plan([ys[k] for k in pick] + [xs[k] for k in pick[:5000]], [xs[k] for k in pick] + [xs[k] for k in pick[:5000]])
+    ep2.run(st); d2 = ep2.fetch()
+    assert np.array_equal(d2[:200000], d[pick]) and not d2[200000:].any()
+    # triangle inequality inside clusters: pair (i, j) of a cluster sits at first_pair + i * per - i (i + 1) / 2 + (j - i - 1)
+    def at(c, i, j):
+        i, j = (i, j) if i < j else (j, i)
+        return first_pair[c] + i * per - i * (i + 1) // 2 + (j - i - 1)
+    for _ in range(20000):
+        c = int(rng.integers(0, ncl)); i, j, k = (int(v) for v in rng.choice(per, 3, replace=False))
+        assert d[at(c, i, k)] <= d[at(c, i, j)] + d[at(c, j, k)]
+    for k in rng.integers(0, npairs, 1500):
+        assert int(d[k]) == oracle_lib.oracle_edit_distance(xs[k], ys[k]), k
+    # junction alignments, all 125 000
+    qd, qo = hip.pack([r + r for r in reads]); fd, fo = hip.pack(juncs)
+    d_q = torch.from_numpy(qd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
+    sp = ctx.plan(qo, fo, hip.score_matrix(10, 4), 8, 2, flag=1, score_size=2, want_score2=False, want_cigar=True)
+    sp.run(d_q.data_ptr(), d_f.data_ptr(), st)
+    rows, cig = sp.fetch()
+    sp.close()
+    assert int((rows['status'] & ~9).sum()) == 0
+    ops = [cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']] for r in rows[:20000]]
+    for r, c in zip(rows[:20000], ops):           # the CIGAR spells the read's span (banded_sw walks every read row, ssw.c:636-714; it may stop short of the first reference column)
+        n, o = c >> 4, c & 15
+        assert int(n[(o == 0) | (o == 1)].sum()) == int(r['read_end1']) - int(r['read_begin1']) + 1
+        assert 0 < int(n[(o == 0) | (o == 2)].sum()) <= int(r['ref_end1']) - int(r['ref_begin1']) + 1
+    for k in rng.integers(0, len(reads), 400):
+        w = oracle_lib.oracle_align(juncs[k], reads[k] + reads[k], 10, 4, 8, 2)
+        r = rows[k]
+        assert (int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])) == (w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']), k
+        assert [int(v) for v in cig[r['cigar_off']:r['cigar_off'] + r['cigar_len']]] == w['cigar'], k
+    # the first 100 clusters as a batch of their own: the same rows and distances
+    m = 100 * per
+    qd, qo = hip.pack([r + r for r in reads[:m]]); fd, fo = hip.pack(juncs[:m])
+    rows_s, cig_s = ctx.ssw_batch(qd, qo, fd, fo, hip.score_matrix(10, 4), 8, 2, want_score2=False, want_cigar=True)
+    for f in ('score1', 'ref_begin1', 'ref_end1', 'read_begin1', 'read_end1', 'cigar_len'):
+        assert np.array_equal(rows_s[f], rows[f][:m]), f
+    ep3 = ctx.edit_plan(xs[:first_pair[100]], ys[:first_pair[100]]); ep3.run(st)
+    assert np.array_equal(ep3.fetch(), d[:first_pair[100]])
+
+
 def test_one_round_of_the_fuzz_harness(monkeypatch, capsys):
     """tests/fuzz_parity.py is the long-running parity hunt (run by hand for minutes); one short run of it belongs to
     the suite, so that the driver's GPU run exercises every kernel family on fresh random shapes too: alignments (six scoring schemes,

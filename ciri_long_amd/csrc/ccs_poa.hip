@@ -106,11 +106,12 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
     const int64_t off = p.read_off[rd];
     const int L = (int)(p.read_off[rd + 1] - off);
     const int8_t* seq = p.reads + off;
-    CcsScan out;
-    out.period = 0; out.ncuts = 0; out.support = 0;
+    // the read's record is written where it lives (a record per thread would sit in scratch: 272 bytes x 256 threads per read)
+    CcsScan* const rec = p.scan + rd;
+    auto none = [&]() { if (lane == 0) { rec->period = 0; rec->ncuts = 0; rec->support = 0; } };
     // lanes exchange data through the arrays: LDS needs a barrier, the HBM workspace also a cache invalidate
     auto sync = [&]() { if constexpr (sizeof(NextT) == 4) phase_sync(); else __syncthreads(); };
-    if (L < 2 * CCS_DMIN) { if (lane == 0) p.scan[rd] = out; return; }
+    if (L < 2 * CCS_DMIN) { none(); return; }
 
     // The specification counts, per offset d, the positions i with equal valid k-mers at i and i+d: that is one count per
     // PAIR of equal k-mers.  A read of L bases has O(L * copies) such pairs, not O(L^2/4): the positions are chained per
@@ -164,7 +165,7 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
         for (int v = 1; v < NT / 64; ++v) { const int b2 = red[2 * v], d2 = red[2 * v + 1]; if (b2 > best || (b2 == best && d2 < bestd)) { best = b2; bestd = d2; } }
     }
     sync();
-    if (best < CCS_MIN_SUPPORT) { if (lane == 0) p.scan[rd] = out; return; }
+    if (best < CCS_MIN_SUPPORT) { none(); return; }
     int p0 = bestd;
     for (int q = 2; q <= 8; ++q) {
         const int c = (bestd + q / 2) / q;
@@ -224,11 +225,11 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
         if (bs < 0) break;
         b += bdel;
         prev = bdel;
-        if (lane == 0) out.cuts[n] = b;
+        if (lane == 0) rec->cuts[n] = b;
         ++n;
     }
-    if (n >= 2) { out.period = p0; out.ncuts = n; out.support = best; }
-    if (lane == 0) p.scan[rd] = out;
+    if (n < 2) { none(); return; }
+    if (lane == 0) { rec->period = p0; rec->ncuts = n; rec->support = best; }
 }
 
 template <int NT>

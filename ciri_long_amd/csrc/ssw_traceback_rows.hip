@@ -16,9 +16,15 @@
 //     X = the cell's value without its horizontal gap), one wave scan per row as in ssw_scan.hip.
 // Cells outside the band or the reference read as H = E = F = 0 exactly as the sentinel slots of ssw.c:596 make them;
 // the one exception (the sentinel at `edge` overwriting the live last reference column, see ssw_traceback.hip) is a
-// per-row fix-up.  The band doubling loop (ssw.c:560,631-632: running maximum not reset) runs score-only passes; only the
-// final band is computed with direction codes, 4 bits per cell (H move: diagonal / E / F; E opened; F opened), row-major:
-// ~16 kB per C2 alignment instead of one byte per cell for every band iteration.
+// per-row fix-up.  The band doubling loop (ssw.c:560,631-632: running maximum not reset): the first iteration score-only, every
+// later one with direction codes (so the last is not run twice), 4 bits per cell (H move: diagonal / E / F; E opened; F opened),
+// row-major: ~16 kB per C2 alignment and iteration instead of one byte per cell.
+//
+// Round 4.  Bands above 512 cells (and bands laid out by reference column) belong to the WIDE form: a workgroup of 8 waves per band
+// pass, the offsets split over the waves (tb_rows_pass<.., NW>: neighbour cells, the F scan's carries and the "F opened" comparison
+// cross the waves through LDS, two light barriers per row); the narrow launch hands over the state of its doubling loop, the next
+// three iterations of every handed-over alignment run side by side (ssw_traceback_rows_wide_pass_kernel), the loop is replayed over
+// their maxima and wave 0 walks (ssw_traceback_rows_wide_kernel).  The walk takes runs of diagonal moves in one step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>

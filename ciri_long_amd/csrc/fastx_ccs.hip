@@ -5,9 +5,10 @@
 // without its leading '>' / '@' characters, consensus of every read, and the two tmp files in the reference's format
 // (find_ccs.py:94-95):  tmp/{prefix}.ccs.fa  ">{header}\t{segments}\t{len(ccs)}\n{ccs}\n"   and
 //                       tmp/{prefix}.raw.fa  ">{header}\n{raw sequence}\n"   -- reads with a consensus only, input order.
-// The Python loop handles ~10^5 reads/s; K2+K3 handle ~4*10^6.  Here three threads work on three rotating batches: a reader
-// parses and encodes (zlib's gzread serves plain and gzip files alike), the calling thread runs the batch on the GPU, a writer
-// formats and writes the two files.
+// The Python loop handles ~10^5 reads/s; K2+K3 handle ~4*10^6.  Here four threads work on six rotating batches of 32 MiB of file: a
+// reader fills a batch (read(2); gzread for gzip files), a parser finds the records in place and encodes the bases, the calling thread
+// keeps two batches on the device (plan, copies and launch of one under the kernels of the other), a writer formats and writes the two
+// files.  The batches' buffers outlive the call (clh_ccs_file_release_buffers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

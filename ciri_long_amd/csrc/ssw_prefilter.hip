@@ -8,7 +8,9 @@
 // most  M * L - c * d(j)  (proof and CPU model: tools/prefilter_model.py, tests/test_prefilter_model.py), so once some score S0
 // has been attained anywhere, only blocks with a minimum <= (M L - S0) / c can hold the maximum or tie it.  ssw_scan.hip
 // (ssw_scan_pick_kernel) attains S0 around the smallest minimum, turns the blocks that pass into slices and K1s runs on those;
-// when too many pass it writes the static slices instead -- the answer never depends on this kernel.
+// when too many pass it writes the static slices instead -- the answer never depends on this kernel.  Windows this bound cannot thin out
+// (clips whose best score is about half their length: the unit-cost distance of a clip to random text is only ~0.46 L) go through a SECOND
+// stage with the indel distance, ssw_prefilter_indel_kernel below.
 //
 // Scheme: Myers' bit-vector recurrence, semi-global (free start in the window: the horizontal delta entering row 0 is 0).  The
 // read's rows are the bits of W = ceil(L / 32) registers (L <= 254: W <= 8; a longer read goes through in PIECES of <= 254 rows, each

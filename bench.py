@@ -171,11 +171,14 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
     """per read-length class HIP-event durations of K1 (and K1b), with their algorithmic bytes and cell counts"""
     ssw_plan.set_profiling(True)
     acc, accb = None, [0.0, 0.0]
+    pf_ms, pf_work = [0.0, 0.0], [(0, 0), (0, 0)]
     for _ in range(PROF):
         run()
         tm, tb = ssw_plan.timing()
         acc = tm if acc is None else [x + y for x, y in zip(acc, tm)]
         accb = [accb[0] + tb[0], accb[1] + tb[1]]
+        for k, (ms, wc, li) in enumerate(ssw_plan.prefilter_timing()):
+            pf_ms[k] += ms / PROF; pf_work[k] = (wc, li)
     srow, _c = ssw_plan.fetch()
     ssw_plan.set_profiling(False)
     qlen = np.diff(qoff)
@@ -216,7 +219,26 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
             'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,
             'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / 6 packed ops per cell pair (gapO == gapE path)'}
     valu['frac'] = valu['achieved'] / valu['peak'] if valu['achieved'] else None
+    if sum(pf_ms) > 0:
+        # the first stage of the prefilter against ITS bound: one lane walks one window column per 11 W + 8 integer instructions (W = 32-row
+        # words of the read), v_addc / v_bitop3 / v_alignbit at one wave instruction per 4 cycles and SIMD; nothing else is counted
+        li = sum(w[1] for w in pf_work); wc = sum(w[0] for w in pf_work); t = sum(pf_ms) * 1e-3
+        valu['prefilter'] = {'bound': 'valu-issue', 'kernel': 'ssw_prefilter_kernel', 'unit': 'T lane-instructions/s', 'ms': sum(pf_ms),
+                             'word_columns': wc, 'lane_instructions': li, 'word_columns_per_s': wc / t,
+                             'achieved': li / t / 1e12, 'peak': PK_ISSUE_PEAK * 64 / 1e12, 'frac': li / t / (PK_ISSUE_PEAK * 64),
+                             'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction x 64 lanes; work = window columns x (11 W + 8), W = ceil(rows / 32) per piece of the read'}
     return out, valu
+
+
+def split_prefilter(valu):
+    """Behind the prefilter most cells of read x window are never computed: cells / time against a cell-update peak is then no roofline
+    fraction (round 4 printed 3.2-3.6).  Such a line carries the prefilter kernel's own issue-rate object instead; the cell rate
+    stays as `effective_gcups`, a figure without a peak."""
+    pf = valu.pop('prefilter', None)
+    if pf is None:
+        return {'valu_roofline': valu}
+    return {'prefilter_roofline': pf, 'effective_gcups': valu.get('achieved'),
+            'effective_note': 'read x window cells of every alignment / K1 time: most of them are never computed behind the prefilter -- an effective rate, no roofline'}
 
 
 class FullStep(object):
@@ -423,7 +445,7 @@ def run_full(torch, dist, hip, synth, ctx, wl, nreads, rank, world, steps, warmu
         same = all((r1[f] == r2[f]).all() for f in ('score1', 'ref_begin1', 'ref_end1', 'read_begin1', 'read_end1'))
         assert same, 'prefilter changed an answer'
         pf_check = '%d clips re-run without the prefilter (static window slices): rows identical' % m
-    res = {'value': world * nreads * steps / el, 'ms_per_step': el / steps * 1e3, 'launches': launches, 'valu_roofline': valu, 'valu_roofline_k3': fs.k3_valu,
+    res = {'value': world * nreads * steps / el, 'ms_per_step': el / steps * 1e3, 'launches': launches, **split_prefilter(valu), 'valu_roofline_k3': fs.k3_valu,
            'roofline': roofline_of(launches), 'reads_with_consensus': int(len(fs.has)),
            'counters': dict(zip(['total', 'consensus', 'raw_unmapped', 'ccs_mapped', 'bsj', 'signal', 'partial'], [int(x) for x in counters])),
            'splice_handed_back': int((sig[:, 0] != 0).sum()), 'counter_exchange': res_exchange}
@@ -551,9 +573,8 @@ def extra_production_shape(torch, hip, synth, ctx, n=4000, r03_strands=False):
     return {'workload': 'production shape: %d clips of 20-300 nt (raw-read error rates) vs hit +- 200 kb windows of a resident 20 Mb genome, both strands (K5 count_n + K1, rows to the host); %s'
                         % (n, 'clips drawn from the plus strand only: the minus-strand half has no locus in its window (the line of rounds 2-3)' if r03_strands else
                            'every clip drawn from its window in the window\'s orientation (find_bsj.py:214: minus-strand hits align against revcomp(window))'),
-            'value': n / el, 'unit': 'clips/s', 'ms_per_step': el * 1e3, 'launches': launches, 'valu_roofline': valu, 'roofline': roofline_of(launches, True),
-            'prefilter': pf, 'mean_score_over_len': float(np.mean(rows['score1'] / np.diff(co))),
-            'valu_note': 'cells = read x window of every alignment: with the prefilter most of them are never computed, so GCUPS here is an EFFECTIVE rate, not an issue rate'}
+            'value': n / el, 'unit': 'clips/s', 'ms_per_step': el * 1e3, 'launches': launches, 'roofline': roofline_of(launches, True),
+            'prefilter': pf, 'mean_score_over_len': float(np.mean(rows['score1'] / np.diff(co))), **split_prefilter(valu)}
 
 
 def extra_collapse(torch, hip, synth, ctx, ncl=200):
@@ -611,7 +632,10 @@ def extra_stage1(hip, synth, ctx, n=100000):
                 s = B_ASCII[r].tobytes()
                 f.write(b'@read%07d\n' % k + s + b'\n+\n' + b'I' * len(s) + b'\n')
         size = os.path.getsize(fq)
+        ctx.release_file_buffers()               # the first call makes the stage's host and device buffers anew: the cold figure
+        t0 = time.perf_counter()
         ctx.ccs_file(fq, 1, os.path.join(d, 'w.ccs.fa'), os.path.join(d, 'w.raw.fa'))
+        cold = time.perf_counter() - t0
         els = []
         for k in range(3):              # three timed calls (own output files each), the median counts: the stage keeps its host buffers between calls
             t0 = time.perf_counter()
@@ -622,7 +646,9 @@ def extra_stage1(hip, synth, ctx, n=100000):
         shutil.rmtree(d, ignore_errors=True)
     return {'workload': 'stage 1 file to files: %d-read FASTQ (%d MB) -> tmp/*.ccs.fa + *.raw.fa (parse, encode, K2+K3, write)' % (tot, size >> 20),
             'e2e_stage1_reads_per_s': tot / el, 'value': tot / el, 'unit': 'reads/s', 'fastq_MB_per_s': size / el / 1e6, 'reads_with_consensus': int(ro),
-            'calls_s': [round(x, 4) for x in els], 'note': 'median of three calls after one warm-up call',
+            'cold_value': tot / cold, 'first_timed_call_value': tot / els[0], 'cold_call_s': round(cold, 4), 'calls_s': [round(x, 4) for x in els],
+            'note': 'value = warm: median of three calls after the cold one (file in the page cache, the stage\'s host and device buffers kept between calls); '
+                    'cold_value = the first call, which allocates and faults in those buffers (~450 MB); first_timed_call_value = the first warm call',
             'roofline': {'bound': 'host', 'note': 'bound by the host threads (read, parse, format + write), not by a kernel (DESIGN.md section 8)'}}
 
 
@@ -660,6 +686,120 @@ def extra_stage2(hip, synth, ctx, n=50000):
             'mapper_calls': m.calls, 'reads_per_s_with_the_double': n / el, 'counters': dict(cnt),
             'roofline': {'bound': 'host', 'note': 'per-read Python around the external mapper (find_bsj.py:236-325, align.py helpers); a real minimap2 call costs '
                                                   'about a millisecond per read, i.e. far more than everything measured here'}}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The record.  stdout carries ONE line of at most LINE_MAX characters (the driver parses the last stdout line and keeps a short
+# tail of it: round 4's 21 kB line came back unparsed); everything else -- per-class launches, the extra workloads in full,
+# notes -- goes to bench_detail.json beside this file and to stderr.
+# ------------------------------------------------------------------------------------------------------------------
+LINE_MAX = 4096
+ROOFLINE_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launch_ms', 'alg_bytes_per_launch')
+
+
+def _r(x, nd=4):
+    """numbers short enough for the line: 4 significant figures for fractions, integers for byte counts"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float('%.*g' % (max(nd, 1) + 2, x))
+    return x
+
+
+def _roofline_short(r):
+    if not r:
+        return None
+    o = {k: _r(r.get(k)) for k in ROOFLINE_KEYS if k in r}
+    if isinstance(o.get('kernel'), str) and len(o['kernel']) > 80:
+        o['kernel'] = o['kernel'][:77] + '...'
+    return o
+
+
+def summary_of(out):
+    """every configuration's number in a few dozen bytes each"""
+    k3 = out.get('valu_roofline_k3') or {}
+    summ = {'c3_or_main_reads_per_s': round(out['value']), 'ms_per_step': round(out['ms_per_step'], 2),
+            'k3_ms': next((round(x['ms'], 2) for x in out.get('launches', []) if x['kernel'] == 'poa_consensus_kernel'), None),
+            'k3_valu_frac': _r(k3.get('frac')), 'roofline_frac': _r((out.get('roofline') or {}).get('frac'))}
+    for k, e in (out.get('extra') or {}).items():
+        if isinstance(e, dict) and 'value' in e:
+            s = {'value': round(e['value']), 'unit': e.get('unit')}
+            if 'ms_per_step' in e:
+                s['ms'] = round(e['ms_per_step'], 2)
+            for name, key in (('hbm_frac', 'roofline'), ('valu_frac', 'valu_roofline'), ('k3_valu_frac', 'valu_roofline_k3'), ('pf_frac', 'prefilter_roofline')):
+                f = (e.get(key) or {}).get('frac')
+                if f is not None:
+                    s[name] = _r(f, 3)
+            for key in ('cold_value',):
+                if key in e:
+                    s[key] = round(e[key])
+            summ[k] = s
+    if (out.get('extra') or {}).get('error'):
+        summ['extra_error'] = out['extra']['error'][:160]
+    return summ
+
+
+def short_line(out, detail_path='bench_detail.json'):
+    """the ONE stdout line: the contract's keys, `roofline` with `traffic`, `valu_roofline_k3`, `cpu_baseline`, `summary`"""
+    cfg = dict(out.get('config') or {})
+    if isinstance(cfg.get('workload'), str) and len(cfg['workload']) > 300:
+        cfg['workload'] = cfg['workload'][:297] + '...'
+    if isinstance(cfg.get('consensus_parity'), str):
+        cfg['consensus_parity'] = cfg['consensus_parity'][:60].split(' (')[0]
+    line = {k: out.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                    'vs_baseline', 'dtype', 'data')}
+    line['value'] = _r(line['value'], 6)
+    line['ms_per_step'] = _r(line['ms_per_step'], 4)
+    line['config'] = cfg
+    line['roofline'] = _roofline_short(out.get('roofline'))
+    k3 = out.get('valu_roofline_k3')
+    if k3:
+        line['valu_roofline_k3'] = {k: _r(k3.get(k)) for k in ('bound', 'kernel', 'unit', 'achieved', 'peak', 'frac', 'cells_per_launch')}
+    v = out.get('valu_roofline')
+    if v:
+        line['valu_roofline'] = {k: _r(v.get(k)) for k in ('bound', 'unit', 'achieved', 'peak', 'frac')}
+    if out.get('prefilter_roofline'):
+        line['prefilter_roofline'] = {k: _r(x) for k, x in out['prefilter_roofline'].items() if k != 'peak_note'}
+    cpu = out.get('cpu_baseline')
+    if cpu:
+        cpu = {k: cpu.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+        cpu['value'] = _r(cpu['value'], 5)
+        if isinstance(cpu.get('sample'), str) and len(cpu['sample']) > 240:
+            cpu['sample'] = cpu['sample'][:237] + '...'
+    line['cpu_baseline'] = cpu
+    if out.get('counters'):
+        line['counters'] = out['counters']
+    if out.get('counter_exchange'):
+        line['counter_exchange'] = out['counter_exchange']
+    line['summary'] = out.get('summary')
+    line['detail'] = detail_path
+    text = json.dumps(line, separators=(',', ':'))
+    if len(text) > LINE_MAX:        # never print a line the driver cannot keep: shed the optional parts, longest first
+        for k in ('counter_exchange', 'counters', 'valu_roofline', 'prefilter_roofline'):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(',', ':'))
+            if len(text) <= LINE_MAX:
+                break
+    if len(text) > LINE_MAX:
+        line['summary'] = {k: (x if not isinstance(x, dict) else {'value': x.get('value'), 'unit': x.get('unit')}) for k, x in (line['summary'] or {}).items()}
+        text = json.dumps(line, separators=(',', ':'))
+    assert len(text) <= LINE_MAX, len(text)
+    return text
+
+
+def emit(out, detail_path=None):
+    """detail to bench_detail.json (and stderr), the short line -- alone -- to stdout"""
+    detail_path = detail_path or os.path.join(ROOT, 'bench_detail.json')
+    full = json.dumps(out)
+    try:
+        with open(detail_path, 'w') as f:
+            f.write(full + '\n')
+    except OSError as ex:
+        sys.stderr.write('bench.py: could not write %s: %r\n' % (detail_path, ex))
+    sys.stderr.write(full + '\n')
+    sys.stderr.flush()
+    sys.stdout.write(short_line(out, os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path) + '\n')
+    sys.stdout.flush()
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -705,6 +845,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--prod-windows', action='store_true', help='c3 / c4 with the reference\'s own clip window (hit +- 200 kb, find_bsj.py:196-197) instead of 2 kb: the extra line c3_production_windows as the main workload (for profiling)')
+    ap.add_argument('--detail', default=None, help='where the full record goes (default: bench_detail.json beside bench.py); stdout carries one short line')
     ap.add_argument('--no-extra', action='store_true', help='skip the extra lines (c2, c4, production shape, collapse, stage 1)')
     args = ap.parse_args()
     wl = args.workload
@@ -774,11 +915,11 @@ def main():
             'reads_per_gpu': nreads, 'window': 'hit +- 200 kb' if args.prod_windows else WINDOW, 'scoring': '1/1/1/1',
             'parallelism': 'reads sharded x%d, no data-path collective%s' % (world, '; int64[7] counter all-reduce on RCCL after the timed loop' if world > 1 else ''),
             'consensus_parity': 'unpinned (pyccs/spoa absent from the reference tree; clh-poa v3 restates the published spoa algorithm, no departures, oracle/poa_oracle.c)' if full else None},
-        'roofline': res['roofline'], 'valu_roofline': res['valu_roofline'],
+        'roofline': res['roofline'], 'valu_roofline': res.get('valu_roofline'),
     }
     if 'valu_roofline_k3' in res:
         out['valu_roofline_k3'] = res['valu_roofline_k3']      # the kernel that is most of the step
-    for k in ('prefilter', 'prefilter_check'):
+    for k in ('prefilter', 'prefilter_check', 'prefilter_roofline', 'effective_gcups', 'effective_note'):
         if k in res:
             out[k] = res[k]
     if 'reads_with_consensus' in res:
@@ -808,22 +949,9 @@ def main():
             extra['error'] = repr(ex)
         out['extra'] = extra
     out['launches'] = res['launches']
-    # LAST, and short: a reader that keeps only the end of this line (the driver's record keeps 2000 characters) still sees every
-    # configuration's number
-    summ = {'c3_or_main_reads_per_s': round(res['value']), 'ms_per_step': round(res['ms_per_step'], 2),
-            'k3_ms': next((round(x['ms'], 2) for x in res['launches'] if x['kernel'] == 'poa_consensus_kernel'), None),
-            'k3_valu_frac': round(res['valu_roofline_k3']['frac'], 4) if res.get('valu_roofline_k3', {}).get('frac') else None,
-            'roofline_frac': res['roofline']['frac']}
-    for k, e in (out.get('extra') or {}).items():
-        if isinstance(e, dict) and 'value' in e:
-            summ[k] = {'value': round(e['value']), 'unit': e.get('unit'), 'ms_per_step': round(e['ms_per_step'], 2) if 'ms_per_step' in e else None,
-                       'roofline_frac': (e.get('roofline') or {}).get('frac'), 'valu_frac': (e.get('valu_roofline') or {}).get('frac'),
-                       'k3_valu_frac': (e.get('valu_roofline_k3') or {}).get('frac')}
-    if out.get('extra', {}).get('error'):
-        summ['extra_error'] = out['extra']['error'][:200]
-    out['summary'] = summ
+    out['summary'] = summary_of(out)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, args.detail)
     if use_dist:
         dist.destroy_process_group()
 

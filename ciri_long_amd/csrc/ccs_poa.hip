@@ -2143,7 +2143,8 @@ __device__ __forceinline__ void poa_kernel_body(const CcsParams& p)
         }
         const int ncap = total + 8, mcap = maxlen + 1;
         // cells beyond int16: the wide form of the pass (spoa's engines do the same), in its own kernel
-        auto to_wide_list = [&]() { if (lane == 0) { const int k = atomicAdd(p.wide_count, 1); p.wide_list[k] = rd; } };
+        // (the read's row is written as "nothing yet": rows are recycled memory, and the second launch takes only rows that say status 1)
+        auto to_wide_list = [&]() { if (lane == 0) { p.results[rd] = res; const int k = atomicAdd(p.wide_count, 1); p.wide_list[k] = rd; } };
         if (!WIDE && (force_wide || maxlen > POA_MAX_COPY)) { if (p.tier == 0) to_wide_list(); continue; }
         constexpr bool wide = WIDE;
         // workspace: this wave's slot, or -- a read that needs more -- one of the large slots, claimed for the duration of
@@ -2213,8 +2214,8 @@ __device__ __forceinline__ void poa_kernel_body(const CcsParams& p)
             }
             break;
         }
-        if (!WIDE && N == -4 && p.tier == 0) {            // a cell left the int16 range: the read once more in the wide form (a read of the
-            to_wide_list();                                // second launch keeps status 6: the wide kernel's list is closed by then)
+        if (!WIDE && N == -4) {                           // a cell left the int16 range: the read once more in the wide form (either launch of the
+            to_wide_list();                                // packed kernel may say so: the wide kernel runs behind both on the same stream)
             __syncthreads();
             if (big >= 0) { __threadfence(); if (lane == 0) atomicExch(&p.big_busy[big], 0); }
             continue;

@@ -151,6 +151,10 @@ struct clh_plan {
              *d_bound = nullptr, *d_parts = nullptr, *d_q2 = nullptr;
         int ws_row0 = 0, ws_slot = 0, ws_wgs = 0;
         int64_t ws_dirs_off = 0;
+        int64_t extent = 0;                      // bytes of the refs buffer the kernel reads: the end of the last 256-byte block a window touches
+        int64_t word_cols = 0, lane_insts = 0;   // the first stage's work: window columns x W words, and x (11 W + 8) instructions
+        hipEvent_t ev[2] = {nullptr, nullptr};   // profiling runs: around ssw_prefilter_kernel
+        bool timed = false;
     } pf[2];
     int n_rows = 0;                          // result rows: n_all + the scratch rows of the K1w long-window class
     std::vector<int32_t> slice_base;         // task-level slices of the anti-diagonal classes: first window column of scratch row k
@@ -166,6 +170,7 @@ struct clh_plan {
     hipEvent_t done_ev = nullptr;           // recorded behind the run's last launch: fetch waits for the RUN, not for what the caller queued later
     bool ran = false;
     bool profiling = false;
+    int64_t refs_bytes = -1;                 // size of the caller's refs buffer if stated (clh_plan_set_refs_bytes), else -1
     std::vector<hipEvent_t> chain_ev;   // between the parts of a split K1w class
     std::vector<hipEvent_t> ev;     // per segment: K1 start, K1 stop; then K1b small-window start/stop, large-window start/stop
 };
@@ -181,6 +186,7 @@ extern "C" void clh_plan_destroy(clh_plan* pl)
     for (void* b : bufs) c->release(b);
     for (auto& f : pl->pf) { void* pb[] = {f.d_win, f.d_pieces, f.d_work, f.d_dmin, f.d_queue, f.d_out, f.d_ctl, f.d_bound, f.d_parts, f.d_q2}; for (void* b : pb) c->release(b); }
     for (hipEvent_t e : pl->ev) (void)hipEventDestroy(e);
+    for (auto& f : pl->pf) for (hipEvent_t e : f.ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : pl->chain_ev) (void)hipEventDestroy(e);
     if (pl->done_ev) (void)hipEventDestroy(pl->done_ev);
     delete pl;
@@ -410,6 +416,7 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
             const int64_t R = t.ref_len;
             if (t.ref_rc) { const int64_t hi = t.ref_off, lo = hi - R + 1; w.mem_block0 = (int32_t)(hi >> 8); w.phase = (int32_t)(255 - (hi & 255)); w.nsub = (int32_t)((hi >> 8) - (lo >> 8) + 1); }
             else { const int64_t lo = t.ref_off, hi = lo + R - 1; w.mem_block0 = (int32_t)(lo >> 8); w.phase = (int32_t)(lo & 255); w.nsub = (int32_t)((hi >> 8) - (lo >> 8) + 1); }
+            f.extent = std::max<int64_t>(f.extent, (((t.ref_rc ? t.ref_off : t.ref_off + R - 1) >> 8) + 1) << 8);
             const int L = t.read_len, K = (L + 253) / 254;
             w.piece_first = (int32_t)pieces.size(); w.piece_count = K; w.d_off = (int32_t)dtot;
             dtot += w.nsub;
@@ -417,6 +424,8 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
                 const int rows = L / K + (q < L % K ? 1 : 0);
                 pieces.push_back({k, r0, rows, (int32_t)total});
                 r0 += rows; total += w.nsub;
+                const int64_t Wq = (rows + 31) / 32;
+                f.word_cols += R * Wq; f.lane_insts += R * (11 * Wq + 8);
             }
             cap += ci == 0 ? std::max<int64_t>(64, w.nsub / 8 + 1) : 2 * 64;
             lmax = std::max(lmax, L);
@@ -742,6 +751,18 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         HIPCHK(clh::launch_traceback_pool(rvbig, PG, first, count, pl->n_all, seg, pool, head, pl->pool_bytes, ls));
         return 0;
     };
+    // the first stage of the prefilter, with its own pair of events in profiling runs (clh_plan_prefilter_timing)
+    auto prefilter = [&](clh_plan::PfClass& f, hipStream_t ls) -> int {
+        f.timed = false;
+        if (!P.pf_dmin) return 0;
+        if (pl->profiling) {
+            for (auto& e : f.ev) if (!e) HIPCHK(hipEventCreate(&e));
+            HIPCHK(hipEventRecord(f.ev[0], ls));
+        }
+        HIPCHK(clh::launch_ssw_prefilter(P, f.nwork, ls));
+        if (pl->profiling) { HIPCHK(hipEventRecord(f.ev[1], ls)); f.timed = true; }
+        return 0;
+    };
     P.slice_base = (const int32_t*)pl->d_slice_base; PG.slice_base = P.slice_base;
     int rv_all = 4;                                              // longest read class of the plan (the combined alignments have any length)
     for (const auto& s : pl->segs) rv_all = std::max(rv_all, s.rv == clh::kRvStrips ? 32 : s.rv);
@@ -762,19 +783,21 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
             // block minima of the bound, then seed + candidate slices (tasks), the slices, the finish -- one chain on the class's stream.
             // The prefilter reads the window text in address-aligned 256-byte blocks of the refs buffer: a buffer that is not
             // aligned so keeps the static slices (the pick kernels write them)
-            const clh_plan::PfClass& f = pl->pf[s.rv == clh::kRvScanSliced ? 0 : 1];
+            clh_plan::PfClass& f = pl->pf[s.rv == clh::kRvScanSliced ? 0 : 1];
             P.pf_win = (const clh::PfWin*)f.d_win; P.pf_tasks = (const clh::PfTask*)f.d_pieces; P.pf_work = (const clh::PfWork*)f.d_work;
             P.pf_out = (clh::PfOut*)f.d_out; P.pf_ctl = (clh::PfCtl*)f.d_ctl; P.pf_bpl = f.bpl; P.pf_cap = f.cap;
-            P.pf_dmin = ((uintptr_t)d_refs & 255) == 0 ? (uint8_t*)f.d_dmin : nullptr;
+            // ... nor does one whose stated size (clh_plan_set_refs_bytes) ends inside the last block a window touches
+            P.pf_dmin = ((uintptr_t)d_refs & 255) == 0 && (pl->refs_bytes < 0 || f.extent <= pl->refs_bytes) ? (uint8_t*)f.d_dmin : nullptr;
             HIPCHK(hipMemsetAsync(f.d_ctl, 0, sizeof(clh::PfCtl), ls));
             if (s.rv == clh::kRvScanSliced) {
                 P.pf_slices = (clh::ScanSlice*)f.d_queue; P.parts = (clh::ScanPart*)f.d_parts; P.pf_q2 = (int32_t*)f.d_q2; P.pf2_always = getenv("CLH_PF2_ALWAYS") != nullptr; P.pf2_share = getenv("CLH_PF2_SHARE") ? std::max(1, atoi(getenv("CLH_PF2_SHARE"))) : 8;
-                if (P.pf_dmin) HIPCHK(clh::launch_ssw_prefilter(P, f.nwork, ls));
+                if (int rc = prefilter(f, ls)) return rc;
                 HIPCHK(clh::launch_ssw_scan_filtered(pl->quirk, P, s.count, std::min(f.cap, c->n_cu * 12), std::min(f.nwork, c->n_cu * 16), ls));
             } else {
                 P.ws_tasks = (clh::WsTask*)f.d_queue; P.ws_bound = (uint16_t*)f.d_bound; P.ws_row0 = f.ws_row0; P.ws_slot_bytes = f.ws_slot;
                 P.ws_dirs_off = f.ws_dirs_off;
-                HIPCHK(clh::launch_ssw_scanw_filtered(pl->quirk, P, s.count, f.ws_wgs, P.pf_dmin != nullptr, f.nwork, ls));
+                if (int rc = prefilter(f, ls)) return rc;
+                HIPCHK(clh::launch_ssw_scanw_filtered(pl->quirk, P, s.count, f.ws_wgs, P.pf_dmin != nullptr, ls));
             }
         } else if (s.rv == clh::kRvScanSliced) {
             P.slices = (const clh::ScanSlice*)pl->d_slices; P.parts = (clh::ScanPart*)pl->d_parts;
@@ -824,6 +847,13 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     HIPCHK(hipEventRecord(pl->done_ev, st));
     pl->last_stream = st;
     pl->ran = true;
+    return 0;
+}
+
+extern "C" int clh_plan_set_refs_bytes(clh_plan* pl, int64_t nbytes)
+{
+    if (!pl) return fail(CLH_E_ARG, "null plan");
+    pl->refs_bytes = nbytes;
     return 0;
 }
 
@@ -894,6 +924,25 @@ extern "C" int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out)
         clh::PfCtl c;
         HIPCHK(hipMemcpy(&c, f.d_ctl, sizeof(c), hipMemcpyDeviceToHost));
         out[0] += f.ntasks; out[1] += c.n_pruned; out[2] += c.qcount; out[3] += (int64_t)c.cols_scanned; out[4] += (int64_t)c.cols_window; out[5] += c.n_stage2;
+    }
+    return 0;
+}
+
+// ssw_prefilter_kernel alone in the last (profiling) run: ms[ci] = its duration for the K1s class (0) and the K1w class (1), 0 when it did
+// not run; work[2 ci] = window columns x W words of the read's pieces, work[2 ci + 1] = the same columns x (11 W + 8), the kernel's
+// instructions per column and lane -- what its issue-rate roofline counts
+extern "C" int clh_plan_prefilter_timing(clh_plan* pl, float* ms, int64_t* work)
+{
+    if (!pl || !ms || !work) return fail(CLH_E_ARG, "clh_plan_prefilter_timing: null argument");
+    if (!pl->ran || !pl->profiling) return fail(CLH_E_ARG, "profiling was not enabled for the last run");
+    HIPCHK(hipSetDevice(pl->ctx->device));
+    HIPCHK(hipStreamSynchronize(pl->last_stream));
+    for (int ci = 0; ci < 2; ++ci) {
+        const auto& f = pl->pf[ci];
+        ms[ci] = 0.f; work[2 * ci] = work[2 * ci + 1] = 0;
+        if (!f.on || !f.timed) continue;
+        HIPCHK(hipEventElapsedTime(&ms[ci], f.ev[0], f.ev[1]));
+        work[2 * ci] = f.word_cols; work[2 * ci + 1] = f.lane_insts;
     }
     return 0;
 }
@@ -1606,7 +1655,9 @@ extern "C" int clh_poa_batch(clh_ctx* ctx, int32_t ngroups, const int8_t* seqs, 
     if (ngroups == 0) return 0;
     int mcap = 1;
     for (int64_t i = 0; i < group_off[ngroups]; ++i) mcap = std::max<int>(mcap, (int)(seq_off[i + 1] - seq_off[i]));
-    clh_ccs_plan* pl = ccs_plan_create(ctx, ngroups, roff.data(), mcap, (sc.algorithm & 0x200) != 0);
+    // (global and overlap alignments can sink below the 16-bit cells with any scores: their large slots are sized for the wide form, so that
+    // a group the packed kernel hands over finds room there)
+    clh_ccs_plan* pl = ccs_plan_create(ctx, ngroups, roff.data(), mcap, (sc.algorithm & 0x200) != 0 || (sc.algorithm & 0xff) != 0);
     if (!pl) return CLH_E_ARG;
     int rc = 0;
     const size_t total = (size_t)roff[ngroups];

@@ -241,7 +241,7 @@ hipError_t launch_ssw_prefilter(const SswParams& p, int nwork, hipStream_t strea
 hipError_t launch_ssw_prefilter_indel(const SswParams& p, int nworkgroups, hipStream_t stream);     // the second stage: persistent workgroups over the device-made queue
 hipError_t launch_ssw_scan_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, int nworkgroups2, hipStream_t stream);
 static constexpr int kRvScanWideSliced = -4;   // pseudo class: K1w on windows of 32 kb and more: prefilter in pieces, seed, candidate tasks, best row
-hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, bool with_prefilter, int nwork, hipStream_t stream);
+hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, bool with_prefilter, hipStream_t stream);
 static constexpr int kRvScanWide = -3;   // pseudo class: K1w, the row-scan kernel for reads of 255..4096 bases / scores above 254 (ssw_scan_wide.hip);
                                          // persistent workgroups; their workspaces inside `dirs` (scanw_task_bytes of the class's longest read)
 hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, int nworkgroups, int* counter, long long ws_off, int ws_slot, hipStream_t stream);
@@ -252,10 +252,11 @@ size_t scanw_task_bytes(int read_len);
 // [36 + seg] alignments handed on to the anti-diagonal kernel; the task indices from word 68 on, two arrays of n_total, a
 // class's entries at the offset of its first task.
 static constexpr int kTbMaxSeg = 32;
-inline size_t tb_head_bytes(int n_total) { return 4 * 68 + 6 * sizeof(int) * (size_t)(n_total > 0 ? n_total : 1); }
+inline size_t tb_lists_len(int n_total) { return ((size_t)(n_total > 0 ? n_total : 1) + 1) & ~(size_t)1; }     // even: the states behind the two lists stay 16-byte aligned (read as int4)
+inline size_t tb_head_bytes(int n_total) { return 4 * 68 + 2 * sizeof(int) * tb_lists_len(n_total) + 4 * sizeof(int) * (size_t)(n_total > 0 ? n_total : 1); }
 // behind the two lists: per entry of the first list, where the narrow kernel left the band doubling (ssw.c:560-632):
 // {band half-width of the next iteration, running maximum, iterations done, 0}
-inline int* tb_state_of(unsigned long long* head, int n_total, int task_base) { return (int*)head + 68 + 2 * (size_t)(n_total > 0 ? n_total : 1) + 4 * (size_t)task_base; }
+inline int* tb_state_of(unsigned long long* head, int n_total, int task_base) { return (int*)head + 68 + 2 * tb_lists_len(n_total) + 4 * (size_t)task_base; }
 inline void tb_lists_of(unsigned long long* head, int n_total, int seg, int task_base, int** n_small, int** n_big, int** list_small, int** list_big)
 {
     int* w = (int*)head;

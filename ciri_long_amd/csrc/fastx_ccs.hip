@@ -334,6 +334,8 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
     std::atomic<bool> stop_reader{false};             // the parser has all it wants (max_records): the reader shall not wait for a slot again
     auto wait_state = [&](int s, int want) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return state[s] == want; }); };
     auto set_state = [&](int s, int v) { { std::lock_guard<std::mutex> lk(mu); state[s] = v; } cv.notify_all(); };
+    // set under the mutex the reader's wait holds: a store between its predicate and its block would otherwise lose the wake-up
+    auto tell_reader_to_stop = [&]() { { std::lock_guard<std::mutex> lk(mu); stop_reader = true; } cv.notify_all(); };
     // plain or gzip?  (the magic bytes; gzread serves both, but copies a plain file once more on the way)
     int fd = -1;
     {
@@ -465,7 +467,7 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
             t_parse += now() - t0;
             set_state(s, 2);
         }
-        // (the reader may still be filling slots nobody will parse: it stops at the end of the file by itself; its slots are released below)
+        tell_reader_to_stop();         // nothing more will be parsed: the reader shall not fill further slots (up to six of 32 MB)
     };
     int wrc = 0;
     auto writer = [&]() {
@@ -573,8 +575,7 @@ extern "C" int clh_ccs_file_at(clh_ctx* ctx, const char* in_path, int is_fastq, 
     tw.join();
     tp.join();
     // the parser may have stopped before the end of the file (max_records): a reader waiting for a free slot is told to stop
-    stop_reader = true;
-    cv.notify_all();
+    tell_reader_to_stop();
     th.join();
     if (fd >= 0) close(fd);
     if (ftrace) fprintf(stderr, "[clh] file stage wall: set-up %.3f s, GPU thread's loop %.3f s, joins %.3f s\n", t_start - t_enter, t_loop - t_start, now() - t_loop);

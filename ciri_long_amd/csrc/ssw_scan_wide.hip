@@ -750,9 +750,9 @@ __global__ void __launch_bounds__(64) ssw_scanw_combine_kernel(const SswParams p
     }
 }
 
-hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, bool with_prefilter, int nwork, hipStream_t stream)
+// (the first stage of the prefilter has been launched by the caller when with_prefilter is set)
+hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, int nworkgroups, bool with_prefilter, hipStream_t stream)
 {
-    if (with_prefilter) { const hipError_t e = launch_ssw_prefilter(p, nwork, stream); if (e != hipSuccess) return e; }
     if (geq) {
         hipLaunchKernelGGL((ssw_scanw_seed_kernel<true>), dim3(ntasks), dim3(64), 0, stream, p);
         if (with_prefilter) hipLaunchKernelGGL((ssw_scanw_queue_kernel<true>), dim3(std::min(nworkgroups, 2 * ntasks)), dim3(64), 0, stream, p, 0, 2 * ntasks);

@@ -119,6 +119,8 @@ def lib():
         L.clh_plan_timing.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.clh_plan_traceback_counts.argtypes = [C.c_void_p, C.c_void_p]
         L.clh_plan_prefilter_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.clh_plan_prefilter_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clh_plan_set_refs_bytes.argtypes = [C.c_void_p, C.c_int64]
         _lib = L
     return _lib
 
@@ -611,6 +613,10 @@ class Plan(object):
             raise ClhError('clh_ssw_fetch failed (%d): %s' % (rc, last_error()))
         return out, cig[:used.value]
 
+    def set_refs_bytes(self, nbytes):
+        """state the size of the refs buffer handed to run() (include/ciri_long_hip.h: padding contract of d_refs); -1 = unstated"""
+        lib().clh_plan_set_refs_bytes(self._h, int(nbytes))
+
     def set_profiling(self, on=True):
         lib().clh_plan_set_profiling(self._h, 1 if on else 0)
 
@@ -636,6 +642,14 @@ class Plan(object):
         if lib().clh_plan_prefilter_stats(self._h, c.ctypes.data) != 0:
             raise ClhError('clh_plan_prefilter_stats: %s' % last_error())
         return dict(zip(('alignments', 'pruned', 'slices', 'cols_computed', 'cols_window', 'second_stage'), (int(x) for x in c)))
+
+    def prefilter_timing(self):
+        """ssw_prefilter_kernel alone in the last profiling run, per long-window class (reads up to 254 bases, longer reads):
+        [(ms, window columns x W words, the same x (11 W + 8) instructions per column and lane), ...]"""
+        ms = np.zeros(2, dtype=np.float32); w = np.zeros(4, dtype=np.int64)
+        if lib().clh_plan_prefilter_timing(self._h, ms.ctypes.data, w.ctypes.data) != 0:
+            raise ClhError('clh_plan_prefilter_timing: %s' % last_error())
+        return [(float(ms[k]), int(w[2 * k]), int(w[2 * k + 1])) for k in range(2)]
 
     def timing(self):
         """([K1 ms per segment], (K1b small-window ms, K1b large-window ms)) for the last run"""

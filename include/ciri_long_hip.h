@@ -98,6 +98,12 @@ int clh_plan_traceback_counts(clh_plan* pl, int32_t* counts);
  * window went through the second stage as well (the indel-distance bound, for windows the first leaves too much of).  Waits for the run. */
 int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out);
 
+/* ssw_prefilter_kernel (the first stage) alone, after a run with profiling on: ms[0] / ms[1] = its duration for the class of reads up to
+ * 254 bases and for the class of longer reads (0 when it did not run); work[2 c] = window columns x W 32-row words of the read (its
+ * pieces), work[2 c + 1] = the same columns x (11 W + 8) -- the integer instructions per column and lane, i.e. what the kernel's
+ * issue-rate roofline counts.  Measurement only (bench.py: prefilter_roofline); no reference counterpart. */
+int clh_plan_prefilter_timing(clh_plan* pl, float* ms, int64_t* work);
+
 /* Launch the batch on packed code arrays that already live in HBM (device pointers).  Asynchronous on `stream`
  * (a hipStream_t).  NULL selects the context's own, private, non-blocking stream -- NOT the legacy default stream: work
  * a caller has queued on the default stream (or on any other stream) is then unordered with these kernels.  A caller
@@ -105,6 +111,14 @@ int clh_plan_prefilter_stats(clh_plan* pl, int64_t* out);
  * hipStreamPerThread are passed through like any other handle.  Results stay in HBM until clh_ssw_fetch, which waits
  * for the stream of the last run.  The same holds for every `stream` argument of this header. */
 int clh_ssw_run(clh_plan* plan, const void* d_reads, const void* d_refs, void* stream);
+
+/* Padding contract of d_refs.  For windows of 32 kb and more the column prefilter reads the window text in whole, address-aligned
+ * 256-byte blocks: when d_refs is 256-byte aligned it may read up to 255 bytes past the last byte any window uses (never in front of
+ * d_refs).  The buffer must be readable up to that boundary -- every hipMalloc / caching-allocator block is (allocations are rounded
+ * to at least 256 bytes), a pointer INTO such a block that ends short of the boundary is not.  A caller who cannot promise it states the
+ * buffer's size here (bytes from d_refs; -1 = unstated, the default): a run whose last block would cross it uses the static window
+ * slices instead of the prefilter.  A d_refs that is not 256-byte aligned always does.  Results are the same either way. */
+int clh_plan_set_refs_bytes(clh_plan* plan, int64_t nbytes);
 
 /* Wait for the last run and copy results out.  cigar_buf may be NULL.  *cigar_used receives the u32 count (the CIGARs come back
  * as one dense array).  It waits for the completion of the plan's last clh_ssw_run (an event recorded behind its last launch),

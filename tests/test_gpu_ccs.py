@@ -267,6 +267,33 @@ def test_poa_batch_of_groups_large_clusters_and_limits():
     assert spoa.poa([a, b], 0, False, 2, -100, -9, -6, -9, -6)[0] == oracle_lib.oracle_poa([a, b], 0, False, 2, -100, -9, -6, -9, -6)
 
 
+def test_a_group_of_the_second_launch_that_leaves_the_16_bit_range_still_runs_wide(monkeypatch):
+    """with the large workspace slots scarce, groups that found none free run in the packed kernel's second launch; one that
+    reaches the floor of the 16-bit cells THERE used to keep status 6 (spoa has no such limit: its engines fall back to wider cells).
+    The wide kernel runs behind both launches, so the second launch hands over as the first does; the large slots of a global / overlap
+    plan are sized for the wide form.  Also: a row of recycled memory that says "status 1" must not send a group that is on the wide
+    list through the second launch as well (nothing is counted as lost)."""
+    import random
+    from ciri_long_amd import hip
+    rng = random.Random(77)
+    ctx = hip.default_context()
+    monkeypatch.setenv('CLH_POA_BUDGET_MB', '1'); monkeypatch.setenv('CLH_POA_BIG_SLOTS', '1')
+    groups = []
+    for k in range(6):        # unrelated pairs under an affine cost of 6 per gap base: the global alignment sinks below -30000
+        n = 2450 + 30 * k
+        groups.append([''.join(rng.choice('AC') for _ in range(n)), ''.join(rng.choice('GT') for _ in range(n))])
+    groups.append(_family(rng, 200, 5, 0.1))
+    flat = [s for g in groups for s in g]
+    data, off = hip.pack(flat)
+    goff = np.cumsum([0] + [len(g) for g in groups]).astype(np.int64)
+    scores = (2, -100, -9, -6, -9, -6)
+    got = ctx.poa_batch(data, off, goff, algorithm=1, scores=scores)
+    st = ctx.poa_last_stats()
+    for k, g in enumerate(groups):
+        assert got[k] == oracle_lib.oracle_poa(g, 1, False, *scores), k
+    assert st['dropped'] == {}, st
+
+
 def test_find_ccs_reads_files_and_resume(tmp_path):
     """Stage driver: FASTA/FASTQ(.gz) in, tmp/{prefix}.ccs.fa + .raw.fa out in the reference's format, resume reads them."""
     import gzip

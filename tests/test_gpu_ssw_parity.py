@@ -823,6 +823,16 @@ def test_prefilter_on_long_windows_vs_oracle(ctx, scheme, monkeypatch):
     rows, _ = plan.fetch()
     assert plan.prefilter_stats()['pruned'] == 0 and (rows == got_rows[True]).all()
     plan.close()
+    # the padding contract of d_refs (include/ciri_long_hip.h): a stated buffer size that ends inside the last 256-byte block a window
+    # touches switches the filter off for the run; a size that covers the block leaves it on; same rows
+    last_block_end = ((int(fo[-1]) - 1) >> 8) + 1 << 8
+    for stated, on in ((int(fo[-1]), int(fo[-1]) == last_block_end), (last_block_end, True), (-1, True)):
+        plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=False, want_cigar=False)
+        plan.set_refs_bytes(stated)
+        plan.run(d_r.data_ptr(), d_f.data_ptr())
+        rows, _ = plan.fetch()
+        assert (plan.prefilter_stats()['pruned'] > 0) == on and (rows == got_rows[True]).all(), stated
+        plan.close()
     # windows of a resident genome, both strands (minus-strand windows run down the addresses)
     text = _rnd(rng, 260000)
     text = text[:5000] + text[5000:5600].lower() + text[5600:]

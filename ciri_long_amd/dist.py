@@ -122,7 +122,8 @@ def _entry(index, lo):
     return index[k], k * INDEX_EVERY
 
 
-def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_file=None, chunk_size=250, stage_setup=None):
+def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_file=None, chunk_size=250, stage_setup=None, threads=1,
+                 recover_aligner=None):
     """`CIRI-long call` for one node, one process per GPU -- every stage of main.py:49-103:
 
       1    consensus of every read (find_ccs_reads) on this rank's contiguous shard of the input records;
@@ -143,24 +144,47 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     (main.py:102-103).  Returns (counters of all ranks, short reads of stage 3 of this rank).
 
     find_consensus_file(in_file, is_fastq, ccs_path, raw_path, first_record, max_records, byte_offset) -> (total, ro, too_long)
-    replaces the native stage 1 (`hip.Context.ccs_file`) in CPU tests; records are counted from byte_offset, the first byte of a record."""
+    replaces the native stage 1 (`hip.Context.ccs_file`) in CPU tests; records are counted from byte_offset, the first byte of a record.
+
+    threads > 1: the mapper phase of stages 2.1 / 2.2 / 3 on that many worker processes per rank (the reference's Pool(threads),
+    find_bsj.py:338-345), forked HERE -- before this function touches the GPU -- from env.ALIGNER (first mapper) and `recover_aligner`
+    (second mapper, the one stage_setup('recover') will switch to).  A caller whose process group is RCCL has initialised the GPU
+    already: it calls find_bsj.start_mapper_pools() itself, before init_process_group."""
     import json
     import os
     import shutil
     from collections import defaultdict
-    from . import find_bsj, find_ccs, hip
+    from . import env, find_bsj, find_ccs, hip, mapper_pool
     from .utils import grouper
     dist = _dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
-    fq, is_fastq, _gz = find_ccs._open_reads(in_file)
+    if int(threads or 1) > 1:
+        find_bsj.THREADS = int(threads)
+        if not mapper_pool.gpu_touched():
+            find_bsj.start_mapper_pools(threads, scan_aligner=env.ALIGNER, recover_aligner=recover_aligner, contig_len=env.CONTIG_LEN)
+    fq, is_fastq, is_gz = find_ccs._open_reads(in_file)
     fq.close()
     import itertools
+    tmp = os.path.join(out_dir, 'tmp')
+    # A gzip stream cannot be entered in the middle: with several ranks, rank 0 inflates it ONCE into tmp/{prefix}.input.fq|fa (on the
+    # node's file system, removed at the end) and every rank enters THAT file at its shard like any plain input -- no rank inflates a
+    # byte it does not use (round 4: every rank inflated the file from its start, for stage 1 and again for stage 3).  The suffix sniffing
+    # is the reference's (find_ccs.py:29-46); a single rank reads the compressed file directly, as the reference does.
+    inflated = None
+    if is_gz and world > 1:
+        inflated = os.path.join(tmp, '%s.input.%s' % (prefix, 'fq' if is_fastq else 'fa'))
+
+        def inflate():
+            import gzip
+            with gzip.open(in_file, 'rb') as src, open(inflated, 'wb') as dst:
+                shutil.copyfileobj(src, dst, 16 << 20)
+        _together('inflate', lambda: inflate() if rank == 0 else None)
+        in_file = inflated
     # counted once, on rank 0, which also notes the byte offset of every 1024th record: a rank enters an uncompressed file at its shard
     # (rounds 2-3: every rank read past everything in front of its shard, and stage 3 parsed the whole input on every rank)
     n, index = _bcast(_together('count', lambda: _count_records(in_file, is_fastq) if rank == 0 else None))
     lo, hi = shard_bounds(n, rank, world)
     byte_off, rec0 = _entry(index, lo)
-    tmp = os.path.join(out_dir, 'tmp')
     part = os.path.join(tmp, '%s.part%d' % (prefix, rank))
     if find_consensus_file is None:
         def find_consensus_file(path, fastq, ccs_path, raw_path, first, count, byte_offset=0):
@@ -233,6 +257,8 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
         dist.barrier()
     for kind in ('ccs.fa', 'raw.fa'):
         os.remove('%s.%s' % (part, kind))
+    if rank == 0 and inflated is not None:
+        os.remove(inflated)
     if rank == 0:
         with open('{}/{}.low_confidence.fa'.format(out_dir, prefix), 'w') as out:
             find_bsj._write_records(out, partial)

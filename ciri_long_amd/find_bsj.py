@@ -79,15 +79,10 @@ def _clip_prepare(circ, hit):
         return _REJECT
     win_start = max(hit.r_st - WINDOW_FLANK, 0)
     win_end = min(hit.r_en + WINDOW_FLANK, env.CONTIG_LEN[hit.ctg])
-    if getattr(env.GENOME, 'device', None) is not None:
-        # genome resident on the GPU: the window stays a coordinate triple; its N count, reverse complement and encoding
-        # happen on the device in _run_clip_jobs
-        return _ClipJob(circ, hit, clip_seq, None, win_start, win_end)
-    window = env.GENOME.seq(hit.ctg, win_start, win_end)
-    if window.count('N') >= WINDOW_MAX_N * (win_end - win_start):
-        return _REJECT
-    # minus-strand hits are aligned against the reverse-complemented window (find_bsj.py:213-216)
-    return _ClipJob(circ, hit, clip_seq, window if hit.strand > 0 else revcomp(window), win_start, win_end)
+    # the window stays a coordinate triple here (this function runs in the mapper phase, possibly in a worker process that has no
+    # genome): its N count, reverse complement and encoding happen in _run_clip_jobs -- on the device when the genome is resident
+    # there, from env.GENOME.seq otherwise
+    return _ClipJob(circ, hit, clip_seq, None, win_start, win_end)
 
 
 def _clip_finish(job, res):
@@ -129,16 +124,26 @@ def _run_clip_jobs(jobs):
     from .ssw_wrap import align_pairs
     # host-window route (no resident genome): a window is a string of up to 400 kb, so the jobs go to the GPU in groups
     # of bounded size instead of one call holding every window of the chunk at once
-    res, group, size = [], [], 0
-    for j in jobs + [None]:
-        if j is None or (group and size + len(j.window) > HOST_WINDOW_BYTES):
-            res += align_pairs([x.window for x in group], [x.clip_seq for x in group], match=1, mismatch=1, gap_open=1, gap_extend=1)
+    res = [None] * len(jobs)            # None = rejected by the N filter (find_bsj.py:199-201)
+    group, size = [], 0
+
+    def flush():
+        got = align_pairs([w for _k, w, _q in group], [q for _k, _w, q in group], match=1, mismatch=1, gap_open=1, gap_extend=1)
+        for (k, _w, _q), r in zip(group, got):
+            if r is None:   # the reference dereferences None here (find_bsj.py:206); make the failure explicit
+                raise RuntimeError('Smith-Waterman of clipped bases returned no result')
+            res[k] = r
+    for k, j in enumerate(jobs):
+        window = env.GENOME.seq(j.hit.ctg, j.win_start, j.win_end)
+        if window.count('N') >= WINDOW_MAX_N * (j.win_end - j.win_start):
+            continue
+        if group and size + len(window) > HOST_WINDOW_BYTES:
+            flush()
             group, size = [], 0
-        if j is not None:
-            group.append(j); size += len(j.window)
-    for r in res:
-        if r is None:   # the reference dereferences None here (find_bsj.py:206); make the failure explicit
-            raise RuntimeError('Smith-Waterman of clipped bases returned no result')
+        # minus-strand hits are aligned against the reverse-complemented window (find_bsj.py:213-216)
+        group.append((k, window if j.hit.strand > 0 else revcomp(window), j.clip_seq)); size += len(window)
+    if group:
+        flush()
     return res
 
 
@@ -196,17 +201,71 @@ def _assemble(read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_s
             '{}|{}-{}'.format(junc, clip_base, len(circ)), segments, seq)
 
 
-THREADS = 1               # mapper calls of a chunk run on this many threads (set by the stage drivers from `threads`).  UNVERIFIED: whether
-                          # mappy.Aligner.map / bwapy release the GIL could not be checked (neither package is installable here); if they hold
-                          # it, `threads` buys nothing for the mapper phase and only this pool would have to change (a process pool in front of
-                          # the GPU process).  Results do not depend on it (tests/test_dist_gloo.py runs with three threads).
-_POOL = None
+THREADS = 1               # workers of the mapper phase of a chunk (set by the stage drivers from `threads`)
+_POOL = None              # the thread route's executor
+_PROC_POOLS = {}          # the process route's pools by role: 'scan' (first mapper: stages 2.1 and 3), 'recover' (second mapper: stage 2.2)
+_WARNED = []
 
 
-def _mapper_pool():
-    """The reference spreads its per-read loop over Pool(threads) (find_bsj.py:340-345).  Here the process owns a GPU and
-    must not fork, and the mappers release the GIL inside map(): a thread pool carries the mapper phase of a chunk while the
-    batched GPU phases stay on the calling thread."""
+def mapper_mode():
+    """CIRI_LONG_MAPPER=threads|processes.  Unset: processes wherever a pool exists or can still be made (the GPU untouched)."""
+    import os
+    m = os.environ.get('CIRI_LONG_MAPPER', '').strip().lower()
+    if m not in ('', 'threads', 'processes'):
+        raise ValueError('CIRI_LONG_MAPPER must be "threads" or "processes", not %r' % m)
+    return m
+
+
+def start_mapper_pools(threads, scan_aligner=None, recover_aligner=None, contig_len=None, scan_factory=None, recover_factory=None,
+                       start='fork'):
+    """Make the worker processes of the mapper phase -- BEFORE this process touches the GPU (module docstring of mapper_pool).
+    One pool per mapper given: `scan_*` = the first mapper (minimap2 splice preset in the reference, find_bsj.py:332; stages 2.1
+    and 3), `recover_*` = the second (bwa, find_bsj.py:455; stage 2.2).  `*_aligner`: built here, inherited by forked workers (as
+    the reference's Pool does); `*_factory`: picklable, builds the mapper inside each (forked or spawned) worker.  With threads <= 1 or
+    CIRI_LONG_MAPPER=threads nothing is started.  Returns the roles that have a pool."""
+    from .mapper_pool import MapperPool
+    if int(threads or 1) <= 1 or mapper_mode() == 'threads':
+        return []
+    for role, aligner, factory in (('scan', scan_aligner, scan_factory), ('recover', recover_aligner, recover_factory)):
+        if (aligner is None and factory is None) or role in _PROC_POOLS:
+            continue
+        _PROC_POOLS[role] = MapperPool(int(threads), aligner=aligner, contig_len=contig_len, factory=factory, start=start)
+    return sorted(_PROC_POOLS)
+
+
+def stop_mapper_pools():
+    for role in list(_PROC_POOLS):
+        _PROC_POOLS.pop(role).close()
+
+
+def _process_pool(role, aligner, contig_len):
+    """The stage drivers' way to a pool: the one made at program start, or -- if this process has not touched the GPU yet (a stage
+    run on its own) -- one forked now from the stage's aligner.  None: the thread route."""
+    from . import mapper_pool
+    if THREADS <= 1 or mapper_mode() == 'threads' or mapper_pool.in_worker():
+        return None
+    pool = _PROC_POOLS.get(role)
+    if pool is not None:
+        return pool
+    if mapper_pool.gpu_touched():
+        if mapper_mode() == 'processes':
+            raise RuntimeError('CIRI_LONG_MAPPER=processes, but this process initialised the GPU before any mapper pool was '
+                               'started: call find_bsj.start_mapper_pools() at program start')
+        if not _WARNED:
+            _WARNED.append(1)
+            import logging
+            logging.getLogger('CIRI-long').warning('mapper phase on %d threads: no worker processes were started before the GPU was '
+                                                   'initialised (find_bsj.start_mapper_pools); if the mapper holds the GIL this is one core',
+                                                   THREADS)
+        return None
+    _PROC_POOLS[role] = mapper_pool.MapperPool(THREADS, aligner=aligner, contig_len=contig_len)
+    return _PROC_POOLS[role]
+
+
+def _thread_pool():
+    """The thread route (CIRI_LONG_MAPPER=threads, or no process pool possible any more): the mapper calls of a chunk on `THREADS`
+    threads of this process.  It scales only as far as the mapper releases the GIL inside map() -- which could not be checked for
+    mappy / bwapy here (neither is installable); the process route does not depend on it."""
     global _POOL
     if THREADS <= 1:
         return None
@@ -214,6 +273,19 @@ def _mapper_pool():
         from concurrent.futures import ThreadPoolExecutor
         _POOL = ThreadPoolExecutor(THREADS)
     return _POOL
+
+
+def _map_chunk(chunk, raw_filters, min_circ_fraction):
+    """Phase 1 of a chunk, input order kept: worker processes (the reference's own parallelism, find_bsj.py:338-345), else threads,
+    else this thread."""
+    role = 'scan' if raw_filters else 'recover'
+    procs = _process_pool(role, env.ALIGNER, env.CONTIG_LEN)
+    if procs is not None:
+        return procs.scan(chunk, raw_filters, min_circ_fraction)
+    pool = _thread_pool()
+    if pool is None:
+        return [_map_read(item, raw_filters, min_circ_fraction) for item in chunk]
+    return list(pool.map(lambda item: _map_read(item, raw_filters, min_circ_fraction), chunk))
 
 
 def _map_read(item, raw_filters, min_circ_fraction):
@@ -251,12 +323,7 @@ def _scan_chunk(chunk, raw_filters, min_circ_fraction):
     short_reads = []
     pending = []          # (read fields..., prepared clip result or job) in input order
     jobs = []
-    pool = _mapper_pool()
-    if pool is None:
-        mapped = [_map_read(item, raw_filters, min_circ_fraction) for item in chunk]
-    else:
-        mapped = list(pool.map(lambda item: _map_read(item, raw_filters, min_circ_fraction), chunk))     # input order kept
-    for keys, short, pend in mapped:
+    for keys, short, pend in _map_chunk(chunk, raw_filters, min_circ_fraction):
         for k in keys:
             reads_cnt[k] += 1
         if short is not None:
@@ -318,9 +385,11 @@ def _resident(genome):
 
 def scan_ccs_reads(ccs_seq, ref_fasta, ss_index, gtf_index, intron_index, is_canonical, out_dir, prefix, threads,
                    aligner=None, genome=None, contig_len=None):
-    """Stage driver (find_bsj.py:328-372).  The reference forks a process pool per stage; here the calling process
-    (one per GPU) walks the chunks itself, with the mapper calls of a chunk on `threads` threads.  ``aligner``/``genome``/``contig_len`` may be injected (tests, or an already
-    built index); by default a mappy splice-preset aligner is built from ``ref_fasta`` exactly as the reference does."""
+    """Stage driver (find_bsj.py:328-372).  The reference forks a process pool per stage and runs the whole per-read loop there; here
+    the calling process (one per GPU) walks the chunks itself, the mapper phase of a chunk on `threads` worker processes
+    (mapper_pool.py; threads of this process with CIRI_LONG_MAPPER=threads), the batched GPU phases on the calling thread.
+    ``aligner``/``genome``/``contig_len`` may be injected (tests, or an already built index); by default a mappy splice-preset
+    aligner is built from ``ref_fasta`` exactly as the reference does."""
     global THREADS
     if aligner is None:
         import mappy as mp
@@ -338,8 +407,9 @@ def scan_ccs_reads(ccs_seq, ref_fasta, ss_index, gtf_index, intron_index, is_can
         if contig_len is None:
             from .align import Fasta
             contig_len = Fasta(ref_fasta).contig_len
-    env.initializer(aligner, contig_len, _resident(genome), gtf_index, intron_index, ss_index)
     THREADS = max(1, int(threads or 1))
+    _process_pool('scan', aligner, contig_len)      # (worker processes, if they can still be made, BEFORE the genome goes to the GPU)
+    env.initializer(aligner, contig_len, _resident(genome), gtf_index, intron_index, ss_index)
 
     reads_count = defaultdict(int)
     short_reads = []
@@ -364,8 +434,9 @@ def recover_ccs_reads(short_reads, ref_fasta, ss_index, gtf_index, intron_index,
         from bwapy import BwaAligner
         aligner = Aligner(BwaAligner(ref_fasta, options='-x ont2d -T 19'))
     global THREADS
-    env.initializer(aligner, genome.contig_len, _resident(genome), gtf_index, intron_index, ss_index)
     THREADS = max(1, int(threads or 1))
+    _process_pool('recover', aligner, genome.contig_len)
+    env.initializer(aligner, genome.contig_len, _resident(genome), gtf_index, intron_index, ss_index)
 
     reads_count = defaultdict(int)
     with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'a') as out:
@@ -434,29 +505,38 @@ def _raw_layout(seq, circ, junc, raw_hits):
     return None
 
 
+def _raw_map_read(read_id, seq):
+    """Phase 1 of stage 3 for one read: every mapper call (find_bsj.py:508-579).  -> None, ('short', (read_id, seq)) or
+    ('laid', (read_id, junc, layout))"""
+    if len(seq) < 300:
+        return 'short', (read_id, seq)
+    raw_hits = _primary_hits(seq)
+    if not raw_hits:
+        return None
+    cand = _raw_junction(seq, raw_hits)
+    if cand is None:
+        return None
+    circ, junc = cand
+    layout = _raw_layout(seq, circ, junc, raw_hits)
+    if layout is None or layout[4] > 20:
+        return None
+    return 'laid', (read_id, junc, layout)
+
+
 def scan_raw_chunk(chunk, is_canonical, circ_reads):
     """[(read_id, seq)] -> (counters, 'partial' records, short reads) (find_bsj.py:499-620)"""
     reads_cnt = defaultdict(int)
     ret, short_reads, laid = [], [], []
-    for read_id, seq in chunk:
-        if read_id in circ_reads:
-            continue
-        if len(seq) < 300:
-            short_reads.append((read_id, seq))
-            continue
-        raw_hits = _primary_hits(seq)
-        if not raw_hits:
-            continue
-        cand = _raw_junction(seq, raw_hits)
-        if cand is None:
-            continue
-        circ, junc = cand
-        layout = _raw_layout(seq, circ, junc, raw_hits)
-        if layout is None:
-            continue
-        if layout[4] > 20:
-            continue
-        laid.append((read_id, junc, layout))
+    todo = [(read_id, seq) for read_id, seq in chunk if read_id not in circ_reads]
+    procs = _process_pool('scan', env.ALIGNER, env.CONTIG_LEN)
+    if procs is not None:
+        mapped = procs.raw(todo)
+    else:
+        pool = _thread_pool()
+        mapped = [_raw_map_read(*it) for it in todo] if pool is None else list(pool.map(lambda it: _raw_map_read(*it), todo))
+    for m in mapped:
+        if m is not None:
+            (short_reads if m[0] == 'short' else laid).append(m[1])
     signals = _signals([(lay[0], lay[1], lay[2], lay[4]) for _, _, lay in laid])
     for (read_id, junc, layout), (ss_site, us_free, ds_free) in zip(laid, signals):
         ctg, start, end, circ_strand, clip_base, exons, circ = layout
@@ -496,6 +576,8 @@ def scan_raw_reads(in_file, ref_fasta, gtf_index, intron_index, ss_index, is_can
         from .align import Fasta
         contig_len = Fasta(ref_fasta).contig_len
     env.initializer(aligner, contig_len, aligner if genome is None else genome, gtf_index, intron_index, ss_index)
+    global THREADS
+    THREADS = max(1, int(threads or 1))
     reads_cnt = defaultdict(int)
     short_reads = []
     with open('{}/{}.low_confidence.fa'.format(out_dir, prefix), 'w') as out:

@@ -52,6 +52,8 @@ def lib():
     """Load libclh.so (once).  Raises HipUnavailable if it has not been built."""
     global _lib
     if _lib is None:
+        if os.environ.get('CIRI_LONG_MAPPER_WORKER') == '1':
+            raise HipUnavailable('a mapper worker process must not touch the GPU (ciri_long_amd/mapper_pool.py)')
         if not os.path.exists(SO_PATH):
             raise HipUnavailable('%s not found: build it with `make -C %s/csrc` (needs hipcc); there is no CPU fallback'
                                  % (SO_PATH, _HERE))

@@ -115,10 +115,10 @@ def _setup_call_world():
     # second, more permissive mapper -- the roles of minimap2 and bwa in the reference (find_bsj.py:336, 451-458)
     main = fm.FakeMapper(w['genome'], min_score=170)
     env.initializer(main, w['genome'].contig_len, w['genome'], w['gtf_index'], None, w['ss_index'])
-    find_bsj.THREADS = 3          # the mapper phase of a chunk on a thread pool: same records, same order
+    w['recover_mapper'] = fm.FakeMapper(w['genome'], min_score=30)
 
     def stage_setup(stage):
-        env.ALIGNER = fm.FakeMapper(w['genome'], min_score=30) if stage == 'recover' else main
+        env.ALIGNER = w['recover_mapper'] if stage == 'recover' else main
     w['stage_setup'] = stage_setup
     return w
 
@@ -131,13 +131,23 @@ def _call_worker(rank, world, port, out_dir, in_file, q):
     from ciri_long_amd import dist as cdist
     cdist.INDEX_EVERY = 3         # a byte offset for every third record: rank 1 enters the file in the middle (stage 1 and stage 3)
     w = _setup_call_world()
-    counts, short = cdist.call_sharded(in_file, out_dir, 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1, stage_setup=w['stage_setup'])
-    q.put((rank, dict(counts), len(short)))
+    # the mapper phase of every stage on three worker processes per rank (forked at the top of call_sharded, before anything could touch
+    # a GPU): same records, same order
+    from ciri_long_amd import find_bsj
+    counts, short = cdist.call_sharded(in_file, out_dir, 'p', True, find_consensus_file=_cpu_stage1, chunk_size=1, stage_setup=w['stage_setup'],
+                                       threads=3, recover_aligner=w['recover_mapper'])
+    pools = sorted(find_bsj._PROC_POOLS)
+    find_bsj.stop_mapper_pools()
+    q.put((rank, dict(counts), len(short), pools))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_call_sharded_files_equal_the_single_rank_run(tmp_path):
+@pytest.mark.parametrize('kind', ['fa', 'fastq.gz'])
+def test_call_sharded_files_equal_the_single_rank_run(tmp_path, kind):
+    """kind 'fastq.gz': the single rank reads the compressed file as the reference does (find_ccs.py:29-46); with two ranks rank 0
+    inflates it once into tmp/p.input.fq and both ranks enter that file at their shard (rank 1 in the middle: an index entry every third
+    record) -- the same five files, and the inflated copy is gone afterwards."""
     sys.path.insert(0, ROOT)
     import fake_mapper as fm
     from ciri_long_amd import dist as cdist, find_bsj
@@ -153,12 +163,14 @@ def test_call_sharded_files_equal_the_single_rank_run(tmp_path):
     for k in range(6):                                               # consensus below 150 bases: stage 2.2's reads
         st = 500 + 700 * k
         shorts.append(('short%02d' % k, fm.mutate(w['genome'].genome['chrA'][st:st + int(rng.integers(70, 120))] * 5, rng, 0.03)))
-    in_file = str(tmp_path / 'reads.fa')
-    with open(in_file, 'w') as f:
+    in_file = str(tmp_path / ('reads.' + kind))
+    import gzip
+    with (gzip.open(in_file, 'wt') if kind.endswith('.gz') else open(in_file, 'w')) as f:
+        rec = (lambda h, s_: '@%s\n%s\n+\n%s\n' % (h, s_, 'I' * len(s_))) if kind.startswith('fastq') else (lambda h, s_: '>%s\n%s\n' % (h, s_))
         for rid, _seg, _ccs, raw in reads:
-            f.write('>%s some description\n%s\n' % (rid, raw))
+            f.write(rec('%s some description' % rid, raw))
         for rid, raw in partial[:3] + shorts[:3] + partial[3:] + shorts[3:]:
-            f.write('>%s\n%s\n' % (rid, raw))
+            f.write(rec(rid, raw))
     n_in = len(reads) + len(partial) + len(shorts)
     one, two = tmp_path / 'one', tmp_path / 'two'
     for d in (one, two):
@@ -181,8 +193,9 @@ def test_call_sharded_files_equal_the_single_rank_run(tmp_path):
         p.start()
     got = {}
     for _ in range(2):
-        rank, counts, nshort = q.get(timeout=280)
+        rank, counts, nshort, pools = q.get(timeout=280)
         got[rank] = (counts, nshort)
+        assert pools == ['recover', 'scan'], pools        # the mapper phases ran on worker processes (forked before stage 1)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -206,11 +219,13 @@ def test_call_sharded_files_equal_the_single_rank_run(tmp_path):
                 self.seq, self.contig_len = g.seq, g.contig_len
         genome, mapper = _Seqs(env.GENOME), env.ALIGNER
         ss, gtf = env.SS_INDEX, env.GTF_INDEX
+        os.environ['CIRI_LONG_MAPPER'] = 'threads'          # the thread route of the mapper phase: same records, same order
         c1, short = find_bsj.scan_ccs_reads(ccs_seq, None, ss, gtf, None, True, str(three), 'p', 3, aligner=mapper, genome=genome, contig_len=genome.contig_len)
         c2 = find_bsj.recover_ccs_reads(short, None, ss, gtf, None, True, str(three), 'p', 3, aligner=fm.FakeMapper(w3['genome'], min_score=30), genome=genome)
         c3, _ = find_bsj.scan_raw_reads(in_file, None, gtf, None, ss, True, str(three), 'p', 3, aligner=mapper, genome=genome, contig_len=genome.contig_len)
     finally:
         find_bsj.THREADS = 1
+        os.environ.pop('CIRI_LONG_MAPPER', None)
     for name in ('p.cand_circ.fa', 'p.low_confidence.fa'):
         assert (three / name).read_bytes() == (one / name).read_bytes(), name
     merged = {'total': n_in, 'consensus': counts1['consensus']}

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "clh_device.h"
+#include "clh_device_ops.h"
 
 namespace clh {
 
@@ -53,21 +54,6 @@ __device__ __forceinline__ void phase_sync() {
 #endif
 }
 
-// inclusive prefix maximum over the 64 lanes: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 and 31 carry
-// the row totals.  The DPP modifier sits on the max itself (v_max_i32_dpp: dst = max(dpp(src), src)); a lane without a
-// valid DPP source is simply not written, so no fill value and no separate v_mov_dpp are needed -- 6 VALU instructions
-// (plus the 2 wait states a DPP read needs after a VALU write) instead of 24.
-__device__ __forceinline__ int wave_prefix_max(int v) {
-    asm volatile("s_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
-                 : "+v"(v));
-    return v;
-}
 
 // two independent scans, their steps interleaved: the other chain's instruction provides the wait states a DPP read needs
 // after a VALU write, so no s_nop inside
@@ -416,40 +402,18 @@ __device__ __forceinline__ int poa_ring(int m) {
     return ring;
 }
 
-__device__ __forceinline__ int dpp_shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1; lane 0 keeps `fill`
-
 // DP rows of one sequence against the graph.  Lane l owns C adjacent columns (C = 2..8: ceil(length / 64)), so a row of up
 // to W = 64*C columns is ONE step; longer sequences are swept in passes of W columns (passes outer, rows inner), the
 // cell that leaves a row on the right handed to the next pass through per-row carries (H, E, Q) in HBM.  Graph rows
-// (w.ri, w.rx) and carries are streamed 64 rows at a time into one register per lane and read with v_readlane; LDS holds
-// the ring of the last RING rows (H int16, vertical states one byte) for near sources that are not the row before -- that
+// (w.ri) and carries are streamed 64 rows at a time into one register per lane and read with v_readlane; LDS holds
+// the ring of the last RING rows (raw packed registers) for near sources that are not the row before -- that
 // one is forwarded from registers; far sources come from "kept" rows in HBM.
-// ---- packed 16-bit form of the pass ---------------------------------------------------------------------------------
+// ---- packed 16-bit form of the pass (the arithmetic: clh_device_ops.h) ------------------------------------------------
 // Two cells per lane-operation: a register holds the cells of two columns in its 16-bit halves (v_pk_* arithmetic;
 // every value of the DP fits int16).  Lane l owns C = 2 CP adjacent columns as two "virtual lanes": the low halves of its
 // CP registers are columns C l .. C l + CP - 1, the high halves the next CP columns -- so the left neighbour of a cell is the
 // same half of the previous register, and only register 0 needs the hand-down (low half <- previous lane's high half of
-// the last register, high half <- own low half of the last register: one DPP move + one v_alignbit).  There is no room for
-// a code beside a 16-bit value, so the cell's back-track code comes from strictly-greater updates in spoa's checking
-// order: (best, code) <- (x, cx) where best < x, i.e. mask = sign(best - x), best = max(best, x), code = bfi(mask, cx,
-// code) -- four packed operations per candidate and pair of cells, the same for any number of in-edges.
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
-__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
-__device__ __forceinline__ uint32_t pk_minu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
-__device__ __forceinline__ uint32_t pk_sra15(uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) >> (short)15); }     // 0xFFFF where the half is negative
-__device__ __forceinline__ uint32_t pk_subu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)); }
-__device__ __forceinline__ uint32_t pk_shr(uint32_t a, int n) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) >> (unsigned short)n); }
-__device__ __forceinline__ uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
-__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return (uint32_t)(lo & 0xffff) | ((uint32_t)hi << 16); }
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }                   // v_bfi_b32
-// hand a packed value to the next virtual lane: new low half = previous lane's high half (lane 0: lane0_lo), new high half = own low half
-__device__ __forceinline__ uint32_t hand_down(uint32_t v, int lane0_lo) {
-    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp((int)((uint32_t)lane0_lo << 16), (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    return __builtin_amdgcn_alignbit(v, x, 16);
-}
+// the last register, high half <- own low half of the last register: one DPP move + one v_alignbit).
 // (best, code) <- (x, cx) in the halves where best < x
 __device__ __forceinline__ void upd(uint32_t& best, uint32_t& code, uint32_t x, uint32_t cx) {
     const uint32_t m = pk_sra15(pk_subs(best, x));
@@ -1443,6 +1407,8 @@ static constexpr int BT_DRIFT = BT_W / 2 - 4;        // how far the walk may lea
 static_assert(4 * 64 * BT_W + BT_SQ + 2 * BT_RING <= POA_LDS_BYTES, "back-track LDS");
 static constexpr int BT_W32 = POA_LDS_BYTES >= 9216 ? 16 : 14;                  // the wide form (int32 H): 6 bytes per staged cell
 static_assert(6 * 64 * BT_W32 + BT_SQ + 2 * BT_RING <= POA_LDS_BYTES, "back-track LDS, wide form");
+// the step out of a cell as a lane decides it: bits 0-2 what; BTC_ON: the gap run goes on (vertical: taken by F + e / O + c, horizontal: by E + e / Q + c)
+static constexpr int BTC_EVAL = 0, BTC_DIAG = 1, BTC_VERT = 2, BTC_LEFT = 3, BTC_STOP = 4, BTC_MISS = 5, BTC_BAD = 6, BTC_ON = 32;
 // A function of its own, NOT inlined: inside the kernel's one big body the register allocator spilled a value of this loop and
 // reloaded it every iteration -- and the wait for that reload is a wait for every store in flight, i.e. for the walk's own result
 // stores to reach memory: 2 us per step.  With its own frame the loop keeps its registers.
@@ -1487,7 +1453,10 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
     for (int i = lane; i < BT_RING / 2; i += 64) ((uint32_t*)lpn)[i] = 0;
     int jflush = j, sb0 = 0;                                        // pn[t] for t in [j, jflush) is in the ring
     auto flush = [&](int jlo) {
-        for (int t = jlo + lane; t < jflush; t += 64) { w.pn[t] = (int32_t)lpn[t & (BT_RING - 1)]; lpn[t & (BT_RING - 1)] = 0; }
+        // entries exist only for the columns of diagonal steps, all of them within BT_RING of jflush: a long horizontal run moves j far
+        // below without writing (what lies under the ring's span keeps the zeros pn was cleared to)
+        const int lo = jlo > jflush - BT_RING ? jlo : jflush - BT_RING;
+        for (int t = lo + lane; t < jflush; t += 64) { w.pn[t] = (int32_t)lpn[t & (BT_RING - 1)]; lpn[t & (BT_RING - 1)] = 0; }
         jflush = jlo;
     };
     auto row0_h = [&](int jj) -> int {
@@ -1496,7 +1465,7 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
     };
     int r0 = -(1 << 20), j0 = 0;
     uint2 rim = make_uint2(0, 0);
-    int csk = 0, csk1 = 0, chain = 0;                        // first column of this lane's band row and of the next lane's; the row's first in-edge is the row before
+    int csk = 0;                                             // first column of this lane's band row
     auto cs_at = [&](int k) -> int { const int x = j0 - k - BT_W / 2; return (x & 1) ? x : x - 1; };    // first column of band row k: odd = a dword boundary of the planes
     // Stage the band around (rr0, jj0).  Row 0 (no node) and column 0 are not in the planes: their cells are written into the band
     // here, so that the walk reads every cell the same way.
@@ -1511,11 +1480,9 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
         }
         const int rr = r0 - lane;
         rim = make_uint2(0, 0);
-        csk = cs_at(lane); csk1 = cs_at(lane + 1);
-        chain = 0;
+        csk = cs_at(lane);
         if (rr >= 1) {
             rim = w.ri[rr];
-            chain = (((rim.x >> 8) & 0xf) == 0 ? 0 : (int)(rim.x >> 16)) == rr - 1;
             if (csk + BT_W > 1) {
                 uint32_t t[BT_W * sizeof(HT) / 4];
                 __builtin_memcpy(t, (const uint32_t*)(w.planeH + (size_t)rr * gp + csk + 7), BT_W * sizeof(HT));
@@ -1581,6 +1548,50 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
     tacc[15] += __builtin_amdgcn_s_memtime() - t_bt0;
 #endif
     int guard = 2 * (N + m) + 64;                           // every step lowers r or j: a longer walk means corrupt planes
+    // a vertical step taken by F + e or O + c: the run goes on upwards from row r (column j) until a row where the gap opened.
+    // returns 0, -1 (guard) or BT_MISS
+    auto up_run = [&]() -> int {
+        while (r > 0) {
+            if (--guard < 0) return -1;
+            uint32_t e0, e1;
+            meta(r, e0, e1);
+            int np2 = (int)((e0 >> 8) & 0xf);
+            if (np2 == 15) np2 = __builtin_amdgcn_readfirstlane((int)A.np[w.order[r - 1]]);
+            const int npp2 = np2 ? np2 : 1;
+            const bool act2 = lane < npp2;
+            int ps2 = 0, xf = -(1 << 30), xo = -(1 << 30), hp2 = 0, fs2 = 0, os2 = 0, miss = 0;
+            if (act2) {
+                ps2 = pred_of(r, e0, e1, lane); hp2 = Hat(ps2, j);
+                if (hp2 == POA_H_NONE) miss = 1;
+                const int dp2 = Dat(ps2, j);
+                fs2 = hp2 + (dp2 & 7) - 1; os2 = hp2 + ((dp2 >> 3) & 31) - 1;
+                xf = hp2 > fs2 ? hp2 : fs2; xo = hp2 > os2 ? hp2 : os2;
+            }
+            if (__builtin_amdgcn_ballot_w64(miss != 0)) return BT_MISS;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { const int f2 = __shfl_xor(xf, d), o2 = __shfl_xor(xo, d); xf = f2 > xf ? f2 : xf; xo = o2 > xo ? o2 : xo; }
+            const int mf = __builtin_amdgcn_readlane(xf, 0), mo = __builtin_amdgcn_readlane(xo, 0);
+            const int k2 = !act2 ? 0 : (hp2 == mf ? 1 : (fs2 == mf ? 2 : (hp2 == mo ? 3 : (os2 == mo ? 4 : 0))));
+            const unsigned long long b2 = __builtin_amdgcn_ballot_w64(k2 != 0);
+            if (!b2) return -1;                   // cannot happen: some in-edge attains the maximum
+            const int s2 = __builtin_ctzll(b2);
+            const int kk = __builtin_amdgcn_readlane(k2, s2);
+            r = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(ps2, s2));
+            if (kk & 1) break;                    // the gap opened here
+        }
+        return 0;
+    };
+    // a horizontal step taken by E + e or Q + c: the run goes on to the left
+    auto left_run = [&]() -> int {
+        for (;;) {
+            if (--guard < 0) return -1;
+            --j;
+            if (Hat(r, j) == POA_H_NONE) return BT_MISS;
+            const int dj = Dat(r, j);
+            if (!(dj >> 8)) break;                // neither E nor Q of this column feeds the next
+        }
+        return 0;
+    };
     for (;;) {
         // (the loop's own test on values the compiler can see to be uniform: else the whole walk is built as a divergent loop, every
         // branch an exec-mask update)
@@ -1592,106 +1603,143 @@ __device__ __attribute__((noinline)) int poa_backtrack(const BtArgs A, const Poa
             const int drift = j - (j0 - a);
             if ((unsigned)a > 48u || drift < -BT_DRIFT || drift >= BT_DRIFT) { SEC0(); reload(r, j); a = 0; DBGCNT(18, 1); SEC(14); }
         }
-        // Everything one step can ask for is read from the band in ONE round: (1) lane a + l: the cells (r - l, j - l) and their diagonal
-        // neighbours -- a run of diagonal steps through first in-edges that are the row before; (2) lane s < in-degree of row r: the
-        // three cells of in-edge s; (3) the left neighbour.  In the band by construction (|drift| is bounded above).
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)rim.x, a), d1 = (uint32_t)__builtin_amdgcn_readlane((int)rim.y, a);
-        int np = (int)((d0 >> 8) & 0xf);
-        if (np == 15) np = __builtin_amdgcn_readfirstlane((int)A.np[w.order[r - 1]]);       // (the graph row's field holds up to 15)
-        const int npp = np ? np : 1;
+        // ONE round of LDS reads per iteration, and one iteration per RUN OF DIAGONAL STEPS PLUS THE STEP THAT ENDS IT (round 5; before, a run
+        // and the step behind it were two iterations, and the walk is a chain of iterations -- ~500 clocks each whatever they compute).
+        // Lane a + l looks at the cell (r - l, j - l) of the diagonal through (r, j) and decides the step OUT of it by spoa's list -- the
+        // diagonal through the row's in-edge; its F + e, H + g, O + c, H + q; then E + e, H + g, Q + c, H + q to the left -- from the
+        // band: the cell, its left neighbour, three cells per in-edge.  That covers the rows with at most three in-edges whose source
+        // rows and cells are in the band; any other cell answers BTC_EVAL and is evaluated with the in-edges across the lanes, as
+        // before.  The cells of a run are those whose step is "diagonal, to the row before" (code bits 3-4: the in-edge); the lane behind the run
+        // holds the step that ends it.  A cell the planes do not hold is a miss only where a test needs it.
         const int l = lane - a, myr = r0 - lane, myc = j - l;
-        bool ok = l >= 0 && lane < 63 && chain && myc >= 1;
-        const int ps = np == 0 ? 0 : (lane == 0 ? (int)(d0 >> 16) : (lane == 1 ? (int)(d1 & 0xffff) : (int)(d1 >> 16)));
-        const int kp = r0 - ps, xp = j - cs_at(kp);
-        const bool act = lane < npp;
-        const bool inb = (unsigned)kp < 64u && xp >= 1 && xp < BT_W;
+        const uint32_t e0 = rim.x, e1 = rim.y;
+        const int npl = (int)((e0 >> 8) & 0xf), nppl = npl ? npl : 1;
+        const bool mine = l >= 0 && myr >= 1 && myc >= 1;
+        // the in-edges' source rows (row 0 for a node without in-edges) and where their cells of column myc sit in the band
+        int pl[3], ipl[3];
+        bool simple = mine && npl <= 3;
+        pl[0] = npl == 0 ? 0 : (int)(e0 >> 16); pl[1] = (int)(e1 & 0xffff); pl[2] = (int)(e1 >> 16);
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            const int kp_ = r0 - pl[s_], xp_ = myc - cs_at(kp_);
+            const bool in_ = (unsigned)kp_ < 64u && xp_ >= 1 && xp_ < BT_W;
+            simple = simple && (in_ || s_ >= nppl);
+            ipl[s_] = in_ && s_ < nppl ? kp_ * BT_W + xp_ : lane * BT_W + 1;
+        }
         // no branches around the reads (a lane with nothing to read reads a cell of its own band row): they issue together, one wait
-        const int i_own = ok ? lane * BT_W + myc - csk : lane * BT_W, i_nb = ok ? (lane + 1) * BT_W + myc - 1 - csk1 : lane * BT_W;
-        const int i_p = act && inb ? kp * BT_W + xp : lane * BT_W + 1, i_s = ok ? myc - 1 : j - 1;
-        const int xl = a * BT_W + j - __builtin_amdgcn_readlane(csk, a);
-        const int hc = (int)Hb[i_own], hd = (int)Hb[i_nb], hp1 = (int)Hb[i_p - 1], hpv = (int)Hb[i_p], dpv = (int)Db[i_p];
-        const int h = (int)Hb[xl], hl = (int)Hb[xl - 1], dl = (int)Db[xl - 1], sb = (int)lsq[i_s - sb0];
-        int hp = hpv, dp = dpv, hp1x = hp1;
-        ok = ok && hc != POA_H_NONE && hd != POA_H_NONE && hc == hd + ((int)(rim.x & 0xff) == sb ? S.m : S.n) && !(sw && hc == 0);
+        const int i_own = mine ? lane * BT_W + myc - csk : lane * BT_W + 1;
+        const int i_s = mine ? myc - 1 : j - 1;
+        const int h = (int)Hb[i_own], hl = (int)Hb[i_own - 1], dl = (int)Db[i_own - 1], sb = (int)lsq[i_s - sb0];
+        int hs1[3], hs[3], ds[3];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) { hs1[s_] = (int)Hb[ipl[s_] - 1]; hs[s_] = (int)Hb[ipl[s_]]; ds[s_] = (int)Db[ipl[s_]]; }
+        int code = BTC_EVAL;
+        if (simple) {
+            const int sc = (int)(e0 & 0xff) == sb ? S.m : S.n;
+            int dec = h == POA_H_NONE ? BTC_MISS : (sw && h == 0 ? BTC_STOP : -1);
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)                               // the diagonal through the in-edges, in their order
+                if (dec < 0 && s_ < nppl) dec = hs1[s_] == POA_H_NONE ? BTC_MISS : (h == hs1[s_] + sc ? (BTC_DIAG | (s_ << 3)) : -1);
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)                               // per in-edge: F + e, H + g, O + c, H + q
+                if (dec < 0 && s_ < nppl) {
+                    const int fs = hs[s_] + (ds[s_] & 7) - 1, os = hs[s_] + ((ds[s_] >> 3) & 31) - 1;
+                    dec = hs[s_] == POA_H_NONE ? BTC_MISS
+                        : h == fs + g ? (BTC_VERT | BTC_ON | (s_ << 3)) : h == hs[s_] + g ? (BTC_VERT | (s_ << 3))
+                        : h == os + q ? (BTC_VERT | BTC_ON | (s_ << 3)) : h == hs[s_] + q ? (BTC_VERT | (s_ << 3)) : -1;
+                }
+            if (dec < 0) {                                                // to the left: E + e, H + g, Q + c, H + q
+                const int es = hl + ((dl >> 8) & 7) - 1, qs = hl + ((dl >> 11) & 31) - 1;
+                dec = hl == POA_H_NONE ? BTC_MISS
+                    : h == es + g ? (BTC_LEFT | BTC_ON) : h == hl + g ? BTC_LEFT : h == qs + q ? (BTC_LEFT | BTC_ON) : h == hl + q ? BTC_LEFT : BTC_BAD;
+            }
+            code = dec;
+        }
+        const int psel = ((code >> 3) & 3) == 0 ? pl[0] : (((code >> 3) & 3) == 1 ? pl[1] : pl[2]);      // source row of the chosen in-edge
         {
-            const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok) >> a;
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(code == BTC_DIAG && psel == myr - 1) >> a;
             const int run = ~okm ? __builtin_ctzll(~okm) : 64;
             if (run > 0) {
                 DBGCNT(16, 1); DBGCNT(17, run);
                 if (l >= 0 && l < run) lpn[(myc - 1) & (BT_RING - 1)] = (unsigned short)myr;
                 r -= run; j -= run; moved = true;
+                a += run;
+                if (a > 63 || r < 1 || j < 1) continue;
+            }
+            // the step out of (r, j), as lane a decided it
+            const int ca = __builtin_amdgcn_readlane(code, a);
+            const int what = ca & 7;
+            if (what == BTC_STOP) break;
+            if (what == BTC_MISS) return BT_MISS;
+            if (what == BTC_BAD) return -1;
+            if (what != BTC_EVAL) {
+                DBGCNT(19, 1);
+                moved = true;
+                if (what == BTC_LEFT) {
+                    --j;
+                    if (ca & BTC_ON) { const int rc_ = left_run(); if (rc_) return rc_; }      // by E + e or Q + c: the run goes on to the left
+                    continue;
+                }
+                const int pa = __builtin_amdgcn_readlane(psel, a);
+                if (what == BTC_DIAG) {                                    // diagonal through an in-edge whose source is not the row before
+                    if (lane == 0) lpn[(j - 1) & (BT_RING - 1)] = (unsigned short)r;
+                    r = pa; --j;
+                    continue;
+                }
+                r = pa;                                                    // BTC_VERT
+                if (ca & BTC_ON) { const int rc_ = up_run(); if (rc_) return rc_; }          // by F + e or O + c: the run goes on upwards
                 continue;
             }
+            if (run > 0) continue;      // (the general evaluation below reads the band at the iteration's starting cell: once more from the top)
         }
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)rim.x, a), d1 = (uint32_t)__builtin_amdgcn_readlane((int)rim.y, a);
+        int np = (int)((d0 >> 8) & 0xf);
+        const int xl = a * BT_W + j - __builtin_amdgcn_readlane(csk, a);
+        const int hx = (int)Hb[xl], hlx = (int)Hb[xl - 1], dlx = (int)Db[xl - 1];
+        // the other rows: in-edge s on lane s (a second round of reads)
+        if (np == 15) np = __builtin_amdgcn_readfirstlane((int)A.np[w.order[r - 1]]);       // (the graph row's field holds up to 15)
+        const int npp = np ? np : 1;
+        const int ps = np == 0 ? 0 : (lane == 0 ? (int)(d0 >> 16) : (lane == 1 ? (int)(d1 & 0xffff) : (int)(d1 >> 16)));
+        const int kp = r0 - ps, xp = j - cs_at(kp);
+        const bool act = lane < npp;
+        const bool inb = (unsigned)kp < 64u && xp >= 1 && xp < BT_W;
+        const int i_p = act && inb ? kp * BT_W + xp : lane * BT_W + 1;
+        const int hp1 = (int)Hb[i_p - 1], hpv = (int)Hb[i_p], dpv = (int)Db[i_p];
+        int hp = hpv, dp = dpv, hp1x = hp1;
         // one step by spoa's full list of tests; lane s looks at in-edge s
-        if (sw && h == 0) break;
+        if (sw && hx == 0) break;
         DBGCNT(19, 1);
         int psx = ps;
         if (np > 3 || __builtin_amdgcn_ballot_w64(act && !inb)) {        // rare: in-edges beyond the third, or a source row outside the band
             if (act) { psx = pred_of(r, d0, d1, lane); hp1x = Hat(psx, j - 1); hp = Hat(psx, j); dp = Dat(psx, j); }
         }
-        if (h == POA_H_NONE || hl == POA_H_NONE || __builtin_amdgcn_ballot_w64(act && (hp1x == POA_H_NONE || hp == POA_H_NONE))) return BT_MISS;
+        if (hx == POA_H_NONE || hlx == POA_H_NONE || __builtin_amdgcn_ballot_w64(act && (hp1x == POA_H_NONE || hp == POA_H_NONE))) return BT_MISS;
         moved = true;
         {
             const int sc = (int)(d0 & 0xff) == (int)lsq[j - 1 - sb0] ? S.m : S.n;
-            unsigned long long bm = __builtin_amdgcn_ballot_w64(act && h == hp1x + sc);
+            unsigned long long bm = __builtin_amdgcn_ballot_w64(act && hx == hp1x + sc);
             if (bm) {
                 if (lane == 0) lpn[(j - 1) & (BT_RING - 1)] = (unsigned short)r;
                 r = __builtin_amdgcn_readlane(psx, __builtin_ctzll(bm)); --j;
                 continue;
             }
             const int fs = hp + (dp & 7) - 1, os = hp + ((dp >> 3) & 31) - 1;
-            const int kind = !act ? 0 : (h == fs + g ? 1 : (h == hp + g ? 2 : (h == os + q ? 3 : (h == hp + q ? 4 : 0))));
+            const int kind = !act ? 0 : (hx == fs + g ? 1 : (hx == hp + g ? 2 : (hx == os + q ? 3 : (hx == hp + q ? 4 : 0))));
             bm = __builtin_amdgcn_ballot_w64(kind != 0);
             if (bm) {
                 const int s = __builtin_ctzll(bm);
                 const int kd = __builtin_amdgcn_readlane(kind, s);
                 r = __builtin_amdgcn_readlane(psx, s);
-                if (kd & 1) {                                 // by F + e or O + c: the run goes on upwards
-                    while (r > 0) {
-                        if (--guard < 0) return -1;
-                        uint32_t e0, e1;
-                        meta(r, e0, e1);
-                        int np2 = (int)((e0 >> 8) & 0xf);
-                        if (np2 == 15) np2 = __builtin_amdgcn_readfirstlane((int)A.np[w.order[r - 1]]);
-                        const int npp2 = np2 ? np2 : 1;
-                        const bool act2 = lane < npp2;
-                        int ps2 = 0, xf = -(1 << 30), xo = -(1 << 30), hp2 = 0, fs2 = 0, os2 = 0, miss = 0;
-                        if (act2) {
-                            ps2 = pred_of(r, e0, e1, lane); hp2 = Hat(ps2, j);
-                            if (hp2 == POA_H_NONE) miss = 1;
-                            const int dp2 = Dat(ps2, j);
-                            fs2 = hp2 + (dp2 & 7) - 1; os2 = hp2 + ((dp2 >> 3) & 31) - 1;
-                            xf = hp2 > fs2 ? hp2 : fs2; xo = hp2 > os2 ? hp2 : os2;
-                        }
-                        if (__builtin_amdgcn_ballot_w64(miss != 0)) return BT_MISS;
-#pragma unroll
-                        for (int d = 1; d < 16; d <<= 1) { const int f2 = __shfl_xor(xf, d), o2 = __shfl_xor(xo, d); xf = f2 > xf ? f2 : xf; xo = o2 > xo ? o2 : xo; }
-                        const int mf = __builtin_amdgcn_readlane(xf, 0), mo = __builtin_amdgcn_readlane(xo, 0);
-                        const int k2 = !act2 ? 0 : (hp2 == mf ? 1 : (fs2 == mf ? 2 : (hp2 == mo ? 3 : (os2 == mo ? 4 : 0))));
-                        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(k2 != 0);
-                        if (!b2) return -1;                   // cannot happen: some in-edge attains the maximum
-                        const int s2 = __builtin_ctzll(b2);
-                        const int kk = __builtin_amdgcn_readlane(k2, s2);
-                        r = __builtin_amdgcn_readlane(ps2, s2);
-                        if (kk & 1) break;                    // the gap opened here
-                    }
-                }
+                if (kd & 1) { const int rc_ = up_run(); if (rc_) return rc_; }      // by F + e or O + c: the run goes on upwards
                 continue;
             }
         }
         {   // to the left
-            const int es = hl + ((dl >> 8) & 7) - 1, qs = hl + ((dl >> 11) & 31) - 1;
+            const int es = hlx + ((dlx >> 8) & 7) - 1, qs = hlx + ((dlx >> 11) & 31) - 1;
             int ext;
-            if (h == es + g) ext = 1; else if (h == hl + g) ext = 0; else if (h == qs + q) ext = 1; else if (h == hl + q) ext = 0; else return -1;
+            if (hx == es + g) ext = 1; else if (hx == hlx + g) ext = 0; else if (hx == qs + q) ext = 1; else if (hx == hlx + q) ext = 0; else return -1;
             --j;
-            if (ext) for (;;) {                               // by E + e or Q + c: the run goes on to the left
-                if (--guard < 0) return -1;
-                --j;
-                if (Hat(r, j) == POA_H_NONE) return BT_MISS;
-                const int dj = Dat(r, j);
-                if (!(dj >> 8)) break;                        // neither E nor Q of this column feeds the next
-            }
+            if (ext) { const int rc_ = left_run(); if (rc_) return rc_; }      // by E + e or Q + c: the run goes on to the left
         }
     }
     flush(j);

@@ -28,49 +28,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "clh_device.h"
+#include "clh_device_ops.h"
 
 namespace clh {
 
 namespace {
 
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
-__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
-__device__ __forceinline__ uint32_t pk_maxu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
-__device__ __forceinline__ uint32_t pk_subus(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
-__device__ __forceinline__ uint32_t pk_madu(uint32_t a, uint32_t b, uint32_t c) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c)); }
-__device__ __forceinline__ uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
-// hand a packed value to the next virtual lane: new low half = previous lane's high half (lane 0: lane0_lo), new high half = own low half
-__device__ __forceinline__ uint32_t hand_down(uint32_t v, int lane0_lo) {
-    const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp((int)((uint32_t)lane0_lo << 16), (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    return __builtin_amdgcn_alignbit(v, x, 16);
-}
-__device__ __forceinline__ int dpp_shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
-// inclusive prefix maximum over the 64 lanes (v_max_i32 with the DPP modifier on the operand: 6 instructions)
-__device__ __forceinline__ int wave_prefix_max(int v) {
-    asm volatile("s_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
-                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
-                 : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
-    return v;
-}
 
 #ifndef SCAN_WAVES
 #define SCAN_WAVES 3      // measured on the C3 clip batch: 2 -> 1.87 ms, 3 -> 1.76 ms, 4 -> 1.88 ms

@@ -46,6 +46,8 @@ class SswOpts(C.Structure):
 
 
 _lib = None
+_gpu_used = False         # set when this process creates its first device context (clh_create: the first call that initialises the HIP runtime);
+                          # loading libclh.so and its host-only entry points (fastx_index, fastx_count, encode) do not
 
 
 def lib():
@@ -206,11 +208,13 @@ class Context(object):
     """One per (process, GPU)."""
 
     def __init__(self, device=0):
+        global _gpu_used
         L = lib()
         _torch_first()
         self._h = L.clh_create(int(device))
         if not self._h:
             raise HipUnavailable('clh_create(%d) failed: %s (there is no CPU fallback)' % (device, last_error()))
+        _gpu_used = True
         self.device = int(device)
 
     def close(self):

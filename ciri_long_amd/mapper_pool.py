@@ -22,9 +22,11 @@ _FORK_PAYLOAD = None       # (aligner, contig_len) a forked worker finds here
 
 
 def gpu_touched():
-    """True once this process may hold GPU state: libclh loaded, or torch's HIP runtime initialised"""
+    """True once this process may hold GPU state: a device context of libclh was created (hip.Context: the first call into the HIP
+    runtime -- loading the library and its host-only entry points, e.g. the record count of dist.call_sharded, do not initialise it),
+    or torch's HIP runtime is initialised"""
     hip = sys.modules.get(__package__ + '.hip')
-    if hip is not None and getattr(hip, '_lib', None) is not None:
+    if hip is not None and getattr(hip, '_gpu_used', False):
         return True
     torch = sys.modules.get('torch')
     try:

@@ -28,6 +28,35 @@ def test_reference_test_poa_structure():
     assert len(msa) == len(SEGMENTS) and all(r.replace('-', '') == s for r, s in zip(msa, SEGMENTS))
 
 
+# The labels the reference's tests/test_poa.py:21-28 holds beside its six copies.  Nothing in the reference asserts them, and their sum does
+# not even match the strings they label (the last one spans 21 bases for a 38-base string) -- but they look like a recorded pyccs `segments`
+# string, which makes them the only evidence there is about pyccs' boundary rule.
+REFERENCE_LABELS = '0-145;145-289;289-433;433-579;579-721;721-742'
+
+
+def test_copy_boundaries_beside_the_labels_the_reference_test_holds(capsys):
+    """NON-BINDING (parity unpinned): prints how clh-ccs v1 cuts the tests/test_poa.py input next to the labels above, and pins only what
+    this repository's specification says today -- so that the day pyccs can be run, the first thing to compare is already written down, and
+    so that a change of the specification shows up here.  Today: the same number of copies, the first three copies' boundaries within two
+    bases of the labels and of the true copy boundaries of the input (cumulative lengths of the six strings); the cuts behind the two copies
+    with long deletions up to ten bases in front of the true ends."""
+    raw = ''.join(SEGMENTS)
+    seg, ccs, period = oracle_lib.oracle_find_consensus(raw)
+    ours = [tuple(map(int, x.split('-'))) for x in seg.split(';')]
+    labels = [tuple(map(int, x.split('-'))) for x in REFERENCE_LABELS.split(';')]
+    true_ends = list(np.cumsum([len(x) for x in SEGMENTS]))
+    with capsys.disabled():
+        print('\n  tests/test_poa.py labels : %s\n  clh-ccs v1 (oracle)     : %s\n  true copy ends          : %s' % (REFERENCE_LABELS, seg, ';'.join(map(str, true_ends))))
+    assert seg == '0-143;143-289;289-431;431-569;569-704;704-751'          # the specification as it stands (oracle/ccs_oracle.c, "clh-ccs v1")
+    assert len(ours) == len(labels) == len(SEGMENTS)
+    for (a, b), (la, lb) in list(zip(ours, labels))[:3]:
+        assert abs(a - la) <= 2 and abs(b - lb) <= 2
+    for (a, b), e in zip(ours[:3], true_ends[:3]):
+        assert abs(b - e) <= 2
+    for (a, b), e in zip(ours[3:5], true_ends[3:5]):      # copies 4 and 5 carry deletions of 9 and 8 bases: the chained cuts sit that far in front of the true ends
+        assert e - 10 <= b <= e
+
+
 def test_recovers_templates_and_rejects_linear_reads():
     from ciri_long_amd import synth
     rng = np.random.Generator(np.random.PCG64(11))

@@ -606,7 +606,10 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
     for (int t = 0; t < CP; ++t) { px[t] = 0; pf[t] = 0; po[t] = 0; }
     // end cell within this pass, per virtual lane: value, rank (16 bits) and column offset within the half
-    uint32_t bsP = sw ? 0u : 0x80008000u, brP = 0, bcP = 0;
+    uint32_t bsP = sw ? 0u : 0x80008000u, brP = 0;
+    uint32_t snapP[CP];                                          // the row's values in the halves where it set the best so far: the column is found from them once, behind the pass
+#pragma unroll
+    for (int t = 0; t < CP; ++t) snapP[t] = 0;
     int nbest = -(1 << 30), nrow = 0;                            // global mode: cells (sink row, column m), wave-uniform
     uint32_t lowP = 0x7fff7fffu;                                 // global / overlap: the lowest H of the pass (local cells are >= 0)
 #ifdef POA_EXP_DP2_NOSTORE     // timing experiment: the second of two runs of the pass writes no planes
@@ -821,21 +824,13 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
                 for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
                 const uint32_t imp = pk_sra15(pk_subs(bsP, rm));                  // halves whose best is exceeded (strictly: the first row stays)
-#ifndef POA_ENDCELL_VOTE
-                // no vote: along an alignment nearly every row improves some lane's best, and a wave-wide vote feeding a scalar branch
-                // is a VALU -> SALU hand-over that stalls the step -- the update is a few masked moves, done unconditionally
-                {
-#else
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(imp != 0u) != 0, 0)) {
-#endif
-                    uint32_t colP = 0;
+                // no vote around the update: along an alignment nearly every row improves some lane's best, and a wave-wide vote feeding a
+                // scalar branch is a VALU -> SALU hand-over that stalls the step -- a few masked moves, done unconditionally.  Round 5: the
+                // improving halves keep the row's values (one v_bfi per register); which column of the virtual lane held the maximum is
+                // worked out once, behind the pass, instead of in every row (four packed operations per register and row).
+                bsP = pk_max(bsP, rm); brP = bfi(imp, dup16(r), brP);
 #pragma unroll
-                    for (int t = CP - 1; t >= 0; --t) {
-                        const uint32_t eqm = pk_subu(pk_minu(pk_subs(rm, hv2[t]), ONE2), ONE2);   // 0xFFFF where this column holds the maximum
-                        colP = bfi(eqm, dup16(t), colP);
-                    }
-                    bsP = bfi(imp, rm, bsP); brP = bfi(imp, dup16(r), brP); bcP = bfi(imp, colP, bcP);
-                }
+                for (int t = 0; t < CP; ++t) snapP[t] = bfi(imp, hv2[t], snapP[t]);
             } else if (nw & sink & last) {
                 uint32_t pick = 0;
 #pragma unroll
@@ -867,6 +862,12 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     // best of this pass: value descending, rank ascending, column ascending -- then against the earlier passes' (their columns
     // are smaller: on equal value and rank the earlier pass stays)
     {
+        uint32_t bcP = 0;                                                         // first register of the virtual lane that held its best value, per half
+#pragma unroll
+        for (int t = CP - 1; t >= 0; --t) {
+            const uint32_t eqm = pk_subu(pk_minu(pk_subs(bsP, snapP[t]), ONE2), ONE2);    // 0xFFFF where this column holds the maximum
+            bcP = bfi(eqm, dup16(t), bcP);
+        }
         const int vlo = (int)(short)(bsP & 0xffffu), vhi = (int)bsP >> 16;
         const int rlo = (int)(brP & 0xffffu), rhi = (int)(brP >> 16);
         const int clo = col0 + (int)(bcP & 0xffffu) + 1, chi = col0 + CP + (int)(bcP >> 16) + 1;

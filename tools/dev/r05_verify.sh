@@ -2,5 +2,5 @@
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q > gpurun_out/r05e_gputests.txt 2>&1; tail -2 gpurun_out/r05e_gputests.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-/usr/bin/time -v python bench.py --steps 20 --warmup 5 --detail gpurun_out/r05e_c3_bench_detail.json > gpurun_out/r05e_c3_bench.json 2> gpurun_out/r05e_c3_bench.err; grep "Elapsed (wall" gpurun_out/r05e_c3_bench.err; wc -c gpurun_out/r05e_c3_bench.json; cut -c1-300 gpurun_out/r05e_c3_bench.json
+t0=$(date +%s); python bench.py --steps 20 --warmup 5 --detail gpurun_out/r05e_c3_bench_detail.json > gpurun_out/r05e_c3_bench.json 2> gpurun_out/r05e_c3_bench.err; echo "default bench wall: $(( $(date +%s) - t0 )) s"; wc -c gpurun_out/r05e_c3_bench.json; cut -c1-300 gpurun_out/r05e_c3_bench.json
 bash tools/pmc_run.sh r05e_c3 --steps 10 --warmup 2 | tail -3

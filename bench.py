@@ -688,6 +688,69 @@ def extra_stage2(hip, synth, ctx, n=50000):
                                                   'about a millisecond per read, i.e. far more than everything measured here'}}
 
 
+POOL_READS, POOL_DELAY_US = 4000, 150
+
+
+class _SeqGenome(object):
+    """serves sequences from one string, as a FASTA does (find_bsj._resident makes it resident in HBM)"""
+
+    def __init__(self, text):
+        self.genome = {'chr1': text}
+        self.contig_len = {'chr1': len(text)}
+
+    def seq(self, ctg, a, b):
+        return self.genome[ctg][max(a, 0):b]
+
+
+def prepare_stage2_pool():
+    """BEFORE this process touches the GPU: a small circRNA world whose mapper double costs POOL_DELAY_US per call while HOLDING the
+    interpreter lock (what a mapper that does not release the GIL would do), and the worker processes of the mapper phase forked from
+    it (find_bsj.start_mapper_pools; the reference's Pool(threads, env.initializer), find_bsj.py:338-345)."""
+    from ciri_long_amd import find_bsj, synth
+    workers = max(2, min(16, (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else 4) // 2))
+    w = synth.circ_world(POOL_READS, seed=synth.SEEDS['C3'] + 5, genome_len=4_000_000, mapper_delay_us=POOL_DELAY_US)
+    find_bsj.THREADS = workers
+    roles = find_bsj.start_mapper_pools(workers, scan_aligner=w['mapper'], contig_len={'chr1': len(w['genome'])})
+    find_bsj.THREADS = 1
+    return {'world': w, 'workers': workers, 'roles': roles}
+
+
+def extra_stage2_pool(prep):
+    """stage 2 file to file (find_bsj.scan_ccs_reads) with the mapper phase on one thread, on N threads and on N worker processes: the
+    same records, and what each route is worth against a mapper that holds the GIL"""
+    import shutil
+    import tempfile
+    from ciri_long_amd import env, find_bsj
+    w, workers = prep['world'], prep['workers']
+    genome = _SeqGenome(w['genome'])
+    out, files = {}, {}
+    d = tempfile.mkdtemp(dir='/tmp')
+    try:
+        for tag, threads, mode in (('one_thread', 1, 'threads'), ('threads', workers, 'threads'), ('processes', workers, 'processes')):
+            os.environ['CIRI_LONG_MAPPER'] = mode
+            sub = os.path.join(d, tag)
+            os.makedirs(sub)
+            t0 = time.perf_counter()
+            cnt, _short = find_bsj.scan_ccs_reads(w['ccs_seq'], None, {}, {}, None, True, sub, 'p', threads, aligner=w['mapper'], genome=genome, contig_len=genome.contig_len)
+            out[tag] = time.perf_counter() - t0
+            files[tag] = (open(os.path.join(sub, 'p.cand_circ.fa'), 'rb').read(), dict(cnt))
+            if getattr(env.GENOME, 'device', None) is not None:
+                env.GENOME.device.close()
+    finally:
+        os.environ.pop('CIRI_LONG_MAPPER', None)
+        find_bsj.THREADS = 1
+        find_bsj.stop_mapper_pools()
+        shutil.rmtree(d, ignore_errors=True)
+    assert files['threads'] == files['one_thread'] and files['processes'] == files['one_thread'], 'the mapper routes disagree'
+    n = len(w['ccs_seq'])
+    return {'workload': 'stage 2 file to file on %d reads with a mapper double that costs %d us per call and HOLDS the interpreter lock: the mapper phase on one thread, on %d '
+                        'threads of the GPU process, on %d worker processes forked before the GPU was touched (ciri_long_amd/mapper_pool.py); cand_circ.fa and counters identical'
+                        % (n, POOL_DELAY_US, workers, workers),
+            'value': n / out['processes'], 'unit': 'reads/s', 'workers': workers, 'one_thread_reads_per_s': n / out['one_thread'], 'threads_reads_per_s': n / out['threads'],
+            'processes_reads_per_s': n / out['processes'], 'speedup_processes': out['one_thread'] / out['processes'], 'speedup_threads': out['one_thread'] / out['threads'],
+            'records_bytes': len(files['one_thread'][0]), 'roofline': {'bound': 'host', 'note': 'the mapper double; the GPU phases of the %d reads are a few milliseconds' % n}}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # The record.  stdout carries ONE line of at most LINE_MAX characters (the driver parses the last stdout line and keeps a short
 # tail of it: round 4's 21 kB line came back unparsed); everything else -- per-class launches, the extra workloads in full,
@@ -733,6 +796,9 @@ def summary_of(out):
             for key in ('cold_value',):
                 if key in e:
                     s[key] = round(e[key])
+            for key in ('workers', 'speedup_processes', 'speedup_threads'):
+                if key in e:
+                    s[key] = round(e[key], 2)
             summ[k] = s
     if (out.get('extra') or {}).get('error'):
         summ['extra_error'] = out['extra']['error'][:160]
@@ -876,6 +942,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu and not profiled:
         cpu = cpu_baseline(args.cpu_seconds, wl)
 
+    # the worker processes of the mapper-pool line: forked now, before this process touches the GPU (a spawned CPU leg is behind us)
+    pool_prep = None
+    if rank == 0 and world == 1 and not args.no_extra and not profiled and wl == 'c3':
+        try:
+            pool_prep = prepare_stage2_pool()
+        except Exception as ex:          # an extra line must not cost the headline
+            pool_prep = {'error': repr(ex)}
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -945,6 +1019,8 @@ def main():
             out['e2e_stage1_reads_per_s'] = extra['stage1_files']['e2e_stage1_reads_per_s']
             extra['stage2_files'] = extra_stage2(hip, synth, ctx)
             out['e2e_stage2_reads_per_s'] = extra['stage2_files']['e2e_stage2_reads_per_s']
+            if pool_prep is not None:
+                extra['stage2_mapper_pool'] = extra_stage2_pool(pool_prep) if 'world' in pool_prep else {'error': pool_prep['error']}
         except Exception as ex:                      # an extra line must not cost the headline
             extra['error'] = repr(ex)
         out['extra'] = extra

@@ -792,15 +792,24 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                if constexpr (CP == 1) { *dh = nh[0]; *dd = nd[0]; }
+                // the planes stream: 20 GB of them per C3 launch against ~100 MB of graph arrays that every other phase chases pointers through.
+                // With the non-temporal hint the stores pass the caches without pushing those arrays out (round 5: 17.63 -> 17.51 ms on C3,
+                // 76.3 -> 75.9 on C4, A/B twice on one box; POA_TEMPORAL_STORES for the A/B).  A hint about retention only: coherence is unchanged.
+#ifdef POA_TEMPORAL_STORES
+#define PLANE_ST(ptr, val) (*(ptr) = (val))
+#else
+#define PLANE_ST(ptr, val) __builtin_nontemporal_store(val, ptr)
+#endif
+                if constexpr (CP == 1) { PLANE_ST(dh, nh[0]); PLANE_ST(dd, nd[0]); }
                 else if constexpr (CP == 2) {
-                    *(__attribute__((address_space(1))) u32x2*)dh = u32x2{nh[0], nh[1]}; *(__attribute__((address_space(1))) u32x2*)dd = u32x2{nd[0], nd[1]};
+                    PLANE_ST((__attribute__((address_space(1))) u32x2*)dh, (u32x2{nh[0], nh[1]})); PLANE_ST((__attribute__((address_space(1))) u32x2*)dd, (u32x2{nd[0], nd[1]}));
                 } else if constexpr (CP == 3) {
                     typedef u32x3 __attribute__((aligned(4))) u32x3u;
-                    *(__attribute__((address_space(1))) u32x3u*)dh = u32x3{nh[0], nh[1], nh[2]}; *(__attribute__((address_space(1))) u32x3u*)dd = u32x3{nd[0], nd[1], nd[2]};
+                    PLANE_ST((__attribute__((address_space(1))) u32x3u*)dh, (u32x3{nh[0], nh[1], nh[2]})); PLANE_ST((__attribute__((address_space(1))) u32x3u*)dd, (u32x3{nd[0], nd[1], nd[2]}));
                 } else {
-                    *(__attribute__((address_space(1))) u32x4*)dh = u32x4{nh[0], nh[1], nh[2], nh[3]}; *(__attribute__((address_space(1))) u32x4*)dd = u32x4{nd[0], nd[1], nd[2], nd[3]};
+                    PLANE_ST((__attribute__((address_space(1))) u32x4*)dh, (u32x4{nh[0], nh[1], nh[2], nh[3]})); PLANE_ST((__attribute__((address_space(1))) u32x4*)dd, (u32x4{nd[0], nd[1], nd[2], nd[3]}));
                 }
+#undef PLANE_ST
             }
             if (__builtin_expect(tolds, 0)) {
                 uint32_t* rp = ring + (r & rmask) * rrow + lane * CP;

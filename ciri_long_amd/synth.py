@@ -125,19 +125,20 @@ class TruthMapper(object):
     hit -- the soft clip a real mapper leaves next to a junction -- so that find_bsj's rotation loop ends with `soft` clipped bases
     and align_clip_segments has to place them by Smith-Waterman in the hit +- 200 kb window (soft = 0 for about half of the reads)."""
 
-    def __init__(self, world):
+    def __init__(self, world, delay_us=0):
         import time
         self.w = world
         self.seconds = 0.0
         self.calls = 0
+        self.delay = delay_us * 1e-6      # a busy wait per call that HOLDS the interpreter lock: the cost of a real mapper call, for the mapper-pool line of bench.py
         self._clock = time.perf_counter
-        self._raw = {}          # id(raw string) -> template
+        self._raw = {}          # raw read -> template (keyed by the string: a worker process of the mapper pool holds copies, not these objects)
         self._bucket = {}       # (length, #A, #C, #G) -> templates: a rotation keeps all four
         for t, o in enumerate(world['oriented']):
             self._bucket.setdefault((len(o), o.count('A'), o.count('C'), o.count('G')), []).append(t)
 
     def note_raw(self, raw, t, phase):
-        self._raw[id(raw)] = (t, phase)
+        self._raw[raw] = (t, phase)
 
     def _hit(self, t, x, y, q_st, primary):
         """oriented-template bases [x, y) at query offset q_st"""
@@ -150,13 +151,17 @@ class TruthMapper(object):
         t0 = self._clock()
         self.calls += 1
         out = self._map(seq)
+        if self.delay:
+            end = t0 + self.delay
+            while self._clock() < end:
+                pass
         self.seconds += self._clock() - t0
         return out
 
     def _map(self, seq):
         if not seq:
             return None
-        known = self._raw.get(id(seq))
+        known = self._raw.get(seq) if len(seq) >= 160 else None      # (raw reads hold two copies and more of a template of >= 80 bases)
         if known is not None:          # the raw read: one full copy of the template somewhere inside it (only the filters read this hit)
             t, phase = known
             n = len(self.w['oriented'][t])
@@ -191,7 +196,7 @@ class TruthMapper(object):
         return None
 
 
-def circ_world(n, seed=SEEDS['C3'] + 2, genome_len=20_000_000, rank=0):
+def circ_world(n, seed=SEEDS['C3'] + 2, genome_len=20_000_000, rank=0, mapper_delay_us=0):
     """n reads of single-exon circRNAs on one contig: {'genome': str, 'loci': [(start, end, strand)], 'oriented': [template in read
     orientation], 'soft': [clipped bases], 'ccs_seq': {read id: [segments, ccs, raw]}, 'mapper': TruthMapper}.  The consensus of a
     read is a rotation of its template (stage 2 starts from stage 1's files; the consensus kernels are measured elsewhere)."""
@@ -208,7 +213,7 @@ def circ_world(n, seed=SEEDS['C3'] + 2, genome_len=20_000_000, rank=0):
         loci.append((a, a + p, strand))
         soft.append(int(rng.integers(20, max(21, min(120, p // 3)))) if rng.random() < 0.5 else 0)
     world = {'genome': genome, 'loci': loci, 'oriented': oriented, 'oriented2': [o + o for o in oriented], 'soft': soft}
-    mapper = TruthMapper(world)
+    mapper = TruthMapper(world, mapper_delay_us)
     ccs_seq = {}
     for t, o in enumerate(oriented):
         n_t = len(o)

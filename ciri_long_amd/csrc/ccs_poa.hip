@@ -41,19 +41,20 @@ static constexpr int POA_OVF_CAP = 2048;             // entries of the overflow 
 static constexpr int POA_MAXA = 7;                   // other members of an aligned set: 8 different letters in one column (implementation limit)
 static constexpr int POA_MAX_COPY = 2800;            // longest sequence: cells are int16 (match score <= 11)
 
-// Phase boundary inside one wave that exchanges data between lanes through HBM: complete the stores, then drop the
-// CU's L1 so that no line read before the stores can be served stale (buffer_inv sc1; a few microseconds, used a
-// handful of times per copy, never per row).
+// Phase boundary inside one wave whose lanes exchange data through HBM.  The workgroup IS that wave, so the block-level guarantee is all it
+// needs: stores before the barrier are visible to every lane of the block behind it (on gfx950 in non-threadgroup-split mode a work-group's
+// waves share one vector L1, which stays coherent with the CU's own stores -- the LLVM memory model's work-group-scope acquire is a wait, not
+// an invalidation).  Rounds 1-4 dropped the CU's whole L1 here (an AGENT-scope acquire, ~17 times per added sequence, 1.45e6 times per C3
+// launch): 0.7 ms of 17.6, paid as latency by all sixteen waves of the CU.  Data that crosses CUs still gets the agent-scope acquire where it
+// crosses: a large slot another wave may have written from another CU (poa_kernel_body, at the claim).  POA_AGENT_PHASE_SYNC: the old form.
 __device__ __forceinline__ void phase_sync() {
     __syncthreads();
-#ifdef POA_EXP_NOINV        // timing experiment only (results may be stale): the stores completed, the CU's L1 kept
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-#else
+#ifdef POA_AGENT_PHASE_SYNC
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #endif
 }
-
 
 // two independent scans, their steps interleaved: the other chain's instruction provides the wait states a DPP read needs
 // after a VALU write, so no s_nop inside
@@ -2226,6 +2227,7 @@ __device__ __forceinline__ void poa_kernel_body(const CcsParams& p)
                     big = __builtin_amdgcn_readfirstlane(big);
                 }
                 if (big < 0) { N = -2; break; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the slot's last user may have run on another CU: nothing of it in this CU's L1
                 ws = p.big_ws + (size_t)big * p.big_slot_bytes; ws_bytes = p.big_slot_bytes;
                 if (lane == 0 && p.stats) atomicAdd(p.stats, 1);
             }

@@ -14,7 +14,7 @@ import fake_mapper as fm
 import oracle_lib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SPIN = 60000          # iterations of the busy loop per map() call (a few ms of pure Python)
+SPIN = 150000         # iterations of the busy loop per map() call (~8 ms of pure Python: well above the C part of the double, which ctypes runs WITHOUT the lock)
 
 
 class BusyMapper(fm.FakeMapper):
@@ -80,6 +80,7 @@ def _stage2(w, tmp, tag, threads, mapper=None, **kw):
 def test_processes_give_the_same_records_and_scale_where_threads_cannot(world, tmp_path, monkeypatch):
     from ciri_long_amd import find_bsj
     monkeypatch.delenv('CIRI_LONG_MAPPER', raising=False)
+    _stage2(world, tmp_path, 'warm', 1)                          # (first-call costs -- imports, the checker library -- stay out of the timings)
     one = _stage2(world, tmp_path, 'one', 1)
     assert one[0]['ccs_mapped'] > 10 and len(one[2]) > 1000 and not find_bsj._PROC_POOLS
     monkeypatch.setenv('CIRI_LONG_MAPPER', 'threads')
@@ -100,8 +101,8 @@ def test_processes_give_the_same_records_and_scale_where_threads_cannot(world, t
         if not t_prc < 0.6 * t_one:
             t_one = min(t_one, _stage2(world, tmp_path, 'one2', 1)[3])
             t_prc = min(t_prc, _stage2(world, tmp_path, 'prc2', 4)[3])
-        assert t_thr > 0.7 * t_one, (t_one, t_thr)
-        assert t_prc < 0.7 * t_one, (t_one, t_prc)
+        assert t_thr > 0.6 * t_one, (t_one, t_thr)          # (the double's C part -- the checker's alignments through ctypes -- does run in parallel)
+        assert t_prc < 0.6 * t_one and t_prc < 0.8 * t_thr, (t_one, t_thr, t_prc)
 
 
 def test_default_mode_forks_a_pool_when_the_gpu_is_untouched_and_falls_back_to_threads_when_it_is_not(world, tmp_path, monkeypatch, caplog):

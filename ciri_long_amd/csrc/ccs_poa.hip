@@ -3,7 +3,7 @@
 //
 // What they replace: pyccs.find_consensus (called at CIRI_long/find_ccs.py:14) and the spoa engine inside it.  Those are
 // external packages that exist neither in the reference tree nor in this environment: PARITY UNPINNED.  Both kernels
-// implement, bit for bit, what oracle/ccs_oracle.c ("clh-ccs v1": period and copy boundaries, this project's own
+// implement, bit for bit, what oracle/ccs_oracle.c ("clh-ccs v2": period and copy boundaries, this project's own
 // specification) and oracle/poa_oracle.c ("clh-poa v3": a restatement of the published spoa algorithm -- two-piece gap
 // cost, local/global/overlap alignment, Graph::TopologicalSort's depth-first order, AddAlignment's node ids, raw-byte letters,
 // heaviest bundle; no departures) state; read those headers for every rule and tie-break.
@@ -35,6 +35,7 @@ static constexpr int CCS_MIN_SUPPORT = 12;
 static constexpr int CCS_SMOOTH = 3;
 static constexpr int CCS_MAX_CUTS = 64;
 static constexpr int CCS_MIN_TAIL = 20;
+static constexpr int CCS_GUARD = 8;                   // an anchor further than this from the voted offset is a chance recurrence
 static constexpr int POA_MAXP = 12;                  // in-edges a node holds in place; further ones go to the graph's overflow table
 static constexpr int POA_MAXP_ALL = 48;              // in-edges of a node, overflow included (the sort's per-node cursor has 6 bits for in-edges + aligned nodes)
 static constexpr int POA_OVF_CAP = 2048;             // entries of the overflow table of one graph
@@ -162,25 +163,30 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
         for (int e = lo; e <= hi; ++e) if (sm[e] > es) { es = sm[e]; eb = e; }
         if (eb >= 0 && 2 * es >= best) p0 = eb;
     }
-    // copy boundaries: per cut, the offsets delta in [p0-tol, p0+tol] are scored by the matches (i, i+delta) with i in
-    // the window [b, b+W).  Same pairs again: the window's positions walk their bucket chains (from the head: partners on
-    // both sides are in it) into a histogram over delta (sm is free by now), the lanes then pick by the specification's
-    // order -- most matches, then closest to the previous step, then smallest delta.
+    // copy boundaries (clh-ccs v2, oracle/ccs_oracle.c step 2): per cut, the anchors (i, delta) -- equal valid k-mers at i and i+delta,
+    // i in [b-W, b+W), delta in [p0-tol, min(p0+tol, L-b)] -- first vote for an offset (a histogram over delta; sm is free by now;
+    // most anchors, then closest to the previous step, then smallest delta), then the anchor whose k-mer centre lies nearest to b among
+    // those within CCS_GUARD of the vote gives the cut.  Same pairs as the period count: the window's positions walk their bucket
+    // chains (from the head: partners on both sides are in it), once per pass.
     const int tol = p0 / 8 > 4 ? p0 / 8 : 4, W = p0 < 96 ? p0 : 96;
-    const int dlo = p0 - tol, nd = 2 * tol + 1;
+    const int dlo = p0 - tol;
     int32_t* dh = sm;
     sync();
     int b = 0, prev = p0, n = 0;
     while (n < CCS_MAX_CUTS) {
+        const int dhi = p0 + tol < L - b ? p0 + tol : L - b;
+        if (dhi < dlo) break;
+        const int nd = dhi - dlo + 1;
+        const int i0 = b - W > 0 ? b - W : 0, i1 = b + W < L ? b + W : L;
         for (int t = lane; t < nd; t += NT) dh[t] = 0;
         sync();
-        for (int i = b + lane; i < b + W && i < L; i += NT) {
+        for (int i = i0 + lane; i < i1; i += NT) {
             if (next[i] == -2) continue;
             const int ci = code[i];
             int j = head[(ci ^ (ci >> 5)) & (nbuckets - 1)];
             while (j >= 0) {
                 const int delta = j - i;
-                if (delta >= dlo && delta < dlo + nd && code[j] == ci) atomicAdd(&dh[delta - dlo], 1);
+                if (delta >= dlo && delta <= dhi && code[j] == ci) atomicAdd(&dh[delta - dlo], 1);
                 j = next[j];
             }
         }
@@ -188,11 +194,9 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
         int bs = -1, bdel = 0, bdist = 0x7fffffff;
         for (int t = lane; t < nd; t += NT) {
             const int delta = dlo + t;
-            if (delta >= 1 && b + delta <= L) {
-                const int sc = dh[t];
-                const int dist = delta > prev ? delta - prev : prev - delta;
-                if (sc > bs || (sc == bs && dist < bdist)) { bs = sc; bdel = delta; bdist = dist; }   // ascending delta within the lane
-            }
+            const int sc = dh[t];
+            const int dist = delta > prev ? delta - prev : prev - delta;
+            if (sc > bs || (sc == bs && dist < bdist)) { bs = sc; bdel = delta; bdist = dist; }   // ascending delta within the lane
         }
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -208,8 +212,45 @@ __device__ void ccs_scan_read(const CcsParams& p, const int rd, const int lane, 
                 if (s2 > bs || (s2 == bs && (t2 < bdist || (t2 == bdist && e2 < bdel)))) { bs = s2; bdel = e2; bdist = t2; }
             }
         }
+        if (bs > 0) {
+            // the anchor nearest to b: smallest |i + K/2 - b|, then the larger i, then smallest |delta - prev|, then smallest delta
+            const int glo = bdel - CCS_GUARD > dlo ? bdel - CCS_GUARD : dlo, ghi = bdel + CCS_GUARD < dhi ? bdel + CCS_GUARD : dhi;
+            int ad = 0x7fffffff, ai = -1, aa = 0x7fffffff, adel = 0x7fffffff;
+            auto closer = [](int d2, int i2, int a2, int e2, int d1, int i1_, int a1, int e1) {
+                return d2 < d1 || (d2 == d1 && (i2 > i1_ || (i2 == i1_ && (a2 < a1 || (a2 == a1 && e2 < e1)))));
+            };
+            for (int i = i0 + lane; i < i1; i += NT) {
+                if (next[i] == -2) continue;
+                const int ci = code[i];
+                const int dist = i + CCS_K / 2 > b ? i + CCS_K / 2 - b : b - i - CCS_K / 2;
+                if (dist > ad) continue;
+                int j = head[(ci ^ (ci >> 5)) & (nbuckets - 1)];
+                while (j >= 0) {
+                    const int delta = j - i;
+                    if (delta >= glo && delta <= ghi && code[j] == ci) {
+                        const int a = delta > prev ? delta - prev : prev - delta;
+                        if (closer(dist, i, a, delta, ad, ai, aa, adel)) { ad = dist; ai = i; aa = a; adel = delta; }
+                    }
+                    j = next[j];
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int d2 = __shfl_xor(ad, d), i2 = __shfl_xor(ai, d), a2 = __shfl_xor(aa, d), e2 = __shfl_xor(adel, d);
+                if (closer(d2, i2, a2, e2, ad, ai, aa, adel)) { ad = d2; ai = i2; aa = a2; adel = e2; }
+            }
+            if constexpr (NT > 64) {
+                if ((lane & 63) == 0) { int* r4 = red + 24 + 4 * (lane >> 6); r4[0] = ad; r4[1] = ai; r4[2] = aa; r4[3] = adel; }
+                __syncthreads();
+                ad = red[24]; ai = red[25]; aa = red[26]; adel = red[27];
+                for (int v = 1; v < NT / 64; ++v) {
+                    const int* r4 = red + 24 + 4 * v;
+                    if (closer(r4[0], r4[1], r4[2], r4[3], ad, ai, aa, adel)) { ad = r4[0]; ai = r4[1]; aa = r4[2]; adel = r4[3]; }
+                }
+            }
+            bdel = adel;                                   // the vote's own anchors pass the guard: there is one
+        }
         sync();
-        if (bs < 0) break;
         b += bdel;
         prev = bdel;
         if (lane == 0) rec->cuts[n] = b;
@@ -242,7 +283,7 @@ __global__ void __launch_bounds__(64) ccs_scan_kernel(const CcsParams p)
 __global__ void __launch_bounds__(256) ccs_scan_kernel_x4(const CcsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t k2_lds[];
-    __shared__ int red[24];
+    __shared__ int red[40];
     ccs_scan_body<256>(p, k2_lds, red);
 }
 

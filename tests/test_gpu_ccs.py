@@ -1,6 +1,9 @@
 """K2/K3 (repeat scan + partial-order consensus) through the C ABI against the CPU statements (oracle/ccs_oracle.c for
 the copy boundaries, oracle/poa_oracle.c for the spoa algorithm).  PARITY UNPINNED with respect to pyccs/spoa (absent);
 bit-exact with respect to the oracle."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -8,14 +11,8 @@ import oracle_lib
 
 pytestmark = pytest.mark.gpu
 
-SEGMENTS = [   # the 6 copies of the reference's tests/test_poa.py:8-15
-    'TCCCGGTCATCATAACCCCGATCGTACCCTCTGTCATAATAGTCTCGGCGGCGAGAACTGCCACTGTAAATCTGATCCCTGTCTTGAGCTGCTCTCCATCCACCTCCCTCCACCACCTCCTCCTCTGTATGATCTGCTGTAATAG',
-    'TCCCGGTCATCATAACCCCGATCATTGCCACCTGTCATAGTCTCGGCGGCGAGAACTGCCACTGTAAATCCCCTGATCCCTGTCTTGAGCTGCTCTCCATCCCCTCCTCCACCACCTCCTCCTCTGTATGATCTGCTGTAATAG',
-    'TCCCGGTCATCATAACCCCGATCGTACCCTCTGTCATAATGGTCTCGGCGGCGAGAACTGCCACTGTAAATCTGATCCCTGTCTTGAGCTGCTCTCCATCCACCTCCTCCACCACCTCCTCCTCTGTATGATCTGCTGTAATAG',
-    'TCCCGGTCATCATAACCCCGATCGTACTCTGTCATAATAGTCTCGGCGGCGAGAGGCGCCACTGTAAATCTGATCCCTGTCTTGAGCTGCTCTCCATCCACCTCCTCCACCACCTCCTCCCCTCTGTATGATCTGCTGTAATAG',
-    'TCCCGGTCATCATAACCCCGATCGTACCCATAATAGTCTCGGCGAGAACTGCCACTGTAAATCCTGATCCCTGTCTTGAGCTGCTCTCCATCCACCTCCTCCACCACCTCCTCCTCTGTATGATCTGCTGTAATAG',
-    'TCCGGTCATCATAACCCCGATCCATAATAGTCTCGGCG',
-]
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'test_poa_input.json')) as _f:
+    SEGMENTS = json.load(_f)['segments']      # the 6 copies of the reference's tests/test_poa.py:8-15
 
 
 def test_reference_test_poa_input():

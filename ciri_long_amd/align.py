@@ -15,6 +15,8 @@ indexers (align.py:226-316) are one-off set-up and stay with the reference.
 import re
 from operator import itemgetter
 
+import numpy as np
+
 from . import env
 from .utils import revcomp
 
@@ -448,6 +450,74 @@ def find_denovo_signal(contig, start, end, host_strand, tmp_signal, us_free, ds_
 _MOTIFS = list(SPLICE_SIGNAL)      # K6 reports the motif as an index into this order
 
 
+def find_signal_rows(cands, hosts, is_canonical=True):
+    """First half of find_signal_batch -- everything that needs the device, the genome or the annotation index:
+    cands = [(contig, start, end, clip_base)], hosts = [find_host_gene(contig, start, end)] -> (rows, extra).
+    rows: int32 array [n, 8] of the kernel's answers (status, us_free, ds_free, found, strand, us_shift, ds_shift, motif), or None
+    when nothing went to the GPU; extra = {k: ('host', (site, us_free, ds_free))} for the candidates answered by the Python
+    functions (no resident genome, or a case the kernel cannot express) and {k: ('ann', us_ss, ds_ss)} for the kernel's annotated
+    pairs, whose id shows the genome's own dinucleotides (align.py:549-556).  `signal_from_row` is the second half: pure string
+    formatting, which a worker process of the mapper pool can do without genome or index."""
+    n = len(cands)
+    extra = {}
+    rows = None
+    dev = getattr(env.GENOME, 'device', None)
+    if not hasattr(dev, 'splice_signals'):
+        dev = None
+    # a host gene on a strand other than '+'/'-' (a '.' in the GTF) is searched under that label by the reference: not a
+    # case of the kernel's two-bit strand mask
+    on_gpu = [k for k in range(n)
+              if dev is not None and cands[k][0] in dev.offset and not (hosts[k] and any(st not in ('+', '-') for st in hosts[k]))]
+    done = [False] * n
+    if on_gpu:
+        if dev._sites_of is not env.SS_INDEX:
+            dev.set_splice_sites(env.SS_INDEX)
+        got = dev.splice_signals([(cands[k][0], cands[k][1], cands[k][2], cands[k][3],
+                                   (1 if hosts[k] and '+' in hosts[k] else 0) | (2 if hosts[k] and '-' in hosts[k] else 0))
+                                  for k in on_gpu], 10, 3, is_canonical, index_slices=getattr(env.GENOME, 'index_slices', False))
+        got = np.asarray(got, dtype=np.int32).reshape(len(on_gpu), 8)
+        if len(on_gpu) == n:
+            rows = got
+        else:
+            rows = np.full((n, 8), -1, dtype=np.int32)
+            rows[on_gpu] = got
+        ok = got[:, 0] == 0
+        for k, good in zip(on_gpu, ok.tolist()):
+            done[k] = good
+        for t in np.nonzero(ok & (got[:, 3] == 2))[0].tolist():
+            k = on_gpu[t]
+            ctg, start, end = cands[k][:3]
+            i, j = int(got[t, 5]), int(got[t, 6])
+            extra[k] = ('ann', env.GENOME.seq(ctg, start + i - 2, start + i), env.GENOME.seq(ctg, end + j, end + j + 2))
+    for k in range(n):
+        if done[k]:
+            continue
+        ctg, start, end, clip_base = cands[k][:4]
+        site, us_free, ds_free, tmp_signal = find_annotated_signal(ctg, start, end, clip_base, clip_base + 10)
+        if site is None:
+            site = find_denovo_signal(ctg, start, end, hosts[k], tmp_signal, us_free, ds_free, clip_base, clip_base + 10, 3, is_canonical)
+        extra[k] = ('host', (site, us_free, ds_free))
+    return rows, extra
+
+
+def signal_from_row(row, extra):
+    """Second half of find_signal_batch for one candidate: (ss_site | None, us_free, ds_free) from its row of find_signal_rows
+    (a sequence of eight ints) and its entry of `extra` (or None)."""
+    if extra is not None and extra[0] == 'host':
+        return extra[1]
+    status, us_free, ds_free, found, strand, i, j, motif = row
+    site = None
+    if found == 1:
+        donor, acceptor = _MOTIFS[motif]
+        site = ('{}-{}*|{}-{}'.format(acceptor, donor, i, j), '-' if strand else '+', i, j)
+    elif found == 2:          # a pair of annotated sites
+        us_ss, ds_ss = extra[1], extra[2]
+        if strand:
+            us_ss, ds_ss = revcomp(ds_ss), revcomp(us_ss)
+        site = ('{}-{}|{}-{}'.format(us_ss, ds_ss, i, j), '-' if strand else '+', i, j)
+    return (site, us_free, ds_free)
+
+
 def find_signal_batch(cands, is_canonical=True):
     """The splice-signal step of find_bsj.py:286-301 for many candidates at once:
     cands = [(contig, start, end, clip_base, host_strand)] -> [(ss_site | None, us_free, ds_free)], each entry what
@@ -456,44 +526,9 @@ def find_signal_batch(cands, is_canonical=True):
     is uploaded once as sorted position runs) -- contig ends and IUPAC / soft-masked flanks included; only candidates
     the kernel cannot express (a host gene on a strand other than '+'/'-', a contig that is not resident, invalid
     coordinates) go through the functions above."""
-    out = [None] * len(cands)
-    dev = getattr(env.GENOME, 'device', None)
-    if not hasattr(dev, 'splice_signals'):
-        dev = None
-    # a host gene on a strand other than '+'/'-' (a '.' in the GTF) is searched under that label by the reference: not a
-    # case of the kernel's two-bit strand mask
-    on_gpu = [k for k, c in enumerate(cands)
-              if dev is not None and c[0] in dev.offset and not (c[4] and any(st not in ('+', '-') for st in c[4]))]
-    if on_gpu:
-        if dev._sites_of is not env.SS_INDEX:
-            dev.set_splice_sites(env.SS_INDEX)
-        rows = dev.splice_signals([(cands[k][0], cands[k][1], cands[k][2], cands[k][3],
-                                    (1 if cands[k][4] and '+' in cands[k][4] else 0) | (2 if cands[k][4] and '-' in cands[k][4] else 0))
-                                   for k in on_gpu], 10, 3, is_canonical, index_slices=getattr(env.GENOME, 'index_slices', False))
-        for k, r in zip(on_gpu, rows.tolist()):
-            status, us_free, ds_free, found, strand, i, j, motif = r
-            if status != 0:
-                continue
-            site = None
-            if found == 1:
-                donor, acceptor = _MOTIFS[motif]
-                site = ('{}-{}*|{}-{}'.format(acceptor, donor, i, j), '-' if strand else '+', i, j)
-            elif found == 2:          # a pair of annotated sites: the id shows the genome's own dinucleotides (align.py:549-556)
-                ctg, start, end = cands[k][:3]
-                us_ss = env.GENOME.seq(ctg, start + i - 2, start + i)
-                ds_ss = env.GENOME.seq(ctg, end + j, end + j + 2)
-                if strand:
-                    us_ss, ds_ss = revcomp(ds_ss), revcomp(us_ss)
-                site = ('{}-{}|{}-{}'.format(us_ss, ds_ss, i, j), '-' if strand else '+', i, j)
-            out[k] = (site, us_free, ds_free)
-    for k, (ctg, start, end, clip_base, host) in enumerate(cands):
-        if out[k] is not None:
-            continue
-        site, us_free, ds_free, tmp_signal = find_annotated_signal(ctg, start, end, clip_base, clip_base + 10)
-        if site is None:
-            site = find_denovo_signal(ctg, start, end, host, tmp_signal, us_free, ds_free, clip_base, clip_base + 10, 3, is_canonical)
-        out[k] = (site, us_free, ds_free)
-    return out
+    rows, extra = find_signal_rows([c[:4] for c in cands], [c[4] for c in cands], is_canonical)
+    rl = rows.tolist() if rows is not None else None
+    return [signal_from_row(rl[k] if rl is not None else None, extra.get(k)) for k in range(len(cands))]
 
 
 def sort_ss(sites, us, ds, clip_base):

@@ -161,7 +161,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     if int(threads or 1) > 1:
         find_bsj.THREADS = int(threads)
         if not mapper_pool.gpu_touched():
-            find_bsj.start_mapper_pools(threads, scan_aligner=env.ALIGNER, recover_aligner=recover_aligner, contig_len=env.CONTIG_LEN)
+            find_bsj.start_mapper_pools(threads, scan_aligner=env.ALIGNER, recover_aligner=recover_aligner, contig_len=env.CONTIG_LEN, gtf_index=env.GTF_INDEX)
     fq, is_fastq, is_gz = find_ccs._open_reads(in_file)
     fq.close()
     import itertools
@@ -210,13 +210,14 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     # ---- stage 2.1 -------------------------------------------------------------------------------------------------------
     short, records = [], []
 
+    # records travel as (read ids, text of the file) per batch: the workers of the mapper pool write the text (find_bsj._phase_assemble)
     def stage21():
-        for group in grouper(list(ccs_seq), chunk_size * find_bsj.GPU_CHUNKS):
-            chunk = [[i, ] + ccs_seq[i] for i in group if i is not None]
-            cnt, sh, ret = find_bsj.scan_ccs_chunk(chunk, is_canonical)
+        names = list(ccs_seq)
+        chunks = ([[i, ] + ccs_seq[i] for i in group if i is not None] for group in grouper(names, find_bsj.chunk_size_for(len(names), chunk_size)))
+        for cnt, sh, ret in find_bsj._scan_chunks(chunks, True, 0.75, as_text=True):
             add(cnt)
             short.extend(sh)
-            records.extend(ret)
+            records.append(ret)
     _together('2.1 (scan_ccs_chunk)', stage21)
     # ---- stage 2.2: the short consensus reads, second mapper ------------------------------------------------------------------
     if stage_setup is not None:
@@ -224,19 +225,21 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     recovered = []
 
     def stage22():
-        for group in grouper(short, chunk_size * find_bsj.GPU_CHUNKS):
-            cnt, ret = find_bsj.recover_ccs_chunk([i for i in group if i is not None], is_canonical)
+        chunks = ([i for i in group if i is not None] for group in grouper(short, find_bsj.chunk_size_for(len(short), chunk_size)))
+        for cnt, _sh, ret in find_bsj._scan_chunks(chunks, False, 0, as_text=True):
             add(cnt)
-            recovered.extend(ret)
+            recovered.append(ret)
     _together('2.2 (recover_ccs_chunk)', stage22)
     records = gather_records(records)
     recovered = gather_records(recovered)
     if rank == 0:
         with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'w') as out:
-            find_bsj._write_records(out, records)
-            find_bsj._write_records(out, recovered)          # the reference appends them (find_bsj.py:471)
+            for _ids, text in records:
+                out.write(text)
+            for _ids, text in recovered:                     # the reference appends them (find_bsj.py:471)
+                out.write(text)
     # ---- stage 3: raw reads that are in no candidate record (find_bsj.py:626-632 reads the ids back from the file) -------------
-    circ_reads = _bcast({rec[0]: 1 for rec in records + recovered} if rank == 0 else None)
+    circ_reads = _bcast({i: 1 for ids, _text in records + recovered for i in ids} if rank == 0 else None)
     if stage_setup is not None:
         stage_setup('raw')
     partial, short_raw = [], []
@@ -244,8 +247,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     def stage3():
         # this rank's records only: the iterator stops at `hi` (rounds 2-3 parsed the whole input on every rank)
         mine = itertools.islice(find_ccs.iter_reads(in_file, byte_off), lo - rec0, hi - rec0)
-        for group in grouper(mine, 1000):
-            cnt, ret, sh = find_bsj.scan_raw_chunk([r for r in group if r is not None], is_canonical, circ_reads)
+        for cnt, ret, sh in find_bsj._raw_chunks(([r for r in group if r is not None] for group in grouper(mine, 1000)), is_canonical, circ_reads):
             add(cnt)
             partial.extend(ret)
             short_raw.extend(sh)

@@ -9,11 +9,12 @@ signal search and record assembly per read -- with identical outputs in identica
 
 The mapper stays external and pluggable: ``env.ALIGNER.map(seq)`` (mappy, bwapy adaptor, or a test double).
 """
+from bisect import bisect_right
 from collections import defaultdict
 
 from . import env
-from .align import (find_signal_batch, find_host_gene, get_blocks, get_parital_blocks,
-                    get_primary_alignment, merge_clip_exon, merge_exons, remove_long_insert)
+from .align import (find_signal_batch, find_signal_rows, find_host_gene, get_blocks, get_parital_blocks,
+                    get_primary_alignment, merge_clip_exon, merge_exons, remove_long_insert, signal_from_row)
 from .utils import grouper, revcomp
 
 CLIP_MIN = 20            # find_bsj.py:191
@@ -85,41 +86,55 @@ def _clip_prepare(circ, hit):
     return _ClipJob(circ, hit, clip_seq, None, win_start, win_end)
 
 
-def _clip_finish(job, res):
+def _clip_finish(job, ref_begin, ref_end, query_begin, query_end):
     """Coordinates and rotation from the alignment result (find_bsj.py:205-226)."""
     circ, hit, clip_seq = job.circ, job.hit, job.clip_seq
     if hit.strand > 0:
-        clip_r_st, clip_r_en = job.win_start + res.ref_begin, job.win_start + res.ref_end
+        clip_r_st, clip_r_en = job.win_start + ref_begin, job.win_start + ref_end
         rotate = clip_r_st < hit.r_st
     else:
-        clip_r_st, clip_r_en = job.win_end - res.ref_end, job.win_end - res.ref_begin
+        clip_r_st, clip_r_en = job.win_end - ref_end, job.win_end - ref_begin
         rotate = clip_r_en > hit.r_en
     if rotate:
-        clipped = clip_seq[res.query_begin:] + circ[hit.q_st:hit.q_en] + clip_seq[:res.query_begin]
+        clipped = clip_seq[query_begin:] + circ[hit.q_st:hit.q_en] + clip_seq[:query_begin]
     else:
         clipped = circ[hit.q_st:] + circ[:hit.q_st]
-    clip_base = hit.q_st + len(circ) - hit.q_en - (res.query_end - res.query_begin) + 1
+    clip_base = hit.q_st + len(circ) - hit.q_en - (query_end - query_begin) + 1
     return clipped, min(hit.r_st, clip_r_st) - 1, max(hit.r_en, clip_r_en), (clip_r_st, clip_r_en, clip_base)
 
 
-def _run_clip_jobs(jobs):
-    """Phase 2: all pending clip alignments of a chunk in ONE GPU call (scoring 1/1/1/1, find_bsj.py:204,214)."""
+def _job_tuple(job):
+    """what phase 2 needs of a _ClipJob: (contig, window start, window end, minus strand, clipped bases)"""
+    return (job.hit.ctg, job.win_start, job.win_end, job.hit.strand <= 0, job.clip_seq)
+
+
+def _run_clip_rows(jobs):
+    """Phase 2: all pending clip alignments of a chunk in ONE GPU call (scoring 1/1/1/1, find_bsj.py:204,214).
+    jobs = [(contig, window start, window end, minus strand, clipped bases)] -> per job (ref_begin, ref_end, query_begin, query_end),
+    or None where the window holds too many N (find_bsj.py:199-201)."""
     if not jobs:
         return []
     device = getattr(env.GENOME, 'device', None)
     if device is not None:
-        from .ssw_wrap import align_windows
-        wins = [(j.hit.ctg, j.win_start, j.win_end) for j in jobs]
-        n_cnt = device.count_n(wins)
-        keep = [k for k, j in enumerate(jobs) if not n_cnt[k] >= WINDOW_MAX_N * (j.win_end - j.win_start)]   # find_bsj.py:199
+        import numpy as np
+        from . import hip
+        off, ln = device._spans([j[:3] for j in jobs])
+        n_cnt = device.count_n_spans(off, ln)
+        keep = np.nonzero(~(n_cnt >= WINDOW_MAX_N * ln))[0]                                           # find_bsj.py:199
         res = [None] * len(jobs)        # None = rejected by the N filter
-        if keep:
-            got = align_windows(device, [wins[k] for k in keep], [jobs[k].hit.strand <= 0 for k in keep],
-                                [jobs[k].clip_seq for k in keep], match=1, mismatch=1, gap_open=1, gap_extend=1)
-            for k, r in zip(keep, got):
-                if r is None:
-                    raise RuntimeError('Smith-Waterman of clipped bases returned no result')
-                res[k] = r
+        if len(keep):
+            all_kept = len(keep) == len(jobs)
+            sel = jobs if all_kept else [jobs[k] for k in keep.tolist()]
+            qd, qo = hip.pack_text([j[4] for j in sel])
+            rows, _ = device.ssw_windows(qd, qo, None, np.array([j[3] for j in sel], dtype=np.uint8), hip.score_matrix(1, 1), 1, 1, flag=1, score_size=2,
+                                         want_score2=False, want_cigar=False, spans=(off, ln) if all_kept else (off[keep], ln[keep]))
+            if (rows['status'] & (hip.ST_NULL | hip.ST_TRACE_ERR | hip.ST_CIGAR_TRUNC)).any():
+                raise RuntimeError('Smith-Waterman of clipped bases returned no result')
+            coords = np.stack([rows['ref_begin1'], rows['ref_end1'], rows['read_begin1'], rows['read_end1']], axis=1).tolist()
+            if all_kept:
+                return [tuple(c) for c in coords]
+            for k, c in zip(keep.tolist(), coords):
+                res[k] = tuple(c)
         return res
     from .ssw_wrap import align_pairs
     # host-window route (no resident genome): a window is a string of up to 400 kb, so the jobs go to the GPU in groups
@@ -132,16 +147,16 @@ def _run_clip_jobs(jobs):
         for (k, _w, _q), r in zip(group, got):
             if r is None:   # the reference dereferences None here (find_bsj.py:206); make the failure explicit
                 raise RuntimeError('Smith-Waterman of clipped bases returned no result')
-            res[k] = r
-    for k, j in enumerate(jobs):
-        window = env.GENOME.seq(j.hit.ctg, j.win_start, j.win_end)
-        if window.count('N') >= WINDOW_MAX_N * (j.win_end - j.win_start):
+            res[k] = (r.ref_begin, r.ref_end, r.query_begin, r.query_end)
+    for k, (ctg, win_start, win_end, minus, clip_seq) in enumerate(jobs):
+        window = env.GENOME.seq(ctg, win_start, win_end)
+        if window.count('N') >= WINDOW_MAX_N * (win_end - win_start):
             continue
         if group and size + len(window) > HOST_WINDOW_BYTES:
             flush()
             group, size = [], 0
         # minus-strand hits are aligned against the reverse-complemented window (find_bsj.py:213-216)
-        group.append((k, window if j.hit.strand > 0 else revcomp(window), j.clip_seq)); size += len(window)
+        group.append((k, revcomp(window) if minus else window, clip_seq)); size += len(window)
     if group:
         flush()
     return res
@@ -152,8 +167,8 @@ def align_clip_segments(circ, hit):
     job = _clip_prepare(circ, hit)
     if not isinstance(job, _ClipJob):
         return job
-    res = _run_clip_jobs([job])[0]
-    return _REJECT if res is None else _clip_finish(job, res)
+    res = _run_clip_rows([_job_tuple(job)])[0]
+    return _REJECT if res is None else _clip_finish(job, *res)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -217,19 +232,21 @@ def mapper_mode():
 
 
 def start_mapper_pools(threads, scan_aligner=None, recover_aligner=None, contig_len=None, scan_factory=None, recover_factory=None,
-                       start='fork'):
+                       start='fork', gtf_index=None):
     """Make the worker processes of the mapper phase -- BEFORE this process touches the GPU (module docstring of mapper_pool).
     One pool per mapper given: `scan_*` = the first mapper (minimap2 splice preset in the reference, find_bsj.py:332; stages 2.1
     and 3), `recover_*` = the second (bwa, find_bsj.py:455; stage 2.2).  `*_aligner`: built here, inherited by forked workers (as
     the reference's Pool does); `*_factory`: picklable, builds the mapper inside each (forked or spawned) worker.  With threads <= 1 or
-    CIRI_LONG_MAPPER=threads nothing is started.  Returns the roles that have a pool."""
+    CIRI_LONG_MAPPER=threads nothing is started.  `gtf_index`: the annotation index of the run (env.GTF_INDEX), if it exists already --
+    the workers then also look up the host genes of their reads (find_host_gene), otherwise the parent does.  Returns the roles that
+    have a pool."""
     from .mapper_pool import MapperPool
     if int(threads or 1) <= 1 or mapper_mode() == 'threads':
         return []
     for role, aligner, factory in (('scan', scan_aligner, scan_factory), ('recover', recover_aligner, recover_factory)):
         if (aligner is None and factory is None) or role in _PROC_POOLS:
             continue
-        _PROC_POOLS[role] = MapperPool(int(threads), aligner=aligner, contig_len=contig_len, factory=factory, start=start)
+        _PROC_POOLS[role] = MapperPool(int(threads), aligner=aligner, contig_len=contig_len, factory=factory, start=start, gtf_index=gtf_index)
     return sorted(_PROC_POOLS)
 
 
@@ -238,7 +255,7 @@ def stop_mapper_pools():
         _PROC_POOLS.pop(role).close()
 
 
-def _process_pool(role, aligner, contig_len):
+def _process_pool(role, aligner, contig_len, gtf_index=None):
     """The stage drivers' way to a pool: the one made at program start, or -- if this process has not touched the GPU yet (a stage
     run on its own) -- one forked now from the stage's aligner.  None: the thread route."""
     from . import mapper_pool
@@ -258,7 +275,7 @@ def _process_pool(role, aligner, contig_len):
                                                    'initialised (find_bsj.start_mapper_pools); if the mapper holds the GIL this is one core',
                                                    THREADS)
         return None
-    _PROC_POOLS[role] = mapper_pool.MapperPool(THREADS, aligner=aligner, contig_len=contig_len)
+    _PROC_POOLS[role] = mapper_pool.MapperPool(THREADS, aligner=aligner, contig_len=contig_len, gtf_index=gtf_index)
     return _PROC_POOLS[role]
 
 
@@ -273,19 +290,6 @@ def _thread_pool():
         from concurrent.futures import ThreadPoolExecutor
         _POOL = ThreadPoolExecutor(THREADS)
     return _POOL
-
-
-def _map_chunk(chunk, raw_filters, min_circ_fraction):
-    """Phase 1 of a chunk, input order kept: worker processes (the reference's own parallelism, find_bsj.py:338-345), else threads,
-    else this thread."""
-    role = 'scan' if raw_filters else 'recover'
-    procs = _process_pool(role, env.ALIGNER, env.CONTIG_LEN)
-    if procs is not None:
-        return procs.scan(chunk, raw_filters, min_circ_fraction)
-    pool = _thread_pool()
-    if pool is None:
-        return [_map_read(item, raw_filters, min_circ_fraction) for item in chunk]
-    return list(pool.map(lambda item: _map_read(item, raw_filters, min_circ_fraction), chunk))
 
 
 def _map_read(item, raw_filters, min_circ_fraction):
@@ -318,40 +322,231 @@ def _map_read(item, raw_filters, min_circ_fraction):
     return keys, short, (read_id, segments, ccs, circ, junc, circ_hit, _clip_prepare(circ, circ_hit))
 
 
-def _scan_chunk(chunk, raw_filters, min_circ_fraction):
-    reads_cnt = defaultdict(int)
-    short_reads = []
-    pending = []          # (read fields..., prepared clip result or job) in input order
-    jobs = []
-    for keys, short, pend in _map_chunk(chunk, raw_filters, min_circ_fraction):
+# ---------------------------------------------------------------------------------------------------------------
+# A chunk in three phases with two batched GPU calls between them.  Each phase works on a PIECE of the chunk (a few dozen reads)
+# and runs where the route puts it: on this thread (one thread), phase 1 on a thread pool (CIRI_LONG_MAPPER=threads), or all
+# three on the worker processes of the mapper pool.  On that route the parent never holds a read as Python objects: what a
+# phase leaves for the next one travels as one pickled blob per piece that the parent only passes on, and the parent itself
+# handles columns -- windows and clipped bases for the Smith-Waterman call, candidates for the splice-signal call, text
+# for the file.  Chunks overlap: while the parent is between two phases of one chunk the workers map the next ones
+# (_drive), as the reference's workers never wait for its parent (find_bsj.py:343-345: every chunk submitted at once, :354-367
+# results taken in order).
+# ---------------------------------------------------------------------------------------------------------------
+def _phase_map(items, raw_filters, min_circ_fraction):
+    """phase 1 of a piece: every mapper call.  -> (counter increments, short reads, clip jobs as tuples, pending reads)"""
+    cnt, shorts, jobs, pend = {}, [], [], []
+    for item in items:
+        keys, short, p = _map_read(item, raw_filters, min_circ_fraction)
         for k in keys:
-            reads_cnt[k] += 1
+            cnt[k] = cnt.get(k, 0) + 1
         if short is not None:
-            short_reads.append(short)
-        if pend is not None:
-            if isinstance(pend[6], _ClipJob):
-                jobs.append(pend[6])
-            pending.append(pend)
+            shorts.append(short)
+        if p is not None:
+            pend.append(p)
+            if isinstance(p[6], _ClipJob):
+                jobs.append(_job_tuple(p[6]))
+    return cnt, shorts, jobs, pend
 
-    results = iter(_run_clip_jobs(jobs))
-    ready = []
-    for read_id, segments, ccs, circ, junc, circ_hit, prep in pending:
+
+def _phase_finish(pend, rows, with_hosts):
+    """phase 3a of a piece: coordinates from the clip alignments (find_bsj.py:205-231), the reads that go on to the splice-signal
+    step and their host genes.  rows: the piece's share of _run_clip_rows, in job order.
+    -> (candidates [(contig, start, end, clip_base)], host genes or None when this process has no annotation index, ready reads)"""
+    ready, it = [], iter(rows)
+    for read_id, segments, ccs, circ, junc, circ_hit, prep in pend:
         if isinstance(prep, _ClipJob):
-            res = next(results)
-            prep = _REJECT if res is None else _clip_finish(prep, res)
+            res = next(it)
+            prep = _REJECT if res is None else _clip_finish(prep, *res)
         clipped_circ, circ_start, circ_end, clip_info = prep
         if circ_start is None or circ_end is None:
             continue
         ready.append((read_id, segments, ccs, circ, junc, circ_hit, clipped_circ, circ_start, circ_end, clip_info))
-    # the splice-signal step of every read that will reach it, as one batch
-    live = [r for r in ready if not (r[9][2] > 0.15 * len(r[2]) or r[9][2] > 20)]
-    signals = dict(zip((id(r) for r in live), _signals([(r[5].ctg, r[7], r[8], r[9][2]) for r in live])))
-    ret = []
+    cands = [(r[5].ctg, r[7], r[8], r[9][2]) for r in ready if not (r[9][2] > 0.15 * len(r[2]) or r[9][2] > 20)]
+    hosts = [find_host_gene(c, st, en) for c, st, en, _cb in cands] if with_hosts else None
+    return cands, hosts, ready
+
+
+def _phase_assemble(ready, sig_rows, sig_extra, as_text):
+    """phase 3b of a piece: records from the ready reads and their splice signals (rows / extra of align.find_signal_rows, in
+    candidate order).  -> (counter increments, records) -- records as tuples, or as (read ids, the text of cand_circ.fa)"""
+    cnt = defaultdict(int)
+    recs, k = [], 0
     for r in ready:
-        rec = _assemble(*r, reads_cnt, signals.get(id(r)))
-        if rec is not None:
-            ret.append(rec)
-    return reads_cnt, short_reads, ret
+        if r[9][2] > 0.15 * len(r[2]) or r[9][2] > 20:          # (the test _assemble opens with: such a read never was a candidate)
+            continue
+        signal = signal_from_row(sig_rows[k] if sig_rows is not None else None, sig_extra.get(k))
+        k += 1
+        recs.append(_assemble(*r, cnt, signal))
+    if as_text:
+        return dict(cnt), ([rec[0] for rec in recs], ''.join(['>{}\t{}\t{}\t{}\t{}\t{}\t{}\n{}\n'.format(*rec) for rec in recs]))
+    return dict(cnt), recs
+
+
+class _Now(object):
+    """the handle of work that was done on the spot"""
+
+    def __init__(self, value):
+        self.value = value
+
+    def ready(self):
+        return True
+
+    def wait(self, timeout=None):
+        pass
+
+    def get(self):
+        return self.value
+
+
+class _Futures(object):
+    """the handle of a list of concurrent.futures"""
+
+    def __init__(self, futures):
+        self.futures = futures
+
+    def ready(self):
+        return all(f.done() for f in self.futures)
+
+    def wait(self, timeout=None):
+        from concurrent.futures import wait
+        wait(self.futures, timeout)
+
+    def get(self):
+        return [f.result() for f in self.futures]
+
+
+class _Route(object):
+    """where the phases of a piece run.  submit_*() -> handle with ready() / wait(timeout) / get(); get() -> one result per piece."""
+
+    def __init__(self, raw_filters):
+        role = 'scan' if raw_filters else 'recover'
+        self.procs = _process_pool(role, env.ALIGNER, env.CONTIG_LEN)
+        self.threads = None if self.procs is not None else _thread_pool()
+        self.depth = 3 if self.procs is not None else 1            # chunks in flight
+        workers = self.procs.workers if self.procs is not None else (THREADS if self.threads is not None else 1)
+        self.piece = 32 if workers > 1 else 1 << 30
+        self.workers = workers
+        # a worker computes the host genes when it was given the annotation index the parent has (fork: the very object)
+        self.worker_hosts = self.procs is not None and self.procs.has_index(env.GTF_INDEX)
+
+    def pieces(self, chunk):
+        # small pieces: the reads of a chunk differ a lot in mapper time (rotation loop of find_bsj), and a worker that draws a
+        # long piece last is the chunk's tail
+        n = max(1, min(self.piece, (len(chunk) + 4 * self.workers - 1) // (4 * self.workers)))
+        return [chunk[i:i + n] for i in range(0, len(chunk), n)]
+
+    def submit_map(self, pieces, raw_filters, min_circ_fraction):
+        if self.procs is not None:
+            return self.procs.submit('map', [(p, raw_filters, min_circ_fraction) for p in pieces])
+        if self.threads is not None:
+            return _Futures([self.threads.submit(_phase_map, p, raw_filters, min_circ_fraction) for p in pieces])
+        return _Now([_phase_map(p, raw_filters, min_circ_fraction) for p in pieces])
+
+    def submit_finish(self, states, rows):
+        if self.procs is not None:
+            return self.procs.submit('finish', [(st, rw, self.worker_hosts) for st, rw in zip(states, rows)], grouped=True)
+        return _Now([_phase_finish(st, rw, True) for st, rw in zip(states, rows)])
+
+    def submit_assemble(self, states, sig_rows, sig_extra, as_text):
+        if self.procs is not None:
+            return self.procs.submit('assemble', [(st, rw, ex, as_text) for st, rw, ex in zip(states, sig_rows, sig_extra)], grouped=True)
+        return _Now([_phase_assemble(st, rw, ex, as_text) for st, rw, ex in zip(states, sig_rows, sig_extra)])
+
+
+def _chunk_program(route, chunk, raw_filters, min_circ_fraction, as_text, is_canonical=True):
+    """One chunk as a generator: yields the handle it waits for, is resumed with that handle's result, returns
+    (counters, short reads, records).  Everything between two yields runs in the calling process: the two GPU calls."""
+    reads_cnt = defaultdict(int)
+    short_reads = []
+    mapped = yield route.submit_map(route.pieces(chunk), raw_filters, min_circ_fraction)
+    jobs, njobs, states = [], [], []
+    for cnt, shorts, jb, state in mapped:
+        for k, v in cnt.items():
+            reads_cnt[k] += v
+        short_reads += shorts
+        jobs += jb
+        njobs.append(len(jb))
+        states.append(state)
+    rows = _run_clip_rows(jobs)                                       # GPU: K5 + prefilter + K1
+    split, at = [], 0
+    for n in njobs:
+        split.append(rows[at:at + n]); at += n
+    finished = yield route.submit_finish(states, split)
+    cands, hosts, ncand, states = [], [], [], []
+    for cd, hs, state in finished:
+        cands += cd
+        hosts += hs if hs is not None else [find_host_gene(c, st, en) for c, st, en, _cb in cd]
+        ncand.append(len(cd))
+        states.append(state)
+    sig_rows, sig_extra = find_signal_rows(cands, hosts, is_canonical)          # GPU: K6
+    srows, sextra, starts, at = [], [{} for _ in ncand], [], 0
+    for n in ncand:
+        srows.append(sig_rows[at:at + n].tolist() if sig_rows is not None else None)
+        starts.append(at)
+        at += n
+    for k, v in sig_extra.items():
+        piece = bisect_right(starts, k) - 1
+        sextra[piece][k - starts[piece]] = v
+    assembled = yield route.submit_assemble(states, srows, sextra, as_text)
+    ids, parts = [], []
+    for cnt, recs in assembled:
+        for k, v in cnt.items():
+            reads_cnt[k] += v
+        if as_text:
+            ids += recs[0]; parts.append(recs[1])
+        else:
+            parts += recs
+    return reads_cnt, short_reads, ((ids, ''.join(parts)) if as_text else parts)
+
+
+def _drive(programs, depth):
+    """Run chunk programs (generators as _chunk_program) with up to `depth` of them in flight; yields their results in order.
+    A program is resumed as soon as what it waits for is there, oldest first -- so the GPU calls of one chunk run while the workers
+    are busy with the phases of the others."""
+    from collections import deque
+    live = deque()              # [generator, handle, result, finished]
+    src = iter(programs)
+    more = True
+
+    def advance(slot, value, first=False):
+        try:
+            slot[1] = next(slot[0]) if first else slot[0].send(value)
+        except StopIteration as stop:
+            slot[1], slot[2], slot[3] = None, stop.value, True
+
+    while True:
+        while more and len(live) < depth:
+            try:
+                gen = next(src)
+            except StopIteration:
+                more = False
+                break
+            slot = [gen, None, None, False]
+            advance(slot, None, first=True)
+            live.append(slot)
+        if not live:
+            return
+        moved = False
+        for slot in live:
+            while not slot[3] and slot[1].ready():
+                advance(slot, slot[1].get())
+                moved = True
+        while live and live[0][3]:
+            yield live.popleft()[2]
+            moved = True
+        if not moved:
+            live[0][1].wait(0.02)
+
+
+def _scan_chunks(chunks, raw_filters, min_circ_fraction, as_text=False):
+    """(counters, short reads, records) per chunk of `chunks` (an iterable of lists of (read_id, segments, ccs, raw)), in order"""
+    route = _Route(raw_filters)
+    return _drive((_chunk_program(route, c, raw_filters, min_circ_fraction, as_text) for c in chunks), route.depth)
+
+
+def _scan_chunk(chunk, raw_filters, min_circ_fraction):
+    for out in _scan_chunks([chunk], raw_filters, min_circ_fraction):
+        return out
 
 
 def scan_ccs_chunk(chunk, is_canonical):
@@ -364,6 +559,13 @@ def recover_ccs_chunk(chunk, is_canonical):
     """Second pass over short consensus reads: no raw-read filters, no 0.75 coverage test (find_bsj.py:375-448)."""
     reads_cnt, _short, ret = _scan_chunk(chunk, raw_filters=False, min_circ_fraction=0)
     return reads_cnt, ret
+
+
+def chunk_size_for(n, per_chunk=250):
+    """reads per GPU batch: GPU_CHUNKS chunks of `per_chunk` -- fewer when the input is small, so that a handful of batches exist to
+    overlap (results do not depend on it)"""
+    full = per_chunk * GPU_CHUNKS
+    return full if n >= 12 * full else max(per_chunk, min(full, (n + 11) // 12))
 
 
 def _write_records(out, records):
@@ -408,19 +610,19 @@ def scan_ccs_reads(ccs_seq, ref_fasta, ss_index, gtf_index, intron_index, is_can
             from .align import Fasta
             contig_len = Fasta(ref_fasta).contig_len
     THREADS = max(1, int(threads or 1))
-    _process_pool('scan', aligner, contig_len)      # (worker processes, if they can still be made, BEFORE the genome goes to the GPU)
+    _process_pool('scan', aligner, contig_len, gtf_index)      # (worker processes, if they can still be made, BEFORE the genome goes to the GPU)
     env.initializer(aligner, contig_len, _resident(genome), gtf_index, intron_index, ss_index)
 
     reads_count = defaultdict(int)
     short_reads = []
+    names = list(ccs_seq)
+    chunks = ([[i, ] + ccs_seq[i] for i in reads if i is not None] for reads in grouper(names, chunk_size_for(len(names))))
     with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'w') as out:
-        for reads in grouper(list(ccs_seq), 250 * GPU_CHUNKS):
-            chunk = [[i, ] + ccs_seq[i] for i in reads if i is not None]
-            cnt, short, ret = scan_ccs_chunk(chunk, is_canonical)
+        for cnt, short, (_ids, text) in _scan_chunks(chunks, True, 0.75, as_text=True):
             for key, value in cnt.items():
                 reads_count[key] += value
             short_reads += short
-            _write_records(out, ret)
+            out.write(text)
     return reads_count, short_reads
 
 
@@ -435,17 +637,16 @@ def recover_ccs_reads(short_reads, ref_fasta, ss_index, gtf_index, intron_index,
         aligner = Aligner(BwaAligner(ref_fasta, options='-x ont2d -T 19'))
     global THREADS
     THREADS = max(1, int(threads or 1))
-    _process_pool('recover', aligner, genome.contig_len)
+    _process_pool('recover', aligner, genome.contig_len, gtf_index)
     env.initializer(aligner, genome.contig_len, _resident(genome), gtf_index, intron_index, ss_index)
 
     reads_count = defaultdict(int)
+    chunks = ([i for i in reads if i is not None] for reads in grouper(short_reads, chunk_size_for(len(short_reads))))
     with open('{}/{}.cand_circ.fa'.format(out_dir, prefix), 'a') as out:
-        for reads in grouper(short_reads, 250 * GPU_CHUNKS):
-            chunk = [i for i in reads if i is not None]
-            cnt, ret = recover_ccs_chunk(chunk, is_canonical)
+        for cnt, _short, (_ids, text) in _scan_chunks(chunks, False, 0, as_text=True):
             for key, value in cnt.items():
                 reads_count[key] += value
-            _write_records(out, ret)
+            out.write(text)
     return reads_count
 
 
@@ -523,14 +724,14 @@ def _raw_map_read(read_id, seq):
     return 'laid', (read_id, junc, layout)
 
 
-def scan_raw_chunk(chunk, is_canonical, circ_reads):
-    """[(read_id, seq)] -> (counters, 'partial' records, short reads) (find_bsj.py:499-620)"""
+def _raw_program(chunk, is_canonical, circ_reads):
+    """scan_raw_chunk as a program for _drive: the mapper phase of the chunk on the workers while the parent finishes the one before"""
     reads_cnt = defaultdict(int)
     ret, short_reads, laid = [], [], []
     todo = [(read_id, seq) for read_id, seq in chunk if read_id not in circ_reads]
     procs = _process_pool('scan', env.ALIGNER, env.CONTIG_LEN)
     if procs is not None:
-        mapped = procs.raw(todo)
+        mapped = yield procs.raw_async(todo)
     else:
         pool = _thread_pool()
         mapped = [_raw_map_read(*it) for it in todo] if pool is None else list(pool.map(lambda it: _raw_map_read(*it), todo))
@@ -558,6 +759,18 @@ def scan_raw_chunk(chunk, is_canonical, circ_reads):
     return reads_cnt, ret, short_reads
 
 
+def _raw_chunks(chunks, is_canonical, circ_reads):
+    """(counters, 'partial' records, short reads) per chunk, in order; two chunks in flight when the mapper phase has workers"""
+    depth = 2 if _process_pool('scan', env.ALIGNER, env.CONTIG_LEN) is not None else 1
+    return _drive((_raw_program(c, is_canonical, circ_reads) for c in chunks), depth)
+
+
+def scan_raw_chunk(chunk, is_canonical, circ_reads):
+    """[(read_id, seq)] -> (counters, 'partial' records, short reads) (find_bsj.py:499-620)"""
+    for out in _raw_chunks([chunk], is_canonical, circ_reads):
+        return out
+
+
 def scan_raw_reads(in_file, ref_fasta, gtf_index, intron_index, ss_index, is_canonical, out_dir, prefix, threads,
                    aligner=None, genome=None, contig_len=None):
     """Stage driver (find_bsj.py:623-720): every read of the input that is not already in cand_circ.fa, chunks of 1000,
@@ -581,8 +794,7 @@ def scan_raw_reads(in_file, ref_fasta, gtf_index, intron_index, ss_index, is_can
     reads_cnt = defaultdict(int)
     short_reads = []
     with open('{}/{}.low_confidence.fa'.format(out_dir, prefix), 'w') as out:
-        for reads in grouper(iter_reads(in_file), 1000):
-            cnt, ret, short = scan_raw_chunk([r for r in reads if r is not None], is_canonical, circ_reads)
+        for cnt, ret, short in _raw_chunks(([r for r in reads if r is not None] for reads in grouper(iter_reads(in_file), 1000)), is_canonical, circ_reads):
             for key, value in cnt.items():
                 reads_cnt[key] += value
             short_reads += short

@@ -196,6 +196,15 @@ def pack(seqs):
     return np.ascontiguousarray(data, dtype=np.int8), off
 
 
+def pack_text(seqs):
+    """pack() for a list of str only, encoded in one pass over their concatenation (a clip batch is thousands of short strings)"""
+    blob = ''.join(seqs).encode('latin-1')
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    if seqs:
+        np.cumsum([len(s) for s in seqs], out=off[1:])
+    return np.ascontiguousarray(_LUT[np.frombuffer(blob, dtype=np.uint8)], dtype=np.int8), off
+
+
 def _torch_first():
     """torch ships its own HIP runtime; when a process uses both, torch's must open the device before libclh's does
     (the other order leaves torch with "No HIP GPUs are available").  Only acts when the caller already imported torch."""
@@ -557,12 +566,13 @@ class Genome(object):
                              np.ascontiguousarray(minus, dtype=np.uint8)))
 
     def ssw_windows(self, reads, read_off, windows, minus, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True,
-                    want_cigar=True, mask_len=None):
-        """ssw_batch with reference k = windows[k] = (contig, start, end), reverse-complemented where minus[k]."""
+                    want_cigar=True, mask_len=None, spans=None):
+        """ssw_batch with reference k = windows[k] = (contig, start, end), reverse-complemented where minus[k].  spans: the windows as
+        genome-wide (offset, length) int64 arrays instead (what _spans(windows) gives)."""
         reads = np.ascontiguousarray(reads, dtype=np.int8)
         read_off = np.ascontiguousarray(read_off, dtype=np.int64)
         n = len(read_off) - 1
-        off, ln = self._spans(windows)
+        off, ln = self._spans(windows) if spans is None else (np.ascontiguousarray(spans[0], dtype=np.int64), np.ascontiguousarray(spans[1], dtype=np.int64))
         ln32 = ln.astype(np.int32)
         rcf = np.ascontiguousarray(np.asarray(minus, dtype=np.uint8))
         o, _keep = self.ctx._opts(mat, gap_open, gap_extend, flag, score_size, want_score2, want_cigar)

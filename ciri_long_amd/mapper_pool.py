@@ -4,9 +4,11 @@ CIRI_long/find_bsj.py:338-345, 459-466, 636-643; CIRI_long/env.py:9-22).
 The reference spreads its whole per-read loop -- mapper calls included -- over ``threads`` forked processes.  Here one process
 per GPU owns the device, and a process that has initialised the GPU must neither fork nor start children that exec.  So the
 pool is made BEFORE anything touches the GPU (``find_bsj.start_mapper_pools`` at program start; ``dist.call_sharded`` does it
-first thing), its workers run only phase 1 of a chunk (``find_bsj._map_read`` / ``_raw_map_read``: every call of
-``env.ALIGNER.map``) and hand the pending tuples back; the batched GPU phases stay in the parent.  A worker never loads
-libclh (``hip.lib()`` refuses in a worker).
+first thing).  Its workers run every per-read phase of a chunk -- phase 1 (``find_bsj._phase_map``: every call of
+``env.ALIGNER.map``), and the two halves of phase 3 around the splice-signal call (``_phase_finish``, ``_phase_assemble``:
+coordinate arithmetic, exon tags, record text) -- while the parent keeps only the two batched GPU calls between them and never
+unpacks a read: what one phase leaves for the next is a pickled blob it passes on (``submit``).  Stage 3 maps its reads there too
+(``_raw_map_read``).  A worker never loads libclh (``hip.lib()`` refuses in a worker).
 
 Two ways to give a worker its mapper:
   * ``start='fork'`` (default): the parent builds the aligner, the workers inherit it -- what the reference does, and the only
@@ -16,6 +18,7 @@ Whether ``mappy.Aligner.map`` releases the GIL is irrelevant on this route.
 """
 import multiprocessing
 import os
+import pickle
 import sys
 
 _FORK_PAYLOAD = None       # (aligner, contig_len) a forked worker finds here
@@ -39,15 +42,41 @@ def in_worker():
     return os.environ.get('CIRI_LONG_MAPPER_WORKER') == '1'
 
 
-def _worker_init(factory, contig_len):
+def _worker_init(factory, contig_len, gtf_index):
     os.environ['CIRI_LONG_MAPPER_WORKER'] = '1'
     from . import env
     if factory is None:
-        aligner, contig_len = _FORK_PAYLOAD
+        aligner, contig_len, gtf_index = _FORK_PAYLOAD
     else:
         aligner = factory()
-    # as env.initializer in the reference's workers; the genome and the annotation indices are the parent's business (phases 2-3)
-    env.initializer(aligner, contig_len, None, None, None, None)
+    # as env.initializer in the reference's workers; the genome and the splice-site index are the parent's business (the GPU calls)
+    env.initializer(aligner, contig_len, None, gtf_index, None, None)
+
+
+def _worker_map(task):
+    items, raw_filters, min_circ_fraction = task
+    from . import find_bsj
+    cnt, shorts, jobs, pend = find_bsj._phase_map(items, raw_filters, min_circ_fraction)
+    return cnt, shorts, jobs, pickle.dumps(pend, -1)
+
+
+def _worker_finish(group):
+    from . import find_bsj
+    out = []
+    for blob, rows, with_hosts in group:
+        cands, hosts, ready = find_bsj._phase_finish(pickle.loads(blob), rows, with_hosts)
+        out.append((cands, hosts, pickle.dumps(ready, -1)))
+    return out
+
+
+def _worker_assemble(group):
+    from . import find_bsj
+    return [find_bsj._phase_assemble(pickle.loads(blob), rows, extra, as_text) for blob, rows, extra, as_text in group]
+
+
+def _worker_raw(items):
+    from . import find_bsj
+    return [find_bsj._raw_map_read(read_id, seq) for read_id, seq in items]
 
 
 def _worker_scan(task):
@@ -56,15 +85,30 @@ def _worker_scan(task):
     return [find_bsj._map_read(it, raw_filters, min_circ_fraction) for it in items]
 
 
-def _worker_raw(items):
-    from . import find_bsj
-    return [find_bsj._raw_map_read(read_id, seq) for read_id, seq in items]
+_TASKS = {'map': _worker_map, 'finish': _worker_finish, 'assemble': _worker_assemble, 'raw': _worker_raw}
+
+
+class _Handle(object):
+    """an AsyncResult whose get() gives one result per submitted task (grouped tasks flattened back)"""
+
+    def __init__(self, result, grouped):
+        self._r, self._grouped = result, grouped
+
+    def ready(self):
+        return self._r.ready()
+
+    def wait(self, timeout=None):
+        self._r.wait(timeout)
+
+    def get(self):
+        out = self._r.get()
+        return [x for part in out for x in part] if self._grouped else out
 
 
 class MapperPool(object):
     """``workers`` processes, each with its own (or the inherited) mapper; ``scan`` / ``raw`` keep the input order."""
 
-    def __init__(self, workers, aligner=None, contig_len=None, factory=None, start='fork', piece=32):
+    def __init__(self, workers, aligner=None, contig_len=None, factory=None, start='fork', piece=32, gtf_index=None):
         global _FORK_PAYLOAD
         if gpu_touched():
             raise RuntimeError('mapper pool: this process has initialised the GPU; worker processes must be started before that '
@@ -74,13 +118,18 @@ class MapperPool(object):
         if start == 'fork' and factory is None:
             if aligner is None:
                 raise ValueError('mapper pool: fork needs the aligner built in the parent')
-            _FORK_PAYLOAD = (aligner, contig_len)
+            _FORK_PAYLOAD = (aligner, contig_len, gtf_index)
         elif factory is None:
             raise ValueError('mapper pool: spawn needs a picklable factory that builds the aligner in the worker')
         self.workers, self.piece = int(workers), int(piece)
+        self._gtf_index = gtf_index
         ctx = multiprocessing.get_context(start)
-        self._pool = ctx.Pool(self.workers, _worker_init, (factory, contig_len))
+        self._pool = ctx.Pool(self.workers, _worker_init, (factory, contig_len, gtf_index if factory is not None else None))
         _FORK_PAYLOAD = None
+
+    def has_index(self, gtf_index):
+        """True when a worker's find_host_gene answers as the caller's would: it was given this very index, or there is none"""
+        return not gtf_index or self._gtf_index is gtf_index
 
     def _pieces(self, items):
         # small pieces: the reads of a chunk differ a lot in mapper time (rotation loop of find_bsj), and a worker that draws a
@@ -88,13 +137,26 @@ class MapperPool(object):
         n = max(1, min(self.piece, (len(items) + 4 * self.workers - 1) // (4 * self.workers)))
         return [items[i:i + n] for i in range(0, len(items), n)]
 
+    def submit(self, kind, tasks, grouped=False):
+        """tasks of one kind ('map', 'finish', 'assemble', 'raw') to the workers, without waiting: -> handle with ready(), wait(timeout),
+        get() -> one result per task, in order.  grouped: the tasks are light (the halves of phase 3) -- a worker takes a run of them per
+        message, two runs per worker."""
+        if grouped:
+            n = max(1, (len(tasks) + 2 * self.workers - 1) // (2 * self.workers))
+            tasks = [tasks[i:i + n] for i in range(0, len(tasks), n)]
+        return _Handle(self._pool.map_async(_TASKS[kind], tasks, 1), grouped)
+
     def scan(self, chunk, raw_filters, min_circ_fraction):
+        """phase 1 of a chunk, input order kept: [(counter keys touched, short read or None, pending tuple or None)] per read"""
+        from . import find_bsj
         out = self._pool.map(_worker_scan, [(p, raw_filters, min_circ_fraction) for p in self._pieces(list(chunk))])
         return [x for part in out for x in part]
 
+    def raw_async(self, items):
+        return _Handle(self._pool.map_async(_worker_raw, self._pieces(list(items)), 1), True)
+
     def raw(self, items):
-        out = self._pool.map(_worker_raw, self._pieces(list(items)))
-        return [x for part in out for x in part]
+        return self.raw_async(items).get()
 
     def close(self):
         if self._pool is not None:

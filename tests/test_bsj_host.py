@@ -196,12 +196,34 @@ def test_window_route_host_logic_on_cpu(golden, world, monkeypatch):
     flags, None for rejected windows -- with the two device calls replaced by CPU stand-ins (test infrastructure)."""
     from ciri_long_amd import env, find_bsj, ssw_wrap, utils
 
-    class FakeDevice(object):
-        def __init__(self, genome):
-            self.genome = genome
+    import numpy as np
+    from ciri_long_amd import hip
 
-        def count_n(self, wins):
-            return [self.genome.seq(c, s, e).count('N') for c, s, e in wins]
+    class FakeDevice(object):
+        """hip.Genome's three calls of this route on the CPU: contigs concatenated, windows as genome-wide (offset, length) spans"""
+
+        def __init__(self, genome):
+            self.offset, parts, pos = {}, [], 0
+            for c, n in genome.contig_len.items():
+                self.offset[c] = pos; parts.append(genome.seq(c, 0, n)); pos += n
+            self.text = ''.join(parts)
+
+        def _spans(self, wins):
+            return (np.array([self.offset[c] + s for c, s, e in wins], dtype=np.int64), np.array([e - s for c, s, e in wins], dtype=np.int64))
+
+        def count_n_spans(self, off, ln):
+            return np.array([self.text[o:o + n].count('N') for o, n in zip(off.tolist(), ln.tolist())], dtype=np.int64)
+
+        def ssw_windows(self, reads, read_off, windows, minus, mat, gap_open, gap_extend, flag=1, score_size=2, want_score2=True, want_cigar=True,
+                        mask_len=None, spans=None):
+            assert windows is None and not want_score2 and not want_cigar and (gap_open, gap_extend) == (1, 1)
+            rows = np.zeros(len(read_off) - 1, dtype=hip.ALIGN_DTYPE)
+            for k, (o, n) in enumerate(zip(spans[0].tolist(), spans[1].tolist())):
+                ref = self.text[o:o + n]
+                d = oracle_lib.oracle_align(utils.revcomp(ref) if minus[k] else ref, oracle_lib.decode(reads[read_off[k]:read_off[k + 1]]), 1, 1, 1, 1)
+                rows[k]['score1'], rows[k]['ref_begin1'], rows[k]['ref_end1'] = d['score'], d['ref_begin'], d['ref_end']
+                rows[k]['read_begin1'], rows[k]['read_end1'] = d['query_begin'], d['query_end']
+            return rows, np.zeros(0, dtype=np.uint32)
 
     class Wrapped(object):
         def __init__(self, genome):
@@ -210,12 +232,6 @@ def test_window_route_host_logic_on_cpu(golden, world, monkeypatch):
         def seq(self, ctg, start, end):
             return self.host.seq(ctg, start, end)
 
-    def align_windows(device, wins, minus, queries, match=2, mismatch=2, gap_open=3, gap_extend=1, **kw):
-        refs = [device.genome.seq(c, s, e) for c, s, e in wins]
-        refs = [utils.revcomp(r) if m else r for r, m in zip(refs, minus)]
-        return _oracle_pairs(refs, queries, match, mismatch, gap_open, gap_extend)
-
-    monkeypatch.setattr(ssw_wrap, 'align_windows', align_windows)
     env.initializer(world['mapper'], world['genome'].contig_len, Wrapped(world['genome']), world['gtf_index'], None, world['ss_index'])
     try:
         cnt, short, ret = find_bsj.scan_ccs_chunk(world['reads'], True)

@@ -288,3 +288,115 @@ def test_one_round_of_the_fuzz_harness(monkeypatch, capsys):
     except SystemExit as ex:
         assert not ex.code, capsys.readouterr().out[-1500:]
     assert 'fuzz ok:' in capsys.readouterr().out
+
+
+def _check_chain_sample(fs, reads, wins, sample, window_of, use_ref):
+    """the reads `sample` of a bench.FullStep that has run one step, against the CPU statements: copy boundaries, consensus (length, CRC,
+    N count), the five Smith-Waterman fields of the clip against its window, and the splice-signal row around the junction"""
+    import bench
+    B = np.frombuffer(b'ACGTN', dtype=np.uint8)
+    crow, csegs, ccs = fs.ccs_plan.fetch()
+    rows, sig = fs.last['rows'], fs.last['sig']
+    pos = {int(k): j for j, k in enumerate(fs.has)}
+    checked = dict(consensus=0, linear=0, ssw=0, splice=0)
+    for i in sample:
+        i = int(i)
+        seg, want_ccs, _ = oracle_lib.oracle_find_consensus(reads[i])
+        nseg = int(crow['nseg'][i])
+        got_seg = ';'.join('%d-%d' % (csegs[i, k, 0], csegs[i, k, 1]) for k in range(nseg)) if nseg > 0 else None
+        assert got_seg == seg, ('copy boundaries', i, got_seg, seg)
+        assert (i in pos) == (seg is not None)
+        if seg is None:
+            checked['linear'] += 1
+            continue
+        codes = ccs[fs.ro[i]:fs.ro[i] + int(crow['ccs_len'][i])]
+        want_codes = oracle_lib.encode(want_ccs)
+        assert len(codes) == len(want_codes) and zlib.crc32(codes.tobytes()) == zlib.crc32(want_codes.tobytes()), ('consensus', i)
+        assert int((codes == 4).sum()) == want_ccs.count('N')
+        checked['consensus'] += 1
+        # the clip the step aligned: the last 30 % (>= 20 bases) of THIS step's consensus, against the read's window
+        j = pos[i]
+        clip = want_codes[len(want_codes) - bench.clip_len(len(want_codes)):]
+        w_off, w_codes = window_of(i, j)
+        a = (oracle_lib.ref_align if use_ref else oracle_lib.oracle_align)(w_codes, clip, 1, 1, 1, 1)
+        r = rows[j]
+        assert [int(r['score1']), int(r['ref_begin1']), int(r['ref_end1']), int(r['read_begin1']), int(r['read_end1'])] == \
+            [a['score'], a['ref_begin'], a['ref_end'], a['query_begin'], a['query_end']], ('clip alignment', i)
+        checked['ssw'] += 1
+        # the splice-signal search around the junction those coordinates give (K6), on a stretch of the genome wide enough for its
+        # free-sliding and search windows (align.py:477-496), contig ends kept where the stretch reaches them
+        start = int(w_off) + a['ref_begin']; end = int(w_off) + a['ref_end'] + 1
+        cb = int(np.clip(len(clip) - (a['query_end'] - a['query_begin'] + 1), 0, 20))
+        lo, hi = max(0, start - 1500), min(fs.glen, end + 1500)
+        if lo > 0 and hi < fs.glen:
+            stretch = B[np.minimum(np.concatenate([wins[k] for k in range(lo // bench.WINDOW, (hi - 1) // bench.WINDOW + 1)]), 4)].tobytes()
+            base = (lo // bench.WINDOW) * bench.WINDOW
+            stretch = stretch[lo - base:hi - base]
+            want = oracle_lib.oracle_splice_signal(stretch, start - lo, end - lo, cb, None, True)
+            s = sig[j]
+            if want == 'edge':
+                assert int(s[0]) != 0
+            else:
+                site, us_free, ds_free = want
+                assert int(s[0]) == 0 and (int(s[1]), int(s[2])) == (us_free, ds_free), ('splice free region', i)
+                if site is None:
+                    assert int(s[3]) == 0, ('splice', i)
+                else:
+                    assert int(s[3]) == 1 and ('-' if s[4] else '+', int(s[5]), int(s[6])) == site[1:], ('splice site', i, site)
+                    assert site[0] == '{}-{}*|{}-{}'.format(oracle_lib._SPLICE_MOTIFS[int(s[7])][1], oracle_lib._SPLICE_MOTIFS[int(s[7])][0], int(s[5]), int(s[6]))
+            checked['splice'] += 1
+    return checked
+
+
+def test_c3_full_chain_step():
+    """THE THING bench.py TIMES, at BASELINE config C3's full size: bench.FullStep on the 100 000 reads, one step -- K2 + K3 of every read,
+    the clip of each consensus gathered on the device from that step's K3 output, K5, K1 against the 2 kb window read in place from the
+    resident genome, rows to the host, K6 -- and 200 seeded reads of it against the oracles, every link of the chain; the seven counters
+    (main.py:50-51, 96-100) as the step fills them."""
+    import torch
+    torch.cuda.init()
+    import bench
+    from ciri_long_amd import hip, synth
+    n = 100000
+    ctx = hip.default_context()
+    fs = bench.FullStep(torch, hip, synth, ctx, 'c3', n, 0, None)
+    fs.step()
+    reads, wins = bench.make_batch(synth, 'c3', n, 0)
+    rng = np.random.default_rng(3)
+    has = fs.has
+    others = np.setdiff1d(np.arange(n), has)
+    sample = np.concatenate([rng.choice(has, 140, replace=False), rng.choice(others, 60, replace=False)])
+    checked = _check_chain_sample(fs, reads, wins, sample, lambda i, j: (i * bench.WINDOW, wins[i]), use_ref=False)
+    assert checked['consensus'] == checked['ssw'] == 140 and checked['linear'] == 60 and checked['splice'] >= 130
+    c = fs.counters()
+    rows, sig = fs.last['rows'], fs.last['sig']
+    assert c.tolist() == [n, len(has), 0, len(has), int((rows['score1'] > 0).sum()), int((sig[:, 3] > 0).sum()), 0]
+    assert 0.3 * n < c[1] < 0.5 * n and c[4] == c[1] and 0 < c[5] <= c[4]           # every clip of a consensus finds its template in the window
+    assert bool(fs.last['keep'].all())                                              # no window of this genome is 30 % N
+    fs.genome.close()
+
+
+def test_c3_full_chain_step_production_windows():
+    """the same step with the reference's own clip window -- the hit +- 200 kb (find_bsj.py:196-197), through the exact column prefilter
+    in front of K1 -- 50 seeded reads against the reference's own libssw.so where it is present (oracle/_ref), else the scalar statement"""
+    import torch
+    torch.cuda.init()
+    import bench
+    from ciri_long_amd import hip, synth
+    n = 100000
+    ctx = hip.default_context()
+    fs = bench.FullStep(torch, hip, synth, ctx, 'c3', n, 0, None, prod_windows=True)
+    fs.step()
+    reads, wins = bench.make_batch(synth, 'c3', n, 0)
+    rng = np.random.default_rng(4)
+    sample = rng.choice(fs.has, 50, replace=False)
+
+    def window_of(i, j):
+        off, ln = int(fs.win_off[j]), int(fs.win_len[j])
+        first, last = off // bench.WINDOW, (off + ln - 1) // bench.WINDOW
+        codes = np.concatenate([wins[k] for k in range(first, last + 1)])
+        return off, codes[off - first * bench.WINDOW:off - first * bench.WINDOW + ln]
+    checked = _check_chain_sample(fs, reads, wins, sample, window_of, use_ref=oracle_lib.have_ref())
+    assert checked['ssw'] == 50 and checked['splice'] >= 45
+    assert int(fs.win_len.max()) == 2 * 200000 + bench.WINDOW
+    fs.genome.close()

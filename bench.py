@@ -43,7 +43,16 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 NCHECK = 256                                # reads of the batch spot-checked against the oracle (by the CPU leg)
-PK_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0       # SIMDs x Hz / 4 cycles: packed-16 ops are half rate (tools/ubench/valu_rate.hip)
+# Issue cost of a wave64 vector instruction per SIMD, MEASURED on this GPU at 1 / 2 / 4 / 8 resident waves per SIMD (profiles/r06_valu_rate.txt,
+# made by tools/ubench/valu_rate.hip): 4 cycles for every packed-16 op (v_pk_max/min/add/sub/mad_i16/u16), every DPP-modified op, v_max/min_i32,
+# the three-operand integer ops, shifts, compares and carries -- everything the DP row steps are made of; 2 cycles only for the plain 32-bit VOP2
+# forms (v_add_u32, v_sub_u32, v_and/or/xor_b32) and the 16-bit v_max_i16; 3.5 for v_bitop3_b32 / v_fma_f32.  MI355X_MICROARCH.md's "2 cycles" is
+# that second class.  The prefilter's loop is a mix of all three (tools/valu_mix.py -> profiles/r06_valu_mix.txt: 3.29 cycles on average).
+PK_OP_CYCLES = 4.0
+PF_MIX_CYCLES = 3.29
+PK_ISSUE_PEAK = 256 * 4 * 2.4e9 / PK_OP_CYCLES       # packed-16 wave instructions per second, whole GPU
+PF_ISSUE_PEAK = 256 * 4 * 2.4e9 / PF_MIX_CYCLES      # wave instructions per second of the prefilter's instruction mix
+VALU_PEAK_SOURCE = 'profiles/r06_valu_rate.txt (measured: v_pk_* 4.15 cycles per instruction and SIMD at 8 waves, 4.27 at 4)'
 K3_FLOOR_OPS = 22                           # packed operations per cell pair of K3's recurrences, nothing else counted (see FullStep.launches)
 WINDOW = 2000
 B_ASCII = np.frombuffer(b'ACGTN', dtype=np.uint8)
@@ -217,16 +226,18 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
     valu = {'bound': 'valu', 'kernel': 'ssw_scan_kernel + ssw_scanw_kernel + ssw_align_kernel (all classes)', 'unit': 'GCUPS',
             'achieved': cells_total / (k1ms * 1e-3) / 1e9 if k1ms > 0 else None,
             'peak': PK_ISSUE_PEAK * 128 / 6 / 1e9,
-            'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / 6 packed ops per cell pair (gapO == gapE path)'}
+            'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op (measured: ' + VALU_PEAK_SOURCE + ') x 128 cells per op / 6 packed ops per cell pair (gapO == gapE path)'}
     valu['frac'] = valu['achieved'] / valu['peak'] if valu['achieved'] else None
     if sum(pf_ms) > 0:
         # the first stage of the prefilter against ITS bound: one lane walks one window column per 11 W + 8 integer instructions (W = 32-row
-        # words of the read), v_addc / v_bitop3 / v_alignbit at one wave instruction per 4 cycles and SIMD; nothing else is counted
+        # words of the read); its loop is v_bitop3 (3.5 cycles), v_or / v_and / v_add (2), v_alignbit / v_addc / shifts (4): 3.29 cycles per
+        # instruction on average (profiles/r06_valu_mix.txt; rounds 4-5 priced all of them at 4 and read 0.84); nothing else is counted
         li = sum(w[1] for w in pf_work); wc = sum(w[0] for w in pf_work); t = sum(pf_ms) * 1e-3
         valu['prefilter'] = {'bound': 'valu-issue', 'kernel': 'ssw_prefilter_kernel', 'unit': 'T lane-instructions/s', 'ms': sum(pf_ms),
                              'word_columns': wc, 'lane_instructions': li, 'word_columns_per_s': wc / t,
-                             'achieved': li / t / 1e12, 'peak': PK_ISSUE_PEAK * 64 / 1e12, 'frac': li / t / (PK_ISSUE_PEAK * 64),
-                             'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction x 64 lanes; work = window columns x (11 W + 8), W = ceil(rows / 32) per piece of the read'}
+                             'achieved': li / t / 1e12, 'peak': PF_ISSUE_PEAK * 64 / 1e12, 'frac': li / t / (PF_ISSUE_PEAK * 64),
+                             'peak_note': '1024 SIMDs x 2.4 GHz / 3.29 cycles per wave instruction of this loop\'s mix (profiles/r06_valu_mix.txt over profiles/r06_valu_rate.txt) x 64 lanes; '
+                                          'work = window columns x (11 W + 8), W = ceil(rows / 32) per piece of the read'}
     return out, valu
 
 
@@ -358,7 +369,7 @@ class FullStep(object):
         # comparison, clamped difference, store, end-cell test or per-row step cost
         self.k3_valu = {'bound': 'valu', 'kernel': 'poa_consensus_kernel', 'unit': 'GCUPS', 'cells_per_launch': kst['dp_cells'],
                         'achieved': kst['dp_cells'] / (k3 * 1e-3) / 1e9 if k3 > 0 else None, 'peak': PK_ISSUE_PEAK * 128 / K3_FLOOR_OPS / 1e9,
-                        'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op x 128 cells per op / %d packed ops per cell pair (five-state convex model: '
+                        'peak_note': '1024 SIMDs x 2.4 GHz / 4 cycles per packed-16 op (measured: ' + VALU_PEAK_SOURCE + ') x 128 cells per op / %d packed ops per cell pair (five-state convex model: '
                                      'diagonal 2, F 3, O 3, candidates 2, E and Q prefix maxima 8, H 2, E from Q 2)' % K3_FLOOR_OPS,
                         'dropped_to_kernel_limits': kst['dropped']}
         self.k3_valu['frac'] = self.k3_valu['achieved'] / self.k3_valu['peak'] if self.k3_valu['achieved'] else None

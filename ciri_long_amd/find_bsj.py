@@ -401,8 +401,11 @@ class _Now(object):
 class _Futures(object):
     """the handle of a list of concurrent.futures"""
 
-    def __init__(self, futures):
+    def __init__(self, futures, wake=None):
         self.futures = futures
+        if wake is not None:
+            for f in futures:
+                f.add_done_callback(lambda _f: wake.set())
 
     def ready(self):
         return all(f.done() for f in self.futures)
@@ -419,10 +422,12 @@ class _Route(object):
     """where the phases of a piece run.  submit_*() -> handle with ready() / wait(timeout) / get(); get() -> one result per piece."""
 
     def __init__(self, raw_filters):
+        import threading
         role = 'scan' if raw_filters else 'recover'
         self.procs = _process_pool(role, env.ALIGNER, env.CONTIG_LEN)
         self.threads = None if self.procs is not None else _thread_pool()
-        self.depth = 3 if self.procs is not None else 1            # chunks in flight
+        self.depth = 4 if self.procs is not None else 1            # chunks in flight
+        self.wake = threading.Event()                              # set whenever something submitted has finished: _drive sleeps on it
         workers = self.procs.workers if self.procs is not None else (THREADS if self.threads is not None else 1)
         self.piece = 32 if workers > 1 else 1 << 30
         self.workers = workers
@@ -437,19 +442,19 @@ class _Route(object):
 
     def submit_map(self, pieces, raw_filters, min_circ_fraction):
         if self.procs is not None:
-            return self.procs.submit('map', [(p, raw_filters, min_circ_fraction) for p in pieces])
+            return self.procs.submit('map', [(p, raw_filters, min_circ_fraction) for p in pieces], wake=self.wake)
         if self.threads is not None:
-            return _Futures([self.threads.submit(_phase_map, p, raw_filters, min_circ_fraction) for p in pieces])
+            return _Futures([self.threads.submit(_phase_map, p, raw_filters, min_circ_fraction) for p in pieces], self.wake)
         return _Now([_phase_map(p, raw_filters, min_circ_fraction) for p in pieces])
 
     def submit_finish(self, states, rows):
         if self.procs is not None:
-            return self.procs.submit('finish', [(st, rw, self.worker_hosts) for st, rw in zip(states, rows)], grouped=True)
+            return self.procs.submit('finish', [(st, rw, self.worker_hosts) for st, rw in zip(states, rows)], grouped=True, wake=self.wake)
         return _Now([_phase_finish(st, rw, True) for st, rw in zip(states, rows)])
 
     def submit_assemble(self, states, sig_rows, sig_extra, as_text):
         if self.procs is not None:
-            return self.procs.submit('assemble', [(st, rw, ex, as_text) for st, rw, ex in zip(states, sig_rows, sig_extra)], grouped=True)
+            return self.procs.submit('assemble', [(st, rw, ex, as_text) for st, rw, ex in zip(states, sig_rows, sig_extra)], grouped=True, wake=self.wake)
         return _Now([_phase_assemble(st, rw, ex, as_text) for st, rw, ex in zip(states, sig_rows, sig_extra)])
 
 
@@ -499,10 +504,10 @@ def _chunk_program(route, chunk, raw_filters, min_circ_fraction, as_text, is_can
     return reads_cnt, short_reads, ((ids, ''.join(parts)) if as_text else parts)
 
 
-def _drive(programs, depth):
+def _drive(programs, depth, wake=None):
     """Run chunk programs (generators as _chunk_program) with up to `depth` of them in flight; yields their results in order.
     A program is resumed as soon as what it waits for is there, oldest first -- so the GPU calls of one chunk run while the workers
-    are busy with the phases of the others."""
+    are busy with the phases of the others.  wake: an event the handles set when they finish (else the oldest handle is polled)."""
     from collections import deque
     live = deque()              # [generator, handle, result, finished]
     src = iter(programs)
@@ -535,13 +540,17 @@ def _drive(programs, depth):
             yield live.popleft()[2]
             moved = True
         if not moved:
-            live[0][1].wait(0.02)
+            if wake is not None:
+                wake.wait(0.05)
+                wake.clear()
+            else:
+                live[0][1].wait(0.02)
 
 
 def _scan_chunks(chunks, raw_filters, min_circ_fraction, as_text=False):
     """(counters, short reads, records) per chunk of `chunks` (an iterable of lists of (read_id, segments, ccs, raw)), in order"""
     route = _Route(raw_filters)
-    return _drive((_chunk_program(route, c, raw_filters, min_circ_fraction, as_text) for c in chunks), route.depth)
+    return _drive((_chunk_program(route, c, raw_filters, min_circ_fraction, as_text) for c in chunks), route.depth, route.wake)
 
 
 def _scan_chunk(chunk, raw_filters, min_circ_fraction):

@@ -137,14 +137,15 @@ class MapperPool(object):
         n = max(1, min(self.piece, (len(items) + 4 * self.workers - 1) // (4 * self.workers)))
         return [items[i:i + n] for i in range(0, len(items), n)]
 
-    def submit(self, kind, tasks, grouped=False):
+    def submit(self, kind, tasks, grouped=False, wake=None):
         """tasks of one kind ('map', 'finish', 'assemble', 'raw') to the workers, without waiting: -> handle with ready(), wait(timeout),
-        get() -> one result per task, in order.  grouped: the tasks are light (the halves of phase 3) -- a worker takes a run of them per
+        get() -> one result per task, in order (wake: a threading.Event set when they are all done).  grouped: the tasks are light (the halves of phase 3) -- a worker takes a run of them per
         message, two runs per worker."""
         if grouped:
             n = max(1, (len(tasks) + 2 * self.workers - 1) // (2 * self.workers))
             tasks = [tasks[i:i + n] for i in range(0, len(tasks), n)]
-        return _Handle(self._pool.map_async(_TASKS[kind], tasks, 1), grouped)
+        cb = (lambda _x: wake.set()) if wake is not None else None
+        return _Handle(self._pool.map_async(_TASKS[kind], tasks, 1, cb, cb), grouped)
 
     def scan(self, chunk, raw_filters, min_circ_fraction):
         """phase 1 of a chunk, input order kept: [(counter keys touched, short read or None, pending tuple or None)] per read"""

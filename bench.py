@@ -176,7 +176,7 @@ def roofline_of(launches, traffic_file=True):
             'note': 'integer DP kernels: hundreds of cell updates per compulsory byte; the VALU issue rate binds, not HBM (DESIGN.md section 3)'}
 
 
-def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1):
+def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1, lanes=False):
     """per read-length class HIP-event durations of K1 (and K1b), with their algorithmic bytes and cell counts"""
     ssw_plan.set_profiling(True)
     acc, accb = None, [0.0, 0.0]
@@ -204,6 +204,11 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
             cls[~scan & (qlen <= 4096) & (np.asarray(wlen) < 32768) & (max_match * qlen < 32000)] = -3
             if not os.environ.get('CLH_NO_SLICES') and not os.environ.get('CLH_NO_PREFILTER'):      # class -4 = K1w tasks on long windows behind the prefilter (scanw_sliced_ok)
                 cls[~scan & (qlen <= 4096) & (np.asarray(wlen) >= 32768) & (np.asarray(wlen) < 1500000) & (max_match * qlen < 32000)] = -4
+    if lanes and len(qlen) and not os.environ.get('CLH_NO_LANES'):   # classes -5..-8 = K1l, one alignment per lane (clh_api.hip: lanes_class_for; no second best, gap_open > gap_extend)
+        w = np.asarray(wlen)
+        short_ref = (w >= 1) & (w <= 64) & (qlen <= 65535)
+        take = short_ref & ((qlen * w <= 16384) | (int(short_ref.sum()) >= 32768))
+        cls[take] = np.where(w[take] <= 20, -5, np.where(w[take] <= 32, -6, np.where(w[take] <= 52, -7, -8)))
     out, cells_total, k1ms = [], 0, 0.0
     merged = []                                  # (a large K1w class runs as several launches: one line for the class)
     for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
@@ -216,7 +221,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_prefilter_indel_kernel + ssw_scan_pick2_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel', -4: 'ssw_prefilter_kernel + ssw_scanw_seed/pick/queue/combine kernels (K1w tasks on long windows)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_prefilter_indel_kernel + ssw_scan_pick2_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel', -5: 'ssw_lanes_kernel<20>', -6: 'ssw_lanes_kernel<32>', -7: 'ssw_lanes_kernel<52>', -8: 'ssw_lanes_kernel<64>', -4: 'ssw_prefilter_kernel + ssw_scanw_seed/pick/queue/combine kernels (K1w tasks on long windows)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         nwide = int(ssw_plan.traceback_counts()[0])
@@ -589,12 +594,15 @@ def extra_production_shape(torch, hip, synth, ctx, n=4000, r03_strands=False):
 
 
 def extra_collapse(torch, hip, synth, ctx, ncl=200):
-    """C5-shaped collapse kernels (collapse.py:373-387, 466-473): pairwise edit distances of 50 homopolymer-compressed reads
-    per cluster (K4) and the per-read alignment of the doubled read against the cluster's 50-nt junction, 10/4/8/2, CIGAR"""
+    """C5-shaped collapse kernels at the stage's scoring 10/4/8/2: per cluster of 50 reads (a) the pairwise edit distances of the homopolymer-
+    compressed reads (K4; collapse.py:466-473), (b) every doubled read against the cluster's 50-nt genomic junction with CIGAR (collapse.py:373-387),
+    (c) curate_junction's grid (collapse.py:161-173): 5 000 candidate 20-nt genomic junctions ((start, end) in +-25 around the cluster's
+    positions) against the cluster's 50-nt consensus junction, begin / end only -- 200 clusters: a million tiny alignments"""
     from ciri_long_amd import utils
     rng = np.random.Generator(np.random.PCG64(synth.SEEDS['C5']))
     B = 'ACGT'
     xs, ys, reads, juncs = [], [], [], []
+    grid_refs, grid_q = [], []
     for _c in range(ncl):
         tm = synth.template(rng)
         circ = ''.join(B[b] for b in tm)
@@ -604,18 +612,29 @@ def extra_collapse(torch, hip, synth, ctx, ncl=200):
             reads.append(cl[i]); juncs.append(circ[-25:] + circ[:25])
             for j in range(i + 1, 50):
                 xs.append(hpc[i]); ys.append(hpc[j])
+        # the genome around the circle's ends: 60 random bases on either side; candidate (start, end) pairs -> 20-nt junctions (end - 10 .. end) + (start .. start + 10)
+        g = ''.join(B[b] for b in rng.integers(0, 4, 60)) + circ + ''.join(B[b] for b in rng.integers(0, 4, 60))
+        s0, e0 = 60, 60 + len(circ)
+        cons = ''.join(B[b] for b in synth.mutate(oracle_codes(circ[-25:] + circ[:25]), rng, 0.02, 0.02, 0.02))
+        for i in range(s0 - 25, s0 + 25):
+            for j in range(e0 - 50, e0 + 50):
+                grid_refs.append(g[j - 10:j] + g[i:i + 10]); grid_q.append(cons)
     tstream = torch.cuda.Stream()
     st = tstream.cuda_stream
     ep = ctx.edit_plan(xs, ys)
     qd, qo = hip.pack([r + r for r in reads]); fd, fo = hip.pack(juncs)
     d_q = torch.from_numpy(qd.view(np.uint8)).cuda(); d_f = torch.from_numpy(fd.view(np.uint8)).cuda()
     sp = ctx.plan(qo, fo, hip.score_matrix(10, 4), 8, 2, flag=1, score_size=2, want_score2=False, want_cigar=True)
+    gqd, gqo = hip.pack_text(grid_q); gfd, gfo = hip.pack_text(grid_refs)
+    d_gq = torch.from_numpy(gqd.view(np.uint8)).cuda(); d_gf = torch.from_numpy(gfd.view(np.uint8)).cuda()
+    gp = ctx.plan(gqo, gfo, hip.score_matrix(10, 4), 8, 2, flag=1, score_size=2, want_score2=False, want_cigar=False)
     torch.cuda.synchronize()
 
     def step():
         ep.run(st)
         sp.run(d_q.data_ptr(), d_f.data_ptr(), st)
-        return ep.fetch(), sp.fetch()
+        gp.run(d_gq.data_ptr(), d_gf.data_ptr(), st)
+        return ep.fetch(), sp.fetch(), gp.fetch()
     step()
     K = 3
     t0 = time.perf_counter()
@@ -624,10 +643,30 @@ def extra_collapse(torch, hip, synth, ctx, ncl=200):
     el = (time.perf_counter() - t0) / K
     ep.run(st); torch.cuda.synchronize()
     k4ms = ep.timing()
-    launches, valu = k1_launches(sp, lambda: sp.run(d_q.data_ptr(), d_f.data_ptr(), st), qo, np.diff(fo), c2=True)
+    launches, valu = k1_launches(sp, lambda: sp.run(d_q.data_ptr(), d_f.data_ptr(), st), qo, np.diff(fo), c2=True, max_match=10, bias=4, lanes=True)
+    glaunches, gvalu = k1_launches(gp, lambda: gp.run(d_gq.data_ptr(), d_gf.data_ptr(), st), gqo, np.diff(gfo), max_match=10, bias=4, lanes=True)
+    for x in glaunches:
+        x['kernel'] += ' (curate_junction grid)'
+    # both K1 batches against the packed-op bound together: cells of both / time of both
+    cells = sum(x.get('cells', 0) for x in launches + glaunches); k1ms = sum(x['ms'] for x in launches + glaunches if 'cells' in x)
+    valu = dict(valu, achieved=cells / (k1ms * 1e-3) / 1e9, kernel='ssw_lanes_kernel + ssw_scanw_kernel (junction alignments and the curate_junction grid)')
+    valu['frac'] = valu['achieved'] / valu['peak']
+    valu['parts'] = {'junction_alignments_gcups': gv(launches), 'curate_grid_gcups': gv(glaunches)}
     launches.insert(0, {'kernel': 'edit_distance_kernel', 'pairs': len(xs), 'ms': k4ms, 'alg_bytes': int(sum(len(x) + len(y) + 4 for x, y in zip(xs, ys)))})
-    return {'workload': 'C5-shaped collapse kernels: %d clusters x 50 reads: %d edit distances (K4) + %d junction alignments 10/4/8/2 with CIGAR (K1+K1b), results to the host' % (ncl, len(xs), len(reads)),
+    launches += glaunches
+    return {'workload': 'C5-shaped collapse kernels: %d clusters x 50 reads: %d edit distances (K4) + %d junction alignments 10/4/8/2 with CIGAR (K1+K1b) + %d grid alignments of curate_junction '
+                        '(20-nt junction vs 50-nt consensus junction, K1), results to the host' % (ncl, len(xs), len(reads), len(grid_refs)),
             'value': len(reads) / el, 'unit': 'reads/s', 'ms_per_step': el * 1e3, 'launches': launches, 'valu_roofline': valu, 'roofline': roofline_of(launches, False)}
+
+
+def gv(launches):
+    c = sum(x.get('cells', 0) for x in launches); t = sum(x['ms'] for x in launches if 'cells' in x)
+    return c / (t * 1e-3) / 1e9 if t > 0 else None
+
+
+def oracle_codes(s):
+    """ACGT text -> int8 codes (bench-local: the product's hip.encode needs no GPU either, but this keeps extra_collapse's generator self-contained)"""
+    return np.frombuffer(s.encode(), dtype=np.uint8).view(np.int8).copy() if False else np.array(['ACGT'.index(c) for c in s], dtype=np.int8)
 
 
 def extra_stage1(hip, synth, ctx, n=100000):

@@ -253,6 +253,23 @@ static bool scanw_sliced_ok(int64_t L, int64_t R, const clh_ssw_opts* o, int max
     return L <= 4096 && R >= kSliceMinWindow && R <= 1500000 && own + overlap < 32768 && (int64_t)max_match * L < 32000 && o->gap_extend <= 16 && o->gap_open <= 255;
 }
 
+// K1l (ssw_lanes.hip): one alignment per lane for references of at most 64 columns -- the collapse stage's junction alignments
+// (collapse.py:161-173, 251-256, 373-387).  Only where its plain recurrence IS what the reference computes: no second best (the column
+// maxima of the reference's wildcard rows are not computed), gap_open > gap_extend or a score that cannot leave the 8-bit regime (the 16-bit
+// pass with gap_open == gap_extend truncates F at stripe boundaries, rowmajor_spec.c), code 4 scoring 0.  A lane walks its alignment alone: a long
+// read against a short reference goes there only when the plan holds enough of them to fill the GPU's lanes (`many`), else to the
+// wave-per-alignment classes.  CLH_NO_LANES=1 switches the class off (A/B measurements, and the parity tests run both ways).
+static int lanes_class_for(int64_t L, int64_t R, const clh_ssw_opts* o, int max_match, int bias, int null_code, bool many)
+{
+    if (getenv("CLH_NO_LANES") != nullptr) return 0;
+    if (o->want_score2 || R < 1 || R > 64 || L < 1 || L > 65535) return 0;
+    if (!(o->n_mat <= 4 || null_code == 4)) return 0;
+    if (o->gap_open > 255 || o->gap_extend < 0) return 0;
+    if (o->gap_open <= o->gap_extend && !((int64_t)max_match * std::min(L, R) + bias < 255 && o->score_size != 1)) return 0;
+    if (!many && L * R > 16384) return 0;
+    return R <= 20 ? clh::kRvLanes20 : (R <= 32 ? clh::kRvLanes32 : (R <= 52 ? clh::kRvLanes52 : clh::kRvLanes64));
+}
+
 // ref_off != nullptr: packed references, alignment a against [ref_off[a], ref_off[a+1]).  Otherwise windows of a resident
 // genome: win_off[a], win_len[a], win_rc[a] (1 = read backwards and complemented).
 static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off, const int64_t* ref_off,
@@ -292,12 +309,19 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
     pl->tasks.resize(n);
     size_t colmax = 0, cig = 0;
     unsigned long long pool = 0;
+    int n_short_ref = 0;                     // alignments K1l could take: enough of them fill the GPU's lanes whatever their read length
+    for (int a = 0; a < n; ++a) {
+        const int64_t L = read_off[a + 1] - read_off[a], R = ref_off ? ref_off[a + 1] - ref_off[a] : (int64_t)win_len[a];
+        n_short_ref += lanes_class_for(L, R, o, mx, -mn, P.null_code, true) != 0;
+    }
+    const bool many_short_ref = n_short_ref >= 32768;
     for (int a = 0; a < n; ++a) {
         const int64_t L = read_off[a + 1] - read_off[a], R = ref_off ? ref_off[a + 1] - ref_off[a] : (int64_t)win_len[a];
         if (L < 1 || R < 0 || L > 0x7fffffff || R > 0x7fffffff) { fail(CLH_E_ARG, "empty read or negative length in batch"); delete pl; return nullptr; }
         const int rc = (!ref_off && win_rc && win_rc[a]) ? 1 : 0;
         const int rows = (int)((L + 15) / 16) * 16;
-        const int rv = scan_class_ok(L, o, mx, -mn) ? (scan_sliced(R, o) ? clh::kRvScanSliced : clh::kRvScan)
+        const int lanes_rv = lanes_class_for(L, R, o, mx, -mn, P.null_code, many_short_ref);
+        const int rv = lanes_rv ? lanes_rv : scan_class_ok(L, o, mx, -mn) ? (scan_sliced(R, o) ? clh::kRvScanSliced : clh::kRvScan)
                                                     : (scanw_class_ok(L, R, o, mx) ? clh::kRvScanWide
                                                        : (scanw_sliced_ok(L, R, o, mx) ? clh::kRvScanWideSliced : rv_class_for(rows)));
         cls[a] = rv;
@@ -802,7 +826,8 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
         } else if (s.rv == clh::kRvScanSliced) {
             P.slices = (const clh::ScanSlice*)pl->d_slices; P.parts = (clh::ScanPart*)pl->d_parts;
             HIPCHK(clh::launch_ssw_scan_sliced(pl->quirk, P, s.count, (int)pl->slices.size(), ls));
-        } else if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
+        } else if (clh::rv_is_lanes(s.rv)) HIPCHK(clh::launch_ssw_lanes(clh::rv_lanes_columns(s.rv), P, s.count, ls));
+        else if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
         else if (s.rv == clh::kRvScanWide) {
             int* ctr = (int*)pl->d_seg_ctr + k;
             HIPCHK(hipMemsetAsync(ctr, 0, sizeof(int), ls));

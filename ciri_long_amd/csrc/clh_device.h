@@ -246,6 +246,11 @@ static constexpr int kRvScanWide = -3;   // pseudo class: K1w, the row-scan kern
                                          // persistent workgroups; their workspaces inside `dirs` (scanw_task_bytes of the class's longest read)
 hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, int nworkgroups, int* counter, long long ws_off, int ws_slot, hipStream_t stream);
 size_t scanw_task_bytes(int read_len);
+// pseudo classes: K1l, one alignment per lane for references of at most 20 / 32 / 52 / 64 columns (ssw_lanes.hip)
+static constexpr int kRvLanes20 = -5, kRvLanes32 = -6, kRvLanes52 = -7, kRvLanes64 = -8;
+inline bool rv_is_lanes(int rv) { return rv <= kRvLanes20 && rv >= kRvLanes64; }
+inline int rv_lanes_columns(int rv) { return rv == kRvLanes20 ? 20 : (rv == kRvLanes32 ? 32 : (rv == kRvLanes52 ? 52 : 64)); }
+hipError_t launch_ssw_lanes(int rmax, const SswParams& p, int ntasks, hipStream_t stream);
 // K1b launches.  All take the plan's WHOLE task table in p.tasks and work on the tasks [task_base, task_base + ntasks) of launch
 // class `seg` (every class has its own hand-over counters and list regions, so the classes' launch chains run on different
 // streams at once).  Words behind the pool's bump pointer: [4 + seg] alignments the row kernel handed to its wide form,

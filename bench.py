@@ -209,6 +209,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         short_ref = (w >= 1) & (w <= 64) & (qlen <= 65535)
         take = short_ref & ((qlen * w <= 16384) | (int(short_ref.sum()) >= 32768))
         cls[take] = np.where(w[take] <= 20, -5, np.where(w[take] <= 32, -6, np.where(w[take] <= 52, -7, -8)))
+        cls[short_ref & ~take & (qlen <= 32767)] = -9            # class -9 = K1w transposed: the short reference as the rows (ssw_scanw_tr_kernel)
     out, cells_total, k1ms = [], 0, 0.0
     merged = []                                  # (a large K1w class runs as several launches: one line for the class)
     for (rv, cnt, _rb, _fb), k1 in zip(ssw_plan.segments(), acc):
@@ -221,7 +222,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
         span = srow['ref_end1'][sel].astype(np.int64) - srow['ref_begin1'][sel] + 1
         cells = int((qlen[sel] * wlen[sel]).sum() + ((srow['read_end1'][sel].astype(np.int64) + 1) * span).sum())
         cells_total += cells; k1ms += k1 / PROF
-        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_prefilter_indel_kernel + ssw_scan_pick2_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel', -5: 'ssw_lanes_kernel<20>', -6: 'ssw_lanes_kernel<32>', -7: 'ssw_lanes_kernel<52>', -8: 'ssw_lanes_kernel<64>', -4: 'ssw_prefilter_kernel + ssw_scanw_seed/pick/queue/combine kernels (K1w tasks on long windows)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
+        out.append({'kernel': 'ssw_align_kernel<RV=%d>' % rv if rv > 0 else {0: 'ssw_scan_kernel', -1: 'ssw_prefilter_kernel + ssw_scan_pick_kernel + ssw_prefilter_indel_kernel + ssw_scan_pick2_kernel + ssw_scan_queue_kernel + ssw_scan_finish_queue_kernel' if not os.environ.get('CLH_NO_PREFILTER') else 'ssw_scan_slice_kernel + ssw_scan_finish_kernel', -2: 'ssw_combine_kernel (best window slice)', -3: 'ssw_scanw_kernel', -9: 'ssw_scanw_tr_kernel', -5: 'ssw_lanes_kernel<20>', -6: 'ssw_lanes_kernel<32>', -7: 'ssw_lanes_kernel<52>', -8: 'ssw_lanes_kernel<64>', -4: 'ssw_prefilter_kernel + ssw_scanw_seed/pick/queue/combine kernels (K1w tasks on long windows)'}[rv], 'alignments': cnt, 'ms': k1 / PROF, 'alg_bytes': int(b_alg[sel].sum()), 'cells': cells})
     if c2:
         out.append({'kernel': 'ssw_traceback_rows_kernel', 'alignments': int(len(qlen)), 'ms': accb[0] / PROF, 'alg_bytes': int(b_alg.sum())})
         nwide = int(ssw_plan.traceback_counts()[0])
@@ -649,7 +650,7 @@ def extra_collapse(torch, hip, synth, ctx, ncl=200):
         x['kernel'] += ' (curate_junction grid)'
     # both K1 batches against the packed-op bound together: cells of both / time of both
     cells = sum(x.get('cells', 0) for x in launches + glaunches); k1ms = sum(x['ms'] for x in launches + glaunches if 'cells' in x)
-    valu = dict(valu, achieved=cells / (k1ms * 1e-3) / 1e9, kernel='ssw_lanes_kernel + ssw_scanw_kernel (junction alignments and the curate_junction grid)')
+    valu = dict(valu, achieved=cells / (k1ms * 1e-3) / 1e9, kernel='ssw_lanes_kernel + ssw_scanw_tr_kernel (junction alignments and the curate_junction grid)')
     valu['frac'] = valu['achieved'] / valu['peak']
     valu['parts'] = {'junction_alignments_gcups': gv(launches), 'curate_grid_gcups': gv(glaunches)}
     launches.insert(0, {'kernel': 'edit_distance_kernel', 'pairs': len(xs), 'ms': k4ms, 'alg_bytes': int(sum(len(x) + len(y) + 4 for x, y in zip(xs, ys)))})
@@ -741,9 +742,6 @@ def extra_stage2(hip, synth, ctx, prep=None):
     finally:
         find_bsj._PROC_POOLS.pop('scan', None)
         find_bsj.THREADS = 1
-        if prep and prep.get('pool_files') is not None:
-            prep['pool_files'].close()
-            prep['pool_files'] = None
         shutil.rmtree(d, ignore_errors=True)
     el, msec, text, cnt = out['one_thread']
     res = {'workload': 'stage 2 file to file: scan_ccs_reads on %d reads with a cyclic consensus (single-exon circRNAs on a 20 Mb genome resident in HBM; half of them '
@@ -761,6 +759,55 @@ def extra_stage2(hip, synth, ctx, prep=None):
         res['value'] = n / (el - msec)
     res['e2e_stage2_reads_per_s'] = res['value']
     return res
+
+
+def extra_call_files(hip, synth, ctx, prep):
+    """`CIRI-long call` file to files on one rank (dist.call_sharded, main.py:9-105): a FASTQ of the 50 000 rolling-circle reads of the stage-2
+    world plus as many linear reads -> stage 1 (K2 + K3 from the file) -> tmp files -> stage 2.1 (mapper phases on the worker processes, clip
+    re-alignment and splice signals on the GPU) -> 2.2 -> cand_circ.fa -> stage 3 over the reads without a candidate -> low_confidence.fa, .json.
+    The mapper is the double that answers from the truth (the reads of this world are error-free copies, so that the consensus the GPU makes IS
+    a rotation of the template the double knows); its time is inside the wall time, spread over the workers."""
+    import shutil
+    import tempfile
+    from ciri_long_amd import dist as cdist, env, find_bsj
+    w, workers = prep['world_files'], prep['workers']
+    genome = _SeqGenome(w['genome'])
+    rng = np.random.Generator(np.random.PCG64(synth.SEEDS['C3'] + 9))
+    d = tempfile.mkdtemp(dir='/tmp')
+    try:
+        fq = os.path.join(d, 'in.fastq')
+        n = 0
+        with open(fq, 'wb') as f:
+            for rid, (_seg, _ccs, raw) in w['ccs_seq'].items():
+                s = raw.encode()
+                f.write(b'@' + rid.encode() + b'\n' + s + b'\n+\n' + b'I' * len(s) + b'\n')
+                lin = B_ASCII[rng.integers(0, 4, int(max(300, rng.normal(1000, 100))))].tobytes()
+                f.write(b'@lin' + rid.encode() + b'\n' + lin + b'\n+\n' + b'I' * len(lin) + b'\n')
+                n += 2
+        size = os.path.getsize(fq)
+        os.makedirs(os.path.join(d, 'tmp'))
+        find_bsj._PROC_POOLS['scan'] = prep['pool_files']
+        env.initializer(w['mapper'], genome.contig_len, find_bsj._resident(genome), {}, None, {})
+        timings = {}
+        t0 = time.perf_counter()
+        counts, _short = cdist.call_sharded(fq, d, 'p', True, threads=workers, timings=timings)
+        el = time.perf_counter() - t0
+        sizes = {k: os.path.getsize(os.path.join(d, 'p.' + k)) for k in ('cand_circ.fa', 'low_confidence.fa', 'json')}
+        if getattr(env.GENOME, 'device', None) is not None:
+            env.GENOME.device.close()
+    finally:
+        find_bsj._PROC_POOLS.pop('scan', None)
+        find_bsj.THREADS = 1
+        if prep.get('pool_files') is not None:
+            prep['pool_files'].close()
+            prep['pool_files'] = None
+        shutil.rmtree(d, ignore_errors=True)
+    assert counts.get('total') == n and counts.get('consensus', 0) >= 0.99 * (n // 2) and counts.get('bsj', 0) > 0.8 * (n // 2), counts
+    return {'workload': '`call` file to files on one rank: %d-read FASTQ (%d MB; half rolling-circle reads of single-exon circRNAs on a 20 Mb genome, half linear) -> '
+                        'tmp/*.ccs.fa, *.raw.fa -> cand_circ.fa (%d MB), low_confidence.fa, .json; %d mapper workers, mapper double answering from the truth'
+                        % (n, size >> 20, sizes['cand_circ.fa'] >> 20, workers),
+            'value': n / el, 'unit': 'reads/s', 'seconds': el, 'stage_seconds': {k: round(v, 4) for k, v in timings.items()}, 'counters': dict(counts), 'workers': workers,
+            'roofline': {'bound': 'host', 'note': 'stage hand-overs (tmp files read back into a dict, the candidate ids broadcast to stage 3) and the per-read host phases on the workers'}}
 
 
 POOL_READS, POOL_DELAY_US = 4000, 150
@@ -1103,6 +1150,8 @@ def main():
             out['e2e_stage1_reads_per_s'] = extra['stage1_files']['e2e_stage1_reads_per_s']
             extra['stage2_files'] = extra_stage2(hip, synth, ctx, pool_prep if pool_prep and 'world' in pool_prep else None)
             out['e2e_stage2_reads_per_s'] = extra['stage2_files']['e2e_stage2_reads_per_s']
+            if pool_prep is not None and 'world_files' in pool_prep:
+                extra['call_files'] = extra_call_files(hip, synth, ctx, pool_prep)
             if pool_prep is not None:
                 extra['stage2_mapper_pool'] = extra_stage2_pool(pool_prep) if 'world' in pool_prep else {'error': pool_prep['error']}
         except Exception as ex:                      # an extra line must not cost the headline

@@ -266,7 +266,7 @@ static int lanes_class_for(int64_t L, int64_t R, const clh_ssw_opts* o, int max_
     if (!(o->n_mat <= 4 || null_code == 4)) return 0;
     if (o->gap_open > 255 || o->gap_extend < 0) return 0;
     if (o->gap_open <= o->gap_extend && !((int64_t)max_match * std::min(L, R) + bias < 255 && o->score_size != 1)) return 0;
-    if (!many && L * R > 16384) return 0;
+    if (!many && L * R > 16384) return (L <= 32767 && !getenv("CLH_NO_SCANW") && !getenv("CLH_NO_SCAN")) ? clh::kRvScanTr : 0;      // a wave per alignment, transposed (ssw_scan_wide.hip)
     return R <= 20 ? clh::kRvLanes20 : (R <= 32 ? clh::kRvLanes32 : (R <= 52 ? clh::kRvLanes52 : clh::kRvLanes64));
 }
 
@@ -412,9 +412,9 @@ static clh_plan* ssw_plan_build(clh_ctx* ctx, int32_t n, const int64_t* read_off
     pl->tasks.swap(sorted);
     pl->n_rows = n_all;
     for (auto& sg : pl->segs) {
-        if (sg.rv != clh::kRvScanWide) continue;
+        if (sg.rv != clh::kRvScanWide && sg.rv != clh::kRvScanTr) continue;
         int lmax = 1;
-        for (int k = 0; k < sg.count; ++k) lmax = std::max(lmax, (int)pl->tasks[sg.begin + k].read_len);
+        for (int k = 0; k < sg.count; ++k) lmax = std::max(lmax, sg.rv == clh::kRvScanTr ? 64 : (int)pl->tasks[sg.begin + k].read_len);
         sg.ws_slot = (int)((clh::scanw_task_bytes(lmax) + 255) & ~(size_t)255);
         sg.ws_wgs = std::min(sg.count, ctx->n_cu * 12);
         pl->strip_bytes = (pl->strip_bytes + 255) & ~(size_t)255;
@@ -753,7 +753,7 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
     std::vector<size_t> ord(pl->segs.size());
     for (size_t k = 0; k < ord.size(); ++k) ord[k] = k;
     std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
-        auto weight = [](int rv) { return rv == clh::kRvStrips ? 1000 : (rv == clh::kRvScanWide ? 900 : (rv == clh::kRvScanWideSliced ? 800 : rv)); };      // (K1w: whole long reads, one wave each)
+        auto weight = [](int rv) { return rv == clh::kRvStrips ? 1000 : (rv == clh::kRvScanWide ? 900 : (rv == clh::kRvScanWideSliced ? 800 : (rv == clh::kRvScanTr ? 700 : rv))); };      // (K1w: whole long reads, one wave each)
         const int rx = weight(pl->segs[x].rv), ry = weight(pl->segs[y].rv);
         return rx > ry;
     });
@@ -828,6 +828,11 @@ extern "C" int clh_ssw_run(clh_plan* pl, const void* d_reads, const void* d_refs
             HIPCHK(clh::launch_ssw_scan_sliced(pl->quirk, P, s.count, (int)pl->slices.size(), ls));
         } else if (clh::rv_is_lanes(s.rv)) HIPCHK(clh::launch_ssw_lanes(clh::rv_lanes_columns(s.rv), P, s.count, ls));
         else if (s.rv == clh::kRvScan) HIPCHK(clh::launch_ssw_scan(pl->quirk, P, s.count, ls));
+        else if (s.rv == clh::kRvScanTr) {
+            int* ctr = (int*)pl->d_seg_ctr + k;
+            HIPCHK(hipMemsetAsync(ctr, 0, sizeof(int), ls));
+            HIPCHK(clh::launch_ssw_scanw_tr(pl->quirk, P, s.count, s.ws_wgs, ctr, (long long)s.ws_off, s.ws_slot, ls));
+        }
         else if (s.rv == clh::kRvScanWide) {
             int* ctr = (int*)pl->d_seg_ctr + k;
             HIPCHK(hipMemsetAsync(ctr, 0, sizeof(int), ls));

@@ -246,6 +246,9 @@ static constexpr int kRvScanWide = -3;   // pseudo class: K1w, the row-scan kern
                                          // persistent workgroups; their workspaces inside `dirs` (scanw_task_bytes of the class's longest read)
 hipError_t launch_ssw_scanw(bool geq, const SswParams& p, int ntasks, int nworkgroups, int* counter, long long ws_off, int ws_slot, hipStream_t stream);
 size_t scanw_task_bytes(int read_len);
+static constexpr int kRvScanTr = -9;     // pseudo class: K1w transposed -- a reference of at most 64 columns as the ROWS, the read's bases as the columns
+                                         // the lanes own (ssw_scan_wide.hip: ssw_scanw_tr_kernel); for the alignments K1l's rule would take if there were more of them
+hipError_t launch_ssw_scanw_tr(bool geq, const SswParams& p, int ntasks, int nworkgroups, int* counter, long long ws_off, int ws_slot, hipStream_t stream);
 // pseudo classes: K1l, one alignment per lane for references of at most 20 / 32 / 52 / 64 columns (ssw_lanes.hip)
 static constexpr int kRvLanes20 = -5, kRvLanes32 = -6, kRvLanes52 = -7, kRvLanes64 = -8;
 inline bool rv_is_lanes(int rv) { return rv <= kRvLanes20 && rv >= kRvLanes64; }

@@ -48,6 +48,7 @@ struct WIn {
     int cstep;            // +1 / -1
     int comp;
     int ncols;
+    int rcomp;            // transposed form only: the ROWS are reference bases, complemented when set (ref_code)
     int terminate;        // column maximum that ends the pass (ssw.c:296, 489); 1 << 30 = never
     int overflow_at;      // byte regime: a column maximum >= this abandons the pass (255 - bias); 1 << 30 = never
     uint16_t* colmax;     // per-column maxima (indexed by column), or nullptr
@@ -63,8 +64,12 @@ struct WMem {
     int rows_cap;
 };
 
-// one chunk of 128*CPR columns starting at column c0
-template <int CPR, bool GEQ, bool WORD>
+// one chunk of 128*CPR columns starting at column c0.
+// TR (the transposed form, for references of at most 64 columns against long reads: ssw_scanw_tr_kernel below): the COLUMNS are the read's
+// bases and the rows the reference's, so that the lanes have something to own; the matrix is the same, and so is every H.  What changes is
+// which of the cells that hold the maximum is reported: the reference's rule -- first REFERENCE position, then the smallest read position there
+// (ssw.c:283,299-308) -- reads here "smallest row, then smallest column".
+template <int CPR, bool GEQ, bool WORD, bool TR = false>
 __device__ bool scanw_chunk(const WIn& in, const WMem& mem, const int c0, const int parity, const bool first, const bool more,
                             const int gapO, const int gapE, int& best_score, int& best_col, int& best_row, int& tcol)
 {
@@ -86,14 +91,21 @@ __device__ bool scanw_chunk(const WIn& in, const WMem& mem, const int c0, const 
         for (int t = 0; t < CPR; ++t) {
             const int jlo = c0 + 2 * CPR * lane + t, jhi = jlo + CPR;
             const int blo = jlo < in.ncols ? (int)in.ref[(int64_t)jlo * in.cstep] : 0, bhi = jhi < in.ncols ? (int)in.ref[(int64_t)jhi * in.cstep] : 0;
-            rlo[t] = jlo < in.ncols ? ref_code(blo, in.comp) : 5;
-            rhi[t] = jhi < in.ncols ? ref_code(bhi, in.comp) : 5;
+            if constexpr (TR) {      // a column is a read base: its code as the row loop of the plain form takes it
+                const int clo = blo & 7, chi = bhi & 7;
+                rlo[t] = jlo < in.ncols ? (clo > 5 ? 5 : clo) : 5;
+                rhi[t] = jhi < in.ncols ? (chi > 5 ? 5 : chi) : 5;
+            } else {
+                rlo[t] = jlo < in.ncols ? ref_code(blo, in.comp) : 5;
+                rhi[t] = jhi < in.ncols ? ref_code(bhi, in.comp) : 5;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
             for (int t = 0; t < CPR; ++t) {
-                const int slo = mem.mat[rlo[t] * 8 + q], shi = mem.mat[rhi[t] * 8 + q];
+                // mat is [reference code][read code]: transposed, the row letter q is the reference's
+                const int slo = TR ? mem.mat[q * 8 + rlo[t]] : mem.mat[rlo[t] * 8 + q], shi = TR ? mem.mat[q * 8 + rhi[t]] : mem.mat[rhi[t] * 8 + q];
                 mem.prof[((q * NCH + t / VEC) * 64 + lane) * VEC + (t % VEC)] = (uint32_t)(slo & 0xffff) | ((uint32_t)shi << 16);
             }
     }
@@ -113,7 +125,10 @@ __device__ bool scanw_chunk(const WIn& in, const WMem& mem, const int c0, const 
     for (int rb = 0; rb < in.rows && !overflow; rb += 64) {
         const int row = rb + lane;
         int qv = 5;
-        if (row < in.L) { const int c = (int)in.read[(int64_t)row * in.rstep] & 7; qv = c > 5 ? 5 : c; }
+        if (row < in.L) {
+            if constexpr (TR) qv = ref_code((int)in.read[(int64_t)row * in.rstep], in.rcomp);
+            else { const int c = (int)in.read[(int64_t)row * in.rstep] & 7; qv = c > 5 ? 5 : c; }
+        }
         int hbv = 0, ebv = 0;
         if (!first && row < in.rows) { hbv = cHin[row]; ebv = cEin[row]; }
         const int cnt = in.rows - rb < 64 ? in.rows - rb : 64;
@@ -255,6 +270,25 @@ __device__ bool scanw_chunk(const WIn& in, const WMem& mem, const int c0, const 
                 if (M == in.terminate) tmin = j < tmin ? j : tmin;
             }
         }
+    if constexpr (TR) {
+        // largest maximum, then the smallest row that holds it (<= 63: 7 bits), then the smallest column (11 bits inside the chunk); maxima stay below 2^13
+        int key = -1;
+#pragma unroll
+        for (int t = 0; t < CPR; ++t)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int jc = 2 * CPR * lane + hf * CPR + t, j = c0 + jc;
+                const int v = (colM[2 * t + hf] << 18) | ((0x7f - (colR[2 * t + hf] & 0x7f)) << 11) | (0x7ff - jc);
+                if (j < in.ncols && colM[2 * t + hf] > 0 && v > key) key = v;
+            }
+        key = wave_max(key);
+        if (key >= 0) {
+            const int sc = key >> 18, rw = 0x7f - ((key >> 11) & 0x7f), cl = c0 + (0x7ff - (key & 0x7ff));
+            if (sc > best_score || (sc == best_score && rw < best_row)) { best_score = sc; best_col = cl; best_row = rw; }      // (an equal row: the earlier chunk's column is the smaller)
+        }
+        tcol = W_INF;
+        return false;
+    }
     tmin = wave_min(tmin);
     int b32 = -1, brow = 0;
 #pragma unroll
@@ -275,7 +309,7 @@ __device__ bool scanw_chunk(const WIn& in, const WMem& mem, const int c0, const 
     return false;
 }
 
-template <bool GEQ, bool WORD>
+template <bool GEQ, bool WORD, bool TR = false>
 __device__ WOut scanw_pass(const WIn& in, const WMem& mem, const int gapO, const int gapE)
 {
     int best_score = 0, best_col = -1, best_row = 0;
@@ -291,12 +325,12 @@ __device__ WOut scanw_pass(const WIn& in, const WMem& mem, const int gapO, const
         // that, not for the window (columns behind the end column are wasted work, narrow chunks pay the row step's fixed part more often)
         const int want = ends ? (c0 == 0 ? in.L + in.L / 8 + 16 : 256) : rem;
         const int width = want < rem ? want : rem;
-        if (width <= 256) { ov = scanw_chunk<2, GEQ, WORD>(in, mem, c0, parity, first, rem > 256, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 256; }
+        if (width <= 256) { ov = scanw_chunk<2, GEQ, WORD, TR>(in, mem, c0, parity, first, rem > 256, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 256; }
 #ifdef SCANW_CPR_CAP4     // (experiment: chunks of at most 512 columns, fewer registers, more waves)
         else { ov = scanw_chunk<4, GEQ, WORD>(in, mem, c0, parity, first, rem > 512, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 512; }
 #else
-        else if (width <= 512) { ov = scanw_chunk<4, GEQ, WORD>(in, mem, c0, parity, first, rem > 512, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 512; }
-        else { ov = scanw_chunk<8, GEQ, WORD>(in, mem, c0, parity, first, rem > 1024, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 1024; }
+        else if (width <= 512) { ov = scanw_chunk<4, GEQ, WORD, TR>(in, mem, c0, parity, first, rem > 512, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 512; }
+        else { ov = scanw_chunk<8, GEQ, WORD, TR>(in, mem, c0, parity, first, rem > 1024, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 1024; }
 #endif
         if (ov) { o.overflow = 1; o.max = 255; o.col = -1; o.row = 0; return o; }
         if (tcol != W_INF) break;
@@ -306,6 +340,46 @@ __device__ WOut scanw_pass(const WIn& in, const WMem& mem, const int gapO, const
     o.col = best_col;
     o.row = best_row < in.L - 1 ? best_row : in.L - 1;
     return o;
+}
+
+// The transposed form of one alignment (class kRvScanTr: a reference of at most 64 columns, no second best, a recurrence that is exact in
+// either regime -- clh_api.hip, lanes_class_for): rows = reference bases, columns = read bases.  One pass each way, in 16-bit arithmetic; the
+// regime the reference would have ended in (ssw.c:804-822) follows from the score, and only labels the result.
+template <bool GEQ>
+__device__ bool scanw_align_tr(const SswParams& p, const int8_t* read, const int8_t* ref, const int L, const int refLen, const int ref_rc, const int mask_len,
+                               const WMem& mem, SswResult& res)
+{
+    const int bias = p.bias, gO = p.gapO, gE = p.gapE;
+    res.score1 = 0; res.score2 = 0; res.ref_begin1 = -1; res.ref_end1 = -1; res.read_begin1 = -1; res.read_end1 = 0;
+    res.ref_end2 = mask_len >= 15 ? 0 : -1; res.status = 0;
+    const int rdir = ref_rc ? -1 : 1;
+    WIn in;
+    in.read = ref; in.rstep = rdir; in.rcomp = ref_rc; in.L = refLen; in.rows = refLen; in.S = 0;
+    in.ref = read; in.cstep = 1; in.comp = 0; in.ncols = L;
+    in.terminate = 1 << 30; in.overflow_at = 1 << 30; in.colmax = nullptr;
+    // gap_open == gap_extend: the byte-regime arithmetic (the word regime's boundary rows cannot occur: the class takes such an alignment only
+    // when its score stays below the 8-bit limit); else the word-regime arithmetic, which has no boundary rows with gap_open > gap_extend
+    const WOut fw = GEQ ? scanw_pass<GEQ, false, true>(in, mem, gO, gE) : scanw_pass<GEQ, true, true>(in, mem, gO, gE);
+    int regime = p.score_size == 1 ? 1 : 0;
+    if (p.score_size != 1 && fw.max + bias >= 255) {
+        if (p.score_size == 0) { res.status = CLH_STATUS_OVERFLOW8; return false; }
+        regime = 1;
+    }
+    res.status = regime ? CLH_STATUS_WORD : 0;
+    res.score1 = fw.max;
+    if (fw.max == 0) { res.ref_end1 = regime ? 0 : -1; res.read_end1 = 0; }
+    else { res.ref_end1 = fw.row; res.read_end1 = fw.col; }
+    const bool want_begin = !(p.flag == 0 || (p.flag == 2 && res.score1 < p.filters));
+    if (want_begin) {
+        WIn rv = in;
+        rv.L = res.ref_end1 + 1; rv.rows = rv.L; rv.read = ref + (int64_t)res.ref_end1 * rdir; rv.rstep = -rdir;
+        rv.ncols = res.read_end1 + 1; rv.ref = read + res.read_end1; rv.cstep = -1;
+        WOut r; r.max = 0; r.col = -1; r.row = 0;
+        if (rv.L > 0 && rv.ncols > 0) r = GEQ ? scanw_pass<GEQ, false, true>(rv, mem, gO, gE) : scanw_pass<GEQ, true, true>(rv, mem, gO, gE);
+        if (r.max == 0) { res.ref_begin1 = regime ? 0 : -1; res.read_begin1 = res.read_end1; }
+        else { res.ref_begin1 = res.ref_end1 - r.row; res.read_begin1 = res.read_end1 - r.col; }
+    }
+    return true;
 }
 
 // masked second-best column maximum, ssw.c:325-340 (8 bit) / 528-541 (16 bit); wave-parallel
@@ -395,7 +469,7 @@ __device__ bool scanw_align(const SswParams& p, const int8_t* read, const int8_t
     // ---- forward: which regime?  (ssw.c:804-822; the order of ssw_wavefront.hip's kernel) -----------------------------------
     const int rdir = ref_rc ? -1 : 1;
     WIn in;
-    in.read = read; in.rstep = 1; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = ref_rc; in.ncols = refLen; in.terminate = 1 << 30;
+    in.read = read; in.rstep = 1; in.rcomp = 0; in.L = L; in.ref = ref; in.cstep = rdir; in.comp = ref_rc; in.ncols = refLen; in.terminate = 1 << 30;
     in.colmax = colmax;
     auto word_rows = [&](WIn& x) { x.S = GEQ ? (x.L + 7) / 8 : 0; x.rows = ((x.L + 7) / 8) * 8; x.overflow_at = 1 << 30; };
     auto byte_rows = [&](WIn& x) { x.S = 0; x.rows = ((x.L + 15) / 16) * 16; x.overflow_at = 255 - bias; };
@@ -479,6 +553,26 @@ __global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_kernel(const SswPar
         SswResult res;
         scanw_align<GEQ>(p, p.reads + task.read_off, p.refs + task.ref_off, task.read_len, task.ref_len, task.ref_rc, task.mask_len,
                          p.colmax ? p.colmax + task.colmax_off : nullptr, mem, false, res);
+        if (lane == 0) p.results[task.out_index] = res;
+        __syncthreads();
+    }
+}
+
+// the transposed class: persistent workgroups as above; the HBM workspace is sized for 64 rows
+template <bool GEQ>
+__global__ void __launch_bounds__(64, SCANW_WAVES) ssw_scanw_tr_kernel(const SswParams p, const int ntasks, int* const counter, const long long ws_off, const int ws_slot)
+{
+    SCANW_LDS_SETUP
+    uint8_t* const ws = p.dirs + ws_off + (long long)blockIdx.x * ws_slot;
+    for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(counter, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= ntasks) break;
+        const SswTask task = p.tasks[idx];
+        scanw_mem_at(mem, ws, 64);
+        SswResult res;
+        scanw_align_tr<GEQ>(p, p.reads + task.read_off, p.refs + task.ref_off, task.read_len, task.ref_len, task.ref_rc, task.mask_len, mem, res);
         if (lane == 0) p.results[task.out_index] = res;
         __syncthreads();
     }
@@ -731,6 +825,13 @@ hipError_t launch_ssw_scanw_filtered(bool geq, const SswParams& p, int ntasks, i
         hipLaunchKernelGGL((ssw_scanw_queue_kernel<false>), dim3(nworkgroups), dim3(64), 0, stream, p, 2 * ntasks, -1);
     }
     hipLaunchKernelGGL(ssw_scanw_combine_kernel, dim3(ntasks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_ssw_scanw_tr(bool geq, const SswParams& p, int ntasks, int nworkgroups, int* counter, long long ws_off, int ws_slot, hipStream_t stream)
+{
+    if (geq) hipLaunchKernelGGL((ssw_scanw_tr_kernel<true>), dim3(nworkgroups), dim3(64), 0, stream, p, ntasks, counter, ws_off, ws_slot);
+    else hipLaunchKernelGGL((ssw_scanw_tr_kernel<false>), dim3(nworkgroups), dim3(64), 0, stream, p, ntasks, counter, ws_off, ws_slot);
     return hipGetLastError();
 }
 

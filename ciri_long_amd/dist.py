@@ -123,7 +123,7 @@ def _entry(index, lo):
 
 
 def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_file=None, chunk_size=250, stage_setup=None, threads=1,
-                 recover_aligner=None):
+                 recover_aligner=None, timings=None):
     """`CIRI-long call` for one node, one process per GPU -- every stage of main.py:49-103:
 
       1    consensus of every read (find_ccs_reads) on this rank's contiguous shard of the input records;
@@ -149,10 +149,20 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     threads > 1: the mapper phase of stages 2.1 / 2.2 / 3 on that many worker processes per rank (the reference's Pool(threads),
     find_bsj.py:338-345), forked HERE -- before this function touches the GPU -- from env.ALIGNER (first mapper) and `recover_aligner`
     (second mapper, the one stage_setup('recover') will switch to).  A caller whose process group is RCCL has initialised the GPU
-    already: it calls find_bsj.start_mapper_pools() itself, before init_process_group."""
+    already: it calls find_bsj.start_mapper_pools() itself, before init_process_group.
+
+    timings: a dict that receives this rank's wall seconds per stage ('count', '1', 'load', '2.1', '2.2', 'gather', '3', 'finish')."""
     import json
     import os
     import shutil
+    import time
+    clock = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + now - clock[0]
+        clock[0] = now
     from collections import defaultdict
     from . import env, find_bsj, find_ccs, hip, mapper_pool
     from .utils import grouper
@@ -185,12 +195,14 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
     n, index = _bcast(_together('count', lambda: _count_records(in_file, is_fastq) if rank == 0 else None))
     lo, hi = shard_bounds(n, rank, world)
     byte_off, rec0 = _entry(index, lo)
+    lap('count')
     part = os.path.join(tmp, '%s.part%d' % (prefix, rank))
     if find_consensus_file is None:
         def find_consensus_file(path, fastq, ccs_path, raw_path, first, count, byte_offset=0):
             return hip.default_context().ccs_file(path, fastq, ccs_path, raw_path, 0, first, count, byte_offset)
     # ---- stage 1 ---------------------------------------------------------------------------------------------------------
     total, ro, _too_long = _together('1 (consensus)', lambda: find_consensus_file(in_file, is_fastq, part + '.ccs.fa', part + '.raw.fa', lo - rec0, hi - lo, byte_off))
+    lap('1')
     ccs_seq = find_ccs.load_ccs_reads(out_dir, '%s.part%d' % (prefix, rank))
     if dist:
         dist.barrier()
@@ -200,6 +212,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
                 for r in range(world):
                     with open(os.path.join(tmp, '%s.part%d.%s' % (prefix, r, kind)), 'rb') as f:
                         shutil.copyfileobj(f, out)
+    lap('load')
     counts = defaultdict(int)
     counts['total'] = total
     counts['consensus'] = ro
@@ -219,6 +232,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
             short.extend(sh)
             records.append(ret)
     _together('2.1 (scan_ccs_chunk)', stage21)
+    lap('2.1')
     # ---- stage 2.2: the short consensus reads, second mapper ------------------------------------------------------------------
     if stage_setup is not None:
         stage_setup('recover')
@@ -230,6 +244,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
             add(cnt)
             recovered.append(ret)
     _together('2.2 (recover_ccs_chunk)', stage22)
+    lap('2.2')
     records = gather_records(records)
     recovered = gather_records(recovered)
     if rank == 0:
@@ -240,6 +255,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
                 out.write(text)
     # ---- stage 3: raw reads that are in no candidate record (find_bsj.py:626-632 reads the ids back from the file) -------------
     circ_reads = _bcast({i: 1 for ids, _text in records + recovered for i in ids} if rank == 0 else None)
+    lap('gather')
     if stage_setup is not None:
         stage_setup('raw')
     partial, short_raw = [], []
@@ -252,6 +268,7 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
             partial.extend(ret)
             short_raw.extend(sh)
     _together('3 (scan_raw_chunk)', stage3)
+    lap('3')
     partial = gather_records(partial)
     # ---- the one exchange of counters: after the last stage --------------------------------------------------------------------
     counts = allreduce_counters(counts)
@@ -266,4 +283,5 @@ def call_sharded(in_file, out_dir, prefix, is_canonical=True, find_consensus_fil
             find_bsj._write_records(out, partial)
         with open('{}/{}.json'.format(out_dir, prefix), 'w') as f:
             json.dump(counts, f)
+    lap('finish')
     return counts, short_raw

@@ -117,3 +117,43 @@ def test_what_the_class_leaves_to_the_others():
     assert not any(-8 <= rv <= -5 for rv, _c, _a, _b in _classes(ctx, [rng.integers(0, 4, 60, dtype=np.int8)] * 4, [rng.integers(0, 4, 80, dtype=np.int8)] * 4, (10, 4, 2, 2)))
     long_reads = [rng.integers(0, 4, 2000, dtype=np.int8)] * 4
     assert not any(-8 <= rv <= -5 for rv, _c, _a, _b in _classes(ctx, [rng.integers(0, 4, 50, dtype=np.int8)] * 4, long_reads, (10, 4, 8, 2)))
+
+
+@pytest.mark.parametrize('scheme', [(10, 4, 8, 2), (1, 1, 1, 1), (2, 3, 5, 2)])
+def test_transposed_class_long_reads_against_short_references(scheme, monkeypatch):
+    """class -9 (ssw_scan_wide.hip, ssw_scanw_tr_kernel): the reference's bases as the rows, the read's as the columns the lanes own -- for a
+    batch too small to fill the GPU's lanes with long reads.  Reads of 300..5000 bases (one to five column chunks), references of 1..64, the
+    junction once or twice in the read (ties between equal maxima: first reference position, then first read position), N on both sides;
+    against the oracle and against the other classes"""
+    from ciri_long_amd import hip, synth
+    ctx = hip.default_context()
+    rng = np.random.default_rng(40 + sum(scheme))
+    refs, qs = [], []
+    for k in range(700):
+        R = int(rng.integers(1, 65)); L = int(rng.choice([300, 600, 1023, 1024, 1025, 1500, 2048, 2100, 3000, 5000]))
+        ref = rng.integers(0, 4, R, dtype=np.int8)
+        q = rng.integers(0, 4, L, dtype=np.int8)
+        for _copy in range(int(rng.integers(0, 3))):
+            core = synth.mutate(ref, rng, sub=0.04, ins=0.03, dele=0.03) if rng.random() < 0.7 else ref.copy()
+            a = int(rng.integers(0, L - len(core)))
+            q[a:a + len(core)] = core
+        if rng.random() < 0.1:
+            q[rng.integers(0, L, 3)] = 4
+        if rng.random() < 0.1:
+            ref[rng.integers(0, R)] = 4
+        refs.append(ref); qs.append(q)
+    monkeypatch.delenv('CLH_NO_LANES', raising=False)
+    seg = _classes(ctx, refs, qs, scheme)
+    assert sum(c for rv, c, _a, _b in seg if rv == -9) >= 0.85 * len(refs), seg          # (R * L <= 16384 stays with K1l)
+    rows, cig = _run(ctx, refs, qs, scheme)
+    monkeypatch.setenv('CLH_NO_LANES', '1')
+    assert not any(rv == -9 or -8 <= rv <= -5 for rv, _c, _a, _b in _classes(ctx, refs, qs, scheme))
+    want, wcig = _run(ctx, refs, qs, scheme)
+    monkeypatch.delenv('CLH_NO_LANES')
+    for f in FIELDS + ('cigar_len', 'status'):
+        assert np.array_equal(rows[f], want[f]), (f, np.nonzero(rows[f] != want[f])[0][:5])
+    assert np.array_equal(cig, wcig)
+    m, x, go, ge = scheme
+    for k in rng.choice(len(refs), 120, replace=False):
+        w = oracle_lib.oracle_align(refs[k], qs[k], m, x, go, ge)
+        assert [int(rows[k][f]) for f in FIELDS] == [w['score'], w['ref_begin'], w['ref_end'], w['query_begin'], w['query_end']], k

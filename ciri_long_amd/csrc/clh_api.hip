@@ -70,7 +70,7 @@ struct clh_ctx {
     }
     // parked blocks are bounded: consensus workspaces are tens of GB and their size differs from batch to batch, so the
     // oldest large blocks go back to the driver once the parked total passes the cap
-    static constexpr size_t kCacheCap = (size_t)72 << 30;
+    static constexpr size_t kCacheCap = (size_t)128 << 30;
     void release(void* p)
     {
         if (!p) return;
@@ -1423,10 +1423,13 @@ static clh_ccs_plan* ccs_plan_create(clh_ctx* ctx, int32_t n, const int64_t* rea
     pl->slot_bytes = std::min<size_t>(need_worst, (size_t)((budget / (unsigned long long)pl->nslots) & ~255ull));
     pl->slot_bytes = std::max<size_t>(pl->slot_bytes, 4096);
     if (pl->slot_bytes < need_worst) {
-        const unsigned long long budget_big = std::min<unsigned long long>(64ull << 30, (unsigned long long)(free_b * 0.35));
+        // a FEW worst-case slots: rounds 2-5 took up to 1024 of them (64 GB); a batch of reads up to 4.5 kb then held 87 GB per plan, more than
+        // the context parks between plans, and the file stage paid a 40 GB hipMalloc / hipFree per 32 MB of input (8.6 s for a 100 000-read
+        // file whose kernels take 30 ms).  What finds no large slot free runs in the second launch over them, as before.
+        const unsigned long long budget_big = std::min<unsigned long long>(12ull << 30, (unsigned long long)(free_b * 0.10));
         pl->slot_bytes_big = need_worst;
         if (const char* e = getenv("CLH_POA_BIG_BYTES")) pl->slot_bytes_big = std::max<size_t>(4096, std::min<size_t>(need_worst, strtoull(e, nullptr, 10)));   // tests: large slots too small (status 1)
-        pl->nslots_big = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(1024, budget_big / pl->slot_bytes_big));
+        pl->nslots_big = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(256, budget_big / pl->slot_bytes_big));
         pl->nslots_big = std::min(pl->nslots_big, std::max(n, 1));
         if (const char* e = getenv("CLH_POA_BIG_SLOTS")) pl->nslots_big = std::max(1, std::min(pl->nslots_big, atoi(e)));       // tests: make the large slots scarce
     }

@@ -144,7 +144,7 @@ def test_transposed_class_long_reads_against_short_references(scheme, monkeypatc
         refs.append(ref); qs.append(q)
     monkeypatch.delenv('CLH_NO_LANES', raising=False)
     seg = _classes(ctx, refs, qs, scheme)
-    assert sum(c for rv, c, _a, _b in seg if rv == -9) >= 0.85 * len(refs), seg          # (R * L <= 16384 stays with K1l)
+    assert sum(c for rv, c, _a, _b in seg if rv == -9) >= 0.7 * len(refs), seg           # (R * L <= 16384 stays with K1l)
     rows, cig = _run(ctx, refs, qs, scheme)
     monkeypatch.setenv('CLH_NO_LANES', '1')
     assert not any(rv == -9 or -8 <= rv <= -5 for rv, _c, _a, _b in _classes(ctx, refs, qs, scheme))

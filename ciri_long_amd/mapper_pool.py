@@ -53,6 +53,15 @@ def _worker_init(factory, contig_len, gtf_index):
     env.initializer(aligner, contig_len, None, gtf_index, None, None)
 
 
+def _light_init(contig_len, gtf_index):
+    """a worker of the light pool: the two halves of phase 3 only -- no mapper"""
+    os.environ['CIRI_LONG_MAPPER_WORKER'] = '1'
+    from . import env
+    if gtf_index is None and _FORK_PAYLOAD is not None:
+        _aligner, contig_len, gtf_index = _FORK_PAYLOAD
+    env.initializer(None, contig_len, None, gtf_index, None, None)
+
+
 def _worker_map(task):
     items, raw_filters, min_circ_fraction = task
     from . import find_bsj
@@ -125,6 +134,13 @@ class MapperPool(object):
         self._gtf_index = gtf_index
         ctx = multiprocessing.get_context(start)
         self._pool = ctx.Pool(self.workers, _worker_init, (factory, contig_len, gtf_index if factory is not None else None))
+        # The halves of phase 3 (finish, assemble) are a few microseconds per read, but a pool serves its tasks first come, first served: behind
+        # the mapper pieces of the chunks in flight they would wait tens of milliseconds, the oldest chunk could not retire, and the next chunk
+        # would be submitted only when the mapper workers had run dry.  They get processes of their own (a quarter as many: they are mostly idle).
+        if start == 'fork' and factory is None:
+            self._light = ctx.Pool(max(2, self.workers // 4), _light_init, (contig_len, None))
+        else:
+            self._light = ctx.Pool(max(2, self.workers // 4), _light_init, (contig_len, gtf_index))
         _FORK_PAYLOAD = None
 
     def has_index(self, gtf_index):
@@ -139,13 +155,15 @@ class MapperPool(object):
 
     def submit(self, kind, tasks, grouped=False, wake=None):
         """tasks of one kind ('map', 'finish', 'assemble', 'raw') to the workers, without waiting: -> handle with ready(), wait(timeout),
-        get() -> one result per task, in order (wake: a threading.Event set when they are all done).  grouped: the tasks are light (the halves of phase 3) -- a worker takes a run of them per
+        get() -> one result per task, in order (wake: a threading.Event set when they are all done).  grouped: the tasks are light (the halves of phase 3) -- a worker of the light pool takes a run of them per
         message, two runs per worker."""
         if grouped:
-            n = max(1, (len(tasks) + 2 * self.workers - 1) // (2 * self.workers))
+            light = max(2, self.workers // 4)
+            n = max(1, (len(tasks) + 2 * light - 1) // (2 * light))
             tasks = [tasks[i:i + n] for i in range(0, len(tasks), n)]
         cb = (lambda _x: wake.set()) if wake is not None else None
-        return _Handle(self._pool.map_async(_TASKS[kind], tasks, 1, cb, cb), grouped)
+        pool = self._light if kind in ('finish', 'assemble') else self._pool
+        return _Handle(pool.map_async(_TASKS[kind], tasks, 1, cb, cb), grouped)
 
     def scan(self, chunk, raw_filters, min_circ_fraction):
         """phase 1 of a chunk, input order kept: [(counter keys touched, short read or None, pending tuple or None)] per read"""
@@ -160,10 +178,12 @@ class MapperPool(object):
         return self.raw_async(items).get()
 
     def close(self):
-        if self._pool is not None:
-            self._pool.terminate()
-            self._pool.join()
-            self._pool = None
+        for name in ('_pool', '_light'):
+            pool = getattr(self, name, None)
+            if pool is not None:
+                pool.terminate()
+                pool.join()
+                setattr(self, name, None)
 
     def __del__(self):
         try:

@@ -207,7 +207,7 @@ def k1_launches(ssw_plan, run, qoff, wlen, PROF=3, c2=False, max_match=1, bias=1
     if lanes and len(qlen) and not os.environ.get('CLH_NO_LANES'):   # classes -5..-8 = K1l, one alignment per lane (clh_api.hip: lanes_class_for; no second best, gap_open > gap_extend)
         w = np.asarray(wlen)
         short_ref = (w >= 1) & (w <= 64) & (qlen <= 65535)
-        take = short_ref & ((qlen * w <= 16384) | (int(short_ref.sum()) >= 32768))
+        take = short_ref & (qlen * w <= 262144) & ((qlen * w <= 2048) | (int(short_ref.sum()) >= 32768))
         cls[take] = np.where(w[take] <= 20, -5, np.where(w[take] <= 32, -6, np.where(w[take] <= 52, -7, -8)))
         cls[short_ref & ~take & (qlen <= 32767)] = -9            # class -9 = K1w transposed: the short reference as the rows (ssw_scanw_tr_kernel)
     out, cells_total, k1ms = [], 0, 0.0

@@ -266,7 +266,9 @@ static int lanes_class_for(int64_t L, int64_t R, const clh_ssw_opts* o, int max_
     if (!(o->n_mat <= 4 || null_code == 4)) return 0;
     if (o->gap_open > 255 || o->gap_extend < 0) return 0;
     if (o->gap_open <= o->gap_extend && !((int64_t)max_match * std::min(L, R) + bias < 255 && o->score_size != 1)) return 0;
-    if (!many && L * R > 16384) return (L <= 32767 && !getenv("CLH_NO_SCANW") && !getenv("CLH_NO_SCAN")) ? clh::kRvScanTr : 0;      // a wave per alignment, transposed (ssw_scan_wide.hip)
+    // a lane is alone with its alignment: ~25 ns per cell and pass.  Up to 2048 cells that is nothing; more only when the plan fills the GPU's lanes
+    // (and then not beyond 262144 cells: a 6 ms chain)
+    if ((!many && L * R > 2048) || L * R > 262144) return (L <= 32767 && !getenv("CLH_NO_SCANW") && !getenv("CLH_NO_SCAN")) ? clh::kRvScanTr : 0;      // a wave per alignment, transposed (ssw_scan_wide.hip)
     return R <= 20 ? clh::kRvLanes20 : (R <= 32 ? clh::kRvLanes32 : (R <= 52 ? clh::kRvLanes52 : clh::kRvLanes64));
 }
 

@@ -22,7 +22,7 @@ while time.time() < t_end:
     scheme = [(1, 1, 1, 1), (10, 4, 8, 2), (2, 2, 3, 1), (3, 5, 7, 7), (1, 3, 5, 2), (5, 4, 6, 6)][it % 6]
     refs, qs = [], []
     for _ in range(150):
-        R = int(rng.choice([30, 200, 800, 2000, 5000])); L = int(rng.choice([5, 17, 64, 130, 300, 700, 1200, 2500, 4500]))
+        R = int(rng.choice([8, 20, 30, 50, 64, 200, 800, 2000, 5000])); L = int(rng.choice([5, 17, 64, 130, 300, 700, 1200, 2500, 4500]))
         ref = rng.integers(0, 4, R, dtype=np.int8)
         st = int(rng.integers(0, max(1, R - 10)))
         core = ref[st:st + L]

@@ -367,7 +367,7 @@ def test_row_scan_class_short_reads_vs_oracle(ctx, scheme):
         plan = ctx.plan(ro, fo, hip.score_matrix(m, x), o, e, flag=1, score_size=2, want_score2=s2, want_cigar=True)
         n0 = sum(c for rv, c, _a, _b in plan.segments() if rv == 0)
         # (without the second best, the references of at most 64 columns are K1l's: csrc/ssw_lanes.hip, tests/test_gpu_lanes.py)
-        assert n0 == sum(1 for q, ref in zip(qs, refs) if len(q) <= 254 and m * len(q) + x < 255 and (s2 or len(ref) > 64)) and n0 > 0.85 * len(qs)
+        assert n0 == sum(1 for q, ref in zip(qs, refs) if len(q) <= 254 and m * len(q) + x < 255 and (s2 or len(ref) > 64)) and n0 > 0.8 * len(qs)
         plan.close()
         rows, cig = ctx.ssw_batch(rd, ro, fd, fo, hip.score_matrix(m, x), o, e, want_score2=s2, want_cigar=True)
         for k, (ref, q, r) in enumerate(zip(refs, qs, rows)):

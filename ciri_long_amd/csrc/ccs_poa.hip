@@ -592,11 +592,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     const uint32_t ge2 = dup16(g - e), qc2 = dup16(q - c);
     const uint32_t NEG2 = dup16(POA_NEG), ONE2 = 0x00010001u;
     const uint32_t floor2 = sw ? 0u : 0x80008000u;           // local mode: a cell is at least 0
-#ifdef POA_NO_BEYOND_FREE
-    const bool beyond_free = false;
-#else
     const bool beyond_free = sw && S.n < 0 && S.g < 0 && S.q < 0;
-#endif
     // ring row: CP dwords of H per lane, then CP dwords of differences per lane; behind the rows one left-boundary H per row
     uint32_t* ring = poa_lds;
     const int rrow = 128 * poa_ring_cp(m);
@@ -654,11 +650,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     for (int t = 0; t < CP; ++t) snapP[t] = 0;
     int nbest = -(1 << 30), nrow = 0;                            // global mode: cells (sink row, column m), wave-uniform
     uint32_t lowP = 0x7fff7fffu;                                 // global / overlap: the lowest H of the pass (local cells are >= 0)
-#ifdef POA_EXP_DP2_NOSTORE     // timing experiment: the second of two runs of the pass writes no planes
-    const bool stores = col0 + 1 <= m && !(S.algorithm & 0x100);
-#else
     const bool stores = col0 + 1 <= m;
-#endif
     // (stores written out as asm with a scalar base and the lane's 32-bit offset saved the 64-bit address arithmetic and cost 2 ms:
     // the blocks pin the schedule)
     const uint32_t lane_off = (uint32_t)(col0 + 8) * 2u;
@@ -796,9 +788,6 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
             for (int t = 0; t < CP; ++t) {
                 Es[t] = pk_max(X[t], pk_adds(t == 0 ? q0 : qhat[t - 1], e2));       // E + e - g with E = max(Ehat, Qhat[j-1] + g), spoa's array
-#ifdef POA_EXP_NOD          // timing experiment: the second of two runs of the pass without the difference words (what they cost)
-                if (S.algorithm & 0x100) { D[t] = Es[t]; continue; }
-#endif
                 const uint32_t Hm = pk_subs(Hf[t], ONE2);
                 const uint32_t dF = pk_max(pk_subs(fsn[t], Hm), 0u), dO = pk_max(pk_subs(osn[t], Hm), 0u);
                 const uint32_t dE = pk_max(pk_subs(Es[t], Hm), 0u), dQ = pk_max(pk_subs(Y[t], Hm), 0u);
@@ -1881,19 +1870,8 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
         // the planes keep a band around the straight line through the matrix (see POA_BAND) unless the sequence is short anyway
         // (the line's end: the longest sequence so far, not this one -- a partial last copy runs along the same line and stops early)
         slope16 = m > 2 * POA_BAND + 64 ? (int)(((unsigned)(mref > m ? mref : m) << 16) / (unsigned)N) : 0;
-#ifdef POA_NO_BAND
-        slope16 = 0;
-#endif
         if constexpr (WIDE) { slope16 = 0; dp_rows_w(w, W, S, N, m, seq, lane, bs, br, bc); }
         else dp_rows(w, S, N, m, seq, lane, slope16, bs, br, bc DBGPASS);
-#ifdef POA_EXP_DP2          // timing experiments (tools/dev/k3_ab.py): a phase run twice costs its marginal time once more
-        phase_sync();
-#ifdef POA_EXP_DP2_NOSTORE
-        { PoaScores S2 = S; S2.algorithm |= 0x100; int b1 = 0, b2 = 0, b3 = 0; dp_rows(w, S2, N, m, seq, lane, slope16, b1, b2, b3 DBGPASS); }
-#else
-        dp_rows(w, S, N, m, seq, lane, slope16, bs, br, bc DBGPASS);
-#endif
-#endif
         phase_sync();
         if (br < 0) return -4;                               // a cell at the floor of the int16 range: no exact answer from this kernel
 #ifdef CLH_DEBUG_POA
@@ -1917,9 +1895,6 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
             phase_sync();
             BtArgs A = {w.pn, wide ? (void*)W.planeH : (void*)w.planeH, wide ? W.planeD : w.planeD, w.ri, wide ? (void*)W.col0 : (void*)w.col0, w.rank, w.pred, w.order, seq, N, m,
                         __builtin_amdgcn_readfirstlane(br), j, slope16, w.ovn, w.ovp, w.ovc, w.np};
-#ifdef POA_EXP_BT2
-            { (void)poa_backtrack<short, BT_W>(A, S DBGPASS); phase_sync(); }
-#endif
             int rc;
             if constexpr (WIDE) rc = poa_backtrack<int, BT_W32>(A, S DBGPASS); else rc = poa_backtrack<short, BT_W>(A, S DBGPASS);
             if (!WIDE && rc == BT_MISS) {
@@ -2017,10 +1992,6 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
     }
     phase_sync();
     TSTAMP(2);
-#ifdef POA_EXP_SORT2
-    if ((n <= POA_SORT_LDS ? poa_sort_lds(w, N, n, m, lane) : poa_sort(w, N, n, m, lane)) != 0) return -1;
-    phase_sync();
-#endif
     if ((n <= POA_SORT_LDS ? poa_sort_lds(w, N, n, m, lane) : poa_sort(w, N, n, m, lane)) != 0) return -1;
     TSTAMP(3);
     return n;
@@ -2292,10 +2263,6 @@ __device__ __forceinline__ void poa_kernel_body(const CcsParams& p)
                 const int mc = S.min_cov >= 0 ? S.min_cov : (nseg + 1) / 2;
 #ifdef CLH_DEBUG_POA
                 const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef POA_EXP_HB2
-                len = poa_consensus(w, N, mc, p.ccs + off, L, lane);
-                phase_sync();
 #endif
                 len = poa_consensus(w, N, mc, p.ccs + off, L, lane);
 #ifdef CLH_DEBUG_POA

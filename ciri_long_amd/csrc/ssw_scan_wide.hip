@@ -326,12 +326,8 @@ __device__ WOut scanw_pass(const WIn& in, const WMem& mem, const int gapO, const
         const int want = ends ? (c0 == 0 ? in.L + in.L / 8 + 16 : 256) : rem;
         const int width = want < rem ? want : rem;
         if (width <= 256) { ov = scanw_chunk<2, GEQ, WORD, TR>(in, mem, c0, parity, first, rem > 256, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 256; }
-#ifdef SCANW_CPR_CAP4     // (experiment: chunks of at most 512 columns, fewer registers, more waves)
-        else { ov = scanw_chunk<4, GEQ, WORD>(in, mem, c0, parity, first, rem > 512, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 512; }
-#else
         else if (width <= 512) { ov = scanw_chunk<4, GEQ, WORD, TR>(in, mem, c0, parity, first, rem > 512, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 512; }
         else { ov = scanw_chunk<8, GEQ, WORD, TR>(in, mem, c0, parity, first, rem > 1024, gapO, gapE, best_score, best_col, best_row, tcol); c0 += 1024; }
-#endif
         if (ov) { o.overflow = 1; o.max = 255; o.col = -1; o.row = 0; return o; }
         if (tcol != W_INF) break;
     }

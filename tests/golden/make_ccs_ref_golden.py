@@ -140,7 +140,11 @@ def main():
     for k, fam in enumerate(fams):
         per = []
         for alg in (0, 1, 2):
-            cons, msa = spoa.poa(list(fam), alg, True, *POA_SCORES)
+            try:
+                cons, msa = spoa.poa(list(fam), alg, True, *POA_SCORES)
+            except Exception as ex:      # spoa throws on an alignment without a base (local mode, unrelated sequences): recorded as such
+                per.append(['!' + type(ex).__name__, 0, 0])
+                continue
             per.append([text(cons), crc('\n'.join(text(r) for r in msa)), len(msa)])
         frows.append([k, crc('\n'.join(fam)), per])
     out['families'] = frows

@@ -60,6 +60,11 @@ def compare(doc, find_consensus_batch, poa, limit=None):
         fam = fams[k]
         assert _crc('\n'.join(fam)) == c, 'family %d is not the one the generator saw' % k
         for alg, (cons, msa_crc, nrows) in zip((0, 1, 2), per):
+            if cons.startswith('!'):          # the real spoa threw here: so must the counterpart
+                with pytest.raises(Exception):
+                    poa(list(fam), alg, True, *scores)
+                n += 2
+                continue
             gc, gm = poa(list(fam), alg, True, *scores)
             assert gc == cons, 'poa consensus differs: family %d algorithm %d' % (k, alg)
             assert len(gm) == nrows and _crc('\n'.join(gm)) == msa_crc, 'poa MSA differs: family %d algorithm %d' % (k, alg)

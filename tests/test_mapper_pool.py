@@ -180,3 +180,33 @@ def test_stage_2_2_and_stage_3_through_their_pools(world, tmp_path, monkeypatch)
         out[tag] = (dict(c2), dict(c3), s3, (d / 'p.cand_circ.fa').read_bytes(), (d / 'p.low_confidence.fa').read_bytes())
     assert out['one'] == out['pool']
     assert len(out['one'][3]) > 20 and len(out['one'][2]) >= 4
+
+
+class FailingMapper(fm.FakeMapper):
+    """raises inside a worker on the third read's consensus"""
+
+    def __init__(self, genome, poison, **kw):
+        fm.FakeMapper.__init__(self, genome, **kw)
+        self.poison = poison
+
+    def map(self, seq):
+        if seq == self.poison:
+            raise ValueError('mapper failed on purpose')
+        return fm.FakeMapper.map(self, seq)
+
+
+def test_a_failure_inside_a_worker_surfaces_in_the_caller_and_the_pool_stays_usable(world, tmp_path, monkeypatch):
+    """an exception of the mapper in a worker process must come out of the stage driver (not hang the chunk programs), and the next run on
+    the same pools must work"""
+    from ciri_long_amd import find_bsj
+    monkeypatch.setenv('CIRI_LONG_MAPPER', 'processes')
+    poison = world['reads'][2][2] * 2                       # the doubled consensus of the third read (find_bsj.py:259)
+    find_bsj.THREADS = 3
+    find_bsj.start_mapper_pools(3, scan_aligner=FailingMapper(world['genome'], poison, min_score=170), contig_len=world['genome'].contig_len)
+    with pytest.raises(ValueError, match='on purpose'):
+        _stage2(world, tmp_path, 'bad', 3, mapper=FailingMapper(world['genome'], poison, min_score=170))
+    one = _stage2(world, tmp_path, 'one', 1, mapper=fm.FakeMapper(world['genome'], min_score=170))
+    find_bsj.stop_mapper_pools()
+    find_bsj.start_mapper_pools(3, scan_aligner=fm.FakeMapper(world['genome'], min_score=170), contig_len=world['genome'].contig_len)
+    again = _stage2(world, tmp_path, 'again', 3, mapper=fm.FakeMapper(world['genome'], min_score=170))
+    assert again[:3] == one[:3]

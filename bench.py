@@ -709,7 +709,7 @@ def extra_stage1(hip, synth, ctx, n=100000):
             'cold_value': tot / cold, 'first_timed_call_value': tot / els[0], 'cold_call_s': round(cold, 4), 'calls_s': [round(x, 4) for x in els],
             'note': 'value = warm: median of three calls after the cold one (file in the page cache, the stage\'s host and device buffers kept between calls); '
                     'cold_value = the first call, which allocates and faults in those buffers (~450 MB); first_timed_call_value = the first warm call',
-            'roofline': {'bound': 'host', 'note': 'bound by the host threads (read, parse, format + write), not by a kernel (DESIGN.md section 8)'}}
+            'roofline': {'bound': 'host', 'note': 'bound by the host threads (read, parse, format + write), not by a kernel (DESIGN.md section 4, stage 1)'}}
 
 
 STAGE2_READS = 50000

@@ -21,7 +21,7 @@
 //     state differences per cell (a band around the matrix diagonal); spoa's value-comparing back-track is replayed from those
 //     on the cells of the path only, staged in LDS.  The graph update is data-parallel; the topological sort reproduces the
 //     order of spoa's sequential depth-first search from independent pieces (one small search per lane); the heaviest bundle
-//     runs wave-uniformly on data staged in LDS.  DESIGN.md section 3 (K3) has the measurements.
+//     runs wave-uniformly on data staged in LDS.  DESIGN.md section 4 (K3) has the bounds, LABNOTES.md sections 3 and 9 the measurements of rounds 2-5.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "clh_device.h"

@@ -272,7 +272,7 @@ def test_c5_full_per_gpu_share_125000_reads_of_the_collapse_kernels():
 
 
 def test_one_round_of_the_fuzz_harness(monkeypatch, capsys):
-    """tests/fuzz_parity.py is the long-running parity hunt (run by hand for minutes, DESIGN.md section 5); one short run of it belongs to
+    """tests/fuzz_parity.py is the long-running parity hunt (run by hand for minutes, DESIGN.md section 6); one short run of it belongs to
     the suite, so that the driver's GPU run exercises every kernel family on fresh random shapes too: alignments (six scoring schemes,
     long windows with and without the second best), consensus calls (periods up to 6 kb: both forms of K3's pass), spoa-shaped
     families, edit distances and splice-signal searches against the CPU oracles.  In this process (a process that has initialised the

@@ -1,4 +1,4 @@
-// Microbenchmark for DESIGN.md section 9, K3 option (c): the five-state recurrences of spoa's SISD engine (H, two vertical and two
+// Microbenchmark for LABNOTES.md section 9, K3 option (c): the five-state recurrences of spoa's SISD engine (H, two vertical and two
 // horizontal gap states: oracle/poa_oracle.c:273-295) with the lanes as ROWS on anti-diagonals -- lane L of a block of 64 rows computes
 // column t - L + 1 at step t: the cells above and on the diagonal come from lane L - 1's previous two steps (DPP), the cell to the left is
 // the lane's own previous step, so there are no prefix scans.  A CHAIN graph only (every row's one in-edge is the row before): what the

@@ -458,9 +458,9 @@ __device__ __forceinline__ int poa_ring(int m) {
 // the last register, high half <- own low half of the last register: one DPP move + one v_alignbit).
 // (best, code) <- (x, cx) in the halves where best < x
 __device__ __forceinline__ void upd(uint32_t& best, uint32_t& code, uint32_t x, uint32_t cx) {
-    const uint32_t m = pk_sra15(pk_subs(best, x));
+    const uint32_t m = pk_lt_mask(best, x);
     best = pk_max(best, x);
-    code = bfi(m, cx, code);
+    code = bfi_keep(m, cx, code);
 }
 
 // exclusive prefix maximum over all columns to the left, packed layout: a[] in, pe[] out; `left` = the value entering the pass
@@ -510,7 +510,6 @@ __device__ __forceinline__ uint32_t pk_nz_select(uint32_t x, uint32_t d, uint32_
     asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_mad_u16 %0, %0, %2, %3" : "=&v"(r) : "v"(x), "v"(d), "v"(lo));
     return r;
 }
-__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }      // a value the compiler shall not re-derive
 __device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t b) {   // (a << sh) | b as ONE instruction (the compiler reassociates a tree of them into shifts and ors)
     uint32_t d;
     asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(sh), "v"(b));
@@ -863,14 +862,14 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 uint32_t rm = hv2[0];
 #pragma unroll
                 for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
-                const uint32_t imp = pk_sra15(pk_subs(bsP, rm));                  // halves whose best is exceeded (strictly: the first row stays)
+                const uint32_t imp = pk_lt_mask(bsP, rm);                         // halves whose best is exceeded (strictly: the first row stays)
                 // no vote around the update: along an alignment nearly every row improves some lane's best, and a wave-wide vote feeding a
                 // scalar branch is a VALU -> SALU hand-over that stalls the step -- a few masked moves, done unconditionally.  Round 5: the
                 // improving halves keep the row's values (one v_bfi per register); which column of the virtual lane held the maximum is
                 // worked out once, behind the pass, instead of in every row (four packed operations per register and row).
-                bsP = pk_max(bsP, rm); brP = bfi(imp, dup16(r), brP);
+                bsP = pk_max(bsP, rm); brP = bfi_keep(imp, dup16(r), brP);
 #pragma unroll
-                for (int t = 0; t < CP; ++t) snapP[t] = bfi(imp, hv2[t], snapP[t]);
+                for (int t = 0; t < CP; ++t) snapP[t] = bfi_keep(imp, hv2[t], snapP[t]);
             } else if (nw & sink & last) {
                 uint32_t pick = 0;
 #pragma unroll
@@ -882,7 +881,8 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 const int rH = (int)__builtin_amdgcn_readlane((int)Hf[CP - 1], 63) >> 16, rEs = (int)__builtin_amdgcn_readlane((int)Es[CP - 1], 63) >> 16,
                           rQ = (int)__builtin_amdgcn_readlane((int)qhat[CP - 1], 63) >> 16;
                 const int rE = rEs - (e - g);
-                cobH = lane == i ? rH : cobH; cobE = lane == i ? (rE < POA_NEG ? POA_NEG : rE) : cobE; cobQ = lane == i ? (rQ < POA_NEG ? POA_NEG : rQ) : cobQ;
+                const uint32_t li = lane_is(lane, i);
+                cobH = set_lane(cobH, rH, li); cobE = set_lane(cobE, rE < POA_NEG ? POA_NEG : rE, li); cobQ = set_lane(cobQ, rQ < POA_NEG ? POA_NEG : rQ, li);
             }
             SEC(13);
             asm volatile("" ::: "memory");   // one wave: LDS operations execute in order; only the compiler must not reorder

@@ -28,6 +28,45 @@ __device__ __forceinline__ uint32_t dup16(int v) { return (uint32_t)(v & 0xffff)
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return (uint32_t)(lo & 0xffff) | ((uint32_t)hi << 16); }
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }                   // v_bfi_b32
 
+// 0xFFFF in the halves where a < b (signed, saturating difference), and the select that uses such a mask -- WRITTEN OUT.  Left to itself the compiler
+// recognises sra15(subs(a, b)) + bfi as "compare, then select" and emits v_cmp + v_cndmask, most of them with the mask in vcc, plus the moves and
+// v_perm that put the halves back together: K1w's row step of 1024 columns held 10 such selects and 149 vector instructions, 111 without them
+// (C2, same box: 10.78 -> 9.61 ms per launch; K3, 3 selects per row step: no measurable difference).  A loop of nothing but v_cndmask_b32 reading vcc
+// issues one per 23 cycles and SIMD on gfx950, through an SGPR pair or as v_bfi_b32 one per 4 (tools/ubench/cndmask_rate.hip ->
+// profiles/r06_cndmask_rate.txt).  CLH_COMPILER_SELECTS builds the plain C forms for the A/B (tools/dev/variants.sh).
+__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }      // a value the compiler shall not re-derive
+// the same mask for values whose difference fits 16 bits (|a - b| < 32768: scores of K1s / K1w, column indices): a WRAPPING unsigned subtraction,
+// which the compiler cannot read as a comparison -- no inline asm, hence none of the wait states it puts around asm blocks (35 s_nop per row step
+// of K1w with the asm form)
+__device__ __forceinline__ uint32_t pk_lt_mask_small(uint32_t a, uint32_t b) { return opaque(pk_sra15(pk_subu(a, b))); }
+#ifdef CLH_COMPILER_SELECTS      // A/B build (tools/dev/variants.sh): the plain C forms, which the compiler turns into v_cmp + v_cndmask
+__device__ __forceinline__ uint32_t pk_lt_mask(uint32_t a, uint32_t b) { return pk_sra15(pk_subs(a, b)); }
+__device__ __forceinline__ uint32_t bfi_keep(uint32_t mask, uint32_t a, uint32_t b) { return bfi(mask, a, b); }
+__device__ __forceinline__ uint32_t mask_keep(uint32_t x) { return x; }
+__device__ __forceinline__ uint32_t lane_is(int lane, int i) { return lane == i ? 0xffffffffu : 0u; }
+__device__ __forceinline__ int set_lane(int v, int x, uint32_t lane_mask) { return lane_mask ? x : v; }
+#else
+__device__ __forceinline__ uint32_t pk_lt_mask(uint32_t a, uint32_t b) {
+    uint32_t m;
+    asm("v_pk_sub_i16 %0, %1, %2 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint32_t bfi_keep(uint32_t mask, uint32_t a, uint32_t b) {      // (mask & a) | (~mask & b), one v_bfi_b32 the compiler cannot turn back into a select
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t mask_keep(uint32_t x) { asm("" : "+v"(x)); return x; }   // a mask the compiler shall not turn back into a compare
+// lane `i` (wave-uniform) of `v` becomes the value x: a mask and v_bfi_b32, not a compare and a select through vcc
+__device__ __forceinline__ uint32_t lane_is(int lane, int i) {      // all ones in lane i (wave-uniform), zero elsewhere -- arithmetic, no compare
+    uint32_t m;
+    asm("v_xor_b32 %0, %2, %1\n\tv_add_u32 %0, -1, %0\n\tv_ashrrev_i32 %0, 31, %0" : "=&v"(m) : "v"(lane), "s"(i));
+    return m;
+}
+__device__ __forceinline__ int set_lane(int v, int x, uint32_t lane_mask) { return (int)bfi_keep(lane_mask, (uint32_t)x, (uint32_t)v); }
+
+#endif
+
 // hand a packed value to the next virtual lane: new low half = previous lane's high half (lane 0: lane0_lo), new high half = own low half
 __device__ __forceinline__ uint32_t hand_down(uint32_t v, int lane0_lo) {
     const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp((int)((uint32_t)lane0_lo << 16), (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);

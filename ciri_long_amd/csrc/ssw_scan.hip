@@ -166,7 +166,7 @@ __device__ void scan_chunk(const ScanIn& in, const ScanLds& lds, const int c0, c
                 int outE = __builtin_amdgcn_readlane(inc, 63);
                 outE = (outE > fill ? outE : fill) - 127 * K;
                 outE = outE < 0 ? 0 : outE;
-                cobH = lane == i ? outH : cobH; cobE = lane == i ? outE : cobE;
+                const uint32_t li = lane_is(lane, i); cobH = set_lane(cobH, outH, li); cobE = set_lane(cobE, outE, li);
             }
         }
         if (more && lane < cnt) { bHout[rb + lane] = (short)cobH; bEout[rb + lane] = (short)cobE; }

@@ -192,7 +192,11 @@ __device__ bool scanw_chunk(const WIn& in, const WMem& mem, const int c0, const 
                     }
                 }
                 if (keyed) {
-                    const uint32_t m = pk_sra15(pk_subs(cmv[t], h));                 // halves where h is a new maximum (strictly)
+#ifdef CLH_COMPILER_SELECTS
+                    const uint32_t m = pk_sra15(pk_subs(cmv[t], h));
+#else
+                    const uint32_t m = pk_lt_mask_small(cmv[t], h);                  // halves where h is a new maximum (strictly); scores stay below 32 000 (scanw_class_ok)
+#endif
                     cmv[t] = pk_max(cmv[t], h);
                     cmr[t] = bfi(m, rowc, cmr[t]);
                 }
@@ -205,7 +209,7 @@ __device__ bool scanw_chunk(const WIn& in, const WMem& mem, const int c0, const 
                 int outE = __builtin_amdgcn_readlane(inc, 63);
                 outE = (outE > fill ? outE : fill) - 127 * K;
                 outE = outE < 0 ? 0 : outE;
-                cobH = lane == i ? outH : cobH; cobE = lane == i ? outE : cobE;
+                const uint32_t li = lane_is(lane, i); cobH = set_lane(cobH, outH, li); cobE = set_lane(cobE, outE, li);
             }
         };
         int i = 0;

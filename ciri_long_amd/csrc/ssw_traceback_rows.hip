@@ -123,7 +123,7 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir, TbX* xs =
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
                     Hu[t] = Hp[t]; Eu[t] = Ep[t]; Hd[t] = t == 0 ? d0 : Hp[t - 1];
-                    bandinv[t] = pk_sra15(pk_subs(inb[t], lo2)) | pk_sra15(pk_subs(hi2, inb[t]));      // j < i - w or i + w < j
+                    bandinv[t] = pk_lt_mask(inb[t], lo2) | pk_lt_mask(hi2, inb[t]);      // j < i - w or i + w < j
                 }
             } else {   // the previous row seen from one offset lower; the reference bases slide the same way
                 uint32_t above = 0;
@@ -157,14 +157,15 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir, TbX* xs =
             for (int t = 0; t < CP; ++t) {
                 const uint32_t t1 = pk_subs(Hu[t], gO2), t2 = pk_subs(Eu[t], gE2);
                 e[t] = pk_max(t1, t2);
-                if (DIRS) mde[t] = pk_sra15(pk_subs(t2, t1));                 // E opened: t1 > t2 (ssw.c:611)
+                if (DIRS) mde[t] = pk_lt_mask(t2, t1);                 // E opened: t1 > t2 (ssw.c:611)
                 e1[t] = pk_max(e[t], 0u);
                 const uint32_t T = __builtin_amdgcn_perm(tb.y, tb.x, refsel[t]);
                 td[t] = pk_subs(pk_adds(Hd[t], T), bias2);
                 X[t] = pk_max(e1[t], td[t]);
                 inv[t] = pk_sra15(refsel[t] << 12);                           // selector bit 3: no base in this cell
                 if constexpr (COLS) inv[t] |= bandinv[t];
-                c[t] = pk_subs(bfi(inv[t], xfix, X[t]), gO2);                 // what the cell offers its right neighbour's F; an absent cell: -gapE
+                inv[t] = mask_keep(inv[t]);                                      // (a mask, used as one: clh_device_ops.h, pk_lt_mask)
+                c[t] = pk_subs(bfi_keep(inv[t], xfix, X[t]), gO2);                 // what the cell offers its right neighbour's F; an absent cell: -gapE
             }
             // F: prefix maximum over the offsets (frame in which crossing a virtual lane costs nothing)
             uint32_t f[CP];
@@ -196,14 +197,14 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir, TbX* xs =
             uint32_t hn[CP], nib[CP], dd[CP];
 #pragma unroll
             for (int t = 0; t < CP; ++t) {
-                const uint32_t h = bfi(inv[t], 0u, pk_max(X[t], f[t]));
+                const uint32_t h = bfi_keep(inv[t], 0u, pk_max(X[t], f[t]));
                 hn[t] = h;
                 itmaxP = pk_max(itmaxP, h);
-                if (DIRS) dd[t] = pk_subs(pk_subs(h, bfi(inv[t], 0u, f[t])), dG2);   // (h - gapO) - (f - gapE), what the right neighbour compares
+                if (DIRS) dd[t] = pk_subs(pk_subs(h, bfi_keep(inv[t], 0u, f[t])), dG2);   // (h - gapO) - (f - gapE), what the right neighbour compares
             }
             if constexpr (NW > 1) {      // what the neighbouring waves read in the next row (and, with DIRS, in this one)
                 if constexpr (COLS) { if (lane == 63) xs->he[par][wave] = hn[CP - 1] >> 16; }
-                else if (lane == 0) xs->he[par][wave] = (hn[0] & 0xffffu) | (bfi(inv[0], 0u, e[0]) << 16);
+                else if (lane == 0) xs->he[par][wave] = (hn[0] & 0xffffu) | (bfi_keep(inv[0], 0u, e[0]) << 16);
                 if (DIRS && lane == 63) xs->dd[par][wave] = (int)(dd[CP - 1] >> 16);
                 tb_barrier();
             }
@@ -215,12 +216,12 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir, TbX* xs =
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
                     const uint32_t ddl = t == 0 ? d0 : dd[t - 1];
-                    const uint32_t mdf = pk_sra15(pk_subs(0u, ddl));          // F opened: h_left - gapO > f_left - gapE (ssw.c:616)
+                    const uint32_t mdf = pk_lt_mask(0u, ddl);          // F opened: h_left - gapO > f_left - gapE (ssw.c:616)
                     const uint32_t f1 = pk_max(f[t], 0u);
                     const uint32_t t1h = pk_max(e1[t], f1);
-                    const uint32_t mgt = pk_sra15(pk_subs(td[t], t1h));       // not the diagonal: max(e1, f1) > diagonal + score (ssw.c:626)
-                    const uint32_t mef = pk_sra15(pk_subs(f1, e1[t]));        // E rather than F: e1 > f1 (ssw.c:627)
-                    x[t] = (mgt & bfi(mef, 0x00010001u, 0x00020002u)) | (mde[t] & 0x00040004u) | (mdf & 0x00080008u);
+                    const uint32_t mgt = pk_lt_mask(td[t], t1h);       // not the diagonal: max(e1, f1) > diagonal + score (ssw.c:626)
+                    const uint32_t mef = pk_lt_mask(f1, e1[t]);        // E rather than F: e1 > f1 (ssw.c:627)
+                    x[t] = (mgt & bfi_keep(mef, 0x00010001u, 0x00020002u)) | (mde[t] & 0x00040004u) | (mdf & 0x00080008u);
                 }
                 uint8_t* drow = dir + (size_t)i * rowbytes + (size_t)(gl - first_lane) * CP;
                 if (gl < first_lane) {}
@@ -244,7 +245,7 @@ __device__ int tb_rows_pass(const TbIn& in, const int w, uint8_t* dir, TbX* xs =
                 }
             }
 #pragma unroll
-            for (int t = 0; t < CP; ++t) { Hp[t] = hn[t]; Ep[t] = bfi(inv[t], 0u, e[t]); }
+            for (int t = 0; t < CP; ++t) { Hp[t] = hn[t]; Ep[t] = bfi_keep(inv[t], 0u, e[t]); }
         }
     }
     const int lo = (int)(short)(itmaxP & 0xffffu), hi = (int)itmaxP >> 16;

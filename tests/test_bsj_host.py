@@ -355,3 +355,53 @@ def test_flatten_splice_sites():
         hip.lib = real
         g._h = None
     assert fake.got[0].tolist() == [103, 110, 100, 110, 7, 110] and fake.got[1].tolist() == [2, 2, 1, 1] and g._sites_of is idx
+
+
+def test_chunk_programs_overlap_and_come_out_in_order():
+    """find_bsj._drive: programs (generators that yield what they wait for) run with up to `depth` in flight, each resumed as soon as its handle is
+    ready -- whatever the order the handles finish in -- and their results come out in submission order"""
+    import random
+    from ciri_long_amd import find_bsj
+
+    class Handle(object):
+        def __init__(self, clock, at, value):
+            self.clock, self.at, self.value = clock, at, value
+
+        def ready(self):
+            return self.clock[0] >= self.at
+
+        def wait(self, timeout=None):
+            self.clock[0] += 1                    # (time passes only while the driver waits)
+
+        def get(self):
+            assert self.ready()
+            return self.value
+
+    rng = random.Random(3)
+    clock = [0]
+    live, peak, log = [0], [0], []
+
+    def program(k):
+        live[0] += 1; peak[0] = max(peak[0], live[0])
+        total = 0
+        for phase in range(3):
+            got = yield Handle(clock, clock[0] + rng.randint(0, 9), (k, phase))
+            assert got == (k, phase)
+            log.append((k, phase, clock[0]))
+            total += phase
+        live[0] -= 1
+        return k, total
+
+    out = list(find_bsj._drive((program(k) for k in range(25)), 4))
+    assert out == [(k, 3) for k in range(25)]                          # in order, every phase run
+    assert peak[0] == 4                                                # never more than `depth` alive, and the depth is used
+    order = [k for k, phase, _t in log if phase == 2]
+    assert order != sorted(order)                                      # (programs did finish out of order: the test means something)
+    assert list(find_bsj._drive(iter(()), 3)) == []
+    # a program that never waits (the one-thread route) and depth 1
+    def quick(k):
+        return k
+        yield                                                           # pragma: no cover
+    assert list(find_bsj._drive((quick(k) for k in range(5)), 1)) == list(range(5))
+    assert find_bsj.chunk_size_for(100000) == 4000 and find_bsj.chunk_size_for(4000) == 334 and find_bsj.chunk_size_for(10) == 250
+    assert find_bsj.chunk_size_for(24, 1) == 2 and find_bsj.chunk_size_for(1000, 1) == 16

@@ -568,14 +568,17 @@ static constexpr int POA_BAND = POA_BAND_W;
 static constexpr int POA_H_NONE = -32768;            // a cell of the staged band that the planes do not hold (H is never below POA_NEG)
 static constexpr int BT_MISS = -2;
 
-template <int CP>
+// SIMPLE: the pass of nearly every sequence of `call` -- local alignment, the whole sequence in ONE pass (no carries in from a pass before, none
+// out) -- with those facts as compile-time constants: the row loop loses its tests of them (a dozen scalar branches and their set-up per row)
+template <int CP, bool SIMPLE = false>
 __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, const int8_t* seq, int lane, const int pass, const int colbase,
-                           const bool more, const int RING, const int slope16, int& bs_io, int& br_io, int& bc_io DBGARG)
+                           const bool more_in, const int RING, const int slope16, int& bs_io, int& br_io, int& bc_io DBGARG)
 {
     constexpr int C = 2 * CP;
     const int gp = poa_pitch(m);
     const int rmask = RING - 1;
-    const bool sw = (S.algorithm & 0xff) == 0, nw = (S.algorithm & 0xff) == 1;
+    const bool more = SIMPLE ? false : more_in;
+    const bool sw = SIMPLE ? true : (S.algorithm & 0xff) == 0, nw = SIMPLE ? false : (S.algorithm & 0xff) == 1;
     // The workspace record lives in memory (this is a function of its own): every pointer of it that the row loop uses is taken out
     // here, once, as a scalar pair.  Left inside the loop the compiler reloads it per row -- and the wait for that load is a wait for
     // every store in flight (loads and stores share one counter), i.e. for the row's own plane stores to reach memory.
@@ -616,7 +619,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
     short* const gcarry = uniform_ptr(w.carry);
     const short* cprev = gcarry + (size_t)(pass & 1) * 3 * cpitch;
     short* cnext = gcarry + (size_t)((pass + 1) & 1) * 3 * cpitch;
-    const bool carried = pass > 0;
+    const bool carried = SIMPLE ? false : pass > 0;
     uint2 blk = make_uint2(0, 0); int cH = 0, cE = POA_NEG, cQ = POA_NEG;
     struct RowIn { uint2 b; int h, e, q; };
     // Every load unconditional, from a clamped index, the unwanted values dropped afterwards: around conditional loads the compiler
@@ -944,6 +947,14 @@ __device__ __attribute__((noinline)) void dp_rows(const PoaWs& w, const PoaScore
         const int rem = m - colbase;
         const bool more = rem > WMAX;
         const int cp = more ? POA_MAXCP : poa_cols(rem);
+        const bool simple = pass == 0 && !more && (S.algorithm & 0xff) == 0;
+        if (simple) {
+            switch (cp) {
+                case 1: dp_pass_lz<1, true>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;
+                case 2: dp_pass_lz<2, true>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;
+                default: dp_pass_lz<3, true>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;
+            }
+        } else
         switch (cp) {
             case 1: dp_pass_lz<1>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;
             case 2: dp_pass_lz<2>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;

@@ -861,7 +861,7 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
                 // be the end cell anyway: every move into such a cell loses score, so it is below the cell it came from
                 uint32_t hv2[CP];
 #pragma unroll
-                for (int t = 0; t < CP; ++t) hv2[t] = bfi(endP[t], 0x80008000u, Hf[t]);
+                for (int t = 0; t < CP; ++t) hv2[t] = SIMPLE ? Hf[t] : bfi(endP[t], 0x80008000u, Hf[t]);      // (SIMPLE: that case, promised by dp_rows)
                 uint32_t rm = hv2[0];
 #pragma unroll
                 for (int t = 1; t < CP; ++t) rm = pk_max(rm, hv2[t]);
@@ -947,7 +947,7 @@ __device__ __attribute__((noinline)) void dp_rows(const PoaWs& w, const PoaScore
         const int rem = m - colbase;
         const bool more = rem > WMAX;
         const int cp = more ? POA_MAXCP : poa_cols(rem);
-        const bool simple = pass == 0 && !more && (S.algorithm & 0xff) == 0;
+        const bool simple = pass == 0 && !more && (S.algorithm & 0xff) == 0 && S.n < 0 && S.g < 0 && S.e < 0 && S.q < 0 && S.c < 0;
         if (simple) {
             switch (cp) {
                 case 1: dp_pass_lz<1, true>(w, S, N, m, seq, lane, pass, colbase, more, RING, slope16, bs, br, bc DBGPASS); break;

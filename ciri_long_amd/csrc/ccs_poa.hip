@@ -791,13 +791,16 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             for (int t = 0; t < CP; ++t) {
                 Es[t] = pk_max(X[t], pk_adds(t == 0 ? q0 : qhat[t - 1], e2));       // E + e - g with E = max(Ehat, Qhat[j-1] + g), spoa's array
                 const uint32_t Hm = pk_subs(Hf[t], ONE2);
-                const uint32_t dF = pk_max(pk_subs(fsn[t], Hm), 0u), dO = pk_max(pk_subs(osn[t], Hm), 0u);
-                const uint32_t dE = pk_max(pk_subs(Es[t], Hm), 0u), dQ = pk_max(pk_subs(Y[t], Hm), 0u);
-                {   // the four fields of both halves: three v_lshl_or_b32 in ONE block (the compiler turns any C form into five operations,
-                    // and pads separate blocks with wait states)
+                // the four fields max(x - Hm, 0) = max(x, Hm) - Hm, put together BEFORE the subtraction: in 16-bit modular arithmetic
+                //   (YQ << 11) + (YE << 8) + (YO << 3) + YF - Hm * (2048 + 256 + 8 + 1)
+                // is the same word -- four maxima and four multiply-adds instead of four subtractions, four maxima and three shift-ors
+                // (one block: the compiler turns any C form of it into shifts and adds, and pads separate blocks with wait states)
+                const uint32_t YF = pk_max(fsn[t], Hm), YO = pk_max(osn[t], Hm), YE = pk_max(Es[t], Hm), YQ = pk_max(Y[t], Hm);
+                {
                     uint32_t dd_, t_;
-                    asm("v_lshl_or_b32 %0, %2, 3, %3\n\tv_lshl_or_b32 %1, %4, 3, %5\n\tv_lshl_or_b32 %0, %0, 8, %1"
-                        : "=&v"(dd_), "=&v"(t_) : "v"(dQ), "v"(dE), "v"(dO), "v"(dF));
+                    asm("v_pk_mad_u16 %0, %2, 8, %3 op_sel_hi:[1,0,1]\n\tv_pk_mad_u16 %1, %4, 8, %5 op_sel_hi:[1,0,1]\n\t"
+                        "v_pk_mad_u16 %0, %1, %6, %0\n\tv_pk_mad_u16 %0, %7, %8, %0"
+                        : "=&v"(dd_), "=&v"(t_) : "v"(YO), "v"(YF), "v"(YQ), "v"(YE), "s"(0x01000100u), "v"(Hm), "s"(dup16(-2313)));
                     D[t] = dd_;
                 }
             }

@@ -543,6 +543,9 @@ def _drive(programs, depth, wake=None):
             if wake is not None:
                 wake.wait(0.05)
                 wake.clear()
+                check = getattr(live[0][1], 'check', None)         # (a pool's handle: has a worker died?)
+                if check is not None:
+                    check()
             else:
                 live[0][1].wait(0.02)
 

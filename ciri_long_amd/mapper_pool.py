@@ -20,8 +20,13 @@ import multiprocessing
 import os
 import pickle
 import sys
+import time
 
 _FORK_PAYLOAD = None       # (aligner, contig_len) a forked worker finds here
+
+
+class WorkerDied(RuntimeError):
+    pass
 
 
 def gpu_touched():
@@ -42,8 +47,21 @@ def in_worker():
     return os.environ.get('CIRI_LONG_MAPPER_WORKER') == '1'
 
 
-def _worker_init(factory, contig_len, gtf_index):
+def _count_start(starts, payload_needed):
+    """Every worker counts itself in.  multiprocessing.Pool replaces a worker that died (killed for memory, a crash inside the mapper) without a
+    word, and the task the dead one held is never answered: the parent would wait for ever.  A count above the pool's size tells it (MapperPool.check).
+    A replacement that was forked AFTER the pool's construction has no mapper to inherit (and its parent may hold GPU state by now): it stays out of
+    the way until the parent, told by the count, ends the pools."""
+    with starts.get_lock():
+        starts.value += 1
+    if payload_needed and _FORK_PAYLOAD is None:
+        while True:
+            time.sleep(3600)
+
+
+def _worker_init(factory, contig_len, gtf_index, starts):
     os.environ['CIRI_LONG_MAPPER_WORKER'] = '1'
+    _count_start(starts, factory is None)
     from . import env
     if factory is None:
         aligner, contig_len, gtf_index = _FORK_PAYLOAD
@@ -53,9 +71,10 @@ def _worker_init(factory, contig_len, gtf_index):
     env.initializer(aligner, contig_len, None, gtf_index, None, None)
 
 
-def _light_init(contig_len, gtf_index):
+def _light_init(contig_len, gtf_index, starts, forked):
     """a worker of the light pool: the two halves of phase 3 only -- no mapper"""
     os.environ['CIRI_LONG_MAPPER_WORKER'] = '1'
+    _count_start(starts, forked)
     from . import env
     if gtf_index is None and _FORK_PAYLOAD is not None:
         _aligner, contig_len, gtf_index = _FORK_PAYLOAD
@@ -98,18 +117,26 @@ _TASKS = {'map': _worker_map, 'finish': _worker_finish, 'assemble': _worker_asse
 
 
 class _Handle(object):
-    """an AsyncResult whose get() gives one result per submitted task (grouped tasks flattened back)"""
+    """an AsyncResult whose get() gives one result per submitted task (grouped tasks flattened back); waiting on it notices a dead worker"""
 
-    def __init__(self, result, grouped):
-        self._r, self._grouped = result, grouped
+    def __init__(self, result, grouped, check=None):
+        self._r, self._grouped, self._check = result, grouped, check
 
     def ready(self):
         return self._r.ready()
 
+    def check(self):
+        if self._check is not None and not self._r.ready():
+            self._check()
+
     def wait(self, timeout=None):
         self._r.wait(timeout)
+        self.check()
 
     def get(self):
+        while not self._r.ready():
+            self._r.wait(0.5)
+            self.check()
         out = self._r.get()
         return [x for part in out for x in part] if self._grouped else out
 
@@ -133,15 +160,23 @@ class MapperPool(object):
         self.workers, self.piece = int(workers), int(piece)
         self._gtf_index = gtf_index
         ctx = multiprocessing.get_context(start)
-        self._pool = ctx.Pool(self.workers, _worker_init, (factory, contig_len, gtf_index if factory is not None else None))
+        nlight = max(2, self.workers // 4)
+        self._starts, self._expected = ctx.Value('i', 0), self.workers + nlight
+        self._pool = ctx.Pool(self.workers, _worker_init, (factory, contig_len, gtf_index if factory is not None else None, self._starts))
         # The halves of phase 3 (finish, assemble) are a few microseconds per read, but a pool serves its tasks first come, first served: behind
         # the mapper pieces of the chunks in flight they would wait tens of milliseconds, the oldest chunk could not retire, and the next chunk
         # would be submitted only when the mapper workers had run dry.  They get processes of their own (a quarter as many: they are mostly idle).
         if start == 'fork' and factory is None:
-            self._light = ctx.Pool(max(2, self.workers // 4), _light_init, (contig_len, None))
+            self._light = ctx.Pool(nlight, _light_init, (contig_len, None, self._starts, True))
         else:
-            self._light = ctx.Pool(max(2, self.workers // 4), _light_init, (contig_len, gtf_index))
+            self._light = ctx.Pool(nlight, _light_init, (contig_len, gtf_index, self._starts, False))
         _FORK_PAYLOAD = None
+
+    def check(self):
+        """raises WorkerDied once a worker process has been replaced: the task it held is lost, and nothing would ever say so"""
+        if self._starts.value > self._expected:
+            raise WorkerDied('mapper pool: a worker process died (killed for memory? a crash inside the mapper?) -- %d processes were started for '
+                             '%d places; the reads it held are lost and the run cannot go on' % (self._starts.value, self._expected))
 
     def has_index(self, gtf_index):
         """True when a worker's find_host_gene answers as the caller's would: it was given this very index, or there is none"""
@@ -163,16 +198,15 @@ class MapperPool(object):
             tasks = [tasks[i:i + n] for i in range(0, len(tasks), n)]
         cb = (lambda _x: wake.set()) if wake is not None else None
         pool = self._light if kind in ('finish', 'assemble') else self._pool
-        return _Handle(pool.map_async(_TASKS[kind], tasks, 1, cb, cb), grouped)
+        return _Handle(pool.map_async(_TASKS[kind], tasks, 1, cb, cb), grouped, self.check)
 
     def scan(self, chunk, raw_filters, min_circ_fraction):
         """phase 1 of a chunk, input order kept: [(counter keys touched, short read or None, pending tuple or None)] per read"""
         from . import find_bsj
-        out = self._pool.map(_worker_scan, [(p, raw_filters, min_circ_fraction) for p in self._pieces(list(chunk))])
-        return [x for part in out for x in part]
+        return _Handle(self._pool.map_async(_worker_scan, [(p, raw_filters, min_circ_fraction) for p in self._pieces(list(chunk))], 1), True, self.check).get()
 
     def raw_async(self, items):
-        return _Handle(self._pool.map_async(_worker_raw, self._pieces(list(items)), 1), True)
+        return _Handle(self._pool.map_async(_worker_raw, self._pieces(list(items)), 1), True, self.check)
 
     def raw(self, items):
         return self.raw_async(items).get()

@@ -210,3 +210,35 @@ def test_a_failure_inside_a_worker_surfaces_in_the_caller_and_the_pool_stays_usa
     find_bsj.start_mapper_pools(3, scan_aligner=fm.FakeMapper(world['genome'], min_score=170), contig_len=world['genome'].contig_len)
     again = _stage2(world, tmp_path, 'again', 3, mapper=fm.FakeMapper(world['genome'], min_score=170))
     assert again[:3] == one[:3]
+
+
+class DyingMapper(fm.FakeMapper):
+    """FakeMapper whose worker process ends without a word at one particular sequence (as when the kernel kills it for memory)"""
+
+    def __init__(self, genome, poison, **kw):
+        fm.FakeMapper.__init__(self, genome, **kw)
+        self.poison = poison
+
+    def map(self, seq):
+        if seq == self.poison and os.environ.get('CIRI_LONG_MAPPER_WORKER') == '1':
+            os._exit(9)
+        return fm.FakeMapper.map(self, seq)
+
+
+def test_a_worker_that_dies_is_reported_instead_of_waited_for(world, tmp_path, monkeypatch):
+    """multiprocessing.Pool replaces a dead worker silently and never answers the task it held: the stage driver must raise (within seconds),
+    not hang; new pools then work"""
+    from ciri_long_amd import find_bsj, mapper_pool
+    monkeypatch.setenv('CIRI_LONG_MAPPER', 'processes')
+    poison = world['reads'][2][2] * 2
+    find_bsj.THREADS = 3
+    find_bsj.start_mapper_pools(3, scan_aligner=DyingMapper(world['genome'], poison, min_score=170), contig_len=world['genome'].contig_len)
+    t0 = time.perf_counter()
+    with pytest.raises(mapper_pool.WorkerDied, match='a worker process died'):
+        _stage2(world, tmp_path, 'dead', 3, mapper=DyingMapper(world['genome'], poison, min_score=170))
+    assert time.perf_counter() - t0 < 30
+    find_bsj.stop_mapper_pools()
+    one = _stage2(world, tmp_path, 'one', 1, mapper=fm.FakeMapper(world['genome'], min_score=170))
+    find_bsj.start_mapper_pools(3, scan_aligner=fm.FakeMapper(world['genome'], min_score=170), contig_len=world['genome'].contig_len)
+    again = _stage2(world, tmp_path, 'again', 3, mapper=fm.FakeMapper(world['genome'], min_score=170))
+    assert again[:3] == one[:3]

@@ -532,6 +532,8 @@ def _drive(programs, depth, wake=None):
         if not live:
             return
         moved = False
+        if wake is not None:
+            wake.clear()          # before the handles are looked at: what finishes from here on sets it again, and the wait below returns at once
         for slot in live:
             while not slot[3] and slot[1].ready():
                 advance(slot, slot[1].get())
@@ -542,7 +544,6 @@ def _drive(programs, depth, wake=None):
         if not moved:
             if wake is not None:
                 wake.wait(0.05)
-                wake.clear()
                 check = getattr(live[0][1], 'check', None)         # (a pool's handle: has a worker died?)
                 if check is not None:
                     check()

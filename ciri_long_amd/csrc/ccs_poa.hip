@@ -725,17 +725,21 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
             };
             SEC(8);
             uint32_t dg[CP], MF[CP], MO[CP];
-            if (__builtin_expect(np <= 1, 1)) {
-                // the common shape.  The source's values are used where they are: the registers of the row before, which a source
-                // that is another row overwrites (nothing else reads them in this step) -- no copies on the way to the arithmetic
-                const int q0 = np == 0 ? 0 : p0;
-                if (__builtin_expect(q0 != r - 1 || q0 == 0, 0)) source(q0, px, pcin, pf, po);     // (row 1 of a node without in-edges: row 0 is not in the registers)
+            // the common shape.  The source's values are used where they are: the registers of the row before, which a source
+            // that is another row overwrites (nothing else reads them in this step) -- no copies on the way to the arithmetic
+            auto one_source = [&]() {
                 const uint32_t hsh0 = hand_down(px[CP - 1], pcin);
 #pragma unroll
                 for (int t = 0; t < CP; ++t) {
                     dg[t] = pk_adds(t == 0 ? hsh0 : px[t - 1], ss[t]);
                     MF[t] = pk_max(px[t], pf[t]); MO[t] = pk_max(px[t], po[t]);
                 }
+            };
+            if (__builtin_expect((d0 & 0x2000u) != 0, 1)) {           // one in-edge, from the row before: said by the graph row, so that the common row tests one bit
+                one_source();
+            } else if (np <= 1) {
+                source(np == 0 ? 0 : p0, px, pcin, pf, po);              // (also row 1 of a node without in-edges: row 0 is not in the registers)
+                one_source();
             } else {
                 const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)blk.y, i);
 #pragma unroll
@@ -1823,7 +1827,7 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
     W.planeH = nullptr; W.planeD = nullptr; W.carry = nullptr; W.cpitch = 0; W.col0 = nullptr;
     if (N > 0) {
         if (N > POA_MAX_ROWS || (S.algorithm == 1 && N > 25000)) return -1;
-        // ---- graph rows in rank space (w.ri: base, in-degree, sink, ranks of the first three sources) ---------------------
+        // ---- graph rows in rank space (w.ri: base, in-degree, sink, 0x2000 = its one source is the row before, ranks of the first three sources) ---------------------
         const int pitch = poa_pitch(m);
         const int RING = poa_ring(m);
         uint32_t* ri32 = (uint32_t*)w.ri;
@@ -1833,7 +1837,7 @@ __device__ __forceinline__ int poa_add(PoaWs& w, const PoaScores S, int N_, int 
             const int np = w.np[v];
             uint32_t pr[3] = {0, 0, 0};
             for (int s2 = 0; s2 < 3; ++s2) if (s2 < np) pr[s2] = (uint32_t)w.rank[w.pred[v * POA_MAXP + s2]];
-            w.ri[r] = make_uint2((uint32_t)(w.base[v] & 0xff) | ((uint32_t)(np < 15 ? np : 15) << 8) | (w.nout[v] == 0 ? 0x1000u : 0u) | (pr[0] << 16), pr[1] | (pr[2] << 16));
+            w.ri[r] = make_uint2((uint32_t)(w.base[v] & 0xff) | ((uint32_t)(np < 15 ? np : 15) << 8) | (w.nout[v] == 0 ? 0x1000u : 0u) | ((np == 1 && pr[0] != 0 && pr[0] == (uint32_t)(r - 1)) ? 0x2000u : 0u) | (pr[0] << 16), pr[1] | (pr[2] << 16));
         }
         phase_sync();
         // where will row r read source p from?  the row before it: registers; another recent row: the LDS ring (0x4000 on

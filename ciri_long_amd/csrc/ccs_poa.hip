@@ -813,22 +813,20 @@ __device__ void dp_pass_lz(const PoaWs& w, const PoaScores S, int N, int m, cons
 #pragma unroll
             for (int t = 0; t < CP; ++t) { px[t] = Hf[t]; pf[t] = fsn[t]; po[t] = osn[t]; }
             pcin = cinH;
-            bool st_row = stores;
-            if (slope16 && !(d0 & 0x8000u)) {            // only the lanes whose columns lie within POA_BAND of the row's centre column
-                const int cen = (int)(((unsigned)r * (unsigned)slope16) >> 16);
-                st_row = stores && (unsigned)(col0 + C - (cen - POA_BAND)) <= (unsigned)(2 * POA_BAND + C - 1);
-            }
+            // the lanes whose columns lie within POA_BAND of the row's centre column -- or every lane, for a row that an older successor reads
+            // back in full and for a short sequence: one comparison either way, the band as a scalar
+            const int band = (slope16 && !(d0 & 0x8000u)) ? POA_BAND : (1 << 20);
+            const int cen = (int)(((unsigned)r * (unsigned)slope16) >> 16);
+            const bool st_row = stores && (unsigned)(col0 + C - (cen - band)) <= (unsigned)(2 * band + C - 1);
             if (__builtin_expect(st_row, 1)) {
                 uint32_t nh[CP], nd[CP];
                 to_natural<CP>(Hf, nh); to_natural<CP>(D, nd);
-                // scalar row base + the lane's 32-bit offset: the row base is made opaque, or the compiler folds the lane's offset
-                // into a 64-bit vector base and pays two 64-bit multiply-adds (quarter rate) per row
-                const unsigned long long roff = (unsigned long long)((unsigned)r * (unsigned)gp) * 2ull;
+                // uniform plane base + ONE 32-bit offset per lane (row offset + the lane's columns; a plane is far below 4 GB): the stores' scalar-base
+                // form.  (Left to a 64-bit sum the compiler pays 64-bit vector adds per plane and row.)
+                const uint32_t voff = (uint32_t)r * (uint32_t)(gp * 2) + lane_off;
                 typedef __attribute__((address_space(1))) char* gchar;
                 typedef __attribute__((address_space(1))) uint32_t* gu32;
-                gchar rowH = (gchar)gH + roff, rowD = (gchar)gD + roff;
-                asm("" : "+s"(rowH), "+s"(rowD));
-                gu32 dh = (gu32)(rowH + lane_off), dd = (gu32)(rowD + lane_off);
+                gu32 dh = (gu32)((gchar)gH + (size_t)voff), dd = (gu32)((gchar)gD + (size_t)voff);
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -484,6 +484,15 @@ __device__ __forceinline__ void scan_left_pk(const uint32_t (&a)[CP], int left, 
     for (int t = 0; t < CP; ++t) pe[t] = pk_max(run[t], ex2);
 }
 
+// (exc, max(exc, low half of tot)) as a packed pair, exc a 16-bit value in an int: ONE operation -- the maximum goes straight into the high half of the
+// register that holds exc (SDWA, the low half kept).  In C it is a maximum, a mask and a shift-or.  (Behind wave_prefix_max2, whose block ends with
+// the wait states a reader of its results needs.)
+__device__ __forceinline__ uint32_t pack_exc(int exc, uint32_t tot) {
+    uint32_t d = (uint32_t)exc;
+    asm("v_max_i32_sdwa %0, %0, sext(%1) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0" : "+v"(d) : "v"(tot));
+    return d;
+}
+
 // the two scans of a row (E frame, Q frame) with their wave-wide parts interleaved
 template <int CP>
 __device__ __forceinline__ void scan_left_pk2(const uint32_t (&a)[CP], int leftA, uint32_t (&pa)[CP], const uint32_t (&b)[CP], int leftB, uint32_t (&pb)[CP])
@@ -498,7 +507,7 @@ __device__ __forceinline__ void scan_left_pk2(const uint32_t (&a)[CP], int leftA
     // exclusive prefix, the entering value included
     int excA = dpp_shr1(leftA, loA > hiA ? loA : hiA), excB = dpp_shr1(leftB, loB > hiB ? loB : hiB);
     wave_prefix_max2(excA, excB);
-    const uint32_t exA = pack16(excA, excA > loA ? excA : loA), exB = pack16(excB, excB > loB ? excB : loB);
+    const uint32_t exA = pack_exc(excA, totA), exB = pack_exc(excB, totB);
 #pragma unroll
     for (int t = 0; t < CP; ++t) { pa[t] = pk_max(runA[t], exA); pb[t] = pk_max(runB[t], exB); }
 }
